@@ -1,0 +1,98 @@
+"""ctypes loader for libdiffqc_hip.so (the C-ABI declared in include/diffqc_hip.h).
+
+The shared object is built in-tree by ``__graft_entry__.build()`` /
+``make -C diffquantum_amd/csrc``.  There is no fallback: if the library is missing the
+import of anything that needs it raises, and if no GPU is present ``dq_create`` returns
+DQ_ERR_NO_DEVICE which surfaces as ``DiffqcNoDevice``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffqc_hip.so")
+
+DQ_OK, DQ_ERR_INVALID, DQ_ERR_STATE, DQ_ERR_HIP, DQ_ERR_NO_DEVICE, DQ_ERR_UNSUPPORTED, DQ_ERR_NOMEM = range(7)
+PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other")
+
+
+class DiffqcError(RuntimeError):
+    pass
+
+
+class DiffqcNoDevice(DiffqcError):
+    pass
+
+
+class DqProfile(C.Structure):
+    _fields_ = [
+        ("launches", C.c_longlong * 5),
+        ("ms", C.c_double * 5),
+        ("flops", C.c_double * 5),
+        ("bytes", C.c_double * 5),
+    ]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every entry must be exported by the library
+SIGNATURES = {
+    "dq_version": (C.c_char_p, []),
+    "dq_last_error": (C.c_char_p, []),
+    "dq_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dq_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
+    "dq_destroy": (C.c_int, [_vp]),
+    "dq_set_stream": (C.c_int, [_vp, _vp]),
+    "dq_synchronize": (C.c_int, [_vp]),
+    "dq_set_hamiltonians": (C.c_int, [_vp, _vp, _vp]),
+    "dq_set_observable": (C.c_int, [_vp, _vp]),
+    "dq_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "dq_get_info": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "dq_propagate": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, C.c_int]),
+    "dq_energy": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "dq_energy_grad": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "dq_zgemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_long, C.c_long,
+                           _vp, C.c_long, C.c_long, C.c_double, _vp, C.c_long, C.c_long, C.c_int]),
+    "dq_expm": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "dq_expm_vjp": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "dq_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "dq_profile_reset": (C.c_int, [_vp]),
+    "dq_profile_get": (C.c_int, [_vp, C.POINTER(DqProfile)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library or raise (never substitutes another implementation)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DiffqcError(
+            "HIP extension missing: {} (build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C diffquantum_amd/csrc`); there is no CPU fallback".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status == DQ_OK:
+        return
+    msg = load().dq_last_error().decode("utf-8", "replace")
+    if status == DQ_ERR_INVALID:
+        raise ValueError(msg)
+    if status == DQ_ERR_NO_DEVICE:
+        raise DiffqcNoDevice(msg)
+    if status == DQ_ERR_NOMEM:
+        raise MemoryError(msg)
+    if status == DQ_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise DiffqcError("diffqc_hip status {}: {}".format(status, msg))

@@ -1,0 +1,863 @@
+// Host-side engine of libdiffqc_hip.so: context, workspace, the matrix-exponential plan
+// (scaled Paterson-Stockmeyer Taylor polynomial + squarings, built only from ZGEMMs), the
+// forward propagator chain and the adjoint (reverse-mode) sweep; plus the extern "C" ABI of
+// include/diffqc_hip.h.
+//
+// What it replaces in the reference (/root/reference):
+//   set_H globals                 diffqc.cc:21-25,43-73        -> dq_ctx + dq_set_hamiltonians
+//   dH assembly                   diffqc.cc:192-197            -> assemble_launch (batched over steps)
+//   dH.exp()                      diffqc.cc:198 (Eigen Pade)   -> expm_forward (Taylor/PS on f64 MFMA)
+//   psi = U psi, time loop        diffqc.cc:190-200            -> dq_propagate (psi is dim x batch)
+//   sim_plain.py:135-150          scipy expm + np.matmul       -> same
+//   gradient                      (reference: MC estimator sim_plain.py:156-231; no adjoint)
+//                                                              -> dq_energy_grad (exact discrete adjoint)
+// No CPU fallback exists anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/diffqc_hip.h"
+#include "dq_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct DqError {
+  int code;
+  std::string msg;
+};
+
+[[noreturn]] void fail(int code, const std::string& msg) { throw DqError{code, msg}; }
+
+#define HIPCK(expr)                                                                              \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      (void)hipGetLastError();                                                                   \
+      fail(e__ == hipErrorOutOfMemory ? DQ_ERR_NOMEM : DQ_ERR_HIP,                               \
+           std::string(#expr) + " failed: " + hipGetErrorString(e__));                           \
+    }                                                                                            \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void ensure(size_t n) {
+    if (n <= bytes) return;
+    release();
+    HIPCK(hipMalloc(&p, n));
+    bytes = n;
+  }
+  double2* z() const { return (double2*)p; }
+  double* d() const { return (double*)p; }
+};
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+// ---- exp(A) plan ---------------------------------------------------------------------------
+// T_m(A/2^s) evaluated with Paterson-Stockmeyer blocks of size q (m = (r+1) q):
+//   P_j = A^j (j <= q),  R_r = B_r,  R_i = P_q R_{i+1} + B_i,  B_i = sum_j c_{iq+j} P_j,
+// followed by s squarings. Products: (q-1) + r + s.  The degree is the smallest whose Taylor
+// remainder theta^(m+1)/(m+1)! is below tol (default 2^-53) for theta >= ||A/2^s||_1.
+struct ExpmPlan {
+  int m = 0, q = 0, r = 0, s = 0;
+  double c[24];
+  int products() const { return (q - 1) + r + s; }
+};
+
+const int kCand[][2] = {{2, 1}, {4, 2}, {6, 2}, {9, 3}, {12, 3}, {16, 4}, {20, 4}};
+constexpr int kNCand = 7;
+
+double taylor_remainder(double theta, int m) {
+  double v = 1.0;
+  for (int j = 1; j <= m + 1; ++j) v *= theta / j;
+  return v;
+}
+
+ExpmPlan make_plan(int m, int q, int s) {
+  ExpmPlan p;
+  p.m = m;
+  p.q = q;
+  p.r = m / q - 1;
+  p.s = s;
+  double f = 1.0;
+  const double sc = std::ldexp(1.0, -s);
+  double pw = 1.0;
+  for (int j = 0; j <= m; ++j) {
+    if (j > 0) { f *= j; pw *= sc; }
+    p.c[j] = pw / f;
+  }
+  return p;
+}
+
+ExpmPlan choose_plan(double theta, double tol, int force_degree, int force_s) {
+  if (!(theta >= 0.0) || !std::isfinite(theta)) fail(DQ_ERR_INVALID, "non-finite generator norm");
+  ExpmPlan best;
+  int best_cost = 1 << 30;
+  for (int s = 0; s <= 60; ++s) {
+    if (force_s >= 0 && s != force_s) continue;
+    const double th = std::ldexp(theta, -s);
+    for (int i = 0; i < kNCand; ++i) {
+      const int m = kCand[i][0], q = kCand[i][1];
+      if (force_degree > 0 && m != force_degree) continue;
+      if (force_degree <= 0 && taylor_remainder(th, m) > tol) continue;
+      const int cost = (q - 1) + (m / q - 1) + s;
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = make_plan(m, q, s);
+      }
+      break;  // candidates are ordered by cost within one s
+    }
+    if (force_s < 0 && best_cost <= s + 1) break;  // larger s cannot win any more
+  }
+  if (best.m == 0) fail(DQ_ERR_INVALID, "no exp(A) plan for the requested degree/squarings");
+  return best;
+}
+
+// ---- profiling -----------------------------------------------------------------------------
+struct ProfRec {
+  int cls;
+  hipEvent_t e0, e1;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct dq_ctx {
+  int d = 0, K = 0, dev = 0;
+  hipStream_t st = nullptr;
+  DevBuf H0, Hs, M;
+  bool have_H = false, have_M = false, hermitian = false;
+  double nH0 = 0.0;
+  std::vector<double> nHk;
+  // options
+  double checkpoint_bytes = 0.0, chunk_bytes = 2.0 * 1024 * 1024 * 1024, expm_tol = 1.1102230246251565e-16;
+  int force_degree = 0, force_s = -1, force_tile = 0;
+  // info
+  double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0;
+  // workspace
+  std::vector<DevBuf> pool;
+  size_t pool_tc = 0;
+  DevBuf u_dev, grad_dev, part, scratch, e_dev, psi[3], lam[2], tmp_in[4];
+  std::vector<DevBuf> ck;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> ev_free;
+  dq_profile prof_acc;
+
+  dq_ctx() : pool(96) { memset(&prof_acc, 0, sizeof(prof_acc)); }
+  ~dq_ctx() {
+    for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : ev_free) (void)hipEventDestroy(e);
+  }
+
+  size_t nn() const { return (size_t)d * d; }
+  size_t mat_bytes() const { return nn() * sizeof(double2); }
+
+  hipEvent_t get_event() {
+    if (!ev_free.empty()) { hipEvent_t e = ev_free.back(); ev_free.pop_back(); return e; }
+    hipEvent_t e;
+    HIPCK(hipEventCreate(&e));
+    return e;
+  }
+  template <class F>
+  void timed(int cls, double flops, double bytes, F&& launch) {
+    if (!prof_on) {
+      HIPCK(launch());
+      return;
+    }
+    ProfRec r{cls, get_event(), get_event(), flops, bytes};
+    HIPCK(hipEventRecord(r.e0, st));
+    HIPCK(launch());
+    HIPCK(hipEventRecord(r.e1, st));
+    recs.push_back(r);
+  }
+  void prof_collect() {
+    if (recs.empty()) return;
+    HIPCK(hipStreamSynchronize(st));
+    for (auto& r : recs) {
+      float ms = 0.f;
+      HIPCK(hipEventElapsedTime(&ms, r.e0, r.e1));
+      prof_acc.launches[r.cls] += 1;
+      prof_acc.ms[r.cls] += ms;
+      prof_acc.flops[r.cls] += r.flops;
+      prof_acc.bytes[r.cls] += r.bytes;
+      ev_free.push_back(r.e0);
+      ev_free.push_back(r.e1);
+    }
+    recs.clear();
+  }
+
+  // pool slot of `tc` stacked d x d matrices
+  double2* mat(int slot, size_t tc) {
+    pool[slot].ensure(tc * mat_bytes());
+    return pool[slot].z();
+  }
+
+  void zgemm(int opA, int opB, int M, int N, int Kd, double alpha, const double2* A, long lda, long sA,
+             const double2* B, long ldb, long sB, double beta, double2* C, long ldc, long sC, int batch) {
+    dq::ZgemmArgs g;
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = Kd;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sA = sA; g.sB = sB; g.sC = sC;
+    g.batch = batch;
+    g.alpha = alpha; g.beta = beta;
+    g.opA = opA; g.opB = opB;
+    const double fl = 8.0 * M * N * (double)Kd * batch;
+    const double by = 16.0 * ((double)M * Kd + (double)Kd * N + (double)M * N * (beta != 0.0 ? 2 : 1)) * batch;
+    const int ft = force_tile;
+    timed(DQ_PROF_ZGEMM, fl, by, [&] { return dq::zgemm_launch(g, st, ft); });
+  }
+  // batched d x d product on pool matrices
+  void mm(int opA, int opB, const double2* A, const double2* B, double2* C, double beta, int batch) {
+    const long s = (long)nn();
+    zgemm(opA, opB, d, d, d, 1.0, A, d, s, B, d, s, beta, C, d, s, batch);
+  }
+  void lincomb(double2* out, int n_in, const double2* const* x, const double* c, double cI, int batch, bool acc) {
+    dq::LincombArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out = out;
+    a.n_in = n_in;
+    for (int j = 0; j < n_in; ++j) { a.x[j] = x[j]; a.c[j] = c[j]; }
+    a.cI = cI;
+    a.d = d;
+    a.stride = (long)nn();
+    a.batch = batch;
+    a.accumulate = acc ? 1 : 0;
+    const double by = 16.0 * nn() * (n_in + 1 + (acc ? 1 : 0)) * batch;
+    timed(DQ_PROF_LINCOMB, 2.0 * 2 * nn() * n_in * batch, by, [&] { return dq::lincomb_launch(a, st); });
+  }
+};
+
+namespace {
+
+// pool slot map
+enum { SLOT_P = 0 /*1..4*/, SLOT_R = 8 /*0..4*/, SLOT_RB = 16 /*0..4*/, SLOT_PB = 24 /*1..4*/,
+       SLOT_SQ = 32 /*1..*/, SLOT_SQB = 94 /*0..1*/, SLOT_IO = 92 };
+
+// Forward exp of `n` stacked matrices sitting in slot P1. Returns the device pointer of U.
+double2* expm_forward(dq_ctx* c, const ExpmPlan& p, int n) {
+  const int q = p.q, r = p.r;
+  double2* P[6] = {nullptr};
+  for (int j = 1; j <= q; ++j) P[j] = c->mat(SLOT_P + j, n);
+  for (int j = 2; j <= q; ++j) c->mm(0, 0, P[j - 1], P[1], P[j], 0.0, n);
+  double2* R[6];
+  for (int i = 0; i <= r; ++i) R[i] = c->mat(SLOT_R + i, n);
+  {  // top block: c_{rq} I + sum_{j=1..q} c_{rq+j} P_j
+    const double2* x[6];
+    double cf[6];
+    for (int j = 1; j <= q; ++j) { x[j - 1] = P[j]; cf[j - 1] = p.c[r * q + j]; }
+    c->lincomb(R[r], q, x, cf, p.c[r * q], n, false);
+  }
+  for (int i = r - 1; i >= 0; --i) {
+    const double2* x[6];
+    double cf[6];
+    for (int j = 1; j <= q - 1; ++j) { x[j - 1] = P[j]; cf[j - 1] = p.c[i * q + j]; }
+    c->lincomb(R[i], q - 1, x, cf, p.c[i * q], n, false);
+    c->mm(0, 0, P[q], R[i + 1], R[i], 1.0, n);  // R_i += P_q R_{i+1}
+  }
+  double2* U = R[0];
+  for (int j = 1; j <= p.s; ++j) {
+    double2* nx = c->mat(SLOT_SQ + j, n);
+    c->mm(0, 0, U, U, nx, 0.0, n);
+    U = nx;
+  }
+  c->last_degree = p.m;
+  c->last_squarings = p.s;
+  c->last_products = p.products();
+  return U;
+}
+
+// Where the caller must put Ubar (cotangent of U) before expm_backward.
+double2* ubar_slot(dq_ctx* c, const ExpmPlan& p, int n) {
+  return p.s == 0 ? c->mat(SLOT_RB + 0, n) : c->mat(SLOT_SQB + 0, n);
+}
+
+// Reverse mode through expm_forward (whose P_j, R_i, squaring chain are still in the pool).
+// Pairing: dL = Re tr(Xbar^H dX). For C = X Y: Xbar += Cbar Y^H, Ybar += X^H Cbar.
+// Returns the device pointer of Abar (n stacked matrices).
+double2* expm_backward(dq_ctx* c, const ExpmPlan& p, int n) {
+  const int q = p.q, r = p.r;
+  double2* P[6] = {nullptr};
+  double2* R[6];
+  double2* Rb[6];
+  double2* Pb[6] = {nullptr};
+  for (int j = 1; j <= q; ++j) { P[j] = c->mat(SLOT_P + j, n); Pb[j] = c->mat(SLOT_PB + j, n); }
+  for (int i = 0; i <= r; ++i) { R[i] = c->mat(SLOT_R + i, n); Rb[i] = c->mat(SLOT_RB + i, n); }
+  if (p.s > 0) {  // undo squarings: U_{j+1} = U_j U_j  ->  Ubar_j = Ubar_{j+1} U_j^H + U_j^H Ubar_{j+1}
+    double2* cur = c->mat(SLOT_SQB + 0, n);
+    for (int j = p.s - 1; j >= 0; --j) {
+      const double2* Uj = (j == 0) ? R[0] : c->mat(SLOT_SQ + j, n);
+      double2* dst = (j == 0) ? Rb[0] : (cur == c->mat(SLOT_SQB + 0, n) ? c->mat(SLOT_SQB + 1, n) : c->mat(SLOT_SQB + 0, n));
+      c->mm(0, 1, cur, Uj, dst, 0.0, n);
+      c->mm(1, 0, Uj, cur, dst, 1.0, n);
+      cur = dst;
+    }
+  }
+  for (int i = 0; i < r; ++i) c->mm(1, 0, P[q], Rb[i], Rb[i + 1], 0.0, n);  // Rbar_{i+1} = P_q^H Rbar_i
+  {  // Pbar_q = c_{rq+q} Rbar_r + sum_i Rbar_i R_{i+1}^H
+    const double2* x[1] = {Rb[r]};
+    const double cf[1] = {p.c[r * q + q]};
+    c->lincomb(Pb[q], 1, x, cf, 0.0, n, false);
+    for (int i = 0; i < r; ++i) c->mm(0, 1, Rb[i], R[i + 1], Pb[q], 1.0, n);
+  }
+  for (int j = 1; j <= q - 1; ++j) {  // Pbar_j = sum_i c_{iq+j} Rbar_i
+    const double2* x[6];
+    double cf[6];
+    for (int i = 0; i <= r; ++i) { x[i] = Rb[i]; cf[i] = p.c[i * q + j]; }
+    c->lincomb(Pb[j], r + 1, x, cf, 0.0, n, false);
+  }
+  for (int j = q; j >= 2; --j) {  // P_j = P_{j-1} P_1
+    c->mm(0, 1, Pb[j], P[1], Pb[j - 1], 1.0, n);
+    c->mm(1, 0, P[j - 1], Pb[j], Pb[1], 1.0, n);
+  }
+  return Pb[1];
+}
+
+void stage_h2d(dq_ctx* c, void* dst, const void* src, size_t bytes) {
+  HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->st));
+}
+
+// returns a device pointer for an input that may live on the host
+const double2* in_dev(dq_ctx* c, const double* p, size_t bytes, DevBuf& tmp) {
+  if (is_device_ptr(p)) return (const double2*)p;
+  tmp.ensure(bytes);
+  stage_h2d(c, tmp.p, p, bytes);
+  return tmp.z();
+}
+
+void out_copy(dq_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+  if (!dst || dst == src_dev) return;
+  HIPCK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, c->st));
+}
+
+double norm1_dev(dq_ctx* c, const double2* X) {
+  c->scratch.ensure(sizeof(double) * (size_t)c->d);
+  HIPCK(dq::colabs_launch(X, c->d, c->scratch.d(), c->st));
+  std::vector<double> h(c->d);
+  HIPCK(hipMemcpyAsync(h.data(), c->scratch.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  double mx = 0.0;
+  for (double v : h) {
+    if (!std::isfinite(v)) fail(DQ_ERR_INVALID, "matrix contains non-finite entries");
+    mx = std::max(mx, v);
+  }
+  return mx;
+}
+
+double herm_defect_dev(dq_ctx* c, const double2* X) {
+  c->scratch.ensure(sizeof(double) * (size_t)std::max(c->d, 1));
+  HIPCK(dq::herm_defect_launch(X, c->d, c->scratch.d(), c->st));
+  double h = 0.0;
+  HIPCK(hipMemcpyAsync(&h, c->scratch.p, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  return h;
+}
+
+void check_ctx(dq_ctx* c) {
+  if (!c) fail(DQ_ERR_INVALID, "null context");
+  HIPCK(hipSetDevice(c->dev));
+}
+
+// number of steps whose exp() is built in one batched pass
+int time_chunk(dq_ctx* c, int n_steps) {
+  const double per_step = 24.0 * (double)c->mat_bytes();  // P, R, Rbar, Pbar, squaring slots
+  long tc = (long)(c->chunk_bytes / per_step);
+  tc = std::max(1L, std::min<long>(tc, n_steps));
+  tc = std::min<long>(tc, 16384);
+  return (int)tc;
+}
+
+double theta_bound(dq_ctx* c, const double* u_row, double dt) {
+  double h = c->nH0;
+  for (int k = 0; k < c->K; ++k) h += std::fabs(u_row[k]) * c->nHk[k];
+  return std::fabs(dt) * h;
+}
+
+std::vector<double> fetch_u(dq_ctx* c, const double* u, int S) {
+  const size_t n = (size_t)S * c->K;
+  std::vector<double> h(n);
+  if (n == 0) return h;
+  if (is_device_ptr(u)) {
+    HIPCK(hipMemcpyAsync(h.data(), u, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+  } else {
+    memcpy(h.data(), u, n * sizeof(double));
+  }
+  for (double v : h)
+    if (!std::isfinite(v)) fail(DQ_ERR_INVALID, "pulse table contains non-finite values");
+  c->u_dev.ensure(std::max<size_t>(n, 1) * sizeof(double));
+  HIPCK(hipMemcpyAsync(c->u_dev.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPCK(hipStreamSynchronize(c->st));  // h may be pageable
+  return h;
+}
+
+ExpmPlan chunk_plan(dq_ctx* c, const std::vector<double>& uh, int c0, int n, double dt) {
+  double th = 0.0;
+  for (int t = c0; t < c0 + n; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
+  c->last_theta = th;
+  return choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
+}
+
+// assemble + exp for steps [c0, c0+n): returns pointer to n stacked propagators
+double2* build_propagators(dq_ctx* c, const ExpmPlan& p, int c0, int n, double dt) {
+  double2* A = c->mat(SLOT_P + 1, n);
+  const double by = 16.0 * c->nn() * (c->K + 2.0) * n;
+  c->timed(DQ_PROF_ASSEMBLE, 2.0 * 2 * c->nn() * (c->K + 1.0) * n, by, [&] {
+    return dq::assemble_launch(A, c->H0.z(), c->Hs.z(), c->u_dev.d() + (size_t)c0 * c->K, c->K, (long)c->nn(), n, dt,
+                               c->st);
+  });
+  return expm_forward(c, p, n);
+}
+
+void require_H(dq_ctx* c) {
+  if (!c->have_H) fail(DQ_ERR_STATE, "dq_set_hamiltonians has not been called");
+}
+
+void do_propagate(dq_ctx* c, const double* u, int S, double dt, const double* psi_in, double* psi_out, int B) {
+  check_ctx(c);
+  require_H(c);
+  if (S < 0 || B < 0) fail(DQ_ERR_INVALID, "n_steps and batch must be >= 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (B == 0) return;
+  if (!psi_in || !psi_out) fail(DQ_ERR_INVALID, "null state pointer");
+  if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
+  const int d = c->d;
+  const size_t sb = (size_t)d * B * sizeof(double2);
+  std::vector<double> uh = fetch_u(c, u, S);
+  c->psi[0].ensure(sb);
+  c->psi[1].ensure(sb);
+  HIPCK(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
+  int cur = 0;
+  const int tc = time_chunk(c, std::max(S, 1));
+  c->last_chunk = tc;
+  for (int c0 = 0; c0 < S; c0 += tc) {
+    const int n = std::min(tc, S - c0);
+    const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
+    const double2* U = build_propagators(c, p, c0, n, dt);
+    for (int t = 0; t < n; ++t) {
+      c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, c->psi[cur].z(), B, 0, 0.0, c->psi[cur ^ 1].z(), B,
+               0, 1);
+      cur ^= 1;
+    }
+  }
+  out_copy(c, psi_out, c->psi[cur].p, sb);
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+void do_energy(dq_ctx* c, const double2* psi_dev, int B, double2* lam_out /*2 M psi*/, double* energies, double* total) {
+  const int d = c->d;
+  c->zgemm(0, 0, d, B, d, 2.0, c->M.z(), d, 0, psi_dev, B, 0, 0.0, lam_out, B, 0, 1);
+  c->e_dev.ensure(sizeof(double) * ((size_t)B + 1));
+  c->timed(DQ_PROF_OTHER, 4.0 * d * B, 32.0 * d * B,
+           [&] { return dq::coldot_launch(psi_dev, B, lam_out, B, d, B, 0.5, c->e_dev.d(), c->st); });
+  c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(c->e_dev.d(), B, c->e_dev.d() + B, c->st); });
+  if (energies) out_copy(c, energies, c->e_dev.p, sizeof(double) * (size_t)B);
+  if (total) out_copy(c, total, c->e_dev.d() + B, sizeof(double));
+}
+
+void do_energy_grad(dq_ctx* c, const double* u, int S, double dt, const double* psi0, int B, double* loss,
+                    double* grad_u, double* psi_final, double* energies) {
+  check_ctx(c);
+  require_H(c);
+  if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
+  if (!c->hermitian)
+    fail(DQ_ERR_UNSUPPORTED,
+         "adjoint sweep needs Hermitian H0/H_k (it rebuilds psi_t = U_t^H psi_{t+1} between checkpoints)");
+  if (S < 0 || B <= 0) fail(DQ_ERR_INVALID, "n_steps must be >= 0 and batch > 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (!psi0) fail(DQ_ERR_INVALID, "null state pointer");
+  if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
+  const int d = c->d, K = c->K;
+  const size_t sb = (size_t)d * B * sizeof(double2);
+  std::vector<double> uh = fetch_u(c, u, S);
+
+  // checkpoint stride from the memory budget
+  double budget = c->checkpoint_bytes;
+  if (budget <= 0.0) {
+    size_t fr = 0, tot = 0;
+    HIPCK(hipMemGetInfo(&fr, &tot));
+    budget = 0.35 * (double)fr;
+  }
+  long ncp_max = std::max(1L, (long)(budget / (double)sb));
+  int cstride = (int)std::max(1L, ((long)S + ncp_max - 1) / ncp_max);
+  const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
+  c->last_cstride = cstride;
+  if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
+  for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
+  for (int i = 0; i < 3; ++i) c->psi[i].ensure(sb);
+  for (int i = 0; i < 2; ++i) c->lam[i].ensure(sb);
+  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
+
+  // ---- forward ----
+  HIPCK(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
+  int cur = 0;
+  const int tc = time_chunk(c, std::max(S, 1));
+  c->last_chunk = tc;
+  for (int c0 = 0; c0 < S; c0 += tc) {
+    const int n = std::min(tc, S - c0);
+    const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
+    const double2* U = build_propagators(c, p, c0, n, dt);
+    for (int t = 0; t < n; ++t) {
+      const int tt = c0 + t;
+      if (tt % cstride == 0) {
+        const size_t bytes = sb;
+        void* dst = c->ck[tt / cstride].p;
+        const void* src = c->psi[cur].p;
+        c->timed(DQ_PROF_OTHER, 0.0, 2.0 * bytes,
+                 [&] { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->st); });
+      }
+      c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, c->psi[cur].z(), B, 0, 0.0, c->psi[cur ^ 1].z(), B,
+               0, 1);
+      cur ^= 1;
+    }
+  }
+  // psi[cur] = Psi_S ; terminal costate Lambda_S = 2 M Psi_S, energies
+  do_energy(c, c->psi[cur].z(), B, c->lam[0].z(), energies, loss);
+  if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
+
+  // ---- backward ----
+  const double2* psi_next = c->psi[cur].z();
+  int lcur = 0;
+  if (S > 0) {
+    const int nblk = dq::grad_contract_blocks((long)c->nn());
+    const int last_c0 = ((S - 1) / tc) * tc;
+    for (int c0 = last_c0; c0 >= 0; c0 -= tc) {
+      const int n = std::min(tc, S - c0);
+      const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
+      const double2* U = build_propagators(c, p, c0, n, dt);
+      double2* G = ubar_slot(c, p, n);
+      for (int t = n - 1; t >= 0; --t) {
+        const int tt = c0 + t;
+        const double2* Ut = U + (size_t)t * c->nn();
+        const double2* psi_t;
+        if (tt % cstride == 0) {
+          psi_t = c->ck[tt / cstride].z();
+        } else {
+          // pick a scratch buffer that does not hold psi_next
+          double2* dst = nullptr;
+          for (int i = 0; i < 3; ++i)
+            if (c->psi[i].z() != psi_next) { dst = c->psi[i].z(); break; }
+          c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, psi_next, B, 0, 0.0, dst, B, 0, 1);  // psi_t = U_t^H psi_{t+1}
+          psi_t = dst;
+        }
+        // G_t = Lambda_{t+1} Psi_t^H    (cotangent of U_t)
+        c->zgemm(0, 1, d, d, B, 1.0, c->lam[lcur].z(), B, 0, psi_t, B, 0, 0.0, G + (size_t)t * c->nn(), d, 0, 1);
+        // Lambda_t = U_t^H Lambda_{t+1}
+        c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, c->lam[lcur].z(), B, 0, 0.0, c->lam[lcur ^ 1].z(), B, 0, 1);
+        lcur ^= 1;
+        psi_next = psi_t;
+      }
+      const double2* Abar = expm_backward(c, p, n);
+      c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
+      const double by = 16.0 * c->nn() * (K + ((K + 7) / 8)) * n;
+      c->timed(DQ_PROF_GRADC, 3.0 * c->nn() * K * n, by, [&] {
+        return dq::grad_contract_launch(Abar, (long)c->nn(), c->Hs.z(), K, (long)c->nn(), n, dt, c->part.d(),
+                                        c->grad_dev.d() + (size_t)c0 * K, c->st);
+      });
+    }
+  }
+  if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return DQ_OK;
+  } catch (const DqError& e) {
+    g_err = e.msg;
+    return e.code;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return DQ_ERR_HIP;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dq_version(void) { return "diffqc_hip 0.1 (gfx950)"; }
+const char* dq_last_error(void) { return g_err.c_str(); }
+
+int dq_device_count(int* n) {
+  return guarded([&] {
+    if (!n) fail(DQ_ERR_INVALID, "null output");
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { (void)hipGetLastError(); k = 0; }
+    *n = k;
+  });
+}
+
+int dq_create(dq_ctx** out, int dim, int n_controls, int device_id) {
+  return guarded([&] {
+    if (!out) fail(DQ_ERR_INVALID, "null output");
+    *out = nullptr;
+    if (dim < 1 || dim > (1 << 15)) fail(DQ_ERR_INVALID, "dim must be in [1, 32768]");
+    if (n_controls < 0 || n_controls > 4096) fail(DQ_ERR_INVALID, "n_controls must be in [0, 4096]");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+      (void)hipGetLastError();
+      fail(DQ_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    }
+    if (device_id < 0 || device_id >= ndev) fail(DQ_ERR_INVALID, "device_id out of range");
+    HIPCK(hipSetDevice(device_id));
+    dq_ctx* c = new dq_ctx();
+    c->d = dim;
+    c->K = n_controls;
+    c->dev = device_id;
+    c->nHk.assign(n_controls, 0.0);
+    *out = c;
+  });
+}
+
+int dq_destroy(dq_ctx* c) {
+  return guarded([&] {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    (void)hipStreamSynchronize(c->st);
+    delete c;
+  });
+}
+
+int dq_set_stream(dq_ctx* c, void* s) {
+  return guarded([&] {
+    check_ctx(c);
+    HIPCK(hipStreamSynchronize(c->st));
+    c->st = (hipStream_t)s;
+  });
+}
+
+int dq_synchronize(dq_ctx* c) {
+  return guarded([&] {
+    check_ctx(c);
+    HIPCK(hipStreamSynchronize(c->st));
+  });
+}
+
+int dq_set_hamiltonians(dq_ctx* c, const double* H0, const double* Hs) {
+  return guarded([&] {
+    check_ctx(c);
+    if (!H0 || (c->K > 0 && !Hs)) fail(DQ_ERR_INVALID, "null Hamiltonian pointer");
+    c->have_H = false;
+    c->H0.ensure(c->mat_bytes());
+    c->Hs.ensure(std::max<size_t>(c->K, 1) * c->mat_bytes());
+    HIPCK(hipMemcpyAsync(c->H0.p, H0, c->mat_bytes(), hipMemcpyDefault, c->st));
+    if (c->K > 0) HIPCK(hipMemcpyAsync(c->Hs.p, Hs, (size_t)c->K * c->mat_bytes(), hipMemcpyDefault, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+    c->nH0 = norm1_dev(c, c->H0.z());
+    double defect = herm_defect_dev(c, c->H0.z());
+    double scale = std::max(1.0, c->nH0);
+    for (int k = 0; k < c->K; ++k) {
+      const double2* Hk = c->Hs.z() + (size_t)k * c->nn();
+      c->nHk[k] = norm1_dev(c, Hk);
+      defect = std::max(defect, herm_defect_dev(c, Hk));
+      scale = std::max(scale, c->nHk[k]);
+    }
+    c->hermitian = defect <= 1e-12 * scale;
+    c->have_H = true;
+  });
+}
+
+int dq_set_observable(dq_ctx* c, const double* M) {
+  return guarded([&] {
+    check_ctx(c);
+    if (!M) fail(DQ_ERR_INVALID, "null observable pointer");
+    c->have_M = false;
+    c->M.ensure(c->mat_bytes());
+    HIPCK(hipMemcpyAsync(c->M.p, M, c->mat_bytes(), hipMemcpyDefault, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+    const double nm = norm1_dev(c, c->M.z());
+    if (herm_defect_dev(c, c->M.z()) > 1e-12 * std::max(1.0, nm)) fail(DQ_ERR_INVALID, "observable must be Hermitian");
+    c->have_M = true;
+  });
+}
+
+int dq_set_option(dq_ctx* c, const char* name, double v) {
+  return guarded([&] {
+    check_ctx(c);
+    if (!name) fail(DQ_ERR_INVALID, "null option name");
+    const std::string s(name);
+    if (s == "checkpoint_bytes") c->checkpoint_bytes = v;
+    else if (s == "chunk_bytes") { if (!(v > 0)) fail(DQ_ERR_INVALID, "chunk_bytes must be > 0"); c->chunk_bytes = v; }
+    else if (s == "expm_tol") { if (!(v > 0)) fail(DQ_ERR_INVALID, "expm_tol must be > 0"); c->expm_tol = v; }
+    else if (s == "force_degree") c->force_degree = (int)v;
+    else if (s == "force_squarings") c->force_s = (int)v;
+    else if (s == "force_tile") {
+      const int t = (int)v;
+      if (t != 0 && t != 32 && t != 64 && t != 128) fail(DQ_ERR_INVALID, "force_tile must be 0, 32, 64 or 128");
+      c->force_tile = t;
+    } else fail(DQ_ERR_INVALID, "unknown option '" + s + "'");
+  });
+}
+
+int dq_get_info(dq_ctx* c, const char* name, double* v) {
+  return guarded([&] {
+    check_ctx(c);
+    if (!name || !v) fail(DQ_ERR_INVALID, "null argument");
+    const std::string s(name);
+    if (s == "degree") *v = c->last_degree;
+    else if (s == "squarings") *v = c->last_squarings;
+    else if (s == "products") *v = c->last_products;
+    else if (s == "time_chunk") *v = c->last_chunk;
+    else if (s == "checkpoint_stride") *v = c->last_cstride;
+    else if (s == "theta") *v = c->last_theta;
+    else if (s == "hermitian") *v = c->hermitian ? 1.0 : 0.0;
+    else if (s == "norm_H0") *v = c->nH0;
+    else if (s == "dim") *v = c->d;
+    else if (s == "n_controls") *v = c->K;
+    else fail(DQ_ERR_INVALID, "unknown info '" + s + "'");
+  });
+}
+
+int dq_propagate(dq_ctx* c, const double* u, int n_steps, double dt, const double* psi_in, double* psi_out, int batch) {
+  return guarded([&] { do_propagate(c, u, n_steps, dt, psi_in, psi_out, batch); });
+}
+
+int dq_energy(dq_ctx* c, const double* psi, int batch, double* energies, double* total) {
+  return guarded([&] {
+    check_ctx(c);
+    if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
+    if (batch <= 0 || !psi) fail(DQ_ERR_INVALID, "need batch > 0 and a state pointer");
+    const size_t sb = (size_t)c->d * batch * sizeof(double2);
+    const double2* p = in_dev(c, psi, sb, c->tmp_in[0]);
+    c->lam[0].ensure(sb);
+    do_energy(c, p, batch, c->lam[0].z(), energies, total);
+    HIPCK(hipStreamSynchronize(c->st));
+  });
+}
+
+int dq_energy_grad(dq_ctx* c, const double* u, int n_steps, double dt, const double* psi0, int batch, double* loss,
+                   double* grad_u, double* psi_final, double* energies) {
+  return guarded([&] { do_energy_grad(c, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, energies); });
+}
+
+int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const double* A, long lda, long strideA,
+             const double* B, long ldb, long strideB, double beta, double* C, long ldc, long strideC, int batch) {
+  return guarded([&] {
+    check_ctx(c);
+    if (M < 0 || N < 0 || K < 0 || batch < 0) fail(DQ_ERR_INVALID, "negative dimension");
+    if ((opA | opB) & ~1) fail(DQ_ERR_INVALID, "op must be 0 (N) or 1 (conjugate transpose)");
+    if (M == 0 || N == 0 || batch == 0) return;
+    if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
+    const long ar = opA ? K : M, ac = opA ? M : K;  // stored shape of A
+    const long br = opB ? N : K, bc = opB ? K : N;
+    if (lda < ac || ldb < bc || ldc < N) fail(DQ_ERR_INVALID, "leading dimension smaller than the row length");
+    auto span = [&](long rows, long ld, long cols, long stride) -> size_t {
+      if (rows == 0 || cols == 0) return 0;
+      return (size_t)((batch - 1) * stride + (rows - 1) * ld + cols) * sizeof(double2);
+    };
+    if (batch > 1 && strideC < (M - 1) * ldc + N) fail(DQ_ERR_INVALID, "overlapping output batch stride");
+    const size_t ba = span(ar, lda, ac, strideA), bb = span(br, ldb, bc, strideB), bcz = span(M, ldc, N, strideC);
+    const double2* dA = ba ? in_dev(c, A, ba, c->tmp_in[0]) : (const double2*)c->tmp_in[0].p;
+    const double2* dB = bb ? in_dev(c, B, bb, c->tmp_in[1]) : (const double2*)c->tmp_in[1].p;
+    double2* dC;
+    const bool c_dev = is_device_ptr(C);
+    if (c_dev) dC = (double2*)C;
+    else {
+      c->tmp_in[2].ensure(bcz);
+      stage_h2d(c, c->tmp_in[2].p, C, bcz);  // beta*C and untouched gaps
+      dC = c->tmp_in[2].z();
+    }
+    c->zgemm(opA, opB, M, N, K, alpha, dA, lda, strideA, dB, ldb, strideB, beta, dC, ldc, strideC, batch);
+    if (!c_dev) out_copy(c, C, dC, bcz);
+    HIPCK(hipStreamSynchronize(c->st));
+  });
+}
+
+int dq_expm(dq_ctx* c, const double* A, double* U, int batch) {
+  return guarded([&] {
+    check_ctx(c);
+    if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
+    if (batch == 0) return;
+    if (!A || !U) fail(DQ_ERR_INVALID, "null matrix pointer");
+    double2* P1 = c->mat(SLOT_P + 1, batch);
+    HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
+    double th = 0.0;
+    for (int z = 0; z < batch; ++z) th = std::max(th, norm1_dev(c, P1 + (size_t)z * c->nn()));
+    c->last_theta = th;
+    const ExpmPlan p = choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
+    const double2* Ud = expm_forward(c, p, batch);
+    out_copy(c, U, Ud, (size_t)batch * c->mat_bytes());
+    HIPCK(hipStreamSynchronize(c->st));
+  });
+}
+
+int dq_expm_vjp(dq_ctx* c, const double* A, const double* Ubar, double* Abar, int batch) {
+  return guarded([&] {
+    check_ctx(c);
+    if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
+    if (batch == 0) return;
+    if (!A || !Ubar || !Abar) fail(DQ_ERR_INVALID, "null matrix pointer");
+    double2* P1 = c->mat(SLOT_P + 1, batch);
+    HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
+    double th = 0.0;
+    for (int z = 0; z < batch; ++z) th = std::max(th, norm1_dev(c, P1 + (size_t)z * c->nn()));
+    c->last_theta = th;
+    const ExpmPlan p = choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
+    (void)expm_forward(c, p, batch);
+    double2* G = ubar_slot(c, p, batch);
+    HIPCK(hipMemcpyAsync(G, Ubar, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
+    const double2* Ab = expm_backward(c, p, batch);
+    out_copy(c, Abar, Ab, (size_t)batch * c->mat_bytes());
+    HIPCK(hipStreamSynchronize(c->st));
+  });
+}
+
+int dq_profile_enable(dq_ctx* c, int on) {
+  return guarded([&] {
+    check_ctx(c);
+    c->prof_collect();
+    c->prof_on = on != 0;
+  });
+}
+
+int dq_profile_reset(dq_ctx* c) {
+  return guarded([&] {
+    check_ctx(c);
+    c->prof_collect();
+    memset(&c->prof_acc, 0, sizeof(c->prof_acc));
+  });
+}
+
+int dq_profile_get(dq_ctx* c, dq_profile* out) {
+  return guarded([&] {
+    check_ctx(c);
+    if (!out) fail(DQ_ERR_INVALID, "null output");
+    c->prof_collect();
+    *out = c->prof_acc;
+  });
+}
+
+}  // extern "C"

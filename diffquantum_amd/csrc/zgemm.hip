@@ -1,0 +1,237 @@
+// Batched complex-double GEMM on the gfx950 f64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+//   C[z] = alpha * op(A[z]) * op(B[z]) + beta * C[z]       op in {N, C (conjugate transpose)}
+//
+// This one kernel is every O(d^3)/O(d^2 B) operation of the propagator hot path:
+//   * propagator . state      U_t Psi_t                /root/reference/diffqc.cc:198, sim_plain.py:146
+//   * the products inside exp(A_t) (Paterson-Stockmeyer Taylor; replaces Eigen's
+//     MatrixBase::exp() diffqc.cc:198 and scipy.linalg.expm sim_plain.py:145)
+//   * the adjoint sweep's U_t^H Lambda, Lambda Psi^H and the reverse-mode products.
+//
+// Data layout: interleaved complex (re, im) pairs, row-major, explicit leading
+// dimension (in complex elements) -- the memory layout of numpy complex128 and of
+// std::complex<double>, so the C-ABI takes the reference's buffers as they are.
+// One 16-byte global load / LDS read moves a whole complex number, and one
+// ds_read_b128 yields both the real and the imaginary MFMA operand of a lane.
+//
+// Tiling (CDNA4): a BM x BN output tile per workgroup, 64-lane waves arranged WGM x WGN,
+// each wave owning (BM/WGM) x (BN/WGN) complex outputs as 16x16 f64 MFMA tiles with
+// separate real/imag accumulators (4 real MFMAs per complex tile and k-step, conjugation
+// and the minus sign of the imag*imag term folded into the instruction's neg bits).
+// <=256 VGPRs so two waves share each SIMD and hipcc emits the VGPR-form MFMA (with a
+// 512-register budget it selects the AGPR form and brackets every MFMA with
+// v_accvgpr copies: measured 138 vs 64 cycles per MFMA, tools/mfma_f64_probe.hip).
+// K is streamed in BK-deep slabs through double-buffered LDS images stored k-major
+// ([k][m] and [k][n], pitch +1 element) so that fragment reads are 16 consecutive
+// 16-byte words; the next slab's global loads are in flight while the MFMAs run.
+// Workgroup ids are remapped so that the 32 workgroups resident on one XCD cover a
+// 4 x 8 block of tiles and share their A/B panels through that XCD's L2.
+#include <hip/hip_runtime.h>
+#include "dq_internal.h"
+
+namespace dq {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// f64 MFMA neg bits (blgp field), decoded with tools/mfma_f64_probe.hip
+#define DQ_NEG_NONE 0
+#define DQ_NEG_A 1
+#define DQ_NEG_B 2
+
+template <int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB>
+__global__ void __launch_bounds__(WGM* WGN * 64, (WGM * WGN * 64 >= 512) ? 2 : 2)
+zgemm_kernel(ZgemmArgs g) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int PA = BM + 1, PB = BN + 1;  // LDS pitch in complex elements
+  constexpr int A_PER_T = (BM * BK + NT - 1) / NT;
+  constexpr int B_PER_T = (BN * BK + NT - 1) / NT;
+  static_assert(BK % 4 == 0, "BK must be a multiple of the MFMA k (4)");
+  static_assert((BM * BK) % NT == 0 && (BN * BK) % NT == 0, "tile/threads mismatch");
+
+  __shared__ double2 lds[2 * BK * (PA + PB)];
+  double2* As = lds;                   // [2][BK][PA]
+  double2* Bs = lds + 2 * BK * PA;     // [2][BK][PB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // ---- workgroup -> tile mapping (XCD-aware, grouped along M) ------------------
+  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+  const int nwg = ntm * ntn;
+  int pid = blockIdx.x;
+  if ((nwg & 7) == 0) pid = (pid & 7) * (nwg >> 3) + (pid >> 3);
+  constexpr int GROUP_M = 4;
+  const int in_group = GROUP_M * ntn;
+  const int group = pid / in_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(ntm - first_m, GROUP_M);
+  const int tile_m = first_m + (pid % in_group) % gsz;
+  const int tile_n = (pid % in_group) / gsz;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const long z = blockIdx.z;
+  const double2* __restrict__ A = g.A + z * g.sA;
+  const double2* __restrict__ B = g.B + z * g.sB;
+  double2* __restrict__ C = g.C + z * g.sC;
+
+  double4_t accr[MI][NI], acci[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      accr[i][j] = {0.0, 0.0, 0.0, 0.0};
+      acci[i][j] = {0.0, 0.0, 0.0, 0.0};
+    }
+
+  double2 ra[A_PER_T], rb[B_PER_T];
+  const double2 zero2 = make_double2(0.0, 0.0);
+
+  // Stage one BK-deep slab into registers. op(A) is M x K.
+  //   OPA == N: stored [m][k] (k contiguous)  -> lanes run along k, LDS write transposes
+  //   OPA == C: stored [k][m] (m contiguous)  -> lanes run along m, LDS write is linear
+  // op(B) is K x N.
+  //   OPB == N: stored [k][n] (n contiguous)  -> linear
+  //   OPB == C: stored [n][k] (k contiguous)  -> transposing
+  auto load_slab = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const int e = tid + j * NT;
+      int m, k;
+      if (OPA == 0) { m = e / BK; k = e % BK; } else { k = e / BM; m = e % BM; }
+      const int gm = m0 + m, gk = k0 + k;
+      const bool ok = (gm < g.M) && (gk < g.K);
+      const long off = (OPA == 0) ? ((long)gm * g.lda + gk) : ((long)gk * g.lda + gm);
+      ra[j] = ok ? A[off] : zero2;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+      const int e = tid + j * NT;
+      int n, k;
+      if (OPB == 0) { k = e / BN; n = e % BN; } else { n = e / BK; k = e % BK; }
+      const int gn = n0 + n, gk = k0 + k;
+      const bool ok = (gn < g.N) && (gk < g.K);
+      const long off = (OPB == 0) ? ((long)gk * g.ldb + gn) : ((long)gn * g.ldb + gk);
+      rb[j] = ok ? B[off] : zero2;
+    }
+  };
+  auto store_slab = [&](int buf) {
+    double2* as = As + buf * BK * PA;
+    double2* bs = Bs + buf * BK * PB;
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const int e = tid + j * NT;
+      int m, k;
+      if (OPA == 0) { m = e / BK; k = e % BK; } else { k = e / BM; m = e % BM; }
+      as[k * PA + m] = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+      const int e = tid + j * NT;
+      int n, k;
+      if (OPB == 0) { k = e / BN; n = e % BN; } else { n = e / BK; k = e % BK; }
+      bs[k * PB + n] = rb[j];
+    }
+  };
+
+  // sign bookkeeping: a = (ar, sa*ai), b = (br, sb*bi)
+  //   Cr += ar*br - (sa*sb) ai*bi ;  Ci += sb * ar*bi + sa * ai*br
+  constexpr int NEG_II = ((OPA != 0) != (OPB != 0)) ? DQ_NEG_NONE : DQ_NEG_A;  // -(sa*sb)
+  constexpr int NEG_RI = (OPB != 0) ? DQ_NEG_B : DQ_NEG_NONE;
+  constexpr int NEG_IR = (OPA != 0) ? DQ_NEG_A : DQ_NEG_NONE;
+
+  auto compute_slab = [&](int buf) {
+    const double2* as = As + buf * BK * PA + wm * TM + (lane & 15);
+    const double2* bs = Bs + buf * BK * PB + wn * TN + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      const int kk = ks * 4 + (lane >> 4);
+      double2 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = as[kk * PA + i * 16];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = bs[kk * PB + j * 16];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, DQ_NEG_NONE);
+          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acci[i][j], 0, 0, NEG_RI);
+          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, accr[i][j], 0, 0, NEG_II);
+          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acci[i][j], 0, 0, NEG_IR);
+        }
+    }
+  };
+
+  const int nkt = (g.K + BK - 1) / BK;
+  load_slab(0);
+  store_slab(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = (kt + 1 < nkt);
+    if (more) load_slab((kt + 1) * BK);
+    compute_slab(kt & 1);
+    if (more) store_slab((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C = alpha*acc + beta*C -----------------------------------------
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * TN + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * TM + i * 16 + (lane >> 4) + 4 * r;
+        if (row < g.M && col < g.N) {
+          const long off = (long)row * g.ldc + col;
+          double2 v = make_double2(alpha * accr[i][j][r], alpha * acci[i][j][r]);
+          if (beta != 0.0) {
+            const double2 c0 = C[off];
+            v.x += beta * c0.x;
+            v.y += beta * c0.y;
+          }
+          C[off] = v;
+        }
+      }
+    }
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+static void launch_cfg(const ZgemmArgs& g, hipStream_t st) {
+  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+  dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)g.batch);
+  dim3 block(WGM * WGN * 64);
+  const int op = (g.opA ? 2 : 0) | (g.opB ? 1 : 0);
+  switch (op) {
+    case 0: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 0>), grid, block, 0, st, g); break;
+    case 1: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 1>), grid, block, 0, st, g); break;
+    case 2: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 0>), grid, block, 0, st, g); break;
+    default: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 1>), grid, block, 0, st, g); break;
+  }
+}
+
+// Tile choice: the 128x128 tile needs >= ~1 wave of workgroups to pay; small problems
+// (d <= 64, or a thin batch) take the 64x64 / 32x32 tiles so that more CUs get work.
+int zgemm_pick_tile(int M, int N, int batch) {
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  if (M >= 128 && N >= 128 && t128 >= 64) return 128;
+  if (M > 32 && N > 32) return 64;
+  return 32;
+}
+
+hipError_t zgemm_launch(const ZgemmArgs& g, hipStream_t st, int force_tile) {
+  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
+  const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
+  if (tile == 128) launch_cfg<128, 128, 8, 2, 4>(g, st);
+  else if (tile == 64) launch_cfg<64, 64, 8, 2, 2>(g, st);
+  else launch_cfg<32, 32, 8, 1, 1>(g, st);
+  return hipGetLastError();
+}
+
+}  // namespace dq

@@ -1,0 +1,265 @@
+"""Python handle on one ``dq_ctx`` of libdiffqc_hip.so.
+
+Thin plumbing over the C-ABI (include/diffqc_hip.h): argument checking, pointer extraction
+from numpy arrays (host) or torch CUDA tensors (device, zero-copy), status -> exception.
+The arithmetic of the reference's hot path -- ``dH`` assembly, ``expm`` and the chained
+``psi = U psi`` (/root/reference/diffqc.cc:190-200, /root/reference/sim_plain.py:135-150) --
+runs entirely inside the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
+
+
+def _c128(x, shape=None, name="array"):
+    """Return (pointer, keepalive) of a complex128 buffer with `shape` (host numpy or CUDA torch)."""
+    if _is_torch(x):
+        import torch
+        if x.dtype != torch.complex128:
+            raise ValueError("{}: torch tensors must be complex128".format(name))
+        if not x.is_contiguous():
+            raise ValueError("{}: torch tensors must be contiguous".format(name))
+        if shape is not None and tuple(x.shape) != tuple(shape):
+            raise ValueError("{}: expected shape {}, got {}".format(name, tuple(shape), tuple(x.shape)))
+        return x.data_ptr(), x
+    a = np.ascontiguousarray(x, dtype=np.complex128)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("{}: expected shape {}, got {}".format(name, tuple(shape), tuple(a.shape)))
+    return a.ctypes.data, a
+
+
+def _f64(x, shape=None, name="array"):
+    if _is_torch(x):
+        import torch
+        if x.dtype != torch.float64 or not x.is_contiguous():
+            raise ValueError("{}: torch tensors must be contiguous float64".format(name))
+        if shape is not None and tuple(x.shape) != tuple(shape):
+            raise ValueError("{}: expected shape {}, got {}".format(name, tuple(shape), tuple(x.shape)))
+        return x.data_ptr(), x
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("{}: expected shape {}, got {}".format(name, tuple(shape), tuple(a.shape)))
+    return a.ctypes.data, a
+
+
+class Engine:
+    """One Hilbert-space dimension + one Hamiltonian set on one GPU."""
+
+    def __init__(self, dim: int, n_controls: int, device: int = 0):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        self.dim = int(dim)
+        self.n_controls = int(n_controls)
+        self.device = int(device)
+        _lib.check(self._lib.dq_create(C.byref(self._ctx), self.dim, self.n_controls, self.device))
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.dq_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration ------------------------------------------------------
+    def set_stream(self, stream_handle):
+        _lib.check(self._lib.dq_set_stream(self._ctx, C.c_void_p(int(stream_handle) if stream_handle else 0)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        _lib.check(self._lib.dq_synchronize(self._ctx))
+
+    def set_hamiltonians(self, H0, Hs):
+        d, K = self.dim, self.n_controls
+        p0, k0 = _c128(H0, (d, d), "H0")
+        if K > 0:
+            if isinstance(Hs, (list, tuple)):
+                Hs = np.stack([np.asarray(h, dtype=np.complex128) for h in Hs])
+            ps, ks = _c128(Hs, (K, d, d), "Hs")
+        else:
+            ps, ks = 0, None
+        _lib.check(self._lib.dq_set_hamiltonians(self._ctx, p0, ps))
+
+    def set_observable(self, M):
+        p, k = _c128(M, (self.dim, self.dim), "M")
+        _lib.check(self._lib.dq_set_observable(self._ctx, p))
+
+    def set_option(self, name: str, value: float):
+        _lib.check(self._lib.dq_set_option(self._ctx, name.encode(), float(value)))
+
+    def info(self, name: str) -> float:
+        v = C.c_double()
+        _lib.check(self._lib.dq_get_info(self._ctx, name.encode(), C.byref(v)))
+        return v.value
+
+    # -- hot path -----------------------------------------------------------
+    def _u(self, u):
+        K = self.n_controls
+        if _is_torch(u):
+            if u.dim() != 2 or u.shape[1] != K:
+                raise ValueError("u must have shape [n_steps][n_controls={}]".format(K))
+            p, keep = _f64(u, None, "u")
+            return p, keep, int(u.shape[0])
+        a = np.ascontiguousarray(u, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != K:
+            raise ValueError("u must have shape [n_steps][n_controls={}], got {}".format(K, a.shape))
+        return a.ctypes.data, a, int(a.shape[0])
+
+    def _psi(self, psi, name="psi"):
+        if _is_torch(psi):
+            if psi.dim() != 2 or psi.shape[0] != self.dim:
+                raise ValueError("{} must have shape [dim={}][batch]".format(name, self.dim))
+            p, keep = _c128(psi, None, name)
+            return p, keep, int(psi.shape[1])
+        a = np.asarray(psi)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+        if a.ndim != 2 or a.shape[0] != self.dim:
+            raise ValueError("{} must have shape [dim={}][batch], got {}".format(name, self.dim, a.shape))
+        return a.ctypes.data, a, int(a.shape[1])
+
+    def propagate(self, u, dt: float, psi, out=None):
+        """psi_out = prod_t exp(-i dt (H0 + sum_k u[t][k] H_k)) psi  for all batch columns."""
+        pu, ku, S = self._u(u)
+        pp, kp, B = self._psi(psi)
+        if out is None:
+            if _is_torch(psi):
+                import torch
+                out = torch.empty_like(psi)
+            else:
+                out = np.empty((self.dim, B), dtype=np.complex128)
+        po, ko, Bo = self._psi(out, "out")
+        if Bo != B or (not _is_torch(out) and ko is not out):
+            raise ValueError("out must be a contiguous complex128 [dim][batch] buffer")
+        _lib.check(self._lib.dq_propagate(self._ctx, pu, S, float(dt), pp, po, B))
+        return out
+
+    def energy(self, psi):
+        pp, kp, B = self._psi(psi)
+        e = np.empty(B, dtype=np.float64)
+        tot = C.c_double()
+        _lib.check(self._lib.dq_energy(self._ctx, pp, B, e.ctypes.data, C.addressof(tot)))
+        return e, tot.value
+
+    def energy_grad(self, u, dt: float, psi0, want_final=True, want_energies=True, grad_out=None):
+        """Forward chain + adjoint sweep.
+
+        Returns (loss, grad_u[n_steps][n_controls], psi_final or None, energies[batch] or None).
+        """
+        pu, ku, S = self._u(u)
+        pp, kp, B = self._psi(psi0)
+        K = self.n_controls
+        if grad_out is None:
+            grad = np.zeros((S, K), dtype=np.float64)
+            pg = grad.ctypes.data
+        else:
+            grad = grad_out
+            pg, _kg = _f64(grad, (S, K), "grad_out")
+        loss = C.c_double()
+        fin = None
+        pf = 0
+        if want_final:
+            if _is_torch(psi0):
+                import torch
+                fin = torch.empty_like(psi0)
+                pf = fin.data_ptr()
+            else:
+                fin = np.empty((self.dim, B), dtype=np.complex128)
+                pf = fin.ctypes.data
+        en = None
+        pe = 0
+        if want_energies:
+            en = np.empty(B, dtype=np.float64)
+            pe = en.ctypes.data
+        _lib.check(self._lib.dq_energy_grad(self._ctx, pu, S, float(dt), pp, B, C.addressof(loss), pg, pf, pe))
+        return loss.value, grad, fin, en
+
+    # -- building blocks ----------------------------------------------------
+    def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None):
+        """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host)."""
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        B = np.ascontiguousarray(B, dtype=np.complex128)
+        batched = A.ndim == 3
+        if not batched:
+            A, B = A[None], B[None]
+        nb = A.shape[0]
+        if B.shape[0] != nb:
+            raise ValueError("batch mismatch")
+        M, K = (A.shape[2], A.shape[1]) if opA else (A.shape[1], A.shape[2])
+        K2, N = (B.shape[2], B.shape[1]) if opB else (B.shape[1], B.shape[2])
+        if K != K2:
+            raise ValueError("inner dimensions differ: {} vs {}".format(K, K2))
+        if C_in is None:
+            Cm = np.zeros((nb, M, N), dtype=np.complex128)
+        else:
+            Cm = np.array(C_in, dtype=np.complex128, order="C").reshape(nb, M, N)
+        _lib.check(self._lib.dq_zgemm(self._ctx, int(opA), int(opB), M, N, K, float(alpha), A.ctypes.data,
+                                      A.shape[2], A.shape[1] * A.shape[2], B.ctypes.data, B.shape[2],
+                                      B.shape[1] * B.shape[2], float(beta), Cm.ctypes.data, N, M * N, nb))
+        return Cm if batched else Cm[0]
+
+    def expm(self, A):
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        batched = A.ndim == 3
+        Ab = A if batched else A[None]
+        if Ab.shape[1:] != (self.dim, self.dim):
+            raise ValueError("expm: matrices must be dim x dim")
+        U = np.empty_like(Ab)
+        _lib.check(self._lib.dq_expm(self._ctx, Ab.ctypes.data, U.ctypes.data, Ab.shape[0]))
+        return U if batched else U[0]
+
+    def expm_vjp(self, A, Ubar):
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        Ubar = np.ascontiguousarray(Ubar, dtype=np.complex128)
+        batched = A.ndim == 3
+        Ab = A if batched else A[None]
+        Ub = Ubar if batched else Ubar[None]
+        if Ab.shape[1:] != (self.dim, self.dim) or Ub.shape != Ab.shape:
+            raise ValueError("expm_vjp: matrices must be dim x dim and shapes must match")
+        out = np.empty_like(Ab)
+        _lib.check(self._lib.dq_expm_vjp(self._ctx, Ab.ctypes.data, Ub.ctypes.data, out.ctypes.data, Ab.shape[0]))
+        return out if batched else out[0]
+
+    # -- profiling ----------------------------------------------------------
+    def profile_enable(self, on=True):
+        _lib.check(self._lib.dq_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        _lib.check(self._lib.dq_profile_reset(self._ctx))
+
+    def profile(self):
+        p = _lib.DqProfile()
+        _lib.check(self._lib.dq_profile_get(self._ctx, C.byref(p)))
+        return {
+            name: {"launches": int(p.launches[i]), "ms": float(p.ms[i]), "flops": float(p.flops[i]),
+                   "bytes": float(p.bytes[i])}
+            for i, name in enumerate(_lib.PROF_CLASSES)
+        }
+
+
+def device_count() -> int:
+    n = C.c_int()
+    _lib.check(_lib.load().dq_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,108 @@
+/* diffqc_hip.h -- C-ABI of libdiffqc_hip.so, the MI355X (gfx950) propagator engine.
+ *
+ * Drop-in boundary for the Schroedinger-propagator hot path of YilingQiao/diffquantum:
+ * these entry points are what a binding of the reference's `diffqc` pybind11 module
+ * (/root/reference/diffqc.cc:210-228) or of `SimulatorPlain.trotter`
+ * (/root/reference/sim_plain.py:119-153) calls instead of Eigen's `dH.exp() * psi0`
+ * (diffqc.cc:198) / `scipy.linalg.expm` + `np.matmul` (sim_plain.py:145-146).
+ * INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *   - Complex data is interleaved (re, im) double pairs, row-major: the memory of a numpy
+ *     complex128 array / std::complex<double>[] . A d x d matrix is 2*d*d doubles.
+ *   - A batch of states Psi is [dim][batch] (batch index contiguous): column b is trajectory b.
+ *   - The pulse table u is [n_steps][n_controls] ("step-major"): row t holds u_k(t_0 + t*dt),
+ *     the LEFT-endpoint sample the reference uses (diffqc.cc:195,199; sim_plain.py:140,150).
+ *   - Every pointer argument may be host memory or device (HIP) memory; the library detects
+ *     which (hipPointerGetAttributes) and only copies host buffers.
+ *   - Every function returns a DQ_* status; dq_last_error() gives the message of the last
+ *     failure on the calling thread. Nothing here falls back to a CPU implementation: without
+ *     a gfx950 device dq_create fails with DQ_ERR_NO_DEVICE.
+ */
+#ifndef DIFFQC_HIP_H
+#define DIFFQC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQ_OK 0
+#define DQ_ERR_INVALID 1      /* bad argument / shape (Python binding raises ValueError) */
+#define DQ_ERR_STATE 2        /* call order: Hamiltonians / observable not set */
+#define DQ_ERR_HIP 3          /* a HIP runtime call failed */
+#define DQ_ERR_NO_DEVICE 4    /* no usable GPU */
+#define DQ_ERR_UNSUPPORTED 5  /* e.g. adjoint of a non-Hermitian generator */
+#define DQ_ERR_NOMEM 6
+
+typedef struct dq_ctx dq_ctx;
+
+/* Kernel classes of the profile (dq_profile_get). */
+#define DQ_PROF_ZGEMM 0     /* batched complex GEMM (f64 MFMA)            */
+#define DQ_PROF_ASSEMBLE 1  /* A_t = -i dt (H0 + sum u_k H_k)             */
+#define DQ_PROF_LINCOMB 2   /* polynomial linear combinations             */
+#define DQ_PROF_GRADC 3     /* control-gradient contractions              */
+#define DQ_PROF_OTHER 4     /* reductions, copies                         */
+#define DQ_PROF_NCLASS 5
+
+typedef struct dq_profile {
+  long long launches[DQ_PROF_NCLASS];
+  double ms[DQ_PROF_NCLASS];     /* sum of HIP-event durations of the class's launches       */
+  double flops[DQ_PROF_NCLASS];  /* algorithmic real flops (ZGEMM: 8*M*N*K per launch*batch) */
+  double bytes[DQ_PROF_NCLASS];  /* algorithmic bytes moved (streaming classes)              */
+} dq_profile;
+
+const char* dq_version(void);
+const char* dq_last_error(void);
+int dq_device_count(int* n);
+
+/* Context = one Hilbert-space dimension + one set of Hamiltonians on one GPU.
+ * Replaces the process-global store g_H0/g_Hs of diffqc.cc:21-25 with an explicit handle. */
+int dq_create(dq_ctx** ctx, int dim, int n_controls, int device_id);
+int dq_destroy(dq_ctx* ctx);
+/* Use the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+int dq_set_stream(dq_ctx* ctx, void* hip_stream);
+int dq_synchronize(dq_ctx* ctx);
+
+/* H0: [dim][dim] complex; Hs: [n_controls][dim][dim] complex.  (set_H, diffqc.cc:43-67) */
+int dq_set_hamiltonians(dq_ctx* ctx, const double* H0, const double* Hs);
+/* Observable M ([dim][dim], Hermitian) of the energy loss <psi|M|psi> (sim_plain.py:281). */
+int dq_set_observable(dq_ctx* ctx, const double* M);
+
+/* Tunables: "checkpoint_bytes", "chunk_bytes", "expm_tol", "force_degree", "force_squarings",
+ * "force_tile".  Unknown names -> DQ_ERR_INVALID. */
+int dq_set_option(dq_ctx* ctx, const char* name, double value);
+int dq_get_info(dq_ctx* ctx, const char* name, double* value);
+
+/* Forward chain: psi_out = prod_{t=n_steps-1..0} exp(-i dt (H0 + sum_k u[t][k] H_k)) psi_in.
+ * The time loop of trotter(), diffqc.cc:190-200 / sim_plain.py:135-150, for `batch` states at once.
+ * dt may be negative (diffqc.cc:183).  psi_out may equal psi_in. */
+int dq_propagate(dq_ctx* ctx, const double* u, int n_steps, double dt, const double* psi_in, double* psi_out,
+                 int batch);
+
+/* energies[b] = Re <psi_b| M |psi_b>, total = sum_b.  Either output may be NULL. */
+int dq_energy(dq_ctx* ctx, const double* psi, int batch, double* energies, double* total);
+
+/* Forward chain + adjoint sweep. loss = sum_b <psi_b(T)|M|psi_b(T)>,
+ * grad_u[t][k] = d loss / d u[t][k] (exact derivative of the discrete chain).
+ * psi_final ([dim][batch]) and energies ([batch]) are optional (NULL to skip). */
+int dq_energy_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const double* psi0, int batch, double* loss,
+                   double* grad_u, double* psi_final, double* energies);
+
+/* Building blocks, exported for parity tests and reuse. */
+/* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */
+int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const double* A, long lda, long strideA,
+             const double* B, long ldb, long strideB, double beta, double* C, long ldc, long strideC, int batch);
+/* U[z] = exp(A[z]) for `batch` dim x dim matrices. */
+int dq_expm(dq_ctx* ctx, const double* A, double* U, int batch);
+/* Abar[z] = adjoint Frechet derivative: <Ubar, dexp_A(E)> = <Abar, E> for all E (real inner product Re tr(X^H Y)). */
+int dq_expm_vjp(dq_ctx* ctx, const double* A, const double* Ubar, double* Abar, int batch);
+
+/* Per-class HIP-event timing of every kernel launch (off by default). */
+int dq_profile_enable(dq_ctx* ctx, int on);
+int dq_profile_reset(dq_ctx* ctx);
+int dq_profile_get(dq_ctx* ctx, dq_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFQC_HIP_H */

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement of the reference path (test infrastructure, see oracle/trotter_oracle.py)."""
+    from oracle import trotter_oracle
+    return trotter_oracle
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")

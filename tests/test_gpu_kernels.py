@@ -1,0 +1,122 @@
+"""GPU parity of the HIP building blocks (ZGEMM, exp, exp-VJP) against numpy/scipy.
+
+Tolerances: fp64, north_star says 1e-10 on amplitudes/gradients; the kernels themselves are
+held to ~1e-13 relative here so that the chain (thousands of steps) stays inside 1e-10.
+"""
+import numpy as np
+import pytest
+import scipy.linalg
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.fixture(scope="module")
+def eng16():
+    from diffquantum_amd.engine import Engine
+    e = Engine(16, 2)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("tile", [0, 32, 64, 128])
+@pytest.mark.parametrize("opA,opB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(16, 1, 16), (16, 16, 16), (33, 17, 9), (64, 64, 64), (130, 257, 70),
+                                   (256, 96, 256), (1, 1, 1), (128, 128, 4), (5, 300, 3)])
+def test_zgemm_matches_numpy(eng16, opA, opB, M, N, K, tile):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K + opA * 2 + opB)
+    A = _rand(rng, *((K, M) if opA else (M, K)))
+    B = _rand(rng, *((N, K) if opB else (K, N)))
+    C0 = _rand(rng, M, N)
+    eng16.set_option("force_tile", tile)
+    try:
+        got = eng16.zgemm(A, B, opA=opA, opB=opB, alpha=0.75, beta=-0.5, C_in=C0)
+    finally:
+        eng16.set_option("force_tile", 0)
+    oa = A.conj().T if opA else A
+    ob = B.conj().T if opB else B
+    ref = 0.75 * (oa @ ob) - 0.5 * C0
+    scale = np.abs(oa) @ np.abs(ob) + np.abs(C0)
+    assert np.max(np.abs(got - ref) / scale) < 5e-15
+
+
+def test_zgemm_asymmetric_identity(eng16):
+    # A = I with an asymmetric B catches a transposed C write (cdna guide section 3)
+    B = np.arange(64 * 48, dtype=np.float64).reshape(64, 48) * (1 + 0.5j)
+    got = eng16.zgemm(np.eye(64), B)
+    assert np.array_equal(got, B.astype(np.complex128))
+
+
+def test_zgemm_batched(eng16):
+    rng = np.random.default_rng(3)
+    A = _rand(rng, 5, 40, 24)
+    B = _rand(rng, 5, 24, 56)
+    got = eng16.zgemm(A, B)
+    assert np.allclose(got, A @ B, rtol=0, atol=1e-12)
+
+
+def test_zgemm_beta_zero_ignores_nan_c(eng16):
+    rng = np.random.default_rng(4)
+    A, B = _rand(rng, 20, 12), _rand(rng, 12, 8)
+    C0 = np.full((20, 8), np.nan + 0j)
+    got = eng16.zgemm(A, B, beta=0.0, C_in=C0)
+    assert np.allclose(got, A @ B, atol=1e-12)
+
+
+@pytest.mark.parametrize("d", [2, 4, 16, 64, 96])
+@pytest.mark.parametrize("norm", [1e-6, 1e-3, 0.1, 1.0, 10.0, 40.0])
+def test_expm_matches_scipy(d, norm):
+    from diffquantum_amd.engine import Engine
+    rng = np.random.default_rng(d + int(norm * 1000))
+    H = _rand(rng, 3, d, d)
+    H = H + np.conj(np.transpose(H, (0, 2, 1)))
+    A = -1j * H
+    A *= norm / np.max([np.linalg.norm(a, 1) for a in A])
+    with Engine(d, 0) as e:
+        U = e.expm(A)
+        deg, sq = e.info("degree"), e.info("squarings")
+    for z in range(3):
+        ref = scipy.linalg.expm(A[z])
+        err = np.max(np.abs(U[z] - ref))
+        assert err < 2e-13 * max(1.0, norm), (d, norm, deg, sq, err)
+        assert np.max(np.abs(U[z].conj().T @ U[z] - np.eye(d))) < 5e-13 * max(1.0, norm)
+
+
+@pytest.mark.parametrize("degree", [2, 4, 6, 9, 12, 16, 20])
+def test_expm_every_polynomial_degree(degree):
+    from diffquantum_amd.engine import Engine
+    rng = np.random.default_rng(degree)
+    d = 24
+    H = _rand(rng, d, d)
+    A = -1j * (H + H.conj().T)
+    A *= 0.5 / np.linalg.norm(A, 1)
+    with Engine(d, 0) as e:
+        e.set_option("force_degree", degree)
+        e.set_option("force_squarings", 6)  # theta/64 ~ 8e-3: every degree >= 4 is exact to rounding
+        U = e.expm(A)
+        assert e.info("degree") == degree and e.info("squarings") == 6
+    tol = 1e-12 if degree >= 4 else 1e-5
+    assert np.max(np.abs(U - scipy.linalg.expm(A))) < tol
+
+
+@pytest.mark.parametrize("d,norm", [(4, 0.05), (8, 0.5), (16, 3.0), (48, 0.15), (8, 20.0)])
+def test_expm_vjp_matches_frechet(d, norm, oracle):
+    from diffquantum_amd.engine import Engine
+    rng = np.random.default_rng(d * 7 + int(norm * 100))
+    H = _rand(rng, 2, d, d)
+    A = -1j * (H + np.conj(np.transpose(H, (0, 2, 1))))
+    A *= norm / np.max([np.linalg.norm(a, 1) for a in A])
+    G = _rand(rng, 2, d, d)
+    with Engine(d, 0) as e:
+        Ab = e.expm_vjp(A, G)
+    for z in range(2):
+        ref = oracle.expm_vjp(A[z], G[z])
+        assert np.max(np.abs(Ab[z] - ref)) < 1e-12 * max(1.0, norm) * np.max(np.abs(G[z])) * d
+        # defining property against a random direction
+        E = _rand(rng, d, d)
+        lhs = np.real(np.vdot(G[z], scipy.linalg.expm_frechet(A[z], E, compute_expm=False)))
+        rhs = np.real(np.vdot(Ab[z], E))
+        assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))
