@@ -1,0 +1,235 @@
+"""GPU parity of the propagator chain and its adjoint gradient against the oracle
+(oracle/trotter_oracle.py = the reference's expm + matmul loop, sim_plain.py:135-150 /
+diffqc.cc:190-200), plus known-answer and size-independent property tests.
+
+Tolerance (BASELINE.json north_star): 1e-10 on final amplitudes and gradients, fp64.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from diffquantum_amd import problems
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _engine(H0, Hs, M=None):
+    from diffquantum_amd.engine import Engine
+    e = Engine(len(H0), len(Hs))
+    e.set_hamiltonians(H0, Hs)
+    if M is not None:
+        e.set_observable(M)
+    return e
+
+
+@pytest.mark.parametrize("n,K,B,S,dt", [(1, 1, 1, 10, 0.05), (2, 2, 5, 7, 0.1), (3, 3, 64, 30, 0.02),
+                                        (4, 8, 1, 30, 2.0 / 30), (4, 4, 130, 12, -0.05), (5, 2, 33, 9, 0.7),
+                                        (2, 0, 3, 4, 0.3)])
+def test_propagate_matches_oracle(oracle, n, K, B, S, dt):
+    H0, Hs, _ = problems.random_hermitian_problem(n, K, seed=n * 10 + K)
+    rng = np.random.default_rng(S)
+    u = rng.uniform(-3, 3, (S, K))
+    psi0 = problems.random_states(1 << n, B, seed=5)
+    with _engine(H0, Hs) as e:
+        got = e.propagate(u, dt, psi0)
+    ref = oracle.propagate(H0, list(Hs), u, dt, psi0)
+    assert np.max(np.abs(got - ref)) < TOL
+    assert np.max(np.abs(np.linalg.norm(got, axis=0) - 1.0)) < 1e-12
+
+
+def test_propagate_edge_cases(oracle):
+    H0, Hs, _ = problems.random_hermitian_problem(2, 2, seed=1)
+    psi0 = problems.random_states(4, 3, seed=2)
+    with _engine(H0, Hs) as e:
+        # zero steps: identity
+        assert np.array_equal(e.propagate(np.zeros((0, 2)), 0.1, psi0), psi0)
+        # 1-D state vector is accepted as a single column (the reference's batch-1 case)
+        v = e.propagate(np.ones((3, 2)), 0.1, psi0[:, 0])
+        assert v.shape == (4, 1)
+        assert np.max(np.abs(v[:, 0] - oracle.propagate(H0, list(Hs), np.ones((3, 2)), 0.1, psi0[:, 0]))) < TOL
+        with pytest.raises(ValueError):
+            e.propagate(np.ones((3, 3)), 0.1, psi0)  # wrong number of controls
+        with pytest.raises(ValueError):
+            e.propagate(np.ones((3, 2)), 0.1, np.ones((5, 2)))  # wrong dimension
+        with pytest.raises(ValueError):
+            e.propagate(np.full((3, 2), np.nan), 0.1, psi0)
+        with pytest.raises(ValueError):
+            e.propagate(np.ones((3, 2)), float("inf"), psi0)
+
+
+def test_call_order_errors():
+    from diffquantum_amd.engine import Engine
+    from diffquantum_amd._lib import DiffqcError
+    with Engine(4, 1) as e:
+        with pytest.raises(DiffqcError):
+            e.propagate(np.ones((2, 1)), 0.1, np.ones((4, 1)))  # Hamiltonians not set
+        H0, Hs, M = problems.random_hermitian_problem(2, 1, seed=0)
+        e.set_hamiltonians(H0, Hs)
+        with pytest.raises(DiffqcError):
+            e.energy_grad(np.ones((2, 1)), 0.1, np.ones((4, 1)))  # observable not set
+        with pytest.raises(ValueError):
+            e.set_observable(np.triu(np.ones((4, 4))))  # not Hermitian
+        e.set_hamiltonians(H0 + 0.1j * np.eye(4), Hs)  # non-Hermitian generator: forward only
+        e.set_observable(M)
+        e.propagate(np.ones((2, 1)), 0.1, np.ones((4, 1)))
+        with pytest.raises(NotImplementedError):
+            e.energy_grad(np.ones((2, 1)), 0.1, np.ones((4, 1)))
+    with pytest.raises(ValueError):
+        Engine(0, 1)
+
+
+def test_time_chunking_is_invisible(oracle):
+    H0, Hs, _ = problems.random_hermitian_problem(3, 2, seed=4)
+    u = np.random.default_rng(0).uniform(-1, 1, (23, 2))
+    psi0 = problems.random_states(8, 4, seed=1)
+    with _engine(H0, Hs) as e:
+        a = e.propagate(u, 0.05, psi0)
+        assert e.info("time_chunk") == 23
+        e.set_option("chunk_bytes", 24 * 8 * 8 * 16 * 5)  # 5 steps per chunk
+        b = e.propagate(u, 0.05, psi0)
+        assert e.info("time_chunk") == 5
+    assert np.max(np.abs(a - b)) < 1e-14
+
+
+def test_rabi_known_answer():
+    # H0 = 0, H_1 = X, psi0 = |0>: psi = (cos th, -i sin th), th = sum_t u_t dt
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    u = np.random.default_rng(1).uniform(0, 2, (40, 1))
+    dt = 0.03
+    with _engine(np.zeros((2, 2)), X[None]) as e:
+        psi = e.propagate(u, dt, np.array([1.0, 0.0]))
+    th = float(u.sum() * dt)
+    assert abs(psi[0, 0] - math.cos(th)) < 1e-13 and abs(psi[1, 0] + 1j * math.sin(th)) < 1e-13
+
+
+def test_diagonal_hamiltonian_gives_phases():
+    diag = np.array([0.3, -1.2, 2.0, 0.7])
+    Z1 = np.diag([1.0, 1.0, -1.0, -1.0]).astype(complex)
+    u = np.random.default_rng(2).uniform(-1, 1, (25, 1))
+    dt = 0.11
+    psi0 = problems.random_states(4, 2, seed=3)
+    with _engine(np.diag(diag), Z1[None]) as e:
+        psi = e.propagate(u, dt, psi0)
+    phase = np.exp(-1j * dt * (25 * diag + u.sum() * np.diag(Z1).real))
+    assert np.max(np.abs(psi - phase[:, None] * psi0)) < 1e-13
+
+
+def test_norm_conservation_1000_steps():
+    p = problems.maxcut_problem()
+    u = problems.pulse_table(8, 1000, 2.0, seed=1)
+    psi0 = problems.random_states(16, 8, seed=0)
+    with _engine(p["H0"], p["Hs"]) as e:
+        psi = e.propagate(u, 2.0 / 1000, psi0)
+    assert np.max(np.abs(np.linalg.norm(psi, axis=0) - 1.0)) < 1e-13 * 10
+
+
+@pytest.mark.parametrize("n,K,B,S,dt", [(2, 2, 1, 6, 0.1), (3, 3, 5, 10, 0.05), (4, 8, 3, 12, 0.15),
+                                        (3, 1, 40, 5, -0.2), (2, 2, 2, 1, 0.3)])
+def test_energy_grad_matches_oracle(oracle, n, K, B, S, dt):
+    H0, Hs, M = problems.random_hermitian_problem(n, K, seed=n + K)
+    u = np.random.default_rng(S + B).uniform(-2, 2, (S, K))
+    psi0 = problems.random_states(1 << n, B, seed=9)
+    with _engine(H0, Hs, M) as e:
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        e2, tot = e.energy(fin)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    assert abs(loss - rl) < TOL * B
+    assert np.max(np.abs(fin - rf)) < TOL
+    assert np.max(np.abs(grad - rg)) < TOL * B
+    assert np.max(np.abs(en - oracle.energies(M, rf))) < TOL
+    assert abs(en.sum() - loss) < 1e-12 * B and abs(tot - loss) < 1e-12 * B and np.allclose(e2, en, atol=1e-13)
+
+
+def test_energy_grad_matches_finite_differences(oracle):
+    H0, Hs, M = problems.random_hermitian_problem(3, 2, seed=21)
+    u = np.random.default_rng(5).uniform(-1, 1, (5, 2))
+    psi0 = problems.random_states(8, 3, seed=2)
+    with _engine(H0, Hs, M) as e:
+        _, grad, _, _ = e.energy_grad(u, 0.1, psi0)
+    fd = oracle.energy_grad_fd(H0, list(Hs), M, u, 0.1, psi0, eps=1e-6)
+    assert np.max(np.abs(grad - fd)) < 5e-8
+
+
+def test_checkpoint_stride_and_chunking_do_not_change_the_gradient():
+    H0, Hs, M = problems.random_hermitian_problem(3, 3, seed=8)
+    u = np.random.default_rng(6).uniform(-1, 1, (37, 3))
+    psi0 = problems.random_states(8, 6, seed=3)
+    with _engine(H0, Hs, M) as e:
+        l0, g0, f0, _ = e.energy_grad(u, 0.04, psi0)
+        assert e.info("checkpoint_stride") == 1
+        e.set_option("checkpoint_bytes", 8 * 6 * 16 * 4)  # 4 checkpoints -> stride 10
+        e.set_option("chunk_bytes", 24 * 8 * 8 * 16 * 7)  # 7 steps per chunk
+        l1, g1, f1, _ = e.energy_grad(u, 0.04, psi0)
+        assert e.info("checkpoint_stride") == 10 and e.info("time_chunk") == 7
+    assert abs(l0 - l1) < 1e-13 and np.max(np.abs(f0 - f1)) < 1e-14
+    assert np.max(np.abs(g0 - g1)) < 1e-12
+
+
+def test_gradient_is_reproducible_bitwise():
+    H0, Hs, M = problems.random_hermitian_problem(3, 3, seed=8)
+    u = np.random.default_rng(6).uniform(-1, 1, (9, 3))
+    psi0 = problems.random_states(8, 6, seed=3)
+    with _engine(H0, Hs, M) as e:
+        a = e.energy_grad(u, 0.04, psi0)
+        b = e.energy_grad(u, 0.04, psi0)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_large_norm_steps_use_squarings(oracle):
+    H0, Hs, M = problems.random_hermitian_problem(3, 1, seed=2)
+    u = np.full((3, 1), 2.0)
+    psi0 = problems.random_states(8, 2, seed=1)
+    with _engine(30 * H0, 10 * Hs, M) as e:
+        loss, grad, fin, _ = e.energy_grad(u, 0.4, psi0)
+        assert e.info("squarings") >= 2
+    rl, rg, rf = oracle.energy_grad(30 * H0, list(10 * Hs), M, u, 0.4, psi0)
+    assert np.max(np.abs(fin - rf)) < TOL and np.max(np.abs(grad - rg)) < 1e-9 and abs(loss - rl) < TOL
+
+
+def test_properties_at_d256_ring_qaoa():
+    """BASELINE config 2 shape (n=8 ring QAOA, d=256) at a reduced step count/batch:
+    size-independent properties -- unitarity, linearity in psi, directional derivative."""
+    p = problems.qaoa_ring(8)
+    K, d, S, B = 16, 256, 20, 48
+    u = problems.pulse_table(K, S, 1.0, seed=3)
+    dt = 1.0 / S
+    psi0 = problems.random_states(d, B, seed=11)
+    with _engine(p["H0"], p["Hs"], p["H_cost"]) as e:
+        out = e.propagate(u, dt, psi0)
+        assert np.max(np.abs(np.linalg.norm(out, axis=0) - 1)) < 1e-12
+        # linearity: P(a x + b y) = a P(x) + b P(y)
+        mix = 0.3 * psi0[:, :8] + (0.1 - 0.7j) * psi0[:, 8:16]
+        assert np.max(np.abs(e.propagate(u, dt, mix) - (0.3 * out[:, :8] + (0.1 - 0.7j) * out[:, 8:16]))) < 1e-12
+        # inverse chain: reversed pulse order with -dt undoes the evolution
+        back = e.propagate(u[::-1].copy(), -dt, out)
+        assert np.max(np.abs(back - psi0)) < 1e-11
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        assert np.max(np.abs(fin - out)) < 1e-13
+        v = np.random.default_rng(0).standard_normal(u.shape)
+        eps = 1e-5
+        lp = e.energy(e.propagate(u + eps * v, dt, psi0))[1]
+        lm = e.energy(e.propagate(u - eps * v, dt, psi0))[1]
+        assert abs((lp - lm) / (2 * eps) - float(np.sum(grad * v))) < 1e-6 * max(1.0, abs(loss))
+
+
+def test_device_resident_torch_buffers():
+    import torch
+    H0, Hs, M = problems.random_hermitian_problem(4, 3, seed=31)
+    u = np.random.default_rng(7).uniform(-1, 1, (8, 3))
+    psi0 = problems.random_states(16, 10, seed=4)
+    dev = torch.device("cuda:0")
+    with _engine(torch.from_numpy(H0).to(dev), torch.from_numpy(Hs).to(dev), torch.from_numpy(M).to(dev)) as e:
+        e.use_torch_stream()
+        tpsi = torch.from_numpy(psi0).to(dev)
+        tu = torch.from_numpy(u).to(dev)
+        out = e.propagate(tu, 0.1, tpsi)
+        loss_t, grad_t, fin_t, _ = e.energy_grad(tu, 0.1, tpsi)
+        torch.cuda.synchronize()
+        out_h = out.cpu().numpy()
+    with _engine(H0, Hs, M) as e:
+        ref = e.propagate(u, 0.1, psi0)
+        loss, grad, fin, _ = e.energy_grad(u, 0.1, psi0)
+    assert np.array_equal(out_h, ref) and loss == loss_t and np.array_equal(grad, grad_t)
+    assert np.array_equal(fin_t.cpu().numpy(), fin)
