@@ -1,0 +1,81 @@
+"""Host-side mirror of the reference's ``diffqc`` pybind11 module (/root/reference/diffqc.cc:210-228).
+
+Same functions, argument meaning and process-global state as the C++ module:
+
+    set_H(H0, Hs, channels, duration, func_type)             diffqc.cc:43-73
+    trotter(psi0, T0, T, per_step, vv) -> list[complex]      diffqc.cc:173-205
+    print_test(), complex_test(v), test_eigen(m), __version__ = "dev"   diffqc.cc:27-38,222-227
+
+but the time loop (``dH`` assembly, ``dH.exp()``, ``exp * psi``) runs in libdiffqc_hip.so on the GPU.
+The pulse envelope ``f_u`` (diffqc.cc:95-135) is evaluated on the host for the whole time grid
+(diffquantum_amd.pulse.f_u_table) and handed to the engine as the u[t][h] table.
+
+Differences from the reference, all deliberate: shape errors raise ValueError instead of being
+undefined behaviour (diffqc.cc:101-103), and ``trotter_batch`` evolves many states at once.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import pulse
+from .engine import Engine
+
+__version__ = "dev"
+
+_state = {"engine": None, "channels": None, "duration": None, "func_type": None, "dim": 0}
+
+
+def print_test():
+    print("hello")
+
+
+def complex_test(psi0):
+    return [complex(z) for z in psi0]
+
+
+def test_eigen(v):
+    return [[float(x) for x in row] for row in v]
+
+
+def set_H(H0, Hs, channels, duration, func_type):
+    H0 = np.asarray(H0, dtype=np.complex128)
+    if H0.ndim != 2 or H0.shape[0] != H0.shape[1] or H0.shape[0] == 0:
+        raise ValueError("H0 must be a non-empty square matrix")
+    d = H0.shape[0]
+    Hs = np.asarray(Hs, dtype=np.complex128).reshape(-1, d, d) if len(Hs) else np.zeros((0, d, d), np.complex128)
+    if len(channels) != Hs.shape[0]:
+        raise ValueError("channels must have one entry per control Hamiltonian ({} != {})".format(len(channels), Hs.shape[0]))
+    chans = [[[float(x) for x in row] for row in ch] for ch in channels]
+    for ch in chans:
+        for row in ch:
+            if len(row) < 4:
+                raise ValueError("each channel row needs at least 4 entries (unused, omega, w, idx)")
+    if _state["engine"] is not None:
+        _state["engine"].close()
+    eng = Engine(d, Hs.shape[0])
+    eng.set_hamiltonians(H0, Hs)
+    _state.update(engine=eng, channels=chans, duration=float(duration), func_type=int(func_type), dim=d)
+
+
+def _table(T0, T, per_step, vv):
+    if _state["engine"] is None:
+        raise RuntimeError("set_H must be called before trotter")
+    n_steps = pulse.n_steps_diffqc(int(per_step), float(T0), float(T))
+    ts, dt = pulse.time_grid(float(T0), float(T), n_steps)
+    u = pulse.f_u_table(vv, _state["channels"], _state["duration"], _state["func_type"], ts)
+    return u, dt
+
+
+def trotter(psi0, T0, T, per_step, vv):
+    psi = np.asarray(psi0, dtype=np.complex128).reshape(-1)
+    if psi.shape[0] != _state["dim"]:
+        raise ValueError("psi0 has length {} but set_H was given dimension {}".format(psi.shape[0], _state["dim"]))
+    u, dt = _table(T0, T, per_step, vv)
+    out = _state["engine"].propagate(u, dt, psi.reshape(-1, 1))
+    return [complex(z) for z in out[:, 0]]
+
+
+def trotter_batch(psi0, T0, T, per_step, vv):
+    """Extension: psi0 is [dim][batch] (numpy or CUDA torch complex128); returns the same kind."""
+    u, dt = _table(T0, T, per_step, vv)
+    return _state["engine"].propagate(u, dt, psi0)

@@ -1,0 +1,198 @@
+"""GPU tests of the host-side mirrors of the reference interfaces (SimulatorPlain, the diffqc module)
+against golden vectors produced by the reference itself (tests/golden/reference_goldens.npz) and
+against the oracle.  These read like the tests the reference never shipped."""
+import os
+
+import numpy as np
+import pytest
+
+from diffquantum_amd import problems, pulse
+from diffquantum_amd.qobj import Qobj, qeye
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "reference_goldens.npz")))
+
+
+@pytest.fixture()
+def demo(G, tmp_path):
+    from diffquantum_amd.sim_plain import SimulatorPlain
+    sim = SimulatorPlain(lr=2e-2, n_basis=6, n_epoch=5, log_dir=str(tmp_path))
+    sim.T = float(G["demo_T"])
+    sim.omegas = list(G["demo_omegas"])
+    H0 = Qobj(G["demo_H0"])
+    Hs = [Qobj(h) for h in G["demo_Hs"]]
+    M = Qobj(G["demo_H_cost"])
+    psi0 = Qobj(G["demo_psi0"])
+    return sim, M, H0, Hs, psi0
+
+
+def _H(sim, H0, Hs, coeff):
+    return [H0] + [[Hs[i], sim.generate_u(i, coeff)] for i in range(len(Hs))]
+
+
+def test_g3_trotter_through_simulator(G, demo):
+    sim, M, H0, Hs, psi0 = demo
+    H = _H(sim, H0, Hs, G["g3_coeff"])
+    fin = sim.trotter(H, psi0, 0, sim.T)
+    assert fin.shape == (16, 1)
+    assert np.max(np.abs(fin.full()[:, 0] - G["g3_final"])) < TOL
+    assert abs(M.matrix_element(fin, fin).real - float(G["g3_energy"])) < TOL
+    # the closures keep the reference's scalar call signature u(t, args)
+    u_scalar = np.array([[H[i + 1][1](float(t), None) for i in range(8)] for t in G["g3_ts"]])
+    assert np.max(np.abs(u_scalar - G["g3_u"])) < 1e-14
+
+
+def test_trotter_accepts_plain_callables_and_validates(G, demo):
+    sim, M, H0, Hs, psi0 = demo
+    H = [H0] + [[Hs[i], (lambda t, args, i=i: float(G["g3_u"][int(round(t / (sim.T / 30))), i]))] for i in range(8)]
+    fin = sim.trotter(H, psi0, 0, sim.T)
+    assert np.max(np.abs(fin.full()[:, 0] - G["g3_final"])) < TOL
+    with pytest.raises(ValueError):
+        sim.trotter([[Hs[0], lambda t, a: 1.0], H0], psi0, 0, sim.T)  # drift must come first
+    with pytest.raises(ValueError):
+        sim.trotter(_H(sim, H0, Hs, G["g3_coeff"]), psi0, 2.0, 0.5)  # n_steps <= 0 (sim_plain.py:123)
+
+
+def test_g4_partial_intervals_and_gates(G, demo):
+    sim, M, H0, Hs, psi0 = demo
+    H = _H(sim, H0, Hs, G["g3_coeff"])
+    s = float(G["g4_s"])
+    phi = sim.trotter(H, psi0, 0, s)
+    assert np.max(np.abs(phi.full()[:, 0] - G["g4_phi"])) < TOL
+    r = 0.5
+    for i in range(8):
+        gate_p = (qeye(16) + r * 1.0j * H[i + 1][0]) / np.sqrt(1.0 + r ** 2)
+        kp = sim.trotter(H, gate_p * phi, s, sim.T)
+        assert np.max(np.abs(kp.full()[:, 0] - G["g4_ket_p"][i])) < TOL
+
+
+def test_g4_mc_gradient_with_pinned_rng(G, demo):
+    import torch
+    sim, M, H0, Hs, psi0 = demo
+    sim.n_Hs = 8
+    sim.spectral_coeff = torch.tensor(G["g3_coeff"], requires_grad=True)
+    H = _H(sim, H0, Hs, G["g3_coeff"])
+    np.random.seed(123)
+    g = sim.compute_energy_grad_MC(M, H, psi0)
+    assert g.dtype == torch.float64 and tuple(g.shape) == (8, 6)
+    assert np.max(np.abs(g.numpy() - G["g4_mc_grad"])) < TOL
+
+
+def test_g6_adjoint_gradient_vs_reference_fd(G, demo, oracle):
+    import torch
+    sim, M, H0, Hs, psi0 = demo
+    sim.n_Hs = 8
+    sim.spectral_coeff = torch.tensor(G["g3_coeff"], requires_grad=True)
+    H = _H(sim, H0, Hs, G["g3_coeff"])
+    g = sim.compute_energy_grad_adjoint(M, H, psi0).numpy()
+    assert np.max(np.abs(g - G["g6_fd_grad"])) < 2e-8  # limited by the FD step of the golden
+    # and to 1e-10 against the oracle's exact derivative of the same chain
+    ts, dt = oracle.time_grid(0, sim.T, 30)
+    u = oracle.generate_u_table(G["g3_coeff"], G["demo_omegas"], sim.T, ts, "BSpline")
+    _, gu, _ = oracle.energy_grad(G["demo_H0"], list(G["demo_Hs"]), G["demo_H_cost"], u, dt, G["demo_psi0"])
+    ref = pulse.grad_coeff_from_grad_u(gu, G["g3_coeff"], G["demo_omegas"], sim.T, ts, "BSpline")
+    assert np.max(np.abs(g - ref)) < TOL
+
+
+def test_g5_training_trace_five_epochs(G, demo):
+    sim, M, H0, Hs, psi0 = demo
+    np.random.seed(0)
+    coeff = sim.train_energy(M, H0, Hs, psi0)
+    assert np.max(np.abs(np.array(sim.losses_energy) - G["g5_losses_energy"])) < 1e-9
+    assert np.max(np.abs(coeff.detach().numpy() - G["g5_coeff"])) < 1e-9
+    assert np.max(np.abs(sim.final_state.full()[:, 0] - G["g5_final_state"])) < 1e-9
+    state, prob = sim.find_state(sim.final_state)
+    assert state == int(G["g5_cut"]) and np.max(np.abs(prob - G["g5_prob"])) < 1e-9
+
+
+def test_g7_batched_legendre_vs_reference_columns(G, tmp_path):
+    from diffquantum_amd.sim_plain import SimulatorPlain
+    sim = SimulatorPlain(n_basis=5, basis="Legendre", per_step=7, log_dir=str(tmp_path))
+    sim.T = float(G["g7_T"])
+    sim.omegas = list(G["g7_omegas"])
+    H = [Qobj(G["g7_H0"])] + [[Qobj(G["g7_Hs"][i]), sim.generate_u(i, G["g7_coeff"])] for i in range(3)]
+    fin = sim.trotter(H, Qobj(G["g7_psi0"]), float(G["g7_T0"]), float(G["g7_T"]))  # 6 columns at once
+    assert fin.shape == (8, 6)
+    assert np.max(np.abs(fin.full() - G["g7_final"])) < TOL
+
+
+def test_demo_full_training_finds_the_cut(tmp_path):
+    """The reference's acceptance run (README.md:21-24): 202 epochs end on an optimal cut of the 4-cycle."""
+    from diffquantum_amd.sim_plain import SimulatorPlain
+    p = problems.maxcut_problem()
+    np.random.seed(0)
+    sim = SimulatorPlain(lr=2e-2, n_basis=6, n_epoch=202, log_dir=str(tmp_path))
+    sim.T, sim.omegas = p["T"], list(p["omegas"])
+    sim.train_energy(Qobj(p["H_cost"]), Qobj(p["H0"]), [Qobj(h) for h in p["Hs"]], Qobj(p["psi0"]))
+    state, prob = sim.find_state(sim.final_state)
+    assert bin(state)[2:].zfill(4) in ("1010", "0101")
+    assert sim.losses_energy[-1] < 0.2
+
+
+def test_adjoint_training_converges_faster(tmp_path):
+    from diffquantum_amd.sim_plain import SimulatorPlain
+    p = problems.maxcut_problem()
+    np.random.seed(1)
+    sim = SimulatorPlain(lr=5e-2, n_basis=6, n_epoch=60, gradient="adjoint", log_dir=str(tmp_path))
+    sim.T, sim.omegas = p["T"], list(p["omegas"])
+    sim.train_energy(Qobj(p["H_cost"]), Qobj(p["H0"]), [Qobj(h) for h in p["Hs"]], Qobj(p["psi0"]))
+    assert sim.losses_energy[-1] < sim.losses_energy[0] - 1.0
+
+
+def test_out_of_scope_methods_say_so(demo):
+    sim = demo[0]
+    for name in ("train_energy_FD", "train_fidelity", "compute_energy_grad_FD"):
+        with pytest.raises(NotImplementedError):
+            getattr(sim, name)()
+
+
+# ---- the diffqc module ---------------------------------------------------------------------------------
+
+def test_diffqc_module_surface(capsys):
+    from diffquantum_amd import diffqc
+    assert diffqc.__version__ == "dev"
+    diffqc.print_test()
+    assert capsys.readouterr().out == "hello\n"
+    assert diffqc.complex_test([1 + 2j, 3]) == [1 + 2j, 3 + 0j]
+    assert diffqc.test_eigen([[1, 2], [3, 4]]) == [[1.0, 2.0], [3.0, 4.0]]
+
+
+@pytest.mark.parametrize("func_type", [0, 1])
+def test_diffqc_trotter_matches_oracle(oracle, func_type):
+    from diffquantum_amd import diffqc
+    H0, Hs, _ = problems.random_hermitian_problem(3, 2, seed=12)
+    rng = np.random.default_rng(func_type)
+    vv = rng.normal(0, 1.0, (2, 3, 6)).tolist()
+    channels = [[[0.0, 2.0, 1.5, 0.0], [0.0, 0.8, -2.5, 1.0]], [[0.0, 3.0, 0.0, 2.0]]]
+    psi0 = problems.random_states(8, 1, seed=3)[:, 0]
+    diffqc.set_H(H0.tolist(), Hs.tolist(), channels, 1.6, func_type)
+    out = diffqc.trotter(psi0.tolist(), 0.0, 1.6, 12, vv)
+    assert isinstance(out, list) and isinstance(out[0], complex) and len(out) == 8
+    ref, u, dt = oracle.trotter_diffqc(H0, list(Hs), channels, 1.6, func_type, psi0, 0.0, 1.6, 12, vv)
+    assert np.max(np.abs(np.array(out) - ref)) < TOL
+    # backward evolution (T < T0 -> dt < 0 with a positive step count, diffqc.cc:182-183)
+    back = diffqc.trotter(out, 1.6, 0.0, 12, vv)
+    refb, _, _ = oracle.trotter_diffqc(H0, list(Hs), channels, 1.6, func_type, ref, 1.6, 0.0, 12, vv)
+    assert np.max(np.abs(np.array(back) - refb)) < TOL
+    # batch extension agrees with the scalar entry point
+    batch = diffqc.trotter_batch(np.stack([psi0, psi0[::-1]], axis=1), 0.0, 1.6, 12, vv)
+    assert np.max(np.abs(batch[:, 0] - np.array(out))) < 1e-14
+
+
+def test_diffqc_errors():
+    from diffquantum_amd import diffqc
+    H0, Hs, _ = problems.random_hermitian_problem(2, 1, seed=1)
+    with pytest.raises(ValueError):
+        diffqc.set_H(H0.tolist(), Hs.tolist(), [], 1.0, 1)  # one channel list per control
+    with pytest.raises(ValueError):
+        diffqc.set_H(H0.tolist(), Hs.tolist(), [[[0.0, 1.0, 0.0]]], 1.0, 1)  # row too short
+    diffqc.set_H(H0.tolist(), Hs.tolist(), [[[0.0, 1.0, 0.0, 0.0]]], 1.0, 1)
+    with pytest.raises(ValueError):
+        diffqc.trotter([1, 0, 0], 0.0, 1.0, 10, np.zeros((2, 1, 6)).tolist())  # wrong length
+    with pytest.raises(ValueError):
+        diffqc.trotter([1, 0, 0, 0], 0.0, 1.0, 10, np.zeros((2, 1, 6)).tolist()[0])  # vv not [2][..][..]
