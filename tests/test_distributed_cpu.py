@@ -1,0 +1,72 @@
+"""world_size-2 gloo test of the batch sharding + single all-reduce (the N>1 path of bench.py).
+The per-shard compute is the ORACLE here (tests may use it); on GPUs it is Engine.energy_grad."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions():
+    from diffquantum_amd.distributed import shard_range
+    for n in (0, 1, 7, 4096, 32768):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from diffquantum_amd import problems
+    from diffquantum_amd.distributed import shard_range, sharded_energy_grad
+    from oracle import trotter_oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (6, 2))
+    B = 5
+    first, count = shard_range(B, rank, world)
+    psi = problems.random_states(4, count, seed=9, first=first)
+
+    def fn(p):
+        loss, grad, _ = orc.energy_grad(H0, list(Hs), M, u, 0.1, p)
+        return loss, grad
+
+    loss, grad = sharded_energy_grad(fn, psi)
+    q.put((rank, loss, grad))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_equals_single_process():
+    import torch.multiprocessing as mp
+    from diffquantum_amd import problems
+    from oracle import trotter_oracle as orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (6, 2))
+    full = problems.random_states(4, 5, seed=9)
+    loss, grad, _ = orc.energy_grad(H0, list(Hs), M, u, 0.1, full)
+    for rank, l, g in res:
+        assert abs(l - loss) < 1e-12 and np.max(np.abs(g - grad)) < 1e-12

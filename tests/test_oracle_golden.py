@@ -196,3 +196,49 @@ def test_no_device_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(_lib.DiffqcNoDevice):
         Engine(4, 1)
+
+
+# ---- the C restatement of diffqc.cc -----------------------------------------------------------------
+
+def test_c_oracle_expm_matches_scipy():
+    import scipy.linalg
+    from oracle import c_oracle
+    rng = np.random.default_rng(0)
+    for d, nrm in ((2, 1e-3), (4, 0.1), (8, 0.5), (16, 1.5), (16, 4.0), (8, 30.0)):
+        H = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        A = -1j * (H + H.conj().T)
+        A *= nrm / np.linalg.norm(A, 1)
+        assert np.max(np.abs(c_oracle.expm(A) - scipy.linalg.expm(A))) < 2e-13 * max(1.0, nrm)
+
+
+def test_c_oracle_pulse_functions(oracle, G):
+    from oracle import c_oracle
+    L = c_oracle.lib()
+    for x in G["g1_x"]:
+        for b in range(6):
+            assert L.dqo_bspline(b, 6, float(x)) == oracle.bspline_cc(b, 6, float(x))
+    for x in (-40.0, -32.0, -1.0, 0.0, 0.3, 32.0, 33.0):
+        assert L.dqo_expit(x) == oracle.my_expit(x)
+    for j in range(6):
+        for x in (-1.0, -0.3, 0.0, 0.77, 1.0):
+            assert abs(L.dqo_legendre(j, x) - oracle.legendre_cc(j, x)) < 1e-15
+
+
+@pytest.mark.parametrize("func_type", [0, 1])
+def test_c_oracle_trotter_matches_numpy_oracle(oracle, func_type):
+    from oracle import c_oracle
+    H0, Hs, _ = problems.random_hermitian_problem(3, 2, seed=12)
+    vv = np.random.default_rng(func_type).normal(0, 1.0, (2, 3, 6))
+    channels = [[[0.0, 2.0, 1.5, 0.0], [0.0, 0.8, -2.5, 1.0]], [[0.0, 3.0, 0.0, 2.0]]]
+    psi0 = problems.random_states(8, 1, seed=3)[:, 0]
+    for (T0, T) in ((0.0, 1.6), (1.6, 0.0)):
+        a = c_oracle.trotter(H0, Hs, channels, 1.6, func_type, psi0, T0, T, 12, vv)
+        b, _, _ = oracle.trotter_diffqc(H0, list(Hs), channels, 1.6, func_type, psi0, T0, T, 12, vv.tolist())
+        assert np.max(np.abs(a - b)) < 1e-12
+
+
+def test_c_oracle_g3_demo_forward(G):
+    """The C stepper with the pinned sim_plain pulse table reproduces the reference's G3 final state."""
+    from oracle import c_oracle
+    out = c_oracle.propagate(G["demo_H0"], G["demo_Hs"], G["g3_u"], float(G["demo_T"]) / 30, G["demo_psi0"])
+    assert np.max(np.abs(out[:, 0] - G["g3_final"])) < 1e-12
