@@ -88,7 +88,6 @@ zgemm_kernel(ZgemmArgs g) {
     }
 
   double2 ra[A_PER_T], rb[B_PER_T];
-  const double2 zero2 = make_double2(0.0, 0.0);
 
   // Stage one BK-deep slab into registers. op(A) is M x K.
   //   OPA == N: stored [m][k] (k contiguous)  -> lanes run along k, LDS write transposes
@@ -96,46 +95,48 @@ zgemm_kernel(ZgemmArgs g) {
   // op(B) is K x N.
   //   OPB == N: stored [k][n] (n contiguous)  -> linear
   //   OPB == C: stored [n][k] (k contiguous)  -> transposing
-  auto load_slab = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < A_PER_T; ++j) {
-      const int e = tid + j * NT;
-      int m, k;
-      if (OPA == 0) { m = e / BK; k = e % BK; } else { k = e / BM; m = e % BM; }
-      const int gm = m0 + m, gk = k0 + k;
-      const bool ok = (gm < g.M) && (gk < g.K);
-      const long off = (OPA == 0) ? ((long)gm * g.lda + gk) : ((long)gk * g.lda + gm);
-      ra[j] = ok ? A[off] : zero2;
-    }
-#pragma unroll
-    for (int j = 0; j < B_PER_T; ++j) {
-      const int e = tid + j * NT;
-      int n, k;
-      if (OPB == 0) { k = e / BN; n = e % BN; } else { n = e / BK; k = e % BK; }
-      const int gn = n0 + n, gk = k0 + k;
-      const bool ok = (gn < g.N) && (gk < g.K);
-      const long off = (OPB == 0) ? ((long)gk * g.ldb + gn) : ((long)gn * g.ldb + gk);
-      rb[j] = ok ? B[off] : zero2;
-    }
-  };
-  auto store_slab = [&](int buf) {
-    double2* as = As + buf * BK * PA;
-    double2* bs = Bs + buf * BK * PB;
-#pragma unroll
-    for (int j = 0; j < A_PER_T; ++j) {
-      const int e = tid + j * NT;
-      int m, k;
-      if (OPA == 0) { m = e / BK; k = e % BK; } else { k = e / BM; m = e % BM; }
-      as[k * PA + m] = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < B_PER_T; ++j) {
-      const int e = tid + j * NT;
-      int n, k;
-      if (OPB == 0) { k = e / BN; n = e % BN; } else { n = e / BK; k = e % BK; }
-      bs[k * PB + n] = rb[j];
-    }
-  };
+  // (Macros, not lambdas: a by-reference capture of ra/rb demoted them to scratch memory --
+  //  4 scratch stores + 4 loads per lane per slab, visible as 3-8x WRITE_SIZE in the PMC profile.)
+#define DQ_LOAD_SLAB(k0_)                                                                    \
+  {                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < A_PER_T; ++j) {                                    \
+      const int e = tid + j * NT;                                                            \
+      const int m = (OPA == 0) ? e / BK : e % BM;                                            \
+      const int k = (OPA == 0) ? e % BK : e / BM;                                            \
+      const int gm = m0 + m, gk = (k0_) + k;                                                 \
+      const long off = (OPA == 0) ? ((long)gm * g.lda + gk) : ((long)gk * g.lda + gm);       \
+      double2 v = make_double2(0.0, 0.0);                                                    \
+      if ((gm < g.M) && (gk < g.K)) v = A[off];                                              \
+      ra[j] = v;                                                                             \
+    }                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < B_PER_T; ++j) {                                    \
+      const int e = tid + j * NT;                                                            \
+      const int n = (OPB == 0) ? e % BN : e / BK;                                            \
+      const int k = (OPB == 0) ? e / BN : e % BK;                                            \
+      const int gn = n0 + n, gk = (k0_) + k;                                                 \
+      const long off = (OPB == 0) ? ((long)gk * g.ldb + gn) : ((long)gn * g.ldb + gk);       \
+      double2 v = make_double2(0.0, 0.0);                                                    \
+      if ((gn < g.N) && (gk < g.K)) v = B[off];                                              \
+      rb[j] = v;                                                                             \
+    }                                                                                        \
+  }
+#define DQ_STORE_SLAB(buf_)                                                                  \
+  {                                                                                          \
+    double2* as_ = As + (buf_) * BK * PA;                                                    \
+    double2* bs_ = Bs + (buf_) * BK * PB;                                                    \
+    _Pragma("unroll") for (int j = 0; j < A_PER_T; ++j) {                                    \
+      const int e = tid + j * NT;                                                            \
+      const int m = (OPA == 0) ? e / BK : e % BM;                                            \
+      const int k = (OPA == 0) ? e % BK : e / BM;                                            \
+      as_[k * PA + m] = ra[j];                                                               \
+    }                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < B_PER_T; ++j) {                                    \
+      const int e = tid + j * NT;                                                            \
+      const int n = (OPB == 0) ? e % BN : e / BK;                                            \
+      const int k = (OPB == 0) ? e / BN : e % BK;                                            \
+      bs_[k * PB + n] = rb[j];                                                               \
+    }                                                                                        \
+  }
 
   // sign bookkeeping: a = (ar, sa*ai), b = (br, sb*bi)
   //   Cr += ar*br - (sa*sb) ai*bi ;  Ci += sb * ar*bi + sa * ai*br
@@ -143,40 +144,38 @@ zgemm_kernel(ZgemmArgs g) {
   constexpr int NEG_RI = (OPB != 0) ? DQ_NEG_B : DQ_NEG_NONE;
   constexpr int NEG_IR = (OPA != 0) ? DQ_NEG_A : DQ_NEG_NONE;
 
-  auto compute_slab = [&](int buf) {
-    const double2* as = As + buf * BK * PA + wm * TM + (lane & 15);
-    const double2* bs = Bs + buf * BK * PB + wn * TN + (lane & 15);
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      const int kk = ks * 4 + (lane >> 4);
-      double2 a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = as[kk * PA + i * 16];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = bs[kk * PB + j * 16];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, DQ_NEG_NONE);
-          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acci[i][j], 0, 0, NEG_RI);
-          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, accr[i][j], 0, 0, NEG_II);
-          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acci[i][j], 0, 0, NEG_IR);
-        }
-    }
-  };
+#define DQ_COMPUTE_SLAB(buf_)                                                                              \
+  {                                                                                                          \
+    const double2* as_ = As + (buf_) * BK * PA + wm * TM + (lane & 15);                                      \
+    const double2* bs_ = Bs + (buf_) * BK * PB + wn * TN + (lane & 15);                                      \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 4; ++ks) {                                                  \
+      const int kk = ks * 4 + (lane >> 4);                                                                   \
+      double2 a[MI], b[NI];                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = as_[kk * PA + i * 16];                           \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = bs_[kk * PB + j * 16];                           \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {        \
+        accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, DQ_NEG_NONE);    \
+        acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acci[i][j], 0, 0, NEG_RI);         \
+        accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, accr[i][j], 0, 0, NEG_II);         \
+        acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acci[i][j], 0, 0, NEG_IR);         \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
 
   const int nkt = (g.K + BK - 1) / BK;
-  load_slab(0);
-  store_slab(0);
+  DQ_LOAD_SLAB(0);
+  DQ_STORE_SLAB(0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    const bool more = (kt + 1 < nkt);
-    if (more) load_slab((kt + 1) * BK);
-    compute_slab(kt & 1);
-    if (more) store_slab((kt + 1) & 1);
+    // the tail slab (k >= K) loads zeros through the bounds check, so no branch is needed here
+    DQ_LOAD_SLAB((kt + 1) * BK);
+    DQ_COMPUTE_SLAB(kt & 1);
+    DQ_STORE_SLAB((kt + 1) & 1);
     __syncthreads();
   }
+#undef DQ_LOAD_SLAB
+#undef DQ_STORE_SLAB
+#undef DQ_COMPUTE_SLAB
 
   // ---- epilogue: C = alpha*acc + beta*C -----------------------------------------
   const double alpha = g.alpha, beta = g.beta;
