@@ -80,18 +80,36 @@ bool is_device_ptr(const void* p) {
 }
 
 // ---- exp(A) plan ---------------------------------------------------------------------------
-// T_m(A/2^s) evaluated with Paterson-Stockmeyer blocks of size q (m = (r+1) q):
-//   P_j = A^j (j <= q),  R_r = B_r,  R_i = P_q R_{i+1} + B_i,  B_i = sum_j c_{iq+j} P_j,
-// followed by s squarings. Products: (q-1) + r + s.  The degree is the smallest whose Taylor
-// remainder theta^(m+1)/(m+1)! is below tol (default 2^-53) for theta >= ||A/2^s||_1.
-struct ExpmPlan {
-  int m = 0, q = 0, r = 0, s = 0;
-  double c[24];
-  int products() const { return (q - 1) + r + s; }
+// U = p(A/2^s)^(2^s) with p the degree-m Taylor polynomial of exp, written as a short TAPE of two op kinds
+//   LIN: dst = cI*I + sum_j c_j * src_j                       (streaming pass)
+//   MUL: dst = a * b + cI*I + sum_j c_j * src_j                (one ZGEMM, the linear part pre-stored in dst)
+// over matrix variables (variable 0 is A itself). Two evaluation schemes produce tapes:
+//   * Paterson-Stockmeyer blocks of size q (m = (r+1) q): P_j = A^j, R_r = B_r, R_i = P_q R_{i+1} + B_i with
+//     B_i = sum_j c_{iq+j} P_j : (q-1) + r products;
+//   * the degree-8 scheme of Bader, Blanes & Casas (Mathematics 7(12):1174, 2019) with 3 products:
+//       A2 = A A;  A4 = A2 (x1 A + x2 A2);  A8 = (x3 A2 + A4)(x4 I + x5 A + x6 A2 + x7 A4);
+//       T8 = y0 I + y1 A + y2 A2 + A8      (coefficients checked symbolically: all nine Taylor terms exact)
+// followed by s squarings. The scaling 2^-s is folded into the coefficients. The degree is the cheapest whose
+// Taylor remainder theta^(m+1)/(m+1)! is below tol (default 2^-53) for theta >= ||A/2^s||_1.
+// The same tape drives the reverse mode (tape_backward): for C = X Y, Xbar += Cbar Y^H and Ybar += X^H Cbar.
+struct TapeOp {
+  int kind;  // 0 = LIN, 1 = MUL
+  int dst, a, b;
+  int nlin;
+  int lsrc[6];
+  double lc[6];
+  double cI;
 };
 
-const int kCand[][2] = {{2, 1}, {4, 2}, {6, 2}, {9, 3}, {12, 3}, {16, 4}, {20, 4}};
-constexpr int kNCand = 7;
+struct ExpmPlan {
+  int m = 0, s = 0, nvars = 0, out = 0, nprod = 0;
+  std::vector<TapeOp> ops;
+  int products() const { return nprod; }
+};
+
+// candidate schemes ordered by cost: {degree, PS block size q (0 = BBC scheme), products}
+const int kCand[][3] = {{2, 1, 1}, {4, 2, 2}, {8, 0, 3}, {6, 2, 3}, {9, 3, 4}, {12, 3, 5}, {16, 4, 6}, {20, 4, 7}};
+constexpr int kNCand = 8;
 
 double taylor_remainder(double theta, int m) {
   double v = 1.0;
@@ -99,44 +117,109 @@ double taylor_remainder(double theta, int m) {
   return v;
 }
 
+TapeOp op_lin(int dst, double cI) {
+  TapeOp o;
+  memset(&o, 0, sizeof(o));
+  o.kind = 0; o.dst = dst; o.a = o.b = -1; o.cI = cI;
+  return o;
+}
+TapeOp op_mul(int dst, int a, int b, double cI = 0.0) {
+  TapeOp o;
+  memset(&o, 0, sizeof(o));
+  o.kind = 1; o.dst = dst; o.a = a; o.b = b; o.cI = cI;
+  return o;
+}
+void add_term(TapeOp& o, int src, double c) {
+  if (c == 0.0) return;
+  o.lsrc[o.nlin] = src;
+  o.lc[o.nlin] = c;
+  o.nlin++;
+}
+
 ExpmPlan make_plan(int m, int q, int s) {
   ExpmPlan p;
   p.m = m;
-  p.q = q;
-  p.r = m / q - 1;
   p.s = s;
-  double f = 1.0;
-  const double sc = std::ldexp(1.0, -s);
-  double pw = 1.0;
-  for (int j = 0; j <= m; ++j) {
-    if (j > 0) { f *= j; pw *= sc; }
-    p.c[j] = pw / f;
+  const double sg = std::ldexp(1.0, -s);
+  int nv = 1;  // variable 0 = A
+  if (q == 0) {  // Bader-Blanes-Casas degree 8
+    const double r177 = std::sqrt(177.0);
+    const double x3 = 2.0 / 3.0;
+    const double x1 = x3 * (1.0 + r177) / 88.0, x2 = x3 * (1.0 + r177) / 352.0;
+    const double x4 = (-271.0 + 29.0 * r177) / (315.0 * x3), x5 = 11.0 * (-1.0 + r177) / (1260.0 * x3);
+    const double x6 = 11.0 * (-9.0 + r177) / (5040.0 * x3), x7 = (89.0 - r177) / (5040.0 * x3 * x3);
+    const double y2 = (857.0 - 58.0 * r177) / 630.0;
+    const double s1 = sg, s2 = sg * sg;
+    const int v1 = nv++, t1 = nv++, v2 = nv++, t2 = nv++, t3 = nv++, u0 = nv++;
+    p.ops.push_back(op_mul(v1, 0, 0));                       // v1 = A^2            (A'^2 = s2 v1)
+    TapeOp o = op_lin(t1, 0.0);                              // t1 = s2 (x1 A' + x2 A'^2)
+    add_term(o, 0, s2 * x1 * s1); add_term(o, v1, s2 * x2 * s2);
+    p.ops.push_back(o);
+    p.ops.push_back(op_mul(v2, v1, t1));                     // v2 = A4'
+    o = op_lin(t2, 0.0);                                     // t2 = x3 A'^2 + A4'
+    add_term(o, v1, x3 * s2); add_term(o, v2, 1.0);
+    p.ops.push_back(o);
+    o = op_lin(t3, x4);                                      // t3 = x4 I + x5 A' + x6 A'^2 + x7 A4'
+    add_term(o, 0, x5 * s1); add_term(o, v1, x6 * s2); add_term(o, v2, x7);
+    p.ops.push_back(o);
+    o = op_mul(u0, t2, t3, 1.0);                             // U0 = t2 t3 + I + A' + y2 A'^2
+    add_term(o, 0, s1); add_term(o, v1, y2 * s2);
+    p.ops.push_back(o);
+    p.out = u0;
+  } else {  // Paterson-Stockmeyer
+    const int r = m / q - 1;
+    double c[32];
+    double f = 1.0, pw = 1.0;
+    for (int j = 0; j <= m; ++j) {
+      if (j > 0) { f *= j; pw *= sg; }
+      c[j] = pw / f;
+    }
+    int P[8];
+    P[1] = 0;
+    for (int j = 2; j <= q; ++j) {
+      P[j] = nv++;
+      p.ops.push_back(op_mul(P[j], P[j - 1], P[1]));
+    }
+    int R[8];
+    for (int i = r; i >= 0; --i) R[i] = nv++;
+    TapeOp o = op_lin(R[r], c[r * q]);
+    for (int j = 1; j <= q; ++j) add_term(o, P[j], c[r * q + j]);
+    p.ops.push_back(o);
+    for (int i = r - 1; i >= 0; --i) {
+      o = op_mul(R[i], P[q], R[i + 1], c[i * q]);
+      for (int j = 1; j <= q - 1; ++j) add_term(o, P[j], c[i * q + j]);
+      p.ops.push_back(o);
+    }
+    p.out = R[0];
   }
+  for (int j = 0; j < s; ++j) {
+    const int nx = nv++;
+    p.ops.push_back(op_mul(nx, p.out, p.out));
+    p.out = nx;
+  }
+  p.nvars = nv;
+  for (const auto& o : p.ops) p.nprod += o.kind;
   return p;
 }
 
 ExpmPlan choose_plan(double theta, double tol, int force_degree, int force_s) {
   if (!(theta >= 0.0) || !std::isfinite(theta)) fail(DQ_ERR_INVALID, "non-finite generator norm");
-  ExpmPlan best;
-  int best_cost = 1 << 30;
+  int bm = 0, bq = 0, bs = 0, best_cost = 1 << 30;
   for (int s = 0; s <= 60; ++s) {
     if (force_s >= 0 && s != force_s) continue;
     const double th = std::ldexp(theta, -s);
     for (int i = 0; i < kNCand; ++i) {
-      const int m = kCand[i][0], q = kCand[i][1];
+      const int m = kCand[i][0];
       if (force_degree > 0 && m != force_degree) continue;
       if (force_degree <= 0 && taylor_remainder(th, m) > tol) continue;
-      const int cost = (q - 1) + (m / q - 1) + s;
-      if (cost < best_cost) {
-        best_cost = cost;
-        best = make_plan(m, q, s);
-      }
+      const int cost = kCand[i][2] + s;
+      if (cost < best_cost) { best_cost = cost; bm = m; bq = kCand[i][1]; bs = s; }
       break;  // candidates are ordered by cost within one s
     }
     if (force_s < 0 && best_cost <= s + 1) break;  // larger s cannot win any more
   }
-  if (best.m == 0) fail(DQ_ERR_INVALID, "no exp(A) plan for the requested degree/squarings");
-  return best;
+  if (bm == 0) fail(DQ_ERR_INVALID, "no exp(A) plan for the requested degree/squarings");
+  return make_plan(bm, bq, bs);
 }
 
 // ---- profiling -----------------------------------------------------------------------------
@@ -258,87 +341,70 @@ struct dq_ctx {
 
 namespace {
 
-// pool slot map
-enum { SLOT_P = 0 /*1..4*/, SLOT_R = 8 /*0..4*/, SLOT_RB = 16 /*0..4*/, SLOT_PB = 24 /*1..4*/,
-       SLOT_SQ = 32 /*1..*/, SLOT_SQB = 94 /*0..1*/, SLOT_IO = 92 };
+// pool slot map: variable v of the tape lives in slot v, its adjoint in slot SLOT_ADJ + v
+enum { SLOT_ADJ = 44, SLOT_MAXV = 44 };
 
-// Forward exp of `n` stacked matrices sitting in slot P1. Returns the device pointer of U.
+// Forward exp of `n` stacked matrices sitting in slot 0 (variable 0 = A). Returns the device pointer of U.
 double2* expm_forward(dq_ctx* c, const ExpmPlan& p, int n) {
-  const int q = p.q, r = p.r;
-  double2* P[6] = {nullptr};
-  for (int j = 1; j <= q; ++j) P[j] = c->mat(SLOT_P + j, n);
-  for (int j = 2; j <= q; ++j) c->mm(0, 0, P[j - 1], P[1], P[j], 0.0, n);
-  double2* R[6];
-  for (int i = 0; i <= r; ++i) R[i] = c->mat(SLOT_R + i, n);
-  {  // top block: c_{rq} I + sum_{j=1..q} c_{rq+j} P_j
-    const double2* x[6];
-    double cf[6];
-    for (int j = 1; j <= q; ++j) { x[j - 1] = P[j]; cf[j - 1] = p.c[r * q + j]; }
-    c->lincomb(R[r], q, x, cf, p.c[r * q], n, false);
-  }
-  for (int i = r - 1; i >= 0; --i) {
-    const double2* x[6];
-    double cf[6];
-    for (int j = 1; j <= q - 1; ++j) { x[j - 1] = P[j]; cf[j - 1] = p.c[i * q + j]; }
-    c->lincomb(R[i], q - 1, x, cf, p.c[i * q], n, false);
-    c->mm(0, 0, P[q], R[i + 1], R[i], 1.0, n);  // R_i += P_q R_{i+1}
-  }
-  double2* U = R[0];
-  for (int j = 1; j <= p.s; ++j) {
-    double2* nx = c->mat(SLOT_SQ + j, n);
-    c->mm(0, 0, U, U, nx, 0.0, n);
-    U = nx;
+  if (p.nvars > SLOT_MAXV) fail(DQ_ERR_INVALID, "exp(A) plan needs too many temporaries");
+  for (const TapeOp& o : p.ops) {
+    double2* dst = c->mat(o.dst, n);
+    const bool has_lin = o.nlin > 0 || o.cI != 0.0;
+    if (o.kind == 0 || has_lin) {
+      const double2* x[6];
+      for (int j = 0; j < o.nlin; ++j) x[j] = c->mat(o.lsrc[j], n);
+      c->lincomb(dst, o.nlin, x, o.lc, o.cI, n, false);
+    }
+    if (o.kind == 1) c->mm(0, 0, c->mat(o.a, n), c->mat(o.b, n), dst, has_lin ? 1.0 : 0.0, n);
   }
   c->last_degree = p.m;
   c->last_squarings = p.s;
   c->last_products = p.products();
-  return U;
+  return c->mat(p.out, n);
 }
 
 // Where the caller must put Ubar (cotangent of U) before expm_backward.
-double2* ubar_slot(dq_ctx* c, const ExpmPlan& p, int n) {
-  return p.s == 0 ? c->mat(SLOT_RB + 0, n) : c->mat(SLOT_SQB + 0, n);
-}
+double2* ubar_slot(dq_ctx* c, const ExpmPlan& p, int n) { return c->mat(SLOT_ADJ + p.out, n); }
 
-// Reverse mode through expm_forward (whose P_j, R_i, squaring chain are still in the pool).
-// Pairing: dL = Re tr(Xbar^H dX). For C = X Y: Xbar += Cbar Y^H, Ybar += X^H Cbar.
-// Returns the device pointer of Abar (n stacked matrices).
+// Reverse mode through expm_forward (whose variables are still in the pool).
+// Pairing: dL = Re tr(Xbar^H dX). For C = X Y: Xbar += Cbar Y^H, Ybar += X^H Cbar; for a linear term
+// C = ... + c X: Xbar += c Cbar. Linear contributions are queued per variable and applied in one streaming
+// pass when that variable's adjoint is needed. Returns the device pointer of Abar (n stacked matrices).
 double2* expm_backward(dq_ctx* c, const ExpmPlan& p, int n) {
-  const int q = p.q, r = p.r;
-  double2* P[6] = {nullptr};
-  double2* R[6];
-  double2* Rb[6];
-  double2* Pb[6] = {nullptr};
-  for (int j = 1; j <= q; ++j) { P[j] = c->mat(SLOT_P + j, n); Pb[j] = c->mat(SLOT_PB + j, n); }
-  for (int i = 0; i <= r; ++i) { R[i] = c->mat(SLOT_R + i, n); Rb[i] = c->mat(SLOT_RB + i, n); }
-  if (p.s > 0) {  // undo squarings: U_{j+1} = U_j U_j  ->  Ubar_j = Ubar_{j+1} U_j^H + U_j^H Ubar_{j+1}
-    double2* cur = c->mat(SLOT_SQB + 0, n);
-    for (int j = p.s - 1; j >= 0; --j) {
-      const double2* Uj = (j == 0) ? R[0] : c->mat(SLOT_SQ + j, n);
-      double2* dst = (j == 0) ? Rb[0] : (cur == c->mat(SLOT_SQB + 0, n) ? c->mat(SLOT_SQB + 1, n) : c->mat(SLOT_SQB + 0, n));
-      c->mm(0, 1, cur, Uj, dst, 0.0, n);
-      c->mm(1, 0, Uj, cur, dst, 1.0, n);
-      cur = dst;
+  struct Pending { const double2* x; double coef; };
+  std::vector<std::vector<Pending>> pend(p.nvars);
+  std::vector<char> init(p.nvars, 0);
+  init[p.out] = 1;
+  auto adj = [&](int v) { return c->mat(SLOT_ADJ + v, n); };
+  auto flush = [&](int v) {
+    auto& q = pend[v];
+    size_t i = 0;
+    while (i < q.size()) {
+      const double2* x[6];
+      double cf[6];
+      int k = 0;
+      for (; k < 6 && i < q.size(); ++k, ++i) { x[k] = q[i].x; cf[k] = q[i].coef; }
+      c->lincomb(adj(v), k, x, cf, 0.0, n, init[v] != 0);
+      init[v] = 1;
     }
+    q.clear();
+  };
+  for (int oi = (int)p.ops.size() - 1; oi >= 0; --oi) {
+    const TapeOp& o = p.ops[oi];
+    flush(o.dst);
+    if (!init[o.dst]) continue;  // this variable does not reach the output
+    const double2* db = adj(o.dst);
+    if (o.kind == 1) {
+      c->mm(0, 1, db, c->mat(o.b, n), adj(o.a), init[o.a] ? 1.0 : 0.0, n);
+      init[o.a] = 1;
+      c->mm(1, 0, c->mat(o.a, n), db, adj(o.b), init[o.b] ? 1.0 : 0.0, n);
+      init[o.b] = 1;
+    }
+    for (int j = 0; j < o.nlin; ++j) pend[o.lsrc[j]].push_back({db, o.lc[j]});
   }
-  for (int i = 0; i < r; ++i) c->mm(1, 0, P[q], Rb[i], Rb[i + 1], 0.0, n);  // Rbar_{i+1} = P_q^H Rbar_i
-  {  // Pbar_q = c_{rq+q} Rbar_r + sum_i Rbar_i R_{i+1}^H
-    const double2* x[1] = {Rb[r]};
-    const double cf[1] = {p.c[r * q + q]};
-    c->lincomb(Pb[q], 1, x, cf, 0.0, n, false);
-    for (int i = 0; i < r; ++i) c->mm(0, 1, Rb[i], R[i + 1], Pb[q], 1.0, n);
-  }
-  for (int j = 1; j <= q - 1; ++j) {  // Pbar_j = sum_i c_{iq+j} Rbar_i
-    const double2* x[6];
-    double cf[6];
-    for (int i = 0; i <= r; ++i) { x[i] = Rb[i]; cf[i] = p.c[i * q + j]; }
-    c->lincomb(Pb[j], r + 1, x, cf, 0.0, n, false);
-  }
-  for (int j = q; j >= 2; --j) {  // P_j = P_{j-1} P_1
-    c->mm(0, 1, Pb[j], P[1], Pb[j - 1], 1.0, n);
-    c->mm(1, 0, P[j - 1], Pb[j], Pb[1], 1.0, n);
-  }
-  return Pb[1];
+  flush(0);
+  if (!init[0]) HIPCK(hipMemsetAsync(adj(0), 0, (size_t)n * c->mat_bytes(), c->st));
+  return adj(0);
 }
 
 void stage_h2d(dq_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -388,7 +454,7 @@ void check_ctx(dq_ctx* c) {
 
 // number of steps whose exp() is built in one batched pass
 int time_chunk(dq_ctx* c, int n_steps) {
-  const double per_step = 24.0 * (double)c->mat_bytes();  // P, R, Rbar, Pbar, squaring slots
+  const double per_step = 24.0 * (double)c->mat_bytes();  // tape variables + their adjoints
   long tc = (long)(c->chunk_bytes / per_step);
   tc = std::max(1L, std::min<long>(tc, n_steps));
   tc = std::min<long>(tc, 16384);
@@ -428,7 +494,7 @@ ExpmPlan chunk_plan(dq_ctx* c, const std::vector<double>& uh, int c0, int n, dou
 
 // assemble + exp for steps [c0, c0+n): returns pointer to n stacked propagators
 double2* build_propagators(dq_ctx* c, const ExpmPlan& p, int c0, int n, double dt) {
-  double2* A = c->mat(SLOT_P + 1, n);
+  double2* A = c->mat(0, n);
   const double by = 16.0 * c->nn() * (c->K + 2.0) * n;
   c->timed(DQ_PROF_ASSEMBLE, 2.0 * 2 * c->nn() * (c->K + 1.0) * n, by, [&] {
     return dq::assemble_launch(A, c->H0.z(), c->Hs.z(), c->u_dev.d() + (size_t)c0 * c->K, c->K, (long)c->nn(), n, dt,
@@ -802,7 +868,7 @@ int dq_expm(dq_ctx* c, const double* A, double* U, int batch) {
     if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
     if (batch == 0) return;
     if (!A || !U) fail(DQ_ERR_INVALID, "null matrix pointer");
-    double2* P1 = c->mat(SLOT_P + 1, batch);
+    double2* P1 = c->mat(0, batch);
     HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
     double th = 0.0;
     for (int z = 0; z < batch; ++z) th = std::max(th, norm1_dev(c, P1 + (size_t)z * c->nn()));
@@ -820,7 +886,7 @@ int dq_expm_vjp(dq_ctx* c, const double* A, const double* Ubar, double* Abar, in
     if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
     if (batch == 0) return;
     if (!A || !Ubar || !Abar) fail(DQ_ERR_INVALID, "null matrix pointer");
-    double2* P1 = c->mat(SLOT_P + 1, batch);
+    double2* P1 = c->mat(0, batch);
     HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
     double th = 0.0;
     for (int z = 0; z < batch; ++z) th = std::max(th, norm1_dev(c, P1 + (size_t)z * c->nn()));

@@ -85,7 +85,7 @@ def test_expm_matches_scipy(d, norm):
         assert np.max(np.abs(U[z].conj().T @ U[z] - np.eye(d))) < 5e-13 * max(1.0, norm)
 
 
-@pytest.mark.parametrize("degree", [2, 4, 6, 9, 12, 16, 20])
+@pytest.mark.parametrize("degree", [2, 4, 6, 8, 9, 12, 16, 20])
 def test_expm_every_polynomial_degree(degree):
     from diffquantum_amd.engine import Engine
     rng = np.random.default_rng(degree)
