@@ -29,6 +29,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_BYTES_PER_LAUNCH = 3.60e9  # HBM-side bytes per ZGEMM launch from rocprofv3 PMC (profiles/r1_*_summary.txt):
+                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.33 GB + 0.27 GB at d = B = 4096
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
 
@@ -126,7 +128,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = eng.profile()
-    info = {k: eng.info(k) for k in ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk")}
+    info = {k: eng.info(k) for k in ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk",
+                                     "zgemm_alg")}
 
     if rank == 0:
         z = prof["zgemm"]
@@ -162,13 +165,18 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "zgemm_kernel<128,128,8,2,4,*> (batched complex GEMM, v_mfma_f64_16x16x4_f64)",
+                "kernel": "zgemm_kernel<128,128,8,2,4,*,*,{}> (batched complex GEMM, v_mfma_f64_16x16x4_f64, {})".format(
+                    int(info["zgemm_alg"]), "3M: 3 real MFMAs per complex tile step" if info["zgemm_alg"] else "4M"),
                 "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": TRAFFIC_BYTES_PER_LAUNCH,
                 "launches": z["launches"], "flops_per_launch": per_launch_flops, "ms_per_launch": per_launch_ms,
-                "note": "achieved = sum over the timed region's ZGEMM launches of 8*M*N*K flops / sum of their HIP-event "
-                        "durations (rank 0); traffic: see profiles/ (PMC pass)",
+                "mfma_executed_tflops": achieved * (0.75 if info["zgemm_alg"] else 1.0),
+                "frac_executed": achieved * (0.75 if info["zgemm_alg"] else 1.0) / PEAK_F64_MFMA_TFLOPS,
+                "note": "achieved = sum over the timed region's ZGEMM launches of the ALGORITHMIC 8*M*N*K flops / sum of "
+                        "their HIP-event durations (rank 0). With the 3M complex product the kernel executes 6*M*N*K MFMA "
+                        "flops for 8*M*N*K algorithmic ones, so `frac` can exceed 1; `frac_executed` is the matrix-pipe "
+                        "utilisation. traffic = PMC FETCH/WRITE per launch (profiles/, separate --pmc passes)",
             },
             "end_to_end": {
                 "algorithmic_flops_per_step": 3 * W_alg,

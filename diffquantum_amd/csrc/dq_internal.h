@@ -17,7 +17,7 @@ struct ZgemmArgs {
   int opA, opB;         // 0 = as stored, 1 = conjugate transpose
 };
 
-hipError_t zgemm_launch(const ZgemmArgs& g, hipStream_t st, int force_tile = 0);
+hipError_t zgemm_launch(const ZgemmArgs& g, hipStream_t st, int force_tile = 0, int alg = 0);
 int zgemm_pick_tile(int M, int N, int batch);
 
 // ---- elementwise / reduction kernels (elementwise.hip) ------------------------------

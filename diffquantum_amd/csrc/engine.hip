@@ -240,7 +240,7 @@ struct dq_ctx {
   std::vector<double> nHk;
   // options
   double checkpoint_bytes = 0.0, chunk_bytes = 2.0 * 1024 * 1024 * 1024, expm_tol = 1.1102230246251565e-16;
-  int force_degree = 0, force_s = -1, force_tile = 0;
+  int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0;
   // workspace
@@ -315,8 +315,8 @@ struct dq_ctx {
     g.opA = opA; g.opB = opB;
     const double fl = 8.0 * M * N * (double)Kd * batch;
     const double by = 16.0 * ((double)M * Kd + (double)Kd * N + (double)M * N * (beta != 0.0 ? 2 : 1)) * batch;
-    const int ft = force_tile;
-    timed(DQ_PROF_ZGEMM, fl, by, [&] { return dq::zgemm_launch(g, st, ft); });
+    const int ft = force_tile, alg = zgemm_alg;
+    timed(DQ_PROF_ZGEMM, fl, by, [&] { return dq::zgemm_launch(g, st, ft, alg); });
   }
   // batched d x d product on pool matrices
   void mm(int opA, int opB, const double2* A, const double2* B, double2* C, double beta, int batch) {
@@ -784,6 +784,10 @@ int dq_set_option(dq_ctx* c, const char* name, double v) {
       const int t = (int)v;
       if (t != 0 && t != 32 && t != 64 && t != 128) fail(DQ_ERR_INVALID, "force_tile must be 0, 32, 64 or 128");
       c->force_tile = t;
+    } else if (s == "zgemm_alg") {
+      const int a = (int)v;
+      if (a != 0 && a != 1) fail(DQ_ERR_INVALID, "zgemm_alg must be 0 (4M) or 1 (3M)");
+      c->zgemm_alg = a;
     } else fail(DQ_ERR_INVALID, "unknown option '" + s + "'");
   });
 }
@@ -800,6 +804,7 @@ int dq_get_info(dq_ctx* c, const char* name, double* v) {
     else if (s == "checkpoint_stride") *v = c->last_cstride;
     else if (s == "theta") *v = c->last_theta;
     else if (s == "hermitian") *v = c->hermitian ? 1.0 : 0.0;
+    else if (s == "zgemm_alg") *v = c->zgemm_alg;
     else if (s == "norm_H0") *v = c->nH0;
     else if (s == "dim") *v = c->d;
     else if (s == "n_controls") *v = c->K;

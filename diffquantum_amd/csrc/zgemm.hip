@@ -38,7 +38,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define DQ_NEG_A 1
 #define DQ_NEG_B 2
 
-template <int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB>
+template <int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int ALG3M>
 __global__ void __launch_bounds__(WGM* WGN * 64, (WGM * WGN * 64 >= 512) ? 2 : 2)
 zgemm_kernel(ZgemmArgs g) {
   constexpr int NT = WGM * WGN * 64;
@@ -78,13 +78,15 @@ zgemm_kernel(ZgemmArgs g) {
   const double2* __restrict__ B = g.B + z * g.sB;
   double2* __restrict__ C = g.C + z * g.sC;
 
-  double4_t accr[MI][NI], acci[MI][NI];
+  // 4M: accr = Re, acci = Im.   3M: accr = sum ar*br, acci = sum ai*bi, acc3 = sum (ar+ai')(br+bi')
+  double4_t accr[MI][NI], acci[MI][NI], acc3[ALG3M ? MI : 1][ALG3M ? NI : 1];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       accr[i][j] = {0.0, 0.0, 0.0, 0.0};
       acci[i][j] = {0.0, 0.0, 0.0, 0.0};
+      if (ALG3M) acc3[i][j] = {0.0, 0.0, 0.0, 0.0};
     }
 
   double2 ra[A_PER_T], rb[B_PER_T];
@@ -153,11 +155,23 @@ zgemm_kernel(ZgemmArgs g) {
       double2 a[MI], b[NI];                                                                                  \
       _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = as_[kk * PA + i * 16];                           \
       _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = bs_[kk * PB + j * 16];                           \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {        \
-        accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, DQ_NEG_NONE);    \
-        acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acci[i][j], 0, 0, NEG_RI);         \
-        accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, accr[i][j], 0, 0, NEG_II);         \
-        acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acci[i][j], 0, 0, NEG_IR);         \
+      if (ALG3M) {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {      \
+          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, 0);            \
+          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acci[i][j], 0, 0, 0);            \
+        }                                                                                                    \
+        /* sums formed after the P1/P2 issue so they can reuse the fragment registers */                     \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i].x = (OPA != 0) ? a[i].x - a[i].y : a[i].x + a[i].y; \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j].x = (OPB != 0) ? b[j].x - b[j].y : b[j].x + b[j].y; \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)        \
+          acc3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc3[i][j], 0, 0, 0);            \
+      } else {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {      \
+          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, DQ_NEG_NONE);  \
+          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acci[i][j], 0, 0, NEG_RI);       \
+          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, accr[i][j], 0, 0, NEG_II);       \
+          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acci[i][j], 0, 0, NEG_IR);       \
+        }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
   }
@@ -189,7 +203,16 @@ zgemm_kernel(ZgemmArgs g) {
         const int row = m0 + wm * TM + i * 16 + (lane >> 4) + 4 * r;
         if (row < g.M && col < g.N) {
           const long off = (long)row * g.ldc + col;
-          double2 v = make_double2(alpha * accr[i][j][r], alpha * acci[i][j][r]);
+          double cr, ci;
+          if (ALG3M) {  // Cr = P1 - s P2, Ci = P3 - P1 - s P2, s = +1 unless exactly one operand is conjugated
+            const double p2 = ((OPA != 0) != (OPB != 0)) ? -acci[i][j][r] : acci[i][j][r];
+            cr = accr[i][j][r] - p2;
+            ci = acc3[i][j][r] - accr[i][j][r] - p2;
+          } else {
+            cr = accr[i][j][r];
+            ci = acci[i][j][r];
+          }
+          double2 v = make_double2(alpha * cr, alpha * ci);
           if (beta != 0.0) {
             const double2 c0 = C[off];
             v.x += beta * c0.x;
@@ -201,17 +224,17 @@ zgemm_kernel(ZgemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, int ALG3M>
 static void launch_cfg(const ZgemmArgs& g, hipStream_t st) {
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)g.batch);
   dim3 block(WGM * WGN * 64);
   const int op = (g.opA ? 2 : 0) | (g.opB ? 1 : 0);
   switch (op) {
-    case 0: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 0>), grid, block, 0, st, g); break;
-    case 1: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 1>), grid, block, 0, st, g); break;
-    case 2: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 0>), grid, block, 0, st, g); break;
-    default: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 1>), grid, block, 0, st, g); break;
+    case 0: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 0, ALG3M>), grid, block, 0, st, g); break;
+    case 1: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 1, ALG3M>), grid, block, 0, st, g); break;
+    case 2: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 0, ALG3M>), grid, block, 0, st, g); break;
+    default: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 1, ALG3M>), grid, block, 0, st, g); break;
   }
 }
 
@@ -224,12 +247,15 @@ int zgemm_pick_tile(int M, int N, int batch) {
   return 32;
 }
 
-hipError_t zgemm_launch(const ZgemmArgs& g, hipStream_t st, int force_tile) {
+// alg: 0 = 4M (four real MFMAs per complex tile step), 1 = 3M (three; P3 trick, normwise-stable)
+hipError_t zgemm_launch(const ZgemmArgs& g, hipStream_t st, int force_tile, int alg) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
   const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
-  if (tile == 128) launch_cfg<128, 128, 8, 2, 4>(g, st);
-  else if (tile == 64) launch_cfg<64, 64, 8, 2, 2>(g, st);
-  else launch_cfg<32, 32, 8, 1, 1>(g, st);
+  if (tile == 128) {
+    if (alg == 1) launch_cfg<128, 128, 8, 2, 4, 1>(g, st);
+    else launch_cfg<128, 128, 8, 2, 4, 0>(g, st);
+  } else if (tile == 64) launch_cfg<64, 64, 8, 2, 2, 0>(g, st);
+  else launch_cfg<32, 32, 8, 1, 1, 0>(g, st);
   return hipGetLastError();
 }
 

@@ -69,7 +69,8 @@ int dq_set_hamiltonians(dq_ctx* ctx, const double* H0, const double* Hs);
 int dq_set_observable(dq_ctx* ctx, const double* M);
 
 /* Tunables: "checkpoint_bytes", "chunk_bytes", "expm_tol", "force_degree", "force_squarings",
- * "force_tile".  Unknown names -> DQ_ERR_INVALID. */
+ * "force_tile", "zgemm_alg" (0 = four real MFMAs per complex tile step, 1 = the three-multiplication
+ * "3M" form on the 128x128 tile).  Unknown names -> DQ_ERR_INVALID. */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 

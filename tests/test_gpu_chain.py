@@ -233,3 +233,22 @@ def test_device_resident_torch_buffers():
         loss, grad, fin, _ = e.energy_grad(u, 0.1, psi0)
     assert np.array_equal(out_h, ref) and loss == loss_t and np.array_equal(grad, grad_t)
     assert np.array_equal(fin_t.cpu().numpy(), fin)
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+def test_d256_through_the_128_tile_matches_oracle(oracle, alg):
+    """Full-tile path (128x128 workgroup tile; alg 1 = 3M complex products) against the oracle at d = 256."""
+    H0, Hs, M = problems.random_hermitian_problem(8, 2, seed=40)
+    S, B, dt = 5, 130, 0.05
+    u = np.random.default_rng(3).uniform(-2, 2, (S, 2))
+    psi0 = problems.random_states(256, B, seed=6)
+    with _engine(H0, Hs, M) as e:
+        e.set_option("force_tile", 128)
+        e.set_option("zgemm_alg", alg)
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        fwd = e.propagate(u, dt, psi0)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    assert np.max(np.abs(fin - rf)) < TOL and np.max(np.abs(fwd - rf)) < TOL
+    assert abs(loss - rl) < TOL * B and np.max(np.abs(grad - rg)) < TOL * B
+    # report the actual error level (3M is normwise-, not componentwise-stable)
+    print("alg", alg, "max amp err %.2e, grad err %.2e" % (np.max(np.abs(fin - rf)), np.max(np.abs(grad - rg))))

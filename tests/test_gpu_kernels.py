@@ -50,6 +50,28 @@ def test_zgemm_asymmetric_identity(eng16):
     assert np.array_equal(got, B.astype(np.complex128))
 
 
+@pytest.mark.parametrize("opA,opB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 130), (512, 256, 257)])
+def test_zgemm_3m_variant(eng16, opA, opB, M, N, K):
+    """The 3M form (three real MFMAs per complex tile step) is normwise-stable, not componentwise:
+    error bound ~ eps * K * max|A| * max|B| instead of eps * (|A||B|)_ij."""
+    rng = np.random.default_rng(M + N + K + opA * 2 + opB)
+    A = _rand(rng, *((K, M) if opA else (M, K)))
+    B = _rand(rng, *((N, K) if opB else (K, N)))
+    C0 = _rand(rng, M, N)
+    eng16.set_option("force_tile", 128)
+    eng16.set_option("zgemm_alg", 1)
+    try:
+        got = eng16.zgemm(A, B, opA=opA, opB=opB, alpha=1.25, beta=0.5, C_in=C0)
+    finally:
+        eng16.set_option("force_tile", 0)
+        eng16.set_option("zgemm_alg", 0)
+    oa = A.conj().T if opA else A
+    ob = B.conj().T if opB else B
+    ref = 1.25 * (oa @ ob) + 0.5 * C0
+    assert np.max(np.abs(got - ref)) < 4e-16 * K * np.max(np.abs(A)) * np.max(np.abs(B)) * 4
+
+
 def test_zgemm_batched(eng16):
     rng = np.random.default_rng(3)
     A = _rand(rng, 5, 40, 24)

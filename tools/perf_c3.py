@@ -17,6 +17,8 @@ e = Engine(d, n)
 e.use_torch_stream()
 e.set_hamiltonians(H0, Hs)
 e.set_observable(M)
+import os
+e.set_option("zgemm_alg", int(os.environ.get("DQ_ALG", "0")))
 tu = torch.from_numpy(u).to(dev)
 for mode in ("propagate", "energy_grad"):
     for rep in range(2):
