@@ -252,3 +252,22 @@ def test_d256_through_the_128_tile_matches_oracle(oracle, alg):
     assert abs(loss - rl) < TOL * B and np.max(np.abs(grad - rg)) < TOL * B
     # report the actual error level (3M is normwise-, not componentwise-stable)
     print("alg", alg, "max amp err %.2e, grad err %.2e" % (np.max(np.abs(fin - rf)), np.max(np.abs(grad - rg))))
+
+
+@pytest.mark.parametrize("n,B,S", [(2, 9, 1), (3, 40, 2), (3, 40, 37), (4, 100, 64), (5, 33, 19)])
+def test_operator_form_forward_for_wide_batches(oracle, n, B, S):
+    """B > d: the step propagators are composed by a tree of batched products and applied once."""
+    H0, Hs, _ = problems.random_hermitian_problem(n, 2, seed=n + S)
+    u = np.random.default_rng(S).uniform(-2, 2, (S, 2))
+    psi0 = problems.random_states(1 << n, B, seed=8)
+    with _engine(H0, Hs) as e:
+        auto = e.propagate(u, 0.07, psi0)
+        assert e.info("composed") == 1
+        e.set_option("chunk_bytes", 24 * (1 << n) ** 2 * 16 * 5)  # 5-step chunks: several trees + odd tails
+        chunked = e.propagate(u, 0.07, psi0)
+        e.set_option("compose", 0)
+        seq = e.propagate(u, 0.07, psi0)
+        assert e.info("composed") == 0
+    ref = oracle.propagate(H0, list(Hs), u, 0.07, psi0)
+    assert np.max(np.abs(auto - ref)) < TOL and np.max(np.abs(chunked - ref)) < TOL
+    assert np.max(np.abs(auto - seq)) < 1e-12
