@@ -13,6 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffqc_hip.so")
 
+DQ_C128, DQ_C64 = 0, 1
 DQ_OK, DQ_ERR_INVALID, DQ_ERR_STATE, DQ_ERR_HIP, DQ_ERR_NO_DEVICE, DQ_ERR_UNSUPPORTED, DQ_ERR_NOMEM = range(7)
 PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other")
 
@@ -43,6 +44,7 @@ SIGNATURES = {
     "dq_last_error": (C.c_char_p, []),
     "dq_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "dq_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
+    "dq_create_ex": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     "dq_destroy": (C.c_int, [_vp]),
     "dq_set_stream": (C.c_int, [_vp, _vp]),
     "dq_synchronize": (C.c_int, [_vp]),

@@ -1,7 +1,8 @@
 // HBM-bound streaming kernels of the propagator path: Hamiltonian assembly, the linear
 // combinations between the polynomial's products, the control-gradient contractions and the
-// small reductions (energies, norms). All operate on interleaved complex128, 16 B per lane
-// per access, consecutive lanes on consecutive elements (fully coalesced 1 KiB per wave).
+// small reductions (energies, norms). All operate on interleaved complex (fp64: 16 B, fp32: 8 B per lane
+// per access), consecutive lanes on consecutive elements (fully coalesced). Reductions accumulate in fp64
+// for both precisions. T = real scalar (double / float).
 #include <hip/hip_runtime.h>
 #include "dq_internal.h"
 
@@ -10,62 +11,82 @@ namespace dq {
 // ---- A_t = -i dt (H0 + sum_k u_k(t) H_k) -------------------------------------------------
 // Reference: /root/reference/diffqc.cc:192-197 (dH = -i*dt*g_H0; dH += -i*dt*coeff*g_Hs[h]),
 //            /root/reference/sim_plain.py:137-143.  One launch assembles `batch` time steps.
-__global__ void __launch_bounds__(256) assemble_kernel(double2* __restrict__ A, const double2* __restrict__ H0,
-                                                       const double2* __restrict__ Hs, const double* __restrict__ u,
-                                                       int K, long n_elem, double dt) {
+template <class T>
+__global__ void __launch_bounds__(256) assemble_kernel(typename Cx<T>::type* __restrict__ A,
+                                                       const typename Cx<T>::type* __restrict__ H0,
+                                                       const typename Cx<T>::type* __restrict__ Hs,
+                                                       const double* __restrict__ u, int K, long n_elem, double dt_) {
+  typedef typename Cx<T>::type T2;
   const long z = blockIdx.z;
   const double* uz = u + z * K;
-  double2* Az = A + z * n_elem;
+  T2* Az = A + z * n_elem;
+  const T dt = (T)dt_;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (long)gridDim.x * blockDim.x) {
-    double2 h = H0[e];
+    T2 h = H0[e];
     for (int k = 0; k < K; ++k) {
-      const double c = uz[k];
-      const double2 x = Hs[(long)k * n_elem + e];
+      const T c = (T)uz[k];
+      const T2 x = Hs[(long)k * n_elem + e];
       h.x = fma(c, x.x, h.x);
       h.y = fma(c, x.y, h.y);
     }
-    Az[e] = make_double2(dt * h.y, -dt * h.x);  // (-i) * (x + i y) = y - i x
+    T2 o;  // (-i) * (x + i y) = y - i x
+    o.x = dt * h.y;
+    o.y = -dt * h.x;
+    Az[e] = o;
   }
 }
 
-hipError_t assemble_launch(double2* A, const double2* H0, const double2* Hs, const double* u, int K, long n_elem,
-                           int batch, double dt, hipStream_t st) {
+template <class T>
+hipError_t assemble_launch(typename Cx<T>::type* A, const typename Cx<T>::type* H0, const typename Cx<T>::type* Hs,
+                           const double* u, int K, long n_elem, int batch, double dt, hipStream_t st) {
   if (n_elem <= 0 || batch <= 0) return hipSuccess;
   long nb = (n_elem + 255) / 256;
   if (nb > 65536) nb = 65536;
   dim3 grid((unsigned)nb, 1, (unsigned)batch);
-  hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, st, A, H0, Hs, u, K, n_elem, dt);
+  hipLaunchKernelGGL(assemble_kernel<T>, grid, dim3(256), 0, st, A, H0, Hs, u, K, n_elem, dt);
   return hipGetLastError();
 }
+template hipError_t assemble_launch<double>(double2*, const double2*, const double2*, const double*, int, long, int,
+                                            double, hipStream_t);
+template hipError_t assemble_launch<float>(float2*, const float2*, const float2*, const double*, int, long, int, double,
+                                           hipStream_t);
 
 // ---- out = [out +] cI*I + sum_j c_j X_j ---------------------------------------------------
-__global__ void __launch_bounds__(256) lincomb_kernel(LincombArgs a) {
+template <class T>
+__global__ void __launch_bounds__(256) lincomb_kernel(LincombArgs<T> a) {
+  typedef typename Cx<T>::type T2;
   const long z = blockIdx.z;
   const long n_elem = (long)a.d * a.d;
   const long base = z * a.stride;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (long)gridDim.x * blockDim.x) {
-    double2 v = a.accumulate ? a.out[base + e] : make_double2(0.0, 0.0);
+    T2 v;
+    v.x = 0;
+    v.y = 0;
+    if (a.accumulate) v = a.out[base + e];
 #pragma unroll
     for (int j = 0; j < 6; ++j)
       if (j < a.n_in) {
-        const double2 x = a.x[j][base + e];
-        v.x = fma(a.c[j], x.x, v.x);
-        v.y = fma(a.c[j], x.y, v.y);
+        const T2 x = a.x[j][base + e];
+        v.x = fma((T)a.c[j], x.x, v.x);
+        v.y = fma((T)a.c[j], x.y, v.y);
       }
-    if (a.cI != 0.0 && (e / a.d) == (e % a.d)) v.x += a.cI;
+    if (a.cI != 0.0 && (e / a.d) == (e % a.d)) v.x += (T)a.cI;
     a.out[base + e] = v;
   }
 }
 
-hipError_t lincomb_launch(const LincombArgs& a, hipStream_t st) {
+template <class T>
+hipError_t lincomb_launch(const LincombArgs<T>& a, hipStream_t st) {
   const long n_elem = (long)a.d * a.d;
   if (n_elem <= 0 || a.batch <= 0) return hipSuccess;
   long nb = (n_elem + 255) / 256;
   if (nb > 65536) nb = 65536;
   dim3 grid((unsigned)nb, 1, (unsigned)a.batch);
-  hipLaunchKernelGGL(lincomb_kernel, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(lincomb_kernel<T>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
+template hipError_t lincomb_launch<double>(const LincombArgs<double>&, hipStream_t);
+template hipError_t lincomb_launch<float>(const LincombArgs<float>&, hipStream_t);
 
 // ---- dL/du_k[t] = Re<Abar_t, -i dt H_k>_F = dt * sum Im(conj(Abar) .* H_k) ---------------
 // Stage 1: per-block partial sums for up to KC controls at a time; stage 2: fixed-order sum over
@@ -73,21 +94,24 @@ hipError_t lincomb_launch(const LincombArgs& a, hipStream_t st) {
 constexpr int KC = 8;
 constexpr int GC_THREADS = 256;
 
-__global__ void __launch_bounds__(GC_THREADS) grad_contract_kernel(const double2* __restrict__ Abar, long strideA,
-                                                                   const double2* __restrict__ Hs, int K, int k0,
-                                                                   long n_elem, double* __restrict__ part) {
+template <class T>
+__global__ void __launch_bounds__(GC_THREADS) grad_contract_kernel(const typename Cx<T>::type* __restrict__ Abar,
+                                                                   long strideA,
+                                                                   const typename Cx<T>::type* __restrict__ Hs, int K,
+                                                                   int k0, long n_elem, double* __restrict__ part) {
+  typedef typename Cx<T>::type T2;
   const long z = blockIdx.z;
-  const double2* Az = Abar + z * strideA;
+  const T2* Az = Abar + z * strideA;
   double acc[KC];
 #pragma unroll
   for (int k = 0; k < KC; ++k) acc[k] = 0.0;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (long)gridDim.x * blockDim.x) {
-    const double2 a = Az[e];
+    const T2 a = Az[e];
 #pragma unroll
     for (int k = 0; k < KC; ++k)
       if (k0 + k < K) {
-        const double2 h = Hs[(long)(k0 + k) * n_elem + e];
-        acc[k] += a.x * h.y - a.y * h.x;  // Im(conj(a) * h)
+        const T2 h = Hs[(long)(k0 + k) * n_elem + e];
+        acc[k] += (double)a.x * (double)h.y - (double)a.y * (double)h.x;  // Im(conj(a) * h)
       }
   }
   __shared__ double red[KC][GC_THREADS / 64];
@@ -123,41 +147,53 @@ int grad_contract_blocks(long n_elem) {
   return (int)nb;
 }
 
-hipError_t grad_contract_launch(const double2* Abar, long strideA, const double2* Hs, int K, long n_elem, int batch,
-                                double scale, double* part, double* grad, hipStream_t st) {
+template <class T>
+hipError_t grad_contract_launch(const typename Cx<T>::type* Abar, long strideA, const typename Cx<T>::type* Hs, int K,
+                                long n_elem, int batch, double scale, double* part, double* grad, hipStream_t st) {
   if (K <= 0 || batch <= 0) return hipSuccess;
   const int nb = grad_contract_blocks(n_elem);
   dim3 grid((unsigned)nb, 1, (unsigned)batch);
   for (int k0 = 0; k0 < K; k0 += KC)
-    hipLaunchKernelGGL(grad_contract_kernel, grid, dim3(GC_THREADS), 0, st, Abar, strideA, Hs, K, k0, n_elem, part);
+    hipLaunchKernelGGL(grad_contract_kernel<T>, grid, dim3(GC_THREADS), 0, st, Abar, strideA, Hs, K, k0, n_elem, part);
   const int threads = ((K + 63) / 64) * 64;
   hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)batch), dim3(threads), 0, st, part, nb, K, scale, grad);
   return hipGetLastError();
 }
+template hipError_t grad_contract_launch<double>(const double2*, long, const double2*, int, long, int, double, double*,
+                                                 double*, hipStream_t);
+template hipError_t grad_contract_launch<float>(const float2*, long, const float2*, int, long, int, double, double*,
+                                                double*, hipStream_t);
 
 // ---- e[b] = scale * sum_i Re(conj(X[i][b]) Y[i][b]) ---------------------------------------
 // Energy <psi_b| M |psi_b> with Y = M Psi (sim_plain.py:281 `M.matrix_element(final, final).real`).
-__global__ void __launch_bounds__(256) coldot_kernel(const double2* __restrict__ X, long ldx,
-                                                     const double2* __restrict__ Y, long ldy, int d, int B,
-                                                     double scale, double* __restrict__ e) {
+template <class T>
+__global__ void __launch_bounds__(256) coldot_kernel(const typename Cx<T>::type* __restrict__ X, long ldx,
+                                                     const typename Cx<T>::type* __restrict__ Y, long ldy, int d,
+                                                     int B, double scale, double* __restrict__ e) {
+  typedef typename Cx<T>::type T2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double s = 0.0;
   for (int i = 0; i < d; ++i) {
-    const double2 x = X[(long)i * ldx + b];
-    const double2 y = Y[(long)i * ldy + b];
-    s += x.x * y.x + x.y * y.y;
+    const T2 x = X[(long)i * ldx + b];
+    const T2 y = Y[(long)i * ldy + b];
+    s += (double)x.x * (double)y.x + (double)x.y * (double)y.y;
   }
   e[b] = scale * s;
 }
 
-hipError_t coldot_launch(const double2* X, long ldx, const double2* Y, long ldy, int d, int B, double scale, double* e,
-                         hipStream_t st) {
+template <class T>
+hipError_t coldot_launch(const typename Cx<T>::type* X, long ldx, const typename Cx<T>::type* Y, long ldy, int d, int B,
+                         double scale, double* e, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, X, ldx, Y, ldy, d, B, scale,
-                     e);
+  hipLaunchKernelGGL(coldot_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, X, ldx, Y, ldy, d, B,
+                     scale, e);
   return hipGetLastError();
 }
+template hipError_t coldot_launch<double>(const double2*, long, const double2*, long, int, int, double, double*,
+                                          hipStream_t);
+template hipError_t coldot_launch<float>(const float2*, long, const float2*, long, int, int, double, double*,
+                                         hipStream_t);
 
 __global__ void __launch_bounds__(256) sum_kernel(const double* __restrict__ e, int n, double* __restrict__ out) {
   __shared__ double red[256];
@@ -177,43 +213,54 @@ hipError_t sum_launch(const double* e, int n, double* out, hipStream_t st) {
   return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) colabs_kernel(const double2* __restrict__ X, int d, double* __restrict__ cs) {
+template <class T>
+__global__ void __launch_bounds__(256) colabs_kernel(const typename Cx<T>::type* __restrict__ X, int d,
+                                                     double* __restrict__ cs) {
+  typedef typename Cx<T>::type T2;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= d) return;
   double s = 0.0;
   for (int i = 0; i < d; ++i) {
-    const double2 x = X[(long)i * d + j];
-    s += hypot(x.x, x.y);
+    const T2 x = X[(long)i * d + j];
+    s += hypot((double)x.x, (double)x.y);
   }
   cs[j] = s;
 }
 
-hipError_t colabs_launch(const double2* X, int d, double* colsum, hipStream_t st) {
-  hipLaunchKernelGGL(colabs_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, X, d, colsum);
+template <class T>
+hipError_t colabs_launch(const typename Cx<T>::type* X, int d, double* colsum, hipStream_t st) {
+  hipLaunchKernelGGL(colabs_kernel<T>, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, X, d, colsum);
   return hipGetLastError();
 }
+template hipError_t colabs_launch<double>(const double2*, int, double*, hipStream_t);
+template hipError_t colabs_launch<float>(const float2*, int, double*, hipStream_t);
 
-__global__ void __launch_bounds__(256) herm_defect_kernel(const double2* __restrict__ X, int d,
+template <class T>
+__global__ void __launch_bounds__(256) herm_defect_kernel(const typename Cx<T>::type* __restrict__ X, int d,
                                                           unsigned long long* __restrict__ out) {
+  typedef typename Cx<T>::type T2;
   const long n = (long)d * d;
   double mx = 0.0;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const long i = e / d, j = e % d;
-    const double2 a = X[e];
-    const double2 b = X[j * d + i];
-    mx = fmax(mx, fmax(fabs(a.x - b.x), fabs(a.y + b.y)));
+    const T2 a = X[e];
+    const T2 b = X[j * d + i];
+    mx = fmax(mx, fmax(fabs((double)a.x - (double)b.x), fabs((double)a.y + (double)b.y)));
   }
   for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));  // mx >= 0: order-preserving
 }
 
-hipError_t herm_defect_launch(const double2* X, int d, double* out, hipStream_t st) {
+template <class T>
+hipError_t herm_defect_launch(const typename Cx<T>::type* X, int d, double* out, hipStream_t st) {
   hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
   if (e != hipSuccess) return e;
   long nb = ((long)d * d + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(herm_defect_kernel, dim3((unsigned)nb), dim3(256), 0, st, X, d, (unsigned long long*)out);
+  hipLaunchKernelGGL(herm_defect_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, X, d, (unsigned long long*)out);
   return hipGetLastError();
 }
+template hipError_t herm_defect_launch<double>(const double2*, int, double*, hipStream_t);
+template hipError_t herm_defect_launch<float>(const float2*, int, double*, hipStream_t);
 
 }  // namespace dq

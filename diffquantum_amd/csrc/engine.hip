@@ -232,6 +232,15 @@ struct ProfRec {
 }  // namespace
 
 struct dq_ctx {
+  int dtype = DQ_C128;
+  virtual ~dq_ctx() {}
+};
+
+namespace {
+
+template <class T>
+struct Ctx : dq_ctx {
+  typedef typename dq::Cx<T>::type T2;
   int d = 0, K = 0, dev = 0;
   hipStream_t st = nullptr;
   DevBuf H0, Hs, M;
@@ -239,7 +248,7 @@ struct dq_ctx {
   double nH0 = 0.0;
   std::vector<double> nHk;
   // options
-  double checkpoint_bytes = 0.0, chunk_bytes = 2.0 * 1024 * 1024 * 1024, expm_tol = 1.1102230246251565e-16;
+  double checkpoint_bytes = 0.0, chunk_bytes = 2.0 * 1024 * 1024 * 1024, expm_tol = 0.0, herm_tol = 0.0;
   int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0;
@@ -254,14 +263,19 @@ struct dq_ctx {
   std::vector<hipEvent_t> ev_free;
   dq_profile prof_acc;
 
-  dq_ctx() : pool(96) { memset(&prof_acc, 0, sizeof(prof_acc)); }
-  ~dq_ctx() {
+  Ctx() : pool(96) {
+    memset(&prof_acc, 0, sizeof(prof_acc));
+    dtype = sizeof(T) == 8 ? DQ_C128 : DQ_C64;
+    expm_tol = sizeof(T) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-08;
+    herm_tol = sizeof(T) == 8 ? 1e-12 : 1e-5;
+  }
+  ~Ctx() override {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : ev_free) (void)hipEventDestroy(e);
   }
 
   size_t nn() const { return (size_t)d * d; }
-  size_t mat_bytes() const { return nn() * sizeof(double2); }
+  size_t mat_bytes() const { return nn() * sizeof(T2); }
 
   hipEvent_t get_event() {
     if (!ev_free.empty()) { hipEvent_t e = ev_free.back(); ev_free.pop_back(); return e; }
@@ -298,14 +312,14 @@ struct dq_ctx {
   }
 
   // pool slot of `tc` stacked d x d matrices
-  double2* mat(int slot, size_t tc) {
+  T2* mat(int slot, size_t tc) {
     pool[slot].ensure(tc * mat_bytes());
-    return pool[slot].z();
+    return (T2*)pool[slot].p;
   }
 
-  void zgemm(int opA, int opB, int M, int N, int Kd, double alpha, const double2* A, long lda, long sA,
-             const double2* B, long ldb, long sB, double beta, double2* C, long ldc, long sC, int batch) {
-    dq::ZgemmArgs g;
+  void zgemm(int opA, int opB, int M, int N, int Kd, double alpha, const T2* A, long lda, long sA,
+             const T2* B, long ldb, long sB, double beta, T2* C, long ldc, long sC, int batch) {
+    dq::ZgemmArgs<T> g;
     g.A = A; g.B = B; g.C = C;
     g.M = M; g.N = N; g.K = Kd;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -314,17 +328,17 @@ struct dq_ctx {
     g.alpha = alpha; g.beta = beta;
     g.opA = opA; g.opB = opB;
     const double fl = 8.0 * M * N * (double)Kd * batch;
-    const double by = 16.0 * ((double)M * Kd + (double)Kd * N + (double)M * N * (beta != 0.0 ? 2 : 1)) * batch;
+    const double by = 2.0 * sizeof(T) * ((double)M * Kd + (double)Kd * N + (double)M * N * (beta != 0.0 ? 2 : 1)) * batch;
     const int ft = force_tile, alg = zgemm_alg;
-    timed(DQ_PROF_ZGEMM, fl, by, [&] { return dq::zgemm_launch(g, st, ft, alg); });
+    timed(DQ_PROF_ZGEMM, fl, by, [&] { return dq::zgemm_launch<T>(g, st, ft, alg); });
   }
   // batched d x d product on pool matrices
-  void mm(int opA, int opB, const double2* A, const double2* B, double2* C, double beta, int batch) {
+  void mm(int opA, int opB, const T2* A, const T2* B, T2* C, double beta, int batch) {
     const long s = (long)nn();
     zgemm(opA, opB, d, d, d, 1.0, A, d, s, B, d, s, beta, C, d, s, batch);
   }
-  void lincomb(double2* out, int n_in, const double2* const* x, const double* c, double cI, int batch, bool acc) {
-    dq::LincombArgs a;
+  void lincomb(T2* out, int n_in, const T2* const* x, const double* c, double cI, int batch, bool acc) {
+    dq::LincombArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.out = out;
     a.n_in = n_in;
@@ -334,24 +348,25 @@ struct dq_ctx {
     a.stride = (long)nn();
     a.batch = batch;
     a.accumulate = acc ? 1 : 0;
-    const double by = 16.0 * nn() * (n_in + 1 + (acc ? 1 : 0)) * batch;
-    timed(DQ_PROF_LINCOMB, 2.0 * 2 * nn() * n_in * batch, by, [&] { return dq::lincomb_launch(a, st); });
+    const double by = 2.0 * sizeof(T) * nn() * (n_in + 1 + (acc ? 1 : 0)) * batch;
+    timed(DQ_PROF_LINCOMB, 2.0 * 2 * nn() * n_in * batch, by, [&] { return dq::lincomb_launch<T>(a, st); });
   }
 };
 
-namespace {
 
 // pool slot map: variable v of the tape lives in slot v, its adjoint in slot SLOT_ADJ + v
 enum { SLOT_ADJ = 44, SLOT_MAXV = 44, SLOT_TREE = 90 };
 
 // Forward exp of `n` stacked matrices sitting in slot 0 (variable 0 = A). Returns the device pointer of U.
-double2* expm_forward(dq_ctx* c, const ExpmPlan& p, int n) {
+template <class T>
+typename dq::Cx<T>::type* expm_forward(Ctx<T>* c, const ExpmPlan& p, int n) {
+  typedef typename dq::Cx<T>::type T2;
   if (p.nvars > SLOT_MAXV) fail(DQ_ERR_INVALID, "exp(A) plan needs too many temporaries");
   for (const TapeOp& o : p.ops) {
-    double2* dst = c->mat(o.dst, n);
+    T2* dst = c->mat(o.dst, n);
     const bool has_lin = o.nlin > 0 || o.cI != 0.0;
     if (o.kind == 0 || has_lin) {
-      const double2* x[6];
+      const T2* x[6];
       for (int j = 0; j < o.nlin; ++j) x[j] = c->mat(o.lsrc[j], n);
       c->lincomb(dst, o.nlin, x, o.lc, o.cI, n, false);
     }
@@ -364,14 +379,18 @@ double2* expm_forward(dq_ctx* c, const ExpmPlan& p, int n) {
 }
 
 // Where the caller must put Ubar (cotangent of U) before expm_backward.
-double2* ubar_slot(dq_ctx* c, const ExpmPlan& p, int n) { return c->mat(SLOT_ADJ + p.out, n); }
+template <class T>
+typename dq::Cx<T>::type* ubar_slot(Ctx<T>* c, const ExpmPlan& p, int n) {
+  typedef typename dq::Cx<T>::type T2; return c->mat(SLOT_ADJ + p.out, n); }
 
 // Reverse mode through expm_forward (whose variables are still in the pool).
 // Pairing: dL = Re tr(Xbar^H dX). For C = X Y: Xbar += Cbar Y^H, Ybar += X^H Cbar; for a linear term
 // C = ... + c X: Xbar += c Cbar. Linear contributions are queued per variable and applied in one streaming
 // pass when that variable's adjoint is needed. Returns the device pointer of Abar (n stacked matrices).
-double2* expm_backward(dq_ctx* c, const ExpmPlan& p, int n) {
-  struct Pending { const double2* x; double coef; };
+template <class T>
+typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
+  typedef typename dq::Cx<T>::type T2;
+  struct Pending { const T2* x; double coef; };
   std::vector<std::vector<Pending>> pend(p.nvars);
   std::vector<char> init(p.nvars, 0);
   init[p.out] = 1;
@@ -380,7 +399,7 @@ double2* expm_backward(dq_ctx* c, const ExpmPlan& p, int n) {
     auto& q = pend[v];
     size_t i = 0;
     while (i < q.size()) {
-      const double2* x[6];
+      const T2* x[6];
       double cf[6];
       int k = 0;
       for (; k < 6 && i < q.size(); ++k, ++i) { x[k] = q[i].x; cf[k] = q[i].coef; }
@@ -393,7 +412,7 @@ double2* expm_backward(dq_ctx* c, const ExpmPlan& p, int n) {
     const TapeOp& o = p.ops[oi];
     flush(o.dst);
     if (!init[o.dst]) continue;  // this variable does not reach the output
-    const double2* db = adj(o.dst);
+    const T2* db = adj(o.dst);
     if (o.kind == 1) {
       c->mm(0, 1, db, c->mat(o.b, n), adj(o.a), init[o.a] ? 1.0 : 0.0, n);
       init[o.a] = 1;
@@ -407,26 +426,32 @@ double2* expm_backward(dq_ctx* c, const ExpmPlan& p, int n) {
   return adj(0);
 }
 
-void stage_h2d(dq_ctx* c, void* dst, const void* src, size_t bytes) {
+#define TT typename dq::Cx<T>::type
+
+template <class T>
+void stage_h2d(Ctx<T>* c, void* dst, const void* src, size_t bytes) {
   HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->st));
 }
 
 // returns a device pointer for an input that may live on the host
-const double2* in_dev(dq_ctx* c, const double* p, size_t bytes, DevBuf& tmp) {
-  if (is_device_ptr(p)) return (const double2*)p;
+template <class T>
+const TT* in_dev(Ctx<T>* c, const void* p, size_t bytes, DevBuf& tmp) {
+  if (is_device_ptr(p)) return (const TT*)p;
   tmp.ensure(bytes);
   stage_h2d(c, tmp.p, p, bytes);
-  return tmp.z();
+  return (const TT*)tmp.p;
 }
 
-void out_copy(dq_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+template <class T>
+void out_copy(Ctx<T>* c, void* dst, const void* src_dev, size_t bytes) {
   if (!dst || dst == src_dev) return;
   HIPCK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, c->st));
 }
 
-double norm1_dev(dq_ctx* c, const double2* X) {
+template <class T>
+double norm1_dev(Ctx<T>* c, const TT* X) {
   c->scratch.ensure(sizeof(double) * (size_t)c->d);
-  HIPCK(dq::colabs_launch(X, c->d, c->scratch.d(), c->st));
+  HIPCK(dq::colabs_launch<T>(X, c->d, c->scratch.d(), c->st));
   std::vector<double> h(c->d);
   HIPCK(hipMemcpyAsync(h.data(), c->scratch.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->st));
   HIPCK(hipStreamSynchronize(c->st));
@@ -438,22 +463,25 @@ double norm1_dev(dq_ctx* c, const double2* X) {
   return mx;
 }
 
-double herm_defect_dev(dq_ctx* c, const double2* X) {
+template <class T>
+double herm_defect_dev(Ctx<T>* c, const TT* X) {
   c->scratch.ensure(sizeof(double) * (size_t)std::max(c->d, 1));
-  HIPCK(dq::herm_defect_launch(X, c->d, c->scratch.d(), c->st));
+  HIPCK(dq::herm_defect_launch<T>(X, c->d, c->scratch.d(), c->st));
   double h = 0.0;
   HIPCK(hipMemcpyAsync(&h, c->scratch.p, sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPCK(hipStreamSynchronize(c->st));
   return h;
 }
 
-void check_ctx(dq_ctx* c) {
+template <class T>
+void check_ctx(Ctx<T>* c) {
   if (!c) fail(DQ_ERR_INVALID, "null context");
   HIPCK(hipSetDevice(c->dev));
 }
 
 // number of steps whose exp() is built in one batched pass
-int time_chunk(dq_ctx* c, int n_steps) {
+template <class T>
+int time_chunk(Ctx<T>* c, int n_steps) {
   const double per_step = 24.0 * (double)c->mat_bytes();  // tape variables + their adjoints
   long tc = (long)(c->chunk_bytes / per_step);
   tc = std::max(1L, std::min<long>(tc, n_steps));
@@ -461,13 +489,15 @@ int time_chunk(dq_ctx* c, int n_steps) {
   return (int)tc;
 }
 
-double theta_bound(dq_ctx* c, const double* u_row, double dt) {
+template <class T>
+double theta_bound(Ctx<T>* c, const double* u_row, double dt) {
   double h = c->nH0;
   for (int k = 0; k < c->K; ++k) h += std::fabs(u_row[k]) * c->nHk[k];
   return std::fabs(dt) * h;
 }
 
-std::vector<double> fetch_u(dq_ctx* c, const double* u, int S) {
+template <class T>
+std::vector<double> fetch_u(Ctx<T>* c, const double* u, int S) {
   const size_t n = (size_t)S * c->K;
   std::vector<double> h(n);
   if (n == 0) return h;
@@ -485,7 +515,8 @@ std::vector<double> fetch_u(dq_ctx* c, const double* u, int S) {
   return h;
 }
 
-ExpmPlan chunk_plan(dq_ctx* c, const std::vector<double>& uh, int c0, int n, double dt) {
+template <class T>
+ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, double dt) {
   double th = 0.0;
   for (int t = c0; t < c0 + n; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
   c->last_theta = th;
@@ -493,21 +524,26 @@ ExpmPlan chunk_plan(dq_ctx* c, const std::vector<double>& uh, int c0, int n, dou
 }
 
 // assemble + exp for steps [c0, c0+n): returns pointer to n stacked propagators
-double2* build_propagators(dq_ctx* c, const ExpmPlan& p, int c0, int n, double dt) {  // n stacked U_t
-  double2* A = c->mat(0, n);
-  const double by = 16.0 * c->nn() * (c->K + 2.0) * n;
+template <class T>
+TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
+  typedef TT T2;
+  T2* A = c->mat(0, n);
+  const double by = 2.0 * sizeof(T) * c->nn() * (c->K + 2.0) * n;
   c->timed(DQ_PROF_ASSEMBLE, 2.0 * 2 * c->nn() * (c->K + 1.0) * n, by, [&] {
-    return dq::assemble_launch(A, c->H0.z(), c->Hs.z(), c->u_dev.d() + (size_t)c0 * c->K, c->K, (long)c->nn(), n, dt,
-                               c->st);
+    return dq::assemble_launch<T>(A, (const T2*)c->H0.p, (const T2*)c->Hs.p, c->u_dev.d() + (size_t)c0 * c->K, c->K,
+                                  (long)c->nn(), n, dt, c->st);
   });
   return expm_forward(c, p, n);
 }
 
-void require_H(dq_ctx* c) {
+template <class T>
+void require_H(Ctx<T>* c) {
   if (!c->have_H) fail(DQ_ERR_STATE, "dq_set_hamiltonians has not been called");
 }
 
-void do_propagate(dq_ctx* c, const double* u, int S, double dt, const double* psi_in, double* psi_out, int B) {
+template <class T>
+void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_in, void* psi_out, int B) {
+  typedef TT T2;
   check_ctx(c);
   require_H(c);
   if (S < 0 || B < 0) fail(DQ_ERR_INVALID, "n_steps and batch must be >= 0");
@@ -516,7 +552,7 @@ void do_propagate(dq_ctx* c, const double* u, int S, double dt, const double* ps
   if (!psi_in || !psi_out) fail(DQ_ERR_INVALID, "null state pointer");
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d;
-  const size_t sb = (size_t)d * B * sizeof(double2);
+  const size_t sb = (size_t)d * B * sizeof(T2);
   std::vector<double> uh = fetch_u(c, u, S);
   c->psi[0].ensure(sb);
   c->psi[1].ensure(sb);
@@ -529,15 +565,15 @@ void do_propagate(dq_ctx* c, const double* u, int S, double dt, const double* ps
   for (int c0 = 0; c0 < S; c0 += tc) {
     const int n = std::min(tc, S - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
-    double2* U = build_propagators(c, p, c0, n, dt);
+    T2* U = build_propagators(c, p, c0, n, dt);
     if (compose && n > 1) {
       // operator form: V = U_{n-1} ... U_0 by a log-depth tree of batched products, then ONE apply.
       // 8 d^3 flop per step instead of 8 d^2 B, and O(log n) launches instead of n.
-      double2* X = U;
+      T2* X = U;
       int m = n, lvl = 0;
       while (m > 1) {
         const int pairs = m / 2;
-        double2* Y = c->mat(SLOT_TREE + (lvl & 1), (size_t)(pairs + (m & 1)));
+        T2* Y = c->mat(SLOT_TREE + (lvl & 1), (size_t)(pairs + (m & 1)));
         const long s2 = 2 * (long)c->nn();
         c->zgemm(0, 0, d, d, d, 1.0, X + c->nn(), d, s2, X, d, s2, 0.0, Y, d, (long)c->nn(), pairs);
         if (m & 1)
@@ -547,12 +583,12 @@ void do_propagate(dq_ctx* c, const double* u, int S, double dt, const double* ps
         m = pairs + (m & 1);
         ++lvl;
       }
-      c->zgemm(0, 0, d, B, d, 1.0, X, d, 0, c->psi[cur].z(), B, 0, 0.0, c->psi[cur ^ 1].z(), B, 0, 1);
+      c->zgemm(0, 0, d, B, d, 1.0, X, d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->psi[cur ^ 1].p, B, 0, 1);
       cur ^= 1;
     } else {
       for (int t = 0; t < n; ++t) {
-        c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, c->psi[cur].z(), B, 0, 0.0, c->psi[cur ^ 1].z(),
-                 B, 0, 1);
+        c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
+                 (T2*)c->psi[cur ^ 1].p, B, 0, 1);
         cur ^= 1;
       }
     }
@@ -562,19 +598,23 @@ void do_propagate(dq_ctx* c, const double* u, int S, double dt, const double* ps
   HIPCK(hipStreamSynchronize(c->st));
 }
 
-void do_energy(dq_ctx* c, const double2* psi_dev, int B, double2* lam_out /*2 M psi*/, double* energies, double* total) {
+template <class T>
+void do_energy(Ctx<T>* c, const TT* psi_dev, int B, TT* lam_out /*2 M psi*/, double* energies, double* total) {
+  typedef TT T2;
   const int d = c->d;
-  c->zgemm(0, 0, d, B, d, 2.0, c->M.z(), d, 0, psi_dev, B, 0, 0.0, lam_out, B, 0, 1);
+  c->zgemm(0, 0, d, B, d, 2.0, (const T2*)c->M.p, d, 0, psi_dev, B, 0, 0.0, lam_out, B, 0, 1);
   c->e_dev.ensure(sizeof(double) * ((size_t)B + 1));
-  c->timed(DQ_PROF_OTHER, 4.0 * d * B, 32.0 * d * B,
-           [&] { return dq::coldot_launch(psi_dev, B, lam_out, B, d, B, 0.5, c->e_dev.d(), c->st); });
+  c->timed(DQ_PROF_OTHER, 4.0 * d * B, 4.0 * sizeof(T) * d * B,
+           [&] { return dq::coldot_launch<T>(psi_dev, B, lam_out, B, d, B, 0.5, c->e_dev.d(), c->st); });
   c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(c->e_dev.d(), B, c->e_dev.d() + B, c->st); });
   if (energies) out_copy(c, energies, c->e_dev.p, sizeof(double) * (size_t)B);
   if (total) out_copy(c, total, c->e_dev.d() + B, sizeof(double));
 }
 
-void do_energy_grad(dq_ctx* c, const double* u, int S, double dt, const double* psi0, int B, double* loss,
-                    double* grad_u, double* psi_final, double* energies) {
+template <class T>
+void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* psi0, int B, double* loss,
+                    double* grad_u, void* psi_final, double* energies) {
+  typedef TT T2;
   check_ctx(c);
   require_H(c);
   if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
@@ -586,7 +626,7 @@ void do_energy_grad(dq_ctx* c, const double* u, int S, double dt, const double* 
   if (!psi0) fail(DQ_ERR_INVALID, "null state pointer");
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d, K = c->K;
-  const size_t sb = (size_t)d * B * sizeof(double2);
+  const size_t sb = (size_t)d * B * sizeof(T2);
   std::vector<double> uh = fetch_u(c, u, S);
 
   // checkpoint stride from the memory budget
@@ -614,7 +654,7 @@ void do_energy_grad(dq_ctx* c, const double* u, int S, double dt, const double* 
   for (int c0 = 0; c0 < S; c0 += tc) {
     const int n = std::min(tc, S - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
-    const double2* U = build_propagators(c, p, c0, n, dt);
+    const T2* U = build_propagators(c, p, c0, n, dt);
     for (int t = 0; t < n; ++t) {
       const int tt = c0 + t;
       if (tt % cstride == 0) {
@@ -624,17 +664,17 @@ void do_energy_grad(dq_ctx* c, const double* u, int S, double dt, const double* 
         c->timed(DQ_PROF_OTHER, 0.0, 2.0 * bytes,
                  [&] { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->st); });
       }
-      c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, c->psi[cur].z(), B, 0, 0.0, c->psi[cur ^ 1].z(), B,
-               0, 1);
+      c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
+               (T2*)c->psi[cur ^ 1].p, B, 0, 1);
       cur ^= 1;
     }
   }
   // psi[cur] = Psi_S ; terminal costate Lambda_S = 2 M Psi_S, energies
-  do_energy(c, c->psi[cur].z(), B, c->lam[0].z(), energies, loss);
+  do_energy(c, (const T2*)c->psi[cur].p, B, (T2*)c->lam[0].p, energies, loss);
   if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
 
   // ---- backward ----
-  const double2* psi_next = c->psi[cur].z();
+  const T2* psi_next = (const T2*)c->psi[cur].p;
   int lcur = 0;
   if (S > 0) {
     const int nblk = dq::grad_contract_blocks((long)c->nn());
@@ -642,41 +682,195 @@ void do_energy_grad(dq_ctx* c, const double* u, int S, double dt, const double* 
     for (int c0 = last_c0; c0 >= 0; c0 -= tc) {
       const int n = std::min(tc, S - c0);
       const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
-      const double2* U = build_propagators(c, p, c0, n, dt);
-      double2* G = ubar_slot(c, p, n);
+      const T2* U = build_propagators(c, p, c0, n, dt);
+      T2* G = ubar_slot(c, p, n);
       for (int t = n - 1; t >= 0; --t) {
         const int tt = c0 + t;
-        const double2* Ut = U + (size_t)t * c->nn();
-        const double2* psi_t;
+        const T2* Ut = U + (size_t)t * c->nn();
+        const T2* psi_t;
         if (tt % cstride == 0) {
-          psi_t = c->ck[tt / cstride].z();
+          psi_t = (const T2*)c->ck[tt / cstride].p;
         } else {
           // pick a scratch buffer that does not hold psi_next
-          double2* dst = nullptr;
+          T2* dst = nullptr;
           for (int i = 0; i < 3; ++i)
-            if (c->psi[i].z() != psi_next) { dst = c->psi[i].z(); break; }
+            if ((const T2*)c->psi[i].p != psi_next) { dst = (T2*)c->psi[i].p; break; }
           c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, psi_next, B, 0, 0.0, dst, B, 0, 1);  // psi_t = U_t^H psi_{t+1}
           psi_t = dst;
         }
         // G_t = Lambda_{t+1} Psi_t^H    (cotangent of U_t)
-        c->zgemm(0, 1, d, d, B, 1.0, c->lam[lcur].z(), B, 0, psi_t, B, 0, 0.0, G + (size_t)t * c->nn(), d, 0, 1);
+        c->zgemm(0, 1, d, d, B, 1.0, (const T2*)c->lam[lcur].p, B, 0, psi_t, B, 0, 0.0, G + (size_t)t * c->nn(), d, 0,
+                 1);
         // Lambda_t = U_t^H Lambda_{t+1}
-        c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, c->lam[lcur].z(), B, 0, 0.0, c->lam[lcur ^ 1].z(), B, 0, 1);
+        c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, (const T2*)c->lam[lcur].p, B, 0, 0.0, (T2*)c->lam[lcur ^ 1].p, B, 0, 1);
         lcur ^= 1;
         psi_next = psi_t;
       }
-      const double2* Abar = expm_backward(c, p, n);
+      const T2* Abar = expm_backward(c, p, n);
       c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
-      const double by = 16.0 * c->nn() * (K + ((K + 7) / 8)) * n;
+      const double by = 2.0 * sizeof(T) * c->nn() * (K + ((K + 7) / 8)) * n;
       c->timed(DQ_PROF_GRADC, 3.0 * c->nn() * K * n, by, [&] {
-        return dq::grad_contract_launch(Abar, (long)c->nn(), c->Hs.z(), K, (long)c->nn(), n, dt, c->part.d(),
-                                        c->grad_dev.d() + (size_t)c0 * K, c->st);
+        return dq::grad_contract_launch<T>(Abar, (long)c->nn(), (const T2*)c->Hs.p, K, (long)c->nn(), n, dt,
+                                           c->part.d(), c->grad_dev.d() + (size_t)c0 * K, c->st);
       });
     }
   }
   if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
   HIPCK(hipStreamSynchronize(c->st));
 }
+
+template <class T>
+void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
+  typedef TT T2;
+  check_ctx(c);
+  if (!H0 || (c->K > 0 && !Hs)) fail(DQ_ERR_INVALID, "null Hamiltonian pointer");
+  c->have_H = false;
+  c->H0.ensure(c->mat_bytes());
+  c->Hs.ensure(std::max<size_t>(c->K, 1) * c->mat_bytes());
+  HIPCK(hipMemcpyAsync(c->H0.p, H0, c->mat_bytes(), hipMemcpyDefault, c->st));
+  if (c->K > 0) HIPCK(hipMemcpyAsync(c->Hs.p, Hs, (size_t)c->K * c->mat_bytes(), hipMemcpyDefault, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  c->nH0 = norm1_dev(c, (const T2*)c->H0.p);
+  double defect = herm_defect_dev(c, (const T2*)c->H0.p);
+  double scale = std::max(1.0, c->nH0);
+  for (int k = 0; k < c->K; ++k) {
+    const T2* Hk = (const T2*)c->Hs.p + (size_t)k * c->nn();
+    c->nHk[k] = norm1_dev(c, Hk);
+    defect = std::max(defect, herm_defect_dev(c, Hk));
+    scale = std::max(scale, c->nHk[k]);
+  }
+  c->hermitian = defect <= c->herm_tol * scale;
+  c->have_H = true;
+}
+
+template <class T>
+void do_set_observable(Ctx<T>* c, const void* M) {
+  typedef TT T2;
+  check_ctx(c);
+  if (!M) fail(DQ_ERR_INVALID, "null observable pointer");
+  c->have_M = false;
+  c->M.ensure(c->mat_bytes());
+  HIPCK(hipMemcpyAsync(c->M.p, M, c->mat_bytes(), hipMemcpyDefault, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  const double nm = norm1_dev(c, (const T2*)c->M.p);
+  if (herm_defect_dev(c, (const T2*)c->M.p) > c->herm_tol * std::max(1.0, nm))
+    fail(DQ_ERR_INVALID, "observable must be Hermitian");
+  c->have_M = true;
+}
+
+template <class T>
+void do_zgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch) {
+  typedef TT T2;
+  check_ctx(c);
+  if (M < 0 || N < 0 || K < 0 || batch < 0) fail(DQ_ERR_INVALID, "negative dimension");
+  if ((opA | opB) & ~1) fail(DQ_ERR_INVALID, "op must be 0 (N) or 1 (conjugate transpose)");
+  if (M == 0 || N == 0 || batch == 0) return;
+  if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
+  const long ar = opA ? K : M, ac = opA ? M : K;  // stored shape of A
+  const long br = opB ? N : K, bc = opB ? K : N;
+  if (lda < ac || ldb < bc || ldc < N) fail(DQ_ERR_INVALID, "leading dimension smaller than the row length");
+  auto span = [&](long rows, long ld, long cols, long stride) -> size_t {
+    if (rows == 0 || cols == 0) return 0;
+    return (size_t)((batch - 1) * stride + (rows - 1) * ld + cols) * sizeof(T2);
+  };
+  if (batch > 1 && strideC < (M - 1) * ldc + N) fail(DQ_ERR_INVALID, "overlapping output batch stride");
+  const size_t ba = span(ar, lda, ac, strideA), bb = span(br, ldb, bc, strideB), bcz = span(M, ldc, N, strideC);
+  const T2* dA = ba ? in_dev(c, A, ba, c->tmp_in[0]) : (const T2*)c->tmp_in[0].p;
+  const T2* dB = bb ? in_dev(c, B, bb, c->tmp_in[1]) : (const T2*)c->tmp_in[1].p;
+  T2* dC;
+  const bool c_dev = is_device_ptr(C);
+  if (c_dev) dC = (T2*)C;
+  else {
+    c->tmp_in[2].ensure(bcz);
+    stage_h2d(c, c->tmp_in[2].p, C, bcz);  // beta*C and untouched gaps
+    dC = (T2*)c->tmp_in[2].p;
+  }
+  c->zgemm(opA, opB, M, N, K, alpha, dA, lda, strideA, dB, ldb, strideB, beta, dC, ldc, strideC, batch);
+  if (!c_dev) out_copy(c, C, dC, bcz);
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+double stacked_theta(Ctx<T>* c, const TT* P, int batch) {
+  double th = 0.0;
+  for (int z = 0; z < batch; ++z) th = std::max(th, norm1_dev(c, P + (size_t)z * c->nn()));
+  c->last_theta = th;
+  return th;
+}
+
+template <class T>
+void do_expm(Ctx<T>* c, const void* A, void* U, int batch) {
+  typedef TT T2;
+  check_ctx(c);
+  if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
+  if (batch == 0) return;
+  if (!A || !U) fail(DQ_ERR_INVALID, "null matrix pointer");
+  T2* P1 = c->mat(0, batch);
+  HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
+  const ExpmPlan p = choose_plan(stacked_theta(c, P1, batch), c->expm_tol, c->force_degree, c->force_s);
+  const T2* Ud = expm_forward(c, p, batch);
+  out_copy(c, U, Ud, (size_t)batch * c->mat_bytes());
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+void do_expm_vjp(Ctx<T>* c, const void* A, const void* Ubar, void* Abar, int batch) {
+  typedef TT T2;
+  check_ctx(c);
+  if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
+  if (batch == 0) return;
+  if (!A || !Ubar || !Abar) fail(DQ_ERR_INVALID, "null matrix pointer");
+  T2* P1 = c->mat(0, batch);
+  HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
+  const ExpmPlan p = choose_plan(stacked_theta(c, P1, batch), c->expm_tol, c->force_degree, c->force_s);
+  (void)expm_forward(c, p, batch);
+  T2* G = ubar_slot(c, p, batch);
+  HIPCK(hipMemcpyAsync(G, Ubar, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
+  const T2* Ab = expm_backward(c, p, batch);
+  out_copy(c, Abar, Ab, (size_t)batch * c->mat_bytes());
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+void do_set_option(Ctx<T>* c, const std::string& s, double v) {
+  if (s == "checkpoint_bytes") c->checkpoint_bytes = v;
+  else if (s == "chunk_bytes") { if (!(v > 0)) fail(DQ_ERR_INVALID, "chunk_bytes must be > 0"); c->chunk_bytes = v; }
+  else if (s == "expm_tol") { if (!(v > 0)) fail(DQ_ERR_INVALID, "expm_tol must be > 0"); c->expm_tol = v; }
+  else if (s == "force_degree") c->force_degree = (int)v;
+  else if (s == "force_squarings") c->force_s = (int)v;
+  else if (s == "force_tile") {
+    const int t = (int)v;
+    if (t != 0 && t != 32 && t != 64 && t != 128) fail(DQ_ERR_INVALID, "force_tile must be 0, 32, 64 or 128");
+    c->force_tile = t;
+  } else if (s == "compose") {  // -1 auto (batch > dim), 0 never, 1 always
+    c->compose_mode = (int)v < 0 ? -1 : ((int)v ? 1 : 0);
+  } else if (s == "zgemm_alg") {
+    const int a = (int)v;
+    if (a != 0 && a != 1) fail(DQ_ERR_INVALID, "zgemm_alg must be 0 (4M) or 1 (3M)");
+    c->zgemm_alg = a;
+  } else fail(DQ_ERR_INVALID, "unknown option '" + s + "'");
+}
+
+template <class T>
+double do_get_info(Ctx<T>* c, const std::string& s) {
+  if (s == "degree") return c->last_degree;
+  if (s == "squarings") return c->last_squarings;
+  if (s == "products") return c->last_products;
+  if (s == "time_chunk") return c->last_chunk;
+  if (s == "checkpoint_stride") return c->last_cstride;
+  if (s == "theta") return c->last_theta;
+  if (s == "hermitian") return c->hermitian ? 1.0 : 0.0;
+  if (s == "zgemm_alg") return sizeof(T) == 8 ? c->zgemm_alg : 1;
+  if (s == "composed") return c->last_composed;
+  if (s == "norm_H0") return c->nH0;
+  if (s == "dim") return c->d;
+  if (s == "n_controls") return c->K;
+  if (s == "dtype") return c->dtype;
+  fail(DQ_ERR_INVALID, "unknown info '" + s + "'");
+}
+
+#undef TT
 
 template <class F>
 int guarded(F&& f) {
@@ -692,11 +886,21 @@ int guarded(F&& f) {
   }
 }
 
+// run f on the typed context behind the type-erased handle
+template <class F>
+int with_ctx(dq_ctx* c, F&& f) {
+  return guarded([&] {
+    if (!c) fail(DQ_ERR_INVALID, "null context");
+    if (c->dtype == DQ_C128) f(static_cast<Ctx<double>*>(c));
+    else f(static_cast<Ctx<float>*>(c));
+  });
+}
+
 }  // namespace
 
 extern "C" {
 
-const char* dq_version(void) { return "diffqc_hip 0.1 (gfx950)"; }
+const char* dq_version(void) { return "diffqc_hip 0.2 (gfx950; complex128 + complex64)"; }
 const char* dq_last_error(void) { return g_err.c_str(); }
 
 int dq_device_count(int* n) {
@@ -709,12 +913,13 @@ int dq_device_count(int* n) {
   });
 }
 
-int dq_create(dq_ctx** out, int dim, int n_controls, int device_id) {
+int dq_create_ex(dq_ctx** out, int dim, int n_controls, int device_id, int dtype) {
   return guarded([&] {
     if (!out) fail(DQ_ERR_INVALID, "null output");
     *out = nullptr;
     if (dim < 1 || dim > (1 << 15)) fail(DQ_ERR_INVALID, "dim must be in [1, 32768]");
     if (n_controls < 0 || n_controls > 4096) fail(DQ_ERR_INVALID, "n_controls must be in [0, 4096]");
+    if (dtype != DQ_C128 && dtype != DQ_C64) fail(DQ_ERR_INVALID, "dtype must be DQ_C128 or DQ_C64");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -723,238 +928,130 @@ int dq_create(dq_ctx** out, int dim, int n_controls, int device_id) {
     }
     if (device_id < 0 || device_id >= ndev) fail(DQ_ERR_INVALID, "device_id out of range");
     HIPCK(hipSetDevice(device_id));
-    dq_ctx* c = new dq_ctx();
-    c->d = dim;
-    c->K = n_controls;
-    c->dev = device_id;
-    c->nHk.assign(n_controls, 0.0);
-    *out = c;
+    auto init = [&](auto* c) {
+      c->d = dim;
+      c->K = n_controls;
+      c->dev = device_id;
+      c->nHk.assign(n_controls, 0.0);
+      *out = c;
+    };
+    if (dtype == DQ_C128) init(new Ctx<double>());
+    else init(new Ctx<float>());
   });
 }
 
+int dq_create(dq_ctx** out, int dim, int n_controls, int device_id) {
+  return dq_create_ex(out, dim, n_controls, device_id, DQ_C128);
+}
+
 int dq_destroy(dq_ctx* c) {
-  return guarded([&] {
-    if (!c) return;
-    (void)hipSetDevice(c->dev);
-    (void)hipStreamSynchronize(c->st);
-    delete c;
+  if (!c) return DQ_OK;
+  return with_ctx(c, [&](auto* t) {
+    (void)hipSetDevice(t->dev);
+    (void)hipStreamSynchronize(t->st);
+    delete t;
   });
 }
 
 int dq_set_stream(dq_ctx* c, void* s) {
-  return guarded([&] {
-    check_ctx(c);
-    HIPCK(hipStreamSynchronize(c->st));
-    c->st = (hipStream_t)s;
+  return with_ctx(c, [&](auto* t) {
+    check_ctx(t);
+    HIPCK(hipStreamSynchronize(t->st));
+    t->st = (hipStream_t)s;
   });
 }
 
 int dq_synchronize(dq_ctx* c) {
-  return guarded([&] {
-    check_ctx(c);
-    HIPCK(hipStreamSynchronize(c->st));
+  return with_ctx(c, [&](auto* t) {
+    check_ctx(t);
+    HIPCK(hipStreamSynchronize(t->st));
   });
 }
 
-int dq_set_hamiltonians(dq_ctx* c, const double* H0, const double* Hs) {
-  return guarded([&] {
-    check_ctx(c);
-    if (!H0 || (c->K > 0 && !Hs)) fail(DQ_ERR_INVALID, "null Hamiltonian pointer");
-    c->have_H = false;
-    c->H0.ensure(c->mat_bytes());
-    c->Hs.ensure(std::max<size_t>(c->K, 1) * c->mat_bytes());
-    HIPCK(hipMemcpyAsync(c->H0.p, H0, c->mat_bytes(), hipMemcpyDefault, c->st));
-    if (c->K > 0) HIPCK(hipMemcpyAsync(c->Hs.p, Hs, (size_t)c->K * c->mat_bytes(), hipMemcpyDefault, c->st));
-    HIPCK(hipStreamSynchronize(c->st));
-    c->nH0 = norm1_dev(c, c->H0.z());
-    double defect = herm_defect_dev(c, c->H0.z());
-    double scale = std::max(1.0, c->nH0);
-    for (int k = 0; k < c->K; ++k) {
-      const double2* Hk = c->Hs.z() + (size_t)k * c->nn();
-      c->nHk[k] = norm1_dev(c, Hk);
-      defect = std::max(defect, herm_defect_dev(c, Hk));
-      scale = std::max(scale, c->nHk[k]);
-    }
-    c->hermitian = defect <= 1e-12 * scale;
-    c->have_H = true;
-  });
+int dq_set_hamiltonians(dq_ctx* c, const void* H0, const void* Hs) {
+  return with_ctx(c, [&](auto* t) { do_set_hamiltonians(t, H0, Hs); });
 }
 
-int dq_set_observable(dq_ctx* c, const double* M) {
-  return guarded([&] {
-    check_ctx(c);
-    if (!M) fail(DQ_ERR_INVALID, "null observable pointer");
-    c->have_M = false;
-    c->M.ensure(c->mat_bytes());
-    HIPCK(hipMemcpyAsync(c->M.p, M, c->mat_bytes(), hipMemcpyDefault, c->st));
-    HIPCK(hipStreamSynchronize(c->st));
-    const double nm = norm1_dev(c, c->M.z());
-    if (herm_defect_dev(c, c->M.z()) > 1e-12 * std::max(1.0, nm)) fail(DQ_ERR_INVALID, "observable must be Hermitian");
-    c->have_M = true;
-  });
+int dq_set_observable(dq_ctx* c, const void* M) {
+  return with_ctx(c, [&](auto* t) { do_set_observable(t, M); });
 }
 
 int dq_set_option(dq_ctx* c, const char* name, double v) {
-  return guarded([&] {
-    check_ctx(c);
+  return with_ctx(c, [&](auto* t) {
+    check_ctx(t);
     if (!name) fail(DQ_ERR_INVALID, "null option name");
-    const std::string s(name);
-    if (s == "checkpoint_bytes") c->checkpoint_bytes = v;
-    else if (s == "chunk_bytes") { if (!(v > 0)) fail(DQ_ERR_INVALID, "chunk_bytes must be > 0"); c->chunk_bytes = v; }
-    else if (s == "expm_tol") { if (!(v > 0)) fail(DQ_ERR_INVALID, "expm_tol must be > 0"); c->expm_tol = v; }
-    else if (s == "force_degree") c->force_degree = (int)v;
-    else if (s == "force_squarings") c->force_s = (int)v;
-    else if (s == "force_tile") {
-      const int t = (int)v;
-      if (t != 0 && t != 32 && t != 64 && t != 128) fail(DQ_ERR_INVALID, "force_tile must be 0, 32, 64 or 128");
-      c->force_tile = t;
-    } else if (s == "compose") {  // -1 auto (batch > dim), 0 never, 1 always
-      c->compose_mode = (int)v < 0 ? -1 : ((int)v ? 1 : 0);
-    } else if (s == "zgemm_alg") {
-      const int a = (int)v;
-      if (a != 0 && a != 1) fail(DQ_ERR_INVALID, "zgemm_alg must be 0 (4M) or 1 (3M)");
-      c->zgemm_alg = a;
-    } else fail(DQ_ERR_INVALID, "unknown option '" + s + "'");
+    do_set_option(t, std::string(name), v);
   });
 }
 
 int dq_get_info(dq_ctx* c, const char* name, double* v) {
-  return guarded([&] {
-    check_ctx(c);
+  return with_ctx(c, [&](auto* t) {
+    check_ctx(t);
     if (!name || !v) fail(DQ_ERR_INVALID, "null argument");
-    const std::string s(name);
-    if (s == "degree") *v = c->last_degree;
-    else if (s == "squarings") *v = c->last_squarings;
-    else if (s == "products") *v = c->last_products;
-    else if (s == "time_chunk") *v = c->last_chunk;
-    else if (s == "checkpoint_stride") *v = c->last_cstride;
-    else if (s == "theta") *v = c->last_theta;
-    else if (s == "hermitian") *v = c->hermitian ? 1.0 : 0.0;
-    else if (s == "zgemm_alg") *v = c->zgemm_alg;
-    else if (s == "composed") *v = c->last_composed;
-    else if (s == "norm_H0") *v = c->nH0;
-    else if (s == "dim") *v = c->d;
-    else if (s == "n_controls") *v = c->K;
-    else fail(DQ_ERR_INVALID, "unknown info '" + s + "'");
+    *v = do_get_info(t, std::string(name));
   });
 }
 
-int dq_propagate(dq_ctx* c, const double* u, int n_steps, double dt, const double* psi_in, double* psi_out, int batch) {
-  return guarded([&] { do_propagate(c, u, n_steps, dt, psi_in, psi_out, batch); });
+int dq_propagate(dq_ctx* c, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out, int batch) {
+  return with_ctx(c, [&](auto* t) { do_propagate(t, u, n_steps, dt, psi_in, psi_out, batch); });
 }
 
-int dq_energy(dq_ctx* c, const double* psi, int batch, double* energies, double* total) {
-  return guarded([&] {
-    check_ctx(c);
-    if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
+int dq_energy(dq_ctx* c, const void* psi, int batch, double* energies, double* total) {
+  return with_ctx(c, [&](auto* t) {
+    typedef typename std::remove_pointer<decltype(t)>::type::T2 T2;
+    check_ctx(t);
+    if (!t->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
     if (batch <= 0 || !psi) fail(DQ_ERR_INVALID, "need batch > 0 and a state pointer");
-    const size_t sb = (size_t)c->d * batch * sizeof(double2);
-    const double2* p = in_dev(c, psi, sb, c->tmp_in[0]);
-    c->lam[0].ensure(sb);
-    do_energy(c, p, batch, c->lam[0].z(), energies, total);
-    HIPCK(hipStreamSynchronize(c->st));
+    const size_t sb = (size_t)t->d * batch * sizeof(T2);
+    const T2* p = in_dev(t, psi, sb, t->tmp_in[0]);
+    t->lam[0].ensure(sb);
+    do_energy(t, p, batch, (T2*)t->lam[0].p, energies, total);
+    HIPCK(hipStreamSynchronize(t->st));
   });
 }
 
-int dq_energy_grad(dq_ctx* c, const double* u, int n_steps, double dt, const double* psi0, int batch, double* loss,
-                   double* grad_u, double* psi_final, double* energies) {
-  return guarded([&] { do_energy_grad(c, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, energies); });
+int dq_energy_grad(dq_ctx* c, const double* u, int n_steps, double dt, const void* psi0, int batch, double* loss,
+                   double* grad_u, void* psi_final, double* energies) {
+  return with_ctx(c, [&](auto* t) { do_energy_grad(t, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, energies); });
 }
 
-int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const double* A, long lda, long strideA,
-             const double* B, long ldb, long strideB, double beta, double* C, long ldc, long strideC, int batch) {
-  return guarded([&] {
-    check_ctx(c);
-    if (M < 0 || N < 0 || K < 0 || batch < 0) fail(DQ_ERR_INVALID, "negative dimension");
-    if ((opA | opB) & ~1) fail(DQ_ERR_INVALID, "op must be 0 (N) or 1 (conjugate transpose)");
-    if (M == 0 || N == 0 || batch == 0) return;
-    if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
-    const long ar = opA ? K : M, ac = opA ? M : K;  // stored shape of A
-    const long br = opB ? N : K, bc = opB ? K : N;
-    if (lda < ac || ldb < bc || ldc < N) fail(DQ_ERR_INVALID, "leading dimension smaller than the row length");
-    auto span = [&](long rows, long ld, long cols, long stride) -> size_t {
-      if (rows == 0 || cols == 0) return 0;
-      return (size_t)((batch - 1) * stride + (rows - 1) * ld + cols) * sizeof(double2);
-    };
-    if (batch > 1 && strideC < (M - 1) * ldc + N) fail(DQ_ERR_INVALID, "overlapping output batch stride");
-    const size_t ba = span(ar, lda, ac, strideA), bb = span(br, ldb, bc, strideB), bcz = span(M, ldc, N, strideC);
-    const double2* dA = ba ? in_dev(c, A, ba, c->tmp_in[0]) : (const double2*)c->tmp_in[0].p;
-    const double2* dB = bb ? in_dev(c, B, bb, c->tmp_in[1]) : (const double2*)c->tmp_in[1].p;
-    double2* dC;
-    const bool c_dev = is_device_ptr(C);
-    if (c_dev) dC = (double2*)C;
-    else {
-      c->tmp_in[2].ensure(bcz);
-      stage_h2d(c, c->tmp_in[2].p, C, bcz);  // beta*C and untouched gaps
-      dC = c->tmp_in[2].z();
-    }
-    c->zgemm(opA, opB, M, N, K, alpha, dA, lda, strideA, dB, ldb, strideB, beta, dC, ldc, strideC, batch);
-    if (!c_dev) out_copy(c, C, dC, bcz);
-    HIPCK(hipStreamSynchronize(c->st));
+int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+             const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch) {
+  return with_ctx(c, [&](auto* t) {
+    do_zgemm(t, opA, opB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch);
   });
 }
 
-int dq_expm(dq_ctx* c, const double* A, double* U, int batch) {
-  return guarded([&] {
-    check_ctx(c);
-    if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
-    if (batch == 0) return;
-    if (!A || !U) fail(DQ_ERR_INVALID, "null matrix pointer");
-    double2* P1 = c->mat(0, batch);
-    HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
-    double th = 0.0;
-    for (int z = 0; z < batch; ++z) th = std::max(th, norm1_dev(c, P1 + (size_t)z * c->nn()));
-    c->last_theta = th;
-    const ExpmPlan p = choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
-    const double2* Ud = expm_forward(c, p, batch);
-    out_copy(c, U, Ud, (size_t)batch * c->mat_bytes());
-    HIPCK(hipStreamSynchronize(c->st));
-  });
+int dq_expm(dq_ctx* c, const void* A, void* U, int batch) {
+  return with_ctx(c, [&](auto* t) { do_expm(t, A, U, batch); });
 }
 
-int dq_expm_vjp(dq_ctx* c, const double* A, const double* Ubar, double* Abar, int batch) {
-  return guarded([&] {
-    check_ctx(c);
-    if (batch < 0) fail(DQ_ERR_INVALID, "negative batch");
-    if (batch == 0) return;
-    if (!A || !Ubar || !Abar) fail(DQ_ERR_INVALID, "null matrix pointer");
-    double2* P1 = c->mat(0, batch);
-    HIPCK(hipMemcpyAsync(P1, A, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
-    double th = 0.0;
-    for (int z = 0; z < batch; ++z) th = std::max(th, norm1_dev(c, P1 + (size_t)z * c->nn()));
-    c->last_theta = th;
-    const ExpmPlan p = choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
-    (void)expm_forward(c, p, batch);
-    double2* G = ubar_slot(c, p, batch);
-    HIPCK(hipMemcpyAsync(G, Ubar, (size_t)batch * c->mat_bytes(), hipMemcpyDefault, c->st));
-    const double2* Ab = expm_backward(c, p, batch);
-    out_copy(c, Abar, Ab, (size_t)batch * c->mat_bytes());
-    HIPCK(hipStreamSynchronize(c->st));
-  });
+int dq_expm_vjp(dq_ctx* c, const void* A, const void* Ubar, void* Abar, int batch) {
+  return with_ctx(c, [&](auto* t) { do_expm_vjp(t, A, Ubar, Abar, batch); });
 }
 
 int dq_profile_enable(dq_ctx* c, int on) {
-  return guarded([&] {
-    check_ctx(c);
-    c->prof_collect();
-    c->prof_on = on != 0;
+  return with_ctx(c, [&](auto* t) {
+    check_ctx(t);
+    t->prof_collect();
+    t->prof_on = on != 0;
   });
 }
 
 int dq_profile_reset(dq_ctx* c) {
-  return guarded([&] {
-    check_ctx(c);
-    c->prof_collect();
-    memset(&c->prof_acc, 0, sizeof(c->prof_acc));
+  return with_ctx(c, [&](auto* t) {
+    check_ctx(t);
+    t->prof_collect();
+    memset(&t->prof_acc, 0, sizeof(t->prof_acc));
   });
 }
 
 int dq_profile_get(dq_ctx* c, dq_profile* out) {
-  return guarded([&] {
-    check_ctx(c);
+  return with_ctx(c, [&](auto* t) {
+    check_ctx(t);
     if (!out) fail(DQ_ERR_INVALID, "null output");
-    c->prof_collect();
-    *out = c->prof_acc;
+    t->prof_collect();
+    *out = t->prof_acc;
   });
 }
 

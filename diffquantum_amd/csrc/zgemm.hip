@@ -1,46 +1,76 @@
-// Batched complex-double GEMM on the gfx950 f64 matrix cores (v_mfma_f64_16x16x4_f64).
+// Batched complex GEMM on the gfx950 matrix cores, fp64 (v_mfma_f64_16x16x4_f64) and fp32
+// (v_mfma_f32_16x16x4_f32) complex.
 //
 //   C[z] = alpha * op(A[z]) * op(B[z]) + beta * C[z]       op in {N, C (conjugate transpose)}
 //
 // This one kernel is every O(d^3)/O(d^2 B) operation of the propagator hot path:
 //   * propagator . state      U_t Psi_t                /root/reference/diffqc.cc:198, sim_plain.py:146
-//   * the products inside exp(A_t) (Paterson-Stockmeyer Taylor; replaces Eigen's
-//     MatrixBase::exp() diffqc.cc:198 and scipy.linalg.expm sim_plain.py:145)
+//   * the products inside exp(A_t) (polynomial evaluation; replaces Eigen's MatrixBase::exp()
+//     diffqc.cc:198 and scipy.linalg.expm sim_plain.py:145)
 //   * the adjoint sweep's U_t^H Lambda, Lambda Psi^H and the reverse-mode products.
+// The reference's `typedef double Scalar` / commented `typedef float Scalar` (diffqc.cc:13-19) is the
+// template parameter T here.
 //
-// Data layout: interleaved complex (re, im) pairs, row-major, explicit leading
-// dimension (in complex elements) -- the memory layout of numpy complex128 and of
-// std::complex<double>, so the C-ABI takes the reference's buffers as they are.
-// One 16-byte global load / LDS read moves a whole complex number, and one
-// ds_read_b128 yields both the real and the imaginary MFMA operand of a lane.
+// Data layout: interleaved complex (re, im) pairs, row-major, explicit leading dimension (in complex
+// elements) -- the memory layout of numpy complex128/complex64 and of std::complex<T>, so the C-ABI takes
+// the reference's buffers as they are. One 16-byte (8-byte for fp32) global load / LDS read moves a whole
+// complex number and yields both the real and the imaginary MFMA operand of a lane.
 //
-// Tiling (CDNA4): a BM x BN output tile per workgroup, 64-lane waves arranged WGM x WGN,
-// each wave owning (BM/WGM) x (BN/WGN) complex outputs as 16x16 f64 MFMA tiles with
-// separate real/imag accumulators (4 real MFMAs per complex tile and k-step, conjugation
-// and the minus sign of the imag*imag term folded into the instruction's neg bits).
-// <=256 VGPRs so two waves share each SIMD and hipcc emits the VGPR-form MFMA (with a
-// 512-register budget it selects the AGPR form and brackets every MFMA with
-// v_accvgpr copies: measured 138 vs 64 cycles per MFMA, tools/mfma_f64_probe.hip).
-// K is streamed in BK-deep slabs through double-buffered LDS images stored k-major
-// ([k][m] and [k][n], pitch +1 element) so that fragment reads are 16 consecutive
-// 16-byte words; the next slab's global loads are in flight while the MFMAs run.
-// Workgroup ids are remapped so that the 32 workgroups resident on one XCD cover a
-// 4 x 8 block of tiles and share their A/B panels through that XCD's L2.
+// Tiling (CDNA4): a BM x BN output tile per workgroup, 64-lane waves arranged WGM x WGN, each wave owning
+// (BM/WGM) x (BN/WGN) complex outputs as 16x16 MFMA tiles. Two arithmetic forms:
+//   4M: separate real/imag accumulators, 4 real MFMAs per complex tile and k-step; conjugation and the
+//       minus sign of the imag*imag term ride on the f64 MFMA's neg bits (fp64 only);
+//   3M: accumulators P1 = sum ar*br, P2 = sum ai*bi, P3 = sum (ar+ai)(br+bi): 3 real MFMAs, Cr = P1 - P2,
+//       Ci = P3 - P1 - P2 formed in the epilogue (normwise- rather than componentwise-stable; measured
+//       end-to-end error equal to 4M, tests/test_gpu_chain.py). Default on the 128 tile, always for fp32.
+// <=256 VGPRs so two waves share each SIMD and hipcc emits the VGPR-form MFMA (with a 512-register budget
+// it selects the AGPR form and brackets every MFMA with v_accvgpr copies: measured 138 vs 64 cycles per
+// f64 MFMA, tools/mfma_f64_probe.hip). K is streamed in BK-deep slabs through double-buffered LDS images
+// stored k-major ([k][m] and [k][n], pitch +1 element) so that fragment reads are 16 consecutive elements;
+// the next slab's global loads are in flight while the MFMAs run. Workgroup ids are remapped so that the 32
+// workgroups resident on one XCD cover a 4 x 8 block of tiles and share their A/B panels through that
+// XCD's L2.
 #include <hip/hip_runtime.h>
 #include "dq_internal.h"
 
 namespace dq {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // f64 MFMA neg bits (blgp field), decoded with tools/mfma_f64_probe.hip
 #define DQ_NEG_NONE 0
 #define DQ_NEG_A 1
 #define DQ_NEG_B 2
 
-template <int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int ALG3M>
-__global__ void __launch_bounds__(WGM* WGN * 64, (WGM * WGN * 64 >= 512) ? 2 : 2)
-zgemm_kernel(ZgemmArgs g) {
+template <class T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+  typedef double4_t acc_t;
+  template <int NEG>
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, NEG);
+  }
+  // C/D: col = lane & 15, row = (lane >> 4) + 4 * reg   (f64 form only)
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct Mfma<float> {
+  typedef float4_t acc_t;
+  template <int NEG>
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    static_assert(NEG == 0, "the f32 MFMA has no neg bits (blgp permutes lanes there)");
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D: col = lane & 15, row = 4 * (lane >> 4) + reg   (the dtype-independent 16x16 map)
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int ALG3M>
+__global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g) {
+  typedef typename Cx<T>::type T2;
+  typedef typename Mfma<T>::acc_t acc_t;
   constexpr int NT = WGM * WGN * 64;
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MI = TM / 16, NI = TN / 16;
@@ -49,10 +79,11 @@ zgemm_kernel(ZgemmArgs g) {
   constexpr int B_PER_T = (BN * BK + NT - 1) / NT;
   static_assert(BK % 4 == 0, "BK must be a multiple of the MFMA k (4)");
   static_assert((BM * BK) % NT == 0 && (BN * BK) % NT == 0, "tile/threads mismatch");
+  static_assert(ALG3M || sizeof(T) == 8, "fp32 uses the 3M form (no MFMA neg bits)");
 
-  __shared__ double2 lds[2 * BK * (PA + PB)];
-  double2* As = lds;                   // [2][BK][PA]
-  double2* Bs = lds + 2 * BK * PA;     // [2][BK][PB]
+  __shared__ T2 lds[2 * BK * (PA + PB)];
+  T2* As = lds;                 // [2][BK][PA]
+  T2* Bs = lds + 2 * BK * PA;   // [2][BK][PB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -74,22 +105,22 @@ zgemm_kernel(ZgemmArgs g) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const long z = blockIdx.z;
-  const double2* __restrict__ A = g.A + z * g.sA;
-  const double2* __restrict__ B = g.B + z * g.sB;
-  double2* __restrict__ C = g.C + z * g.sC;
+  const T2* __restrict__ A = g.A + z * g.sA;
+  const T2* __restrict__ B = g.B + z * g.sB;
+  T2* __restrict__ C = g.C + z * g.sC;
 
   // 4M: accr = Re, acci = Im.   3M: accr = sum ar*br, acci = sum ai*bi, acc3 = sum (ar+ai')(br+bi')
-  double4_t accr[MI][NI], acci[MI][NI], acc3[ALG3M ? MI : 1][ALG3M ? NI : 1];
+  acc_t accr[MI][NI], acci[MI][NI], acc3[ALG3M ? MI : 1][ALG3M ? NI : 1];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      accr[i][j] = {0.0, 0.0, 0.0, 0.0};
-      acci[i][j] = {0.0, 0.0, 0.0, 0.0};
-      if (ALG3M) acc3[i][j] = {0.0, 0.0, 0.0, 0.0};
+      accr[i][j] = {0, 0, 0, 0};
+      acci[i][j] = {0, 0, 0, 0};
+      if (ALG3M) acc3[i][j] = {0, 0, 0, 0};
     }
 
-  double2 ra[A_PER_T], rb[B_PER_T];
+  T2 ra[A_PER_T], rb[B_PER_T];
 
   // Stage one BK-deep slab into registers. op(A) is M x K.
   //   OPA == N: stored [m][k] (k contiguous)  -> lanes run along k, LDS write transposes
@@ -107,7 +138,9 @@ zgemm_kernel(ZgemmArgs g) {
       const int k = (OPA == 0) ? e % BK : e / BM;                                            \
       const int gm = m0 + m, gk = (k0_) + k;                                                 \
       const long off = (OPA == 0) ? ((long)gm * g.lda + gk) : ((long)gk * g.lda + gm);       \
-      double2 v = make_double2(0.0, 0.0);                                                    \
+      T2 v;                                                                                  \
+      v.x = 0;                                                                               \
+      v.y = 0;                                                                               \
       if ((gm < g.M) && (gk < g.K)) v = A[off];                                              \
       ra[j] = v;                                                                             \
     }                                                                                        \
@@ -117,15 +150,17 @@ zgemm_kernel(ZgemmArgs g) {
       const int k = (OPB == 0) ? e / BN : e % BK;                                            \
       const int gn = n0 + n, gk = (k0_) + k;                                                 \
       const long off = (OPB == 0) ? ((long)gk * g.ldb + gn) : ((long)gn * g.ldb + gk);       \
-      double2 v = make_double2(0.0, 0.0);                                                    \
+      T2 v;                                                                                  \
+      v.x = 0;                                                                               \
+      v.y = 0;                                                                               \
       if ((gn < g.N) && (gk < g.K)) v = B[off];                                              \
       rb[j] = v;                                                                             \
     }                                                                                        \
   }
 #define DQ_STORE_SLAB(buf_)                                                                  \
   {                                                                                          \
-    double2* as_ = As + (buf_) * BK * PA;                                                    \
-    double2* bs_ = Bs + (buf_) * BK * PB;                                                    \
+    T2* as_ = As + (buf_) * BK * PA;                                                         \
+    T2* bs_ = Bs + (buf_) * BK * PB;                                                         \
     _Pragma("unroll") for (int j = 0; j < A_PER_T; ++j) {                                    \
       const int e = tid + j * NT;                                                            \
       const int m = (OPA == 0) ? e / BK : e % BM;                                            \
@@ -140,37 +175,37 @@ zgemm_kernel(ZgemmArgs g) {
     }                                                                                        \
   }
 
-  // sign bookkeeping: a = (ar, sa*ai), b = (br, sb*bi)
+  // sign bookkeeping (4M): a = (ar, sa*ai), b = (br, sb*bi)
   //   Cr += ar*br - (sa*sb) ai*bi ;  Ci += sb * ar*bi + sa * ai*br
-  constexpr int NEG_II = ((OPA != 0) != (OPB != 0)) ? DQ_NEG_NONE : DQ_NEG_A;  // -(sa*sb)
-  constexpr int NEG_RI = (OPB != 0) ? DQ_NEG_B : DQ_NEG_NONE;
-  constexpr int NEG_IR = (OPA != 0) ? DQ_NEG_A : DQ_NEG_NONE;
+  constexpr int NEG_II = (ALG3M || ((OPA != 0) != (OPB != 0))) ? DQ_NEG_NONE : DQ_NEG_A;  // -(sa*sb)
+  constexpr int NEG_RI = (!ALG3M && OPB != 0) ? DQ_NEG_B : DQ_NEG_NONE;
+  constexpr int NEG_IR = (!ALG3M && OPA != 0) ? DQ_NEG_A : DQ_NEG_NONE;
 
 #define DQ_COMPUTE_SLAB(buf_)                                                                              \
   {                                                                                                          \
-    const double2* as_ = As + (buf_) * BK * PA + wm * TM + (lane & 15);                                      \
-    const double2* bs_ = Bs + (buf_) * BK * PB + wn * TN + (lane & 15);                                      \
+    const T2* as_ = As + (buf_) * BK * PA + wm * TM + (lane & 15);                                           \
+    const T2* bs_ = Bs + (buf_) * BK * PB + wn * TN + (lane & 15);                                           \
     _Pragma("unroll") for (int ks = 0; ks < BK / 4; ++ks) {                                                  \
       const int kk = ks * 4 + (lane >> 4);                                                                   \
-      double2 a[MI], b[NI];                                                                                  \
+      T2 a[MI], b[NI];                                                                                       \
       _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = as_[kk * PA + i * 16];                           \
       _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = bs_[kk * PB + j * 16];                           \
       if (ALG3M) {                                                                                           \
         _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {      \
-          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, 0);            \
-          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acci[i][j], 0, 0, 0);            \
+          accr[i][j] = Mfma<T>::template run<0>(a[i].x, b[j].x, accr[i][j]);                                 \
+          acci[i][j] = Mfma<T>::template run<0>(a[i].y, b[j].y, acci[i][j]);                                 \
         }                                                                                                    \
         /* sums formed after the P1/P2 issue so they can reuse the fragment registers */                     \
         _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i].x = (OPA != 0) ? a[i].x - a[i].y : a[i].x + a[i].y; \
         _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j].x = (OPB != 0) ? b[j].x - b[j].y : b[j].x + b[j].y; \
         _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)        \
-          acc3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc3[i][j], 0, 0, 0);            \
+          acc3[i][j] = Mfma<T>::template run<0>(a[i].x, b[j].x, acc3[i][j]);                                 \
       } else {                                                                                               \
         _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {      \
-          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, accr[i][j], 0, 0, DQ_NEG_NONE);  \
-          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acci[i][j], 0, 0, NEG_RI);       \
-          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, accr[i][j], 0, 0, NEG_II);       \
-          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acci[i][j], 0, 0, NEG_IR);       \
+          accr[i][j] = Mfma<T>::template run<DQ_NEG_NONE>(a[i].x, b[j].x, accr[i][j]);                       \
+          acci[i][j] = Mfma<T>::template run<NEG_RI>(a[i].x, b[j].y, acci[i][j]);                            \
+          accr[i][j] = Mfma<T>::template run<NEG_II>(a[i].y, b[j].y, accr[i][j]);                            \
+          acci[i][j] = Mfma<T>::template run<NEG_IR>(a[i].y, b[j].x, acci[i][j]);                            \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
@@ -192,7 +227,7 @@ zgemm_kernel(ZgemmArgs g) {
 #undef DQ_COMPUTE_SLAB
 
   // ---- epilogue: C = alpha*acc + beta*C -----------------------------------------
-  const double alpha = g.alpha, beta = g.beta;
+  const T alpha = (T)g.alpha, beta = (T)g.beta;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -200,21 +235,23 @@ zgemm_kernel(ZgemmArgs g) {
       const int col = n0 + wn * TN + j * 16 + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * TM + i * 16 + (lane >> 4) + 4 * r;
+        const int row = m0 + wm * TM + i * 16 + Mfma<T>::row(lane, r);
         if (row < g.M && col < g.N) {
           const long off = (long)row * g.ldc + col;
-          double cr, ci;
+          T cr, ci;
           if (ALG3M) {  // Cr = P1 - s P2, Ci = P3 - P1 - s P2, s = +1 unless exactly one operand is conjugated
-            const double p2 = ((OPA != 0) != (OPB != 0)) ? -acci[i][j][r] : acci[i][j][r];
+            const T p2 = ((OPA != 0) != (OPB != 0)) ? -acci[i][j][r] : acci[i][j][r];
             cr = accr[i][j][r] - p2;
             ci = acc3[i][j][r] - accr[i][j][r] - p2;
           } else {
             cr = accr[i][j][r];
             ci = acci[i][j][r];
           }
-          double2 v = make_double2(alpha * cr, alpha * ci);
-          if (beta != 0.0) {
-            const double2 c0 = C[off];
+          T2 v;
+          v.x = alpha * cr;
+          v.y = alpha * ci;
+          if (g.beta != 0.0) {
+            const T2 c0 = C[off];
             v.x += beta * c0.x;
             v.y += beta * c0.y;
           }
@@ -224,17 +261,17 @@ zgemm_kernel(ZgemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int ALG3M>
-static void launch_cfg(const ZgemmArgs& g, hipStream_t st) {
+template <class T, int BM, int BN, int BK, int WGM, int WGN, int ALG3M>
+static void launch_cfg(const ZgemmArgs<T>& g, hipStream_t st) {
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)g.batch);
   dim3 block(WGM * WGN * 64);
   const int op = (g.opA ? 2 : 0) | (g.opB ? 1 : 0);
   switch (op) {
-    case 0: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 0, ALG3M>), grid, block, 0, st, g); break;
-    case 1: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 0, 1, ALG3M>), grid, block, 0, st, g); break;
-    case 2: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 0, ALG3M>), grid, block, 0, st, g); break;
-    default: hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WGM, WGN, 1, 1, ALG3M>), grid, block, 0, st, g); break;
+    case 0: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 0, ALG3M>), grid, block, 0, st, g); break;
+    case 1: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 1, ALG3M>), grid, block, 0, st, g); break;
+    case 2: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, ALG3M>), grid, block, 0, st, g); break;
+    default: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 1, ALG3M>), grid, block, 0, st, g); break;
   }
 }
 
@@ -248,14 +285,25 @@ int zgemm_pick_tile(int M, int N, int batch) {
 }
 
 // alg: 0 = 4M (four real MFMAs per complex tile step), 1 = 3M (three; P3 trick, normwise-stable)
-hipError_t zgemm_launch(const ZgemmArgs& g, hipStream_t st, int force_tile, int alg) {
+template <>
+hipError_t zgemm_launch<double>(const ZgemmArgs<double>& g, hipStream_t st, int force_tile, int alg) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
   const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
   if (tile == 128) {
-    if (alg == 1) launch_cfg<128, 128, 8, 2, 4, 1>(g, st);
-    else launch_cfg<128, 128, 8, 2, 4, 0>(g, st);
-  } else if (tile == 64) launch_cfg<64, 64, 8, 2, 2, 0>(g, st);
-  else launch_cfg<32, 32, 8, 1, 1, 0>(g, st);
+    if (alg == 1) launch_cfg<double, 128, 128, 8, 2, 4, 1>(g, st);
+    else launch_cfg<double, 128, 128, 8, 2, 4, 0>(g, st);
+  } else if (tile == 64) launch_cfg<double, 64, 64, 8, 2, 2, 0>(g, st);
+  else launch_cfg<double, 32, 32, 8, 1, 1, 0>(g, st);
+  return hipGetLastError();
+}
+
+template <>
+hipError_t zgemm_launch<float>(const ZgemmArgs<float>& g, hipStream_t st, int force_tile, int /*alg*/) {
+  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
+  const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
+  if (tile == 128) launch_cfg<float, 128, 128, 8, 2, 4, 1>(g, st);
+  else if (tile == 64) launch_cfg<float, 64, 64, 8, 2, 2, 1>(g, st);
+  else launch_cfg<float, 32, 32, 8, 1, 1, 1>(g, st);
   return hipGetLastError();
 }
 

@@ -19,18 +19,19 @@ def _is_torch(x):
     return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
 
 
-def _c128(x, shape=None, name="array"):
-    """Return (pointer, keepalive) of a complex128 buffer with `shape` (host numpy or CUDA torch)."""
+def _cx(x, shape=None, name="array", dtype=np.complex128):
+    """Return (pointer, keepalive) of a complex buffer of `dtype` with `shape` (host numpy or CUDA torch)."""
     if _is_torch(x):
         import torch
-        if x.dtype != torch.complex128:
-            raise ValueError("{}: torch tensors must be complex128".format(name))
+        want = torch.complex128 if dtype == np.complex128 else torch.complex64
+        if x.dtype != want:
+            raise ValueError("{}: torch tensors must be {}".format(name, want))
         if not x.is_contiguous():
             raise ValueError("{}: torch tensors must be contiguous".format(name))
         if shape is not None and tuple(x.shape) != tuple(shape):
             raise ValueError("{}: expected shape {}, got {}".format(name, tuple(shape), tuple(x.shape)))
         return x.data_ptr(), x
-    a = np.ascontiguousarray(x, dtype=np.complex128)
+    a = np.ascontiguousarray(x, dtype=dtype)
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise ValueError("{}: expected shape {}, got {}".format(name, tuple(shape), tuple(a.shape)))
     return a.ctypes.data, a
@@ -51,15 +52,26 @@ def _f64(x, shape=None, name="array"):
 
 
 class Engine:
-    """One Hilbert-space dimension + one Hamiltonian set on one GPU."""
+    """One Hilbert-space dimension + one Hamiltonian set on one GPU.
 
-    def __init__(self, dim: int, n_controls: int, device: int = 0):
+    dtype "c128" (default; fp64 complex, the reference's `typedef double Scalar`) or "c64" (fp32 complex, the
+    reference's commented-out `typedef float Scalar`, diffqc.cc:13-19)."""
+
+    def __init__(self, dim: int, n_controls: int, device: int = 0, dtype: str = "c128"):
+        if dtype not in ("c128", "c64"):
+            raise ValueError("dtype must be 'c128' or 'c64'")
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
         self.dim = int(dim)
         self.n_controls = int(n_controls)
         self.device = int(device)
-        _lib.check(self._lib.dq_create(C.byref(self._ctx), self.dim, self.n_controls, self.device))
+        self.dtype = dtype
+        self.cdtype = np.complex128 if dtype == "c128" else np.complex64
+        _lib.check(self._lib.dq_create_ex(C.byref(self._ctx), self.dim, self.n_controls, self.device,
+                                          _lib.DQ_C128 if dtype == "c128" else _lib.DQ_C64))
+
+    def _c(self, x, shape=None, name="array"):
+        return _cx(x, shape, name, self.cdtype)
 
     # -- lifetime -----------------------------------------------------------
     def close(self):
@@ -92,17 +104,17 @@ class Engine:
 
     def set_hamiltonians(self, H0, Hs):
         d, K = self.dim, self.n_controls
-        p0, k0 = _c128(H0, (d, d), "H0")
+        p0, k0 = self._c(H0, (d, d), "H0")
         if K > 0:
             if isinstance(Hs, (list, tuple)):
-                Hs = np.stack([np.asarray(h, dtype=np.complex128) for h in Hs])
-            ps, ks = _c128(Hs, (K, d, d), "Hs")
+                Hs = np.stack([np.asarray(h, dtype=self.cdtype) for h in Hs])
+            ps, ks = self._c(Hs, (K, d, d), "Hs")
         else:
             ps, ks = 0, None
         _lib.check(self._lib.dq_set_hamiltonians(self._ctx, p0, ps))
 
     def set_observable(self, M):
-        p, k = _c128(M, (self.dim, self.dim), "M")
+        p, k = self._c(M, (self.dim, self.dim), "M")
         _lib.check(self._lib.dq_set_observable(self._ctx, p))
 
     def set_option(self, name: str, value: float):
@@ -130,12 +142,12 @@ class Engine:
         if _is_torch(psi):
             if psi.dim() != 2 or psi.shape[0] != self.dim:
                 raise ValueError("{} must have shape [dim={}][batch]".format(name, self.dim))
-            p, keep = _c128(psi, None, name)
+            p, keep = self._c(psi, None, name)
             return p, keep, int(psi.shape[1])
         a = np.asarray(psi)
         if a.ndim == 1:
             a = a.reshape(-1, 1)
-        a = np.ascontiguousarray(a, dtype=np.complex128)
+        a = np.ascontiguousarray(a, dtype=self.cdtype)
         if a.ndim != 2 or a.shape[0] != self.dim:
             raise ValueError("{} must have shape [dim={}][batch], got {}".format(name, self.dim, a.shape))
         return a.ctypes.data, a, int(a.shape[1])
@@ -149,10 +161,10 @@ class Engine:
                 import torch
                 out = torch.empty_like(psi)
             else:
-                out = np.empty((self.dim, B), dtype=np.complex128)
+                out = np.empty((self.dim, B), dtype=self.cdtype)
         po, ko, Bo = self._psi(out, "out")
         if Bo != B or (not _is_torch(out) and ko is not out):
-            raise ValueError("out must be a contiguous complex128 [dim][batch] buffer")
+            raise ValueError("out must be a contiguous [dim][batch] buffer of the engine dtype")
         _lib.check(self._lib.dq_propagate(self._ctx, pu, S, float(dt), pp, po, B))
         return out
 
@@ -186,7 +198,7 @@ class Engine:
                 fin = torch.empty_like(psi0)
                 pf = fin.data_ptr()
             else:
-                fin = np.empty((self.dim, B), dtype=np.complex128)
+                fin = np.empty((self.dim, B), dtype=self.cdtype)
                 pf = fin.ctypes.data
         en = None
         pe = 0
@@ -199,8 +211,8 @@ class Engine:
     # -- building blocks ----------------------------------------------------
     def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None):
         """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host)."""
-        A = np.ascontiguousarray(A, dtype=np.complex128)
-        B = np.ascontiguousarray(B, dtype=np.complex128)
+        A = np.ascontiguousarray(A, dtype=self.cdtype)
+        B = np.ascontiguousarray(B, dtype=self.cdtype)
         batched = A.ndim == 3
         if not batched:
             A, B = A[None], B[None]
@@ -212,16 +224,16 @@ class Engine:
         if K != K2:
             raise ValueError("inner dimensions differ: {} vs {}".format(K, K2))
         if C_in is None:
-            Cm = np.zeros((nb, M, N), dtype=np.complex128)
+            Cm = np.zeros((nb, M, N), dtype=self.cdtype)
         else:
-            Cm = np.array(C_in, dtype=np.complex128, order="C").reshape(nb, M, N)
+            Cm = np.array(C_in, dtype=self.cdtype, order="C").reshape(nb, M, N)
         _lib.check(self._lib.dq_zgemm(self._ctx, int(opA), int(opB), M, N, K, float(alpha), A.ctypes.data,
                                       A.shape[2], A.shape[1] * A.shape[2], B.ctypes.data, B.shape[2],
                                       B.shape[1] * B.shape[2], float(beta), Cm.ctypes.data, N, M * N, nb))
         return Cm if batched else Cm[0]
 
     def expm(self, A):
-        A = np.ascontiguousarray(A, dtype=np.complex128)
+        A = np.ascontiguousarray(A, dtype=self.cdtype)
         batched = A.ndim == 3
         Ab = A if batched else A[None]
         if Ab.shape[1:] != (self.dim, self.dim):
@@ -231,8 +243,8 @@ class Engine:
         return U if batched else U[0]
 
     def expm_vjp(self, A, Ubar):
-        A = np.ascontiguousarray(A, dtype=np.complex128)
-        Ubar = np.ascontiguousarray(Ubar, dtype=np.complex128)
+        A = np.ascontiguousarray(A, dtype=self.cdtype)
+        Ubar = np.ascontiguousarray(Ubar, dtype=self.cdtype)
         batched = A.ndim == 3
         Ab = A if batched else A[None]
         Ub = Ubar if batched else Ubar[None]

@@ -8,8 +8,9 @@
  * INTEGRATION.md shows the reference-side stubs.
  *
  * Conventions
- *   - Complex data is interleaved (re, im) double pairs, row-major: the memory of a numpy
- *     complex128 array / std::complex<double>[] . A d x d matrix is 2*d*d doubles.
+ *   - Complex data is interleaved (re, im) pairs, row-major: the memory of a numpy complex128 array /
+ *     std::complex<double>[] (DQ_C128 contexts) or complex64 / std::complex<float>[] (DQ_C64 contexts);
+ *     such buffers are passed as void*. Pulse tables, gradients, energies and the loss are always fp64.
  *   - A batch of states Psi is [dim][batch] (batch index contiguous): column b is trajectory b.
  *   - The pulse table u is [n_steps][n_controls] ("step-major"): row t holds u_k(t_0 + t*dt),
  *     the LEFT-endpoint sample the reference uses (diffqc.cc:195,199; sim_plain.py:140,150).
@@ -36,6 +37,11 @@ extern "C" {
 
 typedef struct dq_ctx dq_ctx;
 
+/* Element type of every complex buffer of a context (the reference's `typedef double Scalar` /
+ * commented `typedef float Scalar`, diffqc.cc:13-19). */
+#define DQ_C128 0 /* (double re, double im) pairs: numpy complex128 / std::complex<double> */
+#define DQ_C64 1  /* (float re, float im) pairs:   numpy complex64  / std::complex<float>  */
+
 /* Kernel classes of the profile (dq_profile_get). */
 #define DQ_PROF_ZGEMM 0     /* batched complex GEMM (f64 MFMA)            */
 #define DQ_PROF_ASSEMBLE 1  /* A_t = -i dt (H0 + sum u_k H_k)             */
@@ -57,16 +63,17 @@ int dq_device_count(int* n);
 
 /* Context = one Hilbert-space dimension + one set of Hamiltonians on one GPU.
  * Replaces the process-global store g_H0/g_Hs of diffqc.cc:21-25 with an explicit handle. */
-int dq_create(dq_ctx** ctx, int dim, int n_controls, int device_id);
+int dq_create(dq_ctx** ctx, int dim, int n_controls, int device_id);                 /* DQ_C128 */
+int dq_create_ex(dq_ctx** ctx, int dim, int n_controls, int device_id, int dtype);
 int dq_destroy(dq_ctx* ctx);
 /* Use the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream. */
 int dq_set_stream(dq_ctx* ctx, void* hip_stream);
 int dq_synchronize(dq_ctx* ctx);
 
 /* H0: [dim][dim] complex; Hs: [n_controls][dim][dim] complex.  (set_H, diffqc.cc:43-67) */
-int dq_set_hamiltonians(dq_ctx* ctx, const double* H0, const double* Hs);
+int dq_set_hamiltonians(dq_ctx* ctx, const void* H0, const void* Hs);
 /* Observable M ([dim][dim], Hermitian) of the energy loss <psi|M|psi> (sim_plain.py:281). */
-int dq_set_observable(dq_ctx* ctx, const double* M);
+int dq_set_observable(dq_ctx* ctx, const void* M);
 
 /* Tunables: "checkpoint_bytes", "chunk_bytes", "expm_tol", "force_degree", "force_squarings",
  * "force_tile", "zgemm_alg" (0 = four real MFMAs per complex tile step, 1 = the three-multiplication
@@ -79,26 +86,25 @@ int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 /* Forward chain: psi_out = prod_{t=n_steps-1..0} exp(-i dt (H0 + sum_k u[t][k] H_k)) psi_in.
  * The time loop of trotter(), diffqc.cc:190-200 / sim_plain.py:135-150, for `batch` states at once.
  * dt may be negative (diffqc.cc:183).  psi_out may equal psi_in. */
-int dq_propagate(dq_ctx* ctx, const double* u, int n_steps, double dt, const double* psi_in, double* psi_out,
-                 int batch);
+int dq_propagate(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out, int batch);
 
 /* energies[b] = Re <psi_b| M |psi_b>, total = sum_b.  Either output may be NULL. */
-int dq_energy(dq_ctx* ctx, const double* psi, int batch, double* energies, double* total);
+int dq_energy(dq_ctx* ctx, const void* psi, int batch, double* energies, double* total);
 
 /* Forward chain + adjoint sweep. loss = sum_b <psi_b(T)|M|psi_b(T)>,
  * grad_u[t][k] = d loss / d u[t][k] (exact derivative of the discrete chain).
  * psi_final ([dim][batch]) and energies ([batch]) are optional (NULL to skip). */
-int dq_energy_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const double* psi0, int batch, double* loss,
-                   double* grad_u, double* psi_final, double* energies);
+int dq_energy_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* psi0, int batch, double* loss,
+                   double* grad_u, void* psi_final, double* energies);
 
 /* Building blocks, exported for parity tests and reuse. */
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */
-int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const double* A, long lda, long strideA,
-             const double* B, long ldb, long strideB, double beta, double* C, long ldc, long strideC, int batch);
+int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+             const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch);
 /* U[z] = exp(A[z]) for `batch` dim x dim matrices. */
-int dq_expm(dq_ctx* ctx, const double* A, double* U, int batch);
+int dq_expm(dq_ctx* ctx, const void* A, void* U, int batch);
 /* Abar[z] = adjoint Frechet derivative: <Ubar, dexp_A(E)> = <Abar, E> for all E (real inner product Re tr(X^H Y)). */
-int dq_expm_vjp(dq_ctx* ctx, const double* A, const double* Ubar, double* Abar, int batch);
+int dq_expm_vjp(dq_ctx* ctx, const void* A, const void* Ubar, void* Abar, int batch);
 
 /* Per-class HIP-event timing of every kernel launch (off by default). */
 int dq_profile_enable(dq_ctx* ctx, int on);
