@@ -85,8 +85,12 @@ def main():
         print("warning: --gpus {} but WORLD_SIZE {}".format(a.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "MASTER_PORT" in os.environ
+    if use_dist:  # launched by torch.distributed.run (also exercised at world size 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     n, B, K, W = a.qubits, a.batch, a.steps, a.warmup
@@ -114,7 +118,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -123,7 +127,7 @@ def main():
     loss, grad = run(u_t, grad_t)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -196,7 +200,7 @@ def main():
                                        "kind": "port", "sample": "failed: {}".format(e)}
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

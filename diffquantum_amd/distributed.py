@@ -25,7 +25,7 @@ def allreduce_loss_grad(loss: float, grad_u, group=None, device=None):
     """Sum (loss, grad_u) over the ranks with a single all-reduce.  grad_u: numpy [S][K] or a torch tensor."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return loss, grad_u
     is_np = isinstance(grad_u, np.ndarray)
     g = torch.from_numpy(np.ascontiguousarray(grad_u, dtype=np.float64)) if is_np else grad_u

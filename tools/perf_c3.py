@@ -8,12 +8,17 @@ from diffquantum_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+dtype = sys.argv[4] if len(sys.argv) > 4 else "c128"
 d = 1 << n
 dev = torch.device("cuda:0")
 H0, Hs, M = problems.random_ising_torch(n, 0, dev)
+if dtype == "c64":
+    H0, Hs, M = H0.to(torch.complex64), Hs.to(torch.complex64), M.to(torch.complex64)
 u = problems.pulse_table(n, S, 1e-3 * S, seed=0)
 psi0 = torch.from_numpy(problems.random_states(d, min(B, 64), 0)).to(dev).repeat(1, (B + 63) // 64)[:, :B].contiguous()
-e = Engine(d, n)
+if dtype == "c64":
+    psi0 = psi0.to(torch.complex64)
+e = Engine(d, n, dtype=dtype)
 e.use_torch_stream()
 e.set_hamiltonians(H0, Hs)
 e.set_observable(M)
