@@ -35,6 +35,7 @@ for mode in ("propagate", "energy_grad"):
         else:
             loss, grad, fin, en = e.energy_grad(tu, 1e-3, psi0, want_final=False, want_energies=False)
         torch.cuda.synchronize(); t1 = time.time()
+        print("  rep %d (profiling %s): wall %.4f s" % (rep, "on" if rep == 1 else "off", t1 - t0))
     prof = e.profile()
     z = prof["zgemm"]
     print(mode, "S=%d wall %.3f s -> %.3f steps/s; degree %d sq %d theta %.3g ckstride %d" % (
