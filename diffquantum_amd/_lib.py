@@ -62,6 +62,16 @@ SIGNATURES = {
     "dq_profile_enable": (C.c_int, [_vp, C.c_int]),
     "dq_profile_reset": (C.c_int, [_vp]),
     "dq_profile_get": (C.c_int, [_vp, C.POINTER(DqProfile)]),
+    "dq_sctx_last_error": (C.c_char_p, []),
+    "dq_sctx_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dq_sctx_destroy": (C.c_int, [_vp]),
+    "dq_sctx_set_stream": (C.c_int, [_vp, _vp]),
+    "dq_sctx_set_terms": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "dq_sctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "dq_sctx_get_info": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "dq_sctx_propagate": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, C.c_int]),
+    "dq_sctx_energy_grad": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "dq_sctx_apply": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int]),
 }
 
 _lib = None
@@ -85,10 +95,11 @@ def load():
     return lib
 
 
-def check(status: int):
+def check(status: int, structured: bool = False):
     if status == DQ_OK:
         return
-    msg = load().dq_last_error().decode("utf-8", "replace")
+    lib = load()
+    msg = (lib.dq_sctx_last_error() if structured else lib.dq_last_error()).decode("utf-8", "replace")
     if status == DQ_ERR_INVALID:
         raise ValueError(msg)
     if status == DQ_ERR_NO_DEVICE:

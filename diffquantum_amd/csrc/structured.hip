@@ -1,0 +1,901 @@
+// Structured (matrix-free) propagator engine: SURVEY.md section 8-F1 / BASELINE config 5 regime (n >= 14 qubits,
+// where a dense 2^n x 2^n Hamiltonian cannot exist: 550 GB at n = 18 in complex64).
+//
+//   H(t) = H0 + sum_k u_k(t) H_k,   every H_* = sum_m w_m P_m,  P_m a Pauli string (I/X/Y/Z per qubit)
+//
+// keeps the reference's "exponential of the SUM" step  psi <- exp(-i dt H(t)) psi  (diffqc.cc:192-198,
+// sim_plain.py:137-146; NOT the split product formula of the dead code diffqc.cc:137-170), evaluated as the
+// degree-m Taylor polynomial in Horner form  z_m = psi, z_{j-1} = psi + (A z_j)/j, A = -i dt H, with m chosen from
+// theta = |dt| * sum |weights| >= ||A|| so that theta^(m+1)/(m+1)! <= tol. Every A z is a matrix-free pass:
+//   (P psi)[i] = i^{nY} (-1)^{popc((i ^ x) & z)} psi[i ^ x]     (x = X/Y positions, z = Z/Y positions)
+// Diagonal strings are folded into one real vector per step. HBM-bound by construction: the unit of work is one
+// pass over the state batch (2 * 2^n * B * sizeof(T) bytes).
+//
+// Kernel layout (CDNA4): states are [2^n][B], batch contiguous, so any set of rows is coalesced. A workgroup
+// stages a sub-cube of 2^p rows (p "local" qubits, any positions) x 16 batch columns in LDS; every string whose
+// x-mask lies inside the local set is then served from LDS (XOR of the local row index). Strings are grouped
+// by local set on the host (<= p distinct flipped qubits per group); one H application = one pass per group.
+// The same tiling computes the control-gradient overlaps <zbar, P_m z>.
+//
+// Gradient = exact reverse mode of the Horner recursion (not a first-order GRAPE approximation):
+//   zbar_0 = lambda_{t+1};  zbar_j = (A^H zbar_{j-1})/j;  lambda_t = sum_j zbar_j;
+//   dL/du_k[t] = sum_j (dt/j) sum_{m in k} w_m Im( i^{nY_m} <zbar_{j-1}, P'_m z_j> )
+// with psi_t rebuilt as T_m(-A_t) psi_{t+1} between checkpoints.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/diffqc_hip.h"
+#include "dq_internal.h"
+
+namespace {
+
+thread_local std::string s_err;
+struct SErr { int code; std::string msg; };
+[[noreturn]] void sfail(int code, const std::string& m) { throw SErr{code, m}; }
+#define SHIP(expr)                                                                         \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess) {                                                               \
+      (void)hipGetLastError();                                                             \
+      sfail(e__ == hipErrorOutOfMemory ? DQ_ERR_NOMEM : DQ_ERR_HIP,                        \
+            std::string(#expr) + " failed: " + hipGetErrorString(e__));                    \
+    }                                                                                      \
+  } while (0)
+
+struct SBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  SBuf() = default;
+  SBuf(const SBuf&) = delete;
+  SBuf& operator=(const SBuf&) = delete;
+  SBuf(SBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  ~SBuf() { if (p) (void)hipFree(p); }
+  void ensure(size_t n) {
+    if (n <= bytes) return;
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+    SHIP(hipMalloc(&p, n));
+    bytes = n;
+  }
+};
+
+bool s_is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+constexpr int SBC = 16;        // batch columns per tile (128 B rows for complex64, 256 B for complex128)
+constexpr int STHREADS = 256;
+constexpr int SMAXT = 64;      // strings per group
+
+struct DTerm {  // device view of one Pauli string inside a group
+  unsigned xloc;   // x-mask compressed onto the group's local bits (XOR on the local row index)
+  unsigned xmask;  // full masks for the sign
+  unsigned zmask;
+  int slot;        // index into the per-step coefficient table / overlap output
+};
+
+template <class T> struct LocalBits { static constexpr int P = 9; };   // 512 rows x 16 cols x 8 B  = 64 KB
+template <> struct LocalBits<double> { static constexpr int P = 8; };  // 256 rows x 16 cols x 16 B = 64 KB
+
+__device__ __forceinline__ unsigned deposit_bits(unsigned v, unsigned mask) {  // software pdep
+  unsigned out = 0;
+  while (mask) {
+    const unsigned low = mask & (0u - mask);
+    if (v & 1u) out |= low;
+    v >>= 1;
+    mask ^= low;
+  }
+  return out;
+}
+
+template <class T>
+struct SApply {
+  typedef typename dq::Cx<T>::type T2;
+  const T2* y;      // input state
+  const T2* prev;   // partial sums of earlier groups (may be null)
+  const T2* add;    // addend of the final pass (may be null)
+  T2* out;
+  T2* acc;          // optional: acc += out (lambda_t = sum_j zbar_j)
+  const T* diag;    // per-step real diagonal (first group only) or null
+  const DTerm* terms;
+  const T2* coef;   // per-slot complex coefficient for this step (weight * u_k * i^{nY})
+  int nterms;
+  int n, p;         // qubits, local bits
+  unsigned lmask;
+  int B;
+  T sr, si;         // complex scale of the bracket
+};
+
+// out = add + (sr + i si) * ( prev + diag .* y + sum_m coef_m sign_m P'_m y )
+template <class T>
+__global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
+  typedef typename dq::Cx<T>::type T2;
+  constexpr int PMAX = LocalBits<T>::P;
+  __shared__ T2 tile[(1 << PMAX) * SBC];
+  __shared__ unsigned rowidx[1 << PMAX];
+  __shared__ DTerm tt[SMAXT];
+  __shared__ T2 tc[SMAXT];
+  const int R = 1 << a.p;
+  const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
+  const unsigned base = deposit_bits(blockIdx.x, full & ~a.lmask);
+  const int c0 = blockIdx.y * SBC;
+  for (int r = threadIdx.x; r < R; r += STHREADS) rowidx[r] = base | deposit_bits((unsigned)r, a.lmask);
+  for (int m = threadIdx.x; m < a.nterms; m += STHREADS) { tt[m] = a.terms[m]; tc[m] = a.coef[a.terms[m].slot]; }
+  __syncthreads();
+  const int c = threadIdx.x % SBC;
+  const bool col_ok = (c0 + c) < a.B;
+  for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
+    T2 v; v.x = 0; v.y = 0;
+    if (col_ok) v = a.y[(size_t)rowidx[r] * a.B + c0 + c];
+    tile[r * SBC + c] = v;
+  }
+  __syncthreads();
+  if (!col_ok) return;
+  for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
+    const unsigned i = rowidx[r];
+    const size_t off = (size_t)i * a.B + c0 + c;
+    T sx = 0, sy = 0;
+    if (a.diag) {
+      const T dd = a.diag[i];
+      const T2 v = tile[r * SBC + c];
+      sx = dd * v.x; sy = dd * v.y;
+    }
+    for (int m = 0; m < a.nterms; ++m) {
+      const T2 v = tile[(r ^ tt[m].xloc) * SBC + c];
+      const T2 cf = tc[m];
+      const T sg = (__popc((i ^ tt[m].xmask) & tt[m].zmask) & 1) ? (T)-1 : (T)1;
+      sx += sg * (cf.x * v.x - cf.y * v.y);
+      sy += sg * (cf.x * v.y + cf.y * v.x);
+    }
+    if (a.prev) { const T2 q = a.prev[off]; sx += q.x; sy += q.y; }
+    T2 o;
+    o.x = a.sr * sx - a.si * sy;
+    o.y = a.sr * sy + a.si * sx;
+    if (a.add) { const T2 q = a.add[off]; o.x += q.x; o.y += q.y; }
+    a.out[off] = o;
+    if (a.acc) { T2 q = a.acc[off]; q.x += o.x; q.y += o.y; a.acc[off] = q; }
+  }
+}
+
+template <class T>
+struct SOverlap {
+  typedef typename dq::Cx<T>::type T2;
+  const T2* za;   // cotangent (read at its own row)
+  const T2* zb;   // state (tile in LDS, read at row ^ x)
+  const DTerm* terms;
+  int nterms;
+  int n, p;
+  unsigned lmask;
+  int B;
+  double* part;   // [nblocks][nterms][2]
+};
+
+// part[blk][m] = sum over the block's tile of conj(za[i][c]) * sign_m(i) * zb[i ^ x_m][c]
+template <class T>
+__global__ void __launch_bounds__(STHREADS) soverlap_kernel(SOverlap<T> a) {
+  typedef typename dq::Cx<T>::type T2;
+  constexpr int PMAX = LocalBits<T>::P;
+  __shared__ T2 tile[(1 << PMAX) * SBC];
+  __shared__ unsigned rowidx[1 << PMAX];
+  __shared__ DTerm tt[SMAXT];
+  __shared__ double red[2][STHREADS / 64];
+  const int R = 1 << a.p;
+  const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
+  const unsigned base = deposit_bits(blockIdx.x, full & ~a.lmask);
+  const int c0 = blockIdx.y * SBC;
+  for (int r = threadIdx.x; r < R; r += STHREADS) rowidx[r] = base | deposit_bits((unsigned)r, a.lmask);
+  for (int m = threadIdx.x; m < a.nterms; m += STHREADS) tt[m] = a.terms[m];
+  __syncthreads();
+  const int c = threadIdx.x % SBC;
+  const bool col_ok = (c0 + c) < a.B;
+  for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
+    T2 v; v.x = 0; v.y = 0;
+    if (col_ok) v = a.zb[(size_t)rowidx[r] * a.B + c0 + c];
+    tile[r * SBC + c] = v;
+  }
+  __syncthreads();
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = 0; m < a.nterms; ++m) {
+    double sx = 0.0, sy = 0.0;
+    if (col_ok)
+      for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
+        const unsigned i = rowidx[r];
+        const T2 u = a.za[(size_t)i * a.B + c0 + c];
+        const T2 v = tile[(r ^ tt[m].xloc) * SBC + c];
+        const double sg = (__popc((i ^ tt[m].xmask) & tt[m].zmask) & 1) ? -1.0 : 1.0;
+        sx += sg * ((double)u.x * v.x + (double)u.y * v.y);   // conj(u) * v
+        sy += sg * ((double)u.x * v.y - (double)u.y * v.x);
+      }
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); }
+    if (lane == 0) { red[0][wave] = sx; red[1][wave] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tx = 0, ty = 0;
+      for (int w = 0; w < STHREADS / 64; ++w) { tx += red[0][w]; ty += red[1][w]; }
+      a.part[((size_t)blk * a.nterms + m) * 2 + 0] = tx;
+      a.part[((size_t)blk * a.nterms + m) * 2 + 1] = ty;
+    }
+    __syncthreads();
+  }
+}
+
+// grad[k(slot)] += fac * Im( phase_slot * sum_blk part[blk][m] ) * weight_slot      (fixed-order sum: deterministic)
+__global__ void soverlap_finish_kernel(const double* part, int nblk, int nterms, const int* slots, const int* owner,
+                                       const double* wre, const double* wim, double fac, double* grad_row) {
+  const int m = threadIdx.x;
+  if (m >= nterms) return;
+  double sx = 0, sy = 0;
+  for (int b = 0; b < nblk; ++b) { sx += part[((size_t)b * nterms + m) * 2]; sy += part[((size_t)b * nterms + m) * 2 + 1]; }
+  const int s = slots[m];
+  const int k = owner[s];
+  if (k < 0) return;
+  // (wre + i wim) = weight * i^{nY};  Im((wre + i wim)(sx + i sy))
+  const double im = wre[s] * sy + wim[s] * sx;
+  atomicAdd(&grad_row[k], fac * im);  // few adds per step; order fixed within a launch, launches are stream-ordered
+}
+
+// D[i] = sum_m w_m (-1)^{popc(i & z_m)}
+template <class T>
+__global__ void sdiag_build_kernel(T* D, unsigned d, const unsigned* z, const double* w, int nt) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  double s = 0.0;
+  for (int m = 0; m < nt; ++m) s += (__popc(i & z[m]) & 1) ? -w[m] : w[m];
+  D[i] = (T)s;
+}
+
+// D_t[i] = D0[i] + sum_k u[k] Dk[k][i]
+template <class T>
+__global__ void sdiag_step_kernel(T* D, const T* D0, const T* Dk, const double* u, const int* kidx, int nk, unsigned d) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  T s = D0 ? D0[i] : (T)0;
+  for (int j = 0; j < nk; ++j) s += (T)u[kidx[j]] * Dk[(size_t)j * d + i];
+  D[i] = s;
+}
+
+// per-step complex coefficients: coef[slot] = (wre + i wim)[slot] * (owner < 0 ? 1 : u[owner])
+template <class T>
+__global__ void scoef_kernel(typename dq::Cx<T>::type* coef, const double* wre, const double* wim, const int* owner,
+                             const double* u, int nslots) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const double f = owner[s] < 0 ? 1.0 : (u ? u[owner[s]] : 0.0);
+  coef[s].x = (T)(wre[s] * f);
+  coef[s].y = (T)(wim[s] * f);
+}
+
+struct HostTerm { int owner; unsigned x, z; double w; };  // owner: -1 drift, 0..K-1 control, -2 observable
+struct Group {
+  unsigned lmask = 0;
+  int p = 0;
+  std::vector<DTerm> apply;   // off-diagonal strings applied in this pass
+  std::vector<DTerm> ovl;     // strings whose overlaps are taken in this pass (control strings, incl. diagonal ones)
+  SBuf d_apply, d_ovl, d_ovl_slots;
+};
+
+}  // namespace
+
+struct dq_sctx {
+  int dtype = DQ_C64;
+  virtual ~dq_sctx() {}
+};
+
+namespace {
+
+template <class T>
+struct SCtx : dq_sctx {
+  typedef typename dq::Cx<T>::type T2;
+  int n = 0, K = 0, dev = 0;
+  unsigned d = 0;
+  hipStream_t st = nullptr;
+  bool have_terms = false, have_obs = false;
+  std::vector<HostTerm> hterms;     // slots of H (drift + controls), then observable slots
+  int n_hslots = 0, n_slots = 0;
+  std::vector<Group> hgroups, mgroups;
+  SBuf d_wre, d_wim, d_owner, d_coef, d_coefM;
+  SBuf D0, Dk, Dkidx, Dt, DM;       // diagonals: drift, per-control, step, observable
+  std::vector<int> diag_controls;
+  bool has_D0 = false, has_DM = false;
+  double wsum0 = 0;                 // sum |w| of the drift strings
+  std::vector<double> wsumk;        // per control
+  double tol = 0, checkpoint_bytes = 0;
+  int force_degree = 0;
+  double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0;
+  SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
+  std::vector<SBuf> zs, ck;
+  // profile of the streaming passes
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> recs;
+  std::vector<double> rec_bytes;
+  double prof_ms = 0, prof_bytes = 0;
+  long long prof_launches = 0;
+
+  SCtx() {
+    dtype = sizeof(T) == 8 ? DQ_C128 : DQ_C64;
+    tol = sizeof(T) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-08;
+  }
+  ~SCtx() override {
+    for (auto& r : recs) { (void)hipEventDestroy(r.first); (void)hipEventDestroy(r.second); }
+  }
+  size_t state_bytes(int B) const { return (size_t)d * B * sizeof(T2); }
+
+  template <class F>
+  void timed(double bytes, F&& f) {
+    if (!prof_on) { f(); SHIP(hipGetLastError()); return; }
+    hipEvent_t e0, e1;
+    SHIP(hipEventCreate(&e0)); SHIP(hipEventCreate(&e1));
+    SHIP(hipEventRecord(e0, st));
+    f();
+    SHIP(hipGetLastError());
+    SHIP(hipEventRecord(e1, st));
+    recs.push_back({e0, e1});
+    rec_bytes.push_back(bytes);
+  }
+  void collect() {
+    if (recs.empty()) return;
+    SHIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < recs.size(); ++i) {
+      float ms = 0;
+      SHIP(hipEventElapsedTime(&ms, recs[i].first, recs[i].second));
+      prof_ms += ms; prof_bytes += rec_bytes[i]; prof_launches++;
+      (void)hipEventDestroy(recs[i].first); (void)hipEventDestroy(recs[i].second);
+    }
+    recs.clear(); rec_bytes.clear();
+  }
+};
+
+unsigned compress_bits(unsigned v, unsigned mask) {  // software pext (host)
+  unsigned out = 0, bit = 1;
+  while (mask) {
+    const unsigned low = mask & (0u - mask);
+    if (v & low) out |= bit;
+    bit <<= 1;
+    mask ^= low;
+  }
+  return out;
+}
+
+int popc(unsigned v) { return __builtin_popcount(v); }
+
+// Partition strings into groups whose flipped qubits fit in p local bits (first fit, widest strings first).
+template <class T>
+void build_groups(SCtx<T>* c, const std::vector<int>& slots, std::vector<Group>& groups, bool with_overlaps) {
+  const int P = std::min(LocalBits<T>::P, c->n);
+  groups.clear();
+  std::vector<int> offd;
+  for (int s : slots) if (c->hterms[s].x != 0) offd.push_back(s);
+  std::stable_sort(offd.begin(), offd.end(), [&](int a, int b) { return popc(c->hterms[a].x) > popc(c->hterms[b].x); });
+  std::vector<std::vector<int>> members;
+  for (int s : offd) {
+    const unsigned x = c->hterms[s].x;
+    if (popc(x) > P) sfail(DQ_ERR_UNSUPPORTED, "a Pauli string flips more qubits than fit in one LDS tile");
+    int g = -1;
+    for (size_t i = 0; i < groups.size(); ++i)
+      if (popc(groups[i].lmask | x) <= P && (int)members[i].size() < SMAXT) { g = (int)i; break; }
+    if (g < 0) { groups.emplace_back(); members.emplace_back(); g = (int)groups.size() - 1; }
+    groups[g].lmask |= x;
+    members[g].push_back(s);
+  }
+  if (groups.empty()) { groups.emplace_back(); members.emplace_back(); }
+  const unsigned full = (c->n >= 32) ? 0xffffffffu : ((1u << c->n) - 1u);
+  for (size_t g = 0; g < groups.size(); ++g) {
+    // fill the local set up to P bits (lowest free qubits) so that tiles have a fixed size
+    unsigned lm = groups[g].lmask;
+    for (int q = 0; q < c->n && popc(lm) < P; ++q) if (!(lm & (1u << q))) lm |= (1u << q);
+    groups[g].lmask = lm & full;
+    groups[g].p = popc(groups[g].lmask);
+    for (int s : members[g]) {
+      DTerm t;
+      t.xmask = c->hterms[s].x; t.zmask = c->hterms[s].z; t.slot = s;
+      t.xloc = compress_bits(t.xmask, groups[g].lmask);
+      groups[g].apply.push_back(t);
+      if (with_overlaps && c->hterms[s].owner >= 0) groups[g].ovl.push_back(t);
+    }
+  }
+  if (with_overlaps) {  // diagonal control strings: overlaps in group 0 (x = 0 is local to every tiling)
+    for (int s : slots)
+      if (c->hterms[s].x == 0 && c->hterms[s].owner >= 0) {
+        size_t g = 0;
+        while (g < groups.size() && (int)groups[g].ovl.size() >= SMAXT) ++g;
+        if (g == groups.size()) sfail(DQ_ERR_UNSUPPORTED, "too many diagonal control strings");
+        DTerm t;
+        t.xmask = 0; t.zmask = c->hterms[s].z; t.slot = s; t.xloc = 0;
+        groups[g].ovl.push_back(t);
+      }
+  }
+  for (auto& g : groups) {
+    g.d_apply.ensure(std::max<size_t>(1, g.apply.size()) * sizeof(DTerm));
+    if (!g.apply.empty()) SHIP(hipMemcpy(g.d_apply.p, g.apply.data(), g.apply.size() * sizeof(DTerm), hipMemcpyHostToDevice));
+    g.d_ovl.ensure(std::max<size_t>(1, g.ovl.size()) * sizeof(DTerm));
+    g.d_ovl_slots.ensure(std::max<size_t>(1, g.ovl.size()) * sizeof(int));
+    if (!g.ovl.empty()) {
+      SHIP(hipMemcpy(g.d_ovl.p, g.ovl.data(), g.ovl.size() * sizeof(DTerm), hipMemcpyHostToDevice));
+      std::vector<int> sl;
+      for (auto& t : g.ovl) sl.push_back(t.slot);
+      SHIP(hipMemcpy(g.d_ovl_slots.p, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
+}
+
+template <class T>
+void build_diag(SCtx<T>* c, SBuf& out, const std::vector<int>& slots, bool& present) {
+  std::vector<unsigned> z;
+  std::vector<double> w;
+  for (int s : slots) { z.push_back(c->hterms[s].z); w.push_back(c->hterms[s].w); }
+  present = !slots.empty();
+  if (!present) return;
+  SBuf dz, dw;
+  dz.ensure(z.size() * sizeof(unsigned)); dw.ensure(w.size() * sizeof(double));
+  SHIP(hipMemcpy(dz.p, z.data(), z.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  SHIP(hipMemcpy(dw.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(sdiag_build_kernel<T>, dim3((c->d + 255) / 256), dim3(256), 0, c->st, (T*)out.p, c->d,
+                     (const unsigned*)dz.p, (const double*)dw.p, (int)z.size());
+  SHIP(hipGetLastError());
+  SHIP(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+void set_terms(SCtx<T>* c, int nt, const int* owner, const unsigned* x, const unsigned* z, const double* w) {
+  SHIP(hipSetDevice(c->dev));
+  if (nt < 0 || (nt > 0 && (!owner || !x || !z || !w))) sfail(DQ_ERR_INVALID, "bad term arrays");
+  const unsigned full = (c->n >= 32) ? 0xffffffffu : ((1u << c->n) - 1u);
+  c->hterms.clear();
+  std::vector<HostTerm> H, M;
+  for (int i = 0; i < nt; ++i) {
+    if (owner[i] < -2 || owner[i] >= c->K) sfail(DQ_ERR_INVALID, "term owner out of range");
+    if ((x[i] | z[i]) & ~full) sfail(DQ_ERR_INVALID, "term acts on a qubit >= n_qubits");
+    if (!std::isfinite(w[i])) sfail(DQ_ERR_INVALID, "non-finite term weight");
+    HostTerm t{owner[i], x[i], z[i], w[i]};
+    (owner[i] == -2 ? M : H).push_back(t);
+  }
+  c->hterms = H;
+  c->n_hslots = (int)H.size();
+  c->hterms.insert(c->hterms.end(), M.begin(), M.end());
+  c->n_slots = (int)c->hterms.size();
+  // coefficient tables: weight * i^{nY}
+  std::vector<double> wre(c->n_slots), wim(c->n_slots);
+  std::vector<int> own(c->n_slots);
+  c->wsum0 = 0;
+  c->wsumk.assign(c->K, 0.0);
+  for (int s = 0; s < c->n_slots; ++s) {
+    const HostTerm& t = c->hterms[s];
+    const int ny = popc(t.x & t.z) & 3;
+    const double re[4] = {1, 0, -1, 0}, im[4] = {0, 1, 0, -1};
+    wre[s] = t.w * re[ny]; wim[s] = t.w * im[ny];
+    own[s] = t.owner;
+    if (t.owner == -1) c->wsum0 += std::fabs(t.w);
+    else if (t.owner >= 0) c->wsumk[t.owner] += std::fabs(t.w);
+  }
+  const size_t ns = std::max(1, c->n_slots);
+  c->d_wre.ensure(ns * 8); c->d_wim.ensure(ns * 8); c->d_owner.ensure(ns * 4);
+  c->d_coef.ensure(ns * sizeof(typename SCtx<T>::T2)); c->d_coefM.ensure(ns * sizeof(typename SCtx<T>::T2));
+  if (c->n_slots) {
+    SHIP(hipMemcpy(c->d_wre.p, wre.data(), c->n_slots * 8, hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(c->d_wim.p, wim.data(), c->n_slots * 8, hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(c->d_owner.p, own.data(), c->n_slots * 4, hipMemcpyHostToDevice));
+  }
+  // groups
+  std::vector<int> hs, ms;
+  for (int s = 0; s < c->n_hslots; ++s) hs.push_back(s);
+  for (int s = c->n_hslots; s < c->n_slots; ++s) ms.push_back(s);
+  build_groups(c, hs, c->hgroups, true);
+  build_groups(c, ms, c->mgroups, false);
+  // diagonals
+  std::vector<int> d0, dm;
+  std::vector<std::vector<int>> dk(c->K);
+  for (int s = 0; s < c->n_slots; ++s) {
+    const HostTerm& t = c->hterms[s];
+    if (t.x != 0) continue;
+    if (t.owner == -1) d0.push_back(s);
+    else if (t.owner == -2) dm.push_back(s);
+    else dk[t.owner].push_back(s);
+  }
+  c->D0.ensure((size_t)c->d * sizeof(T)); c->DM.ensure((size_t)c->d * sizeof(T)); c->Dt.ensure((size_t)c->d * sizeof(T));
+  build_diag(c, c->D0, d0, c->has_D0);
+  build_diag(c, c->DM, dm, c->has_DM);
+  c->diag_controls.clear();
+  for (int k = 0; k < c->K; ++k) if (!dk[k].empty()) c->diag_controls.push_back(k);
+  c->Dk.ensure(std::max<size_t>(1, c->diag_controls.size()) * c->d * sizeof(T));
+  c->Dkidx.ensure(std::max<size_t>(1, c->diag_controls.size()) * sizeof(int));
+  for (size_t j = 0; j < c->diag_controls.size(); ++j) {
+    SBuf one; bool pr;
+    one.ensure((size_t)c->d * sizeof(T));
+    build_diag(c, one, dk[c->diag_controls[j]], pr);
+    SHIP(hipMemcpy((char*)c->Dk.p + j * (size_t)c->d * sizeof(T), one.p, (size_t)c->d * sizeof(T), hipMemcpyDeviceToDevice));
+  }
+  if (!c->diag_controls.empty())
+    SHIP(hipMemcpy(c->Dkidx.p, c->diag_controls.data(), c->diag_controls.size() * sizeof(int), hipMemcpyHostToDevice));
+  // observable coefficients are static: weight * i^{nY}
+  if (c->n_slots) {
+    hipLaunchKernelGGL(scoef_kernel<T>, dim3((c->n_slots + 63) / 64), dim3(64), 0, c->st,
+                       (typename SCtx<T>::T2*)c->d_coefM.p, (const double*)c->d_wre.p, (const double*)c->d_wim.p,
+                       (const int*)c->d_owner.p, (const double*)nullptr, c->n_slots);
+    // (control slots get 0 here: u = null; only the observable's slots are ever read from d_coefM)
+  }
+  SHIP(hipStreamSynchronize(c->st));
+  c->have_terms = true;
+  c->have_obs = !ms.empty() || !dm.empty();
+  c->last_groups = (double)c->hgroups.size();
+}
+
+// one application  out = add + scale * (H_like y)   over the groups of `groups`
+template <class T>
+void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>::T2* coef, const T* diag,
+                  const typename SCtx<T>::T2* y, const typename SCtx<T>::T2* add, typename SCtx<T>::T2* out,
+                  typename SCtx<T>::T2* acc, double sr, double si, int B) {
+  typedef typename SCtx<T>::T2 T2;
+  const size_t sb = c->state_bytes(B);
+  const int ng = (int)groups.size();
+  const T2* prev = nullptr;
+  for (int g = 0; g < ng; ++g) {
+    const bool last = (g == ng - 1);
+    SApply<T> a;
+    a.y = y; a.prev = prev;
+    a.add = last ? add : nullptr;
+    a.acc = last ? acc : nullptr;
+    a.diag = (g == 0) ? diag : nullptr;
+    a.terms = (const DTerm*)groups[g].d_apply.p;
+    a.coef = coef;
+    a.nterms = (int)groups[g].apply.size();
+    a.n = c->n; a.p = groups[g].p; a.lmask = groups[g].lmask; a.B = B;
+    a.sr = last ? (T)sr : (T)1; a.si = last ? (T)si : (T)0;
+    if (!last) c->tmp[g & 1].ensure(sb);
+    T2* dst = last ? out : (T2*)c->tmp[g & 1].p;
+    a.out = dst;
+    dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
+    const double units = 2.0 + (prev ? 1 : 0) + (a.add ? 1 : 0) + (a.acc ? 2 : 0);
+    c->timed(units * sb, [&] { hipLaunchKernelGGL(sapply_kernel<T>, grid, dim3(STHREADS), 0, c->st, a); });
+    c->last_passes += 1;
+    c->last_bytes += units * sb;
+    prev = dst;
+  }
+}
+
+template <class T>
+void step_coefficients(SCtx<T>* c, int t) {
+  typedef typename SCtx<T>::T2 T2;
+  const double* u_row = (const double*)c->u_dev.p + (size_t)t * c->K;
+  if (c->n_hslots)
+    hipLaunchKernelGGL(scoef_kernel<T>, dim3((c->n_hslots + 63) / 64), dim3(64), 0, c->st, (T2*)c->d_coef.p,
+                       (const double*)c->d_wre.p, (const double*)c->d_wim.p, (const int*)c->d_owner.p, u_row, c->n_hslots);
+  if (c->has_D0 || !c->diag_controls.empty())
+    hipLaunchKernelGGL(sdiag_step_kernel<T>, dim3((c->d + 255) / 256), dim3(256), 0, c->st, (T*)c->Dt.p,
+                       c->has_D0 ? (const T*)c->D0.p : (const T*)nullptr, (const T*)c->Dk.p, u_row,
+                       (const int*)c->Dkidx.p, (int)c->diag_controls.size(), c->d);
+  SHIP(hipGetLastError());
+}
+
+template <class T>
+const T* step_diag(SCtx<T>* c) {
+  return (c->has_D0 || !c->diag_controls.empty()) ? (const T*)c->Dt.p : (const T*)nullptr;
+}
+
+int taylor_degree(double theta, double tol, int force) {
+  if (force > 0) return force;
+  for (int m = 1; m <= 60; ++m) {
+    double v = 1.0;
+    for (int j = 1; j <= m + 1; ++j) v *= theta / j;
+    if (v <= tol) return m;
+  }
+  sfail(DQ_ERR_INVALID, "step generator norm too large for the Taylor apply (reduce dt)");
+}
+
+template <class T>
+std::vector<double> s_fetch_u(SCtx<T>* c, const double* u, int S) {
+  const size_t n = (size_t)S * c->K;
+  std::vector<double> h(n);
+  if (n) {
+    if (s_is_device_ptr(u)) { SHIP(hipMemcpy(h.data(), u, n * 8, hipMemcpyDeviceToHost)); }
+    else memcpy(h.data(), u, n * 8);
+    for (double v : h) if (!std::isfinite(v)) sfail(DQ_ERR_INVALID, "pulse table contains non-finite values");
+  }
+  c->u_dev.ensure(std::max<size_t>(n, 1) * 8);
+  if (n) SHIP(hipMemcpy(c->u_dev.p, h.data(), n * 8, hipMemcpyHostToDevice));
+  return h;
+}
+
+template <class T>
+int plan_degree(SCtx<T>* c, const std::vector<double>& uh, int S, double dt) {
+  double th = 0.0;
+  for (int t = 0; t < S; ++t) {
+    double h = c->wsum0;
+    for (int k = 0; k < c->K; ++k) h += std::fabs(uh[(size_t)t * c->K + k]) * c->wsumk[k];
+    th = std::max(th, std::fabs(dt) * h);
+  }
+  c->last_theta = th;
+  const int m = taylor_degree(th, c->tol, c->force_degree);
+  c->last_degree = m;
+  return m;
+}
+
+// z_out = T_m(sign * A_t) z_in  (Horner); if zs_store != null keeps the iterates z_m..z_1 there (z_j in zs_store[j])
+template <class T>
+void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx<T>::T2* in, typename SCtx<T>::T2* out,
+                  int B, std::vector<SBuf>* store) {
+  typedef typename SCtx<T>::T2 T2;
+  const size_t sb = c->state_bytes(B);
+  // z_m = in;  z_{j-1} = in + (A z_j)/j,  A = -i dt H * sign  ->  scale = (0, -sign*dt/j)
+  const T2* zj = in;
+  for (int j = m; j >= 1; --j) {
+    T2* dst;
+    if (j == 1) dst = out;
+    else if (store) { (*store)[j - 1].ensure(sb); dst = (T2*)(*store)[j - 1].p; }
+    else { c->zbar[j & 1].ensure(sb); dst = (T2*)c->zbar[j & 1].p; }
+    apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, in, dst, (T2*)nullptr, 0.0, -sign * dt / j, B);
+    zj = dst;
+  }
+  if (m == 0) SHIP(hipMemcpyAsync(out, in, sb, hipMemcpyDeviceToDevice, c->st));
+}
+
+template <class T>
+void s_check(SCtx<T>* c) {
+  SHIP(hipSetDevice(c->dev));
+  if (!c->have_terms) sfail(DQ_ERR_STATE, "dq_sctx_set_terms has not been called");
+}
+
+template <class T>
+void s_propagate(SCtx<T>* c, const double* u, int S, double dt, const void* psi_in, void* psi_out, int B) {
+  typedef typename SCtx<T>::T2 T2;
+  s_check(c);
+  if (S < 0 || B < 0 || !std::isfinite(dt)) sfail(DQ_ERR_INVALID, "bad n_steps / batch / dt");
+  if (B == 0) return;
+  if (!psi_in || !psi_out || (S > 0 && c->K > 0 && !u)) sfail(DQ_ERR_INVALID, "null pointer");
+  const size_t sb = c->state_bytes(B);
+  std::vector<double> uh = s_fetch_u(c, u, S);
+  const int m = plan_degree(c, uh, S, dt);
+  c->psi[0].ensure(sb); c->psi[1].ensure(sb);
+  SHIP(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
+  c->last_passes = 0; c->last_bytes = 0;
+  int cur = 0;
+  for (int t = 0; t < S; ++t) {
+    step_coefficients(c, t);
+    taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
+    cur ^= 1;
+  }
+  SHIP(hipMemcpyAsync(psi_out, c->psi[cur].p, sb, hipMemcpyDefault, c->st));
+  SHIP(hipStreamSynchronize(c->st));
+}
+
+// lam = 2 M psi, energies
+template <class T>
+void s_energy(SCtx<T>* c, const typename SCtx<T>::T2* psi, typename SCtx<T>::T2* lam, int B, double* energies, double* total) {
+  typedef typename SCtx<T>::T2 T2;
+  apply_groups(c, c->mgroups, (const T2*)c->d_coefM.p, c->has_DM ? (const T*)c->DM.p : (const T*)nullptr, psi,
+               (const T2*)nullptr, lam, (T2*)nullptr, 2.0, 0.0, B);
+  c->e_dev.ensure(8 * ((size_t)B + 1));
+  SHIP(dq::coldot_launch<T>(psi, B, lam, B, (int)c->d, B, 0.5, (double*)c->e_dev.p, c->st));
+  SHIP(dq::sum_launch((const double*)c->e_dev.p, B, (double*)c->e_dev.p + B, c->st));
+  if (energies) SHIP(hipMemcpyAsync(energies, c->e_dev.p, 8 * (size_t)B, hipMemcpyDefault, c->st));
+  if (total) SHIP(hipMemcpyAsync(total, (double*)c->e_dev.p + B, 8, hipMemcpyDefault, c->st));
+}
+
+template <class T>
+void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* psi0, int B, double* loss, double* grad_u,
+                   void* psi_final, double* energies) {
+  typedef typename SCtx<T>::T2 T2;
+  s_check(c);
+  if (!c->have_obs) sfail(DQ_ERR_STATE, "no observable strings (owner -2) were given to dq_sctx_set_terms");
+  if (S < 0 || B <= 0 || !std::isfinite(dt)) sfail(DQ_ERR_INVALID, "bad n_steps / batch / dt");
+  if (!psi0 || (S > 0 && c->K > 0 && !u)) sfail(DQ_ERR_INVALID, "null pointer");
+  const size_t sb = c->state_bytes(B);
+  const int K = c->K;
+  std::vector<double> uh = s_fetch_u(c, u, S);
+  const int m = plan_degree(c, uh, S, dt);
+  double budget = c->checkpoint_bytes;
+  if (budget <= 0) { size_t fr = 0, tot = 0; SHIP(hipMemGetInfo(&fr, &tot)); budget = 0.35 * (double)fr; }
+  const long ncp_max = std::max(1L, (long)(budget / (double)sb));
+  const int cstride = (int)std::max(1L, ((long)S + ncp_max - 1) / ncp_max);
+  const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
+  c->last_cstride = cstride;
+  if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
+  for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
+  c->psi[0].ensure(sb); c->psi[1].ensure(sb); c->lam[0].ensure(sb); c->lam[1].ensure(sb);
+  if ((int)c->zs.size() < m + 1) c->zs.resize(m + 1);
+  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * 8);
+  SHIP(hipMemsetAsync(c->grad_dev.p, 0, std::max<size_t>((size_t)S * K, 1) * 8, c->st));
+  c->last_passes = 0; c->last_bytes = 0;
+
+  // ---- forward ----
+  SHIP(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
+  int cur = 0;
+  for (int t = 0; t < S; ++t) {
+    if (t % cstride == 0) SHIP(hipMemcpyAsync(c->ck[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToDevice, c->st));
+    step_coefficients(c, t);
+    taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
+    cur ^= 1;
+  }
+  s_energy(c, (const T2*)c->psi[cur].p, (T2*)c->lam[0].p, B, energies, loss);
+  if (psi_final) SHIP(hipMemcpyAsync(psi_final, c->psi[cur].p, sb, hipMemcpyDefault, c->st));
+
+  // ---- backward ----
+  int lcur = 0;
+  for (int t = S - 1; t >= 0; --t) {
+    step_coefficients(c, t);
+    // psi_t: checkpoint, or T_m(-A_t) psi_{t+1}
+    const T2* psi_t;
+    if (t % cstride == 0) psi_t = (const T2*)c->ck[t / cstride].p;
+    else {
+      taylor_apply(c, m, dt, -1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
+      cur ^= 1;
+      psi_t = (const T2*)c->psi[cur].p;
+    }
+    // Horner iterates z_m = psi_t, ..., z_1 (z_0 = psi_{t+1} is not needed)
+    std::vector<const T2*> z(m + 1);
+    z[m] = psi_t;
+    {
+      const T2* zj = psi_t;
+      for (int j = m; j >= 2; --j) {
+        c->zs[j - 1].ensure(sb);
+        T2* dst = (T2*)c->zs[j - 1].p;
+        apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, psi_t, dst, (T2*)nullptr, 0.0, -dt / j, B);
+        z[j - 1] = dst;
+        zj = dst;
+      }
+    }
+    // reverse: zbar_0 = lambda_{t+1}; lambda_t = sum_j zbar_j; overlaps <zbar_{j-1}, P z_j>
+    T2* lam_new = (T2*)c->lam[lcur ^ 1].p;
+    SHIP(hipMemcpyAsync(lam_new, c->lam[lcur].p, sb, hipMemcpyDeviceToDevice, c->st));
+    const T2* zb_prev = (const T2*)c->lam[lcur].p;
+    for (int j = 1; j <= m; ++j) {
+      for (auto& g : c->hgroups) {
+        if (g.ovl.empty()) continue;
+        SOverlap<T> o;
+        o.za = zb_prev; o.zb = z[j];
+        o.terms = (const DTerm*)g.d_ovl.p; o.nterms = (int)g.ovl.size();
+        o.n = c->n; o.p = g.p; o.lmask = g.lmask; o.B = B;
+        dim3 grid(c->d >> g.p, (B + SBC - 1) / SBC);
+        const int nblk = grid.x * grid.y;
+        c->part.ensure((size_t)nblk * o.nterms * 16);
+        o.part = (double*)c->part.p;
+        c->timed(2.0 * sb, [&] { hipLaunchKernelGGL(soverlap_kernel<T>, grid, dim3(STHREADS), 0, c->st, o); });
+        c->last_passes += 1; c->last_bytes += 2.0 * sb;
+        hipLaunchKernelGGL(soverlap_finish_kernel, dim3(1), dim3(64), 0, c->st, (const double*)c->part.p, nblk, o.nterms,
+                           (const int*)g.d_ovl_slots.p, (const int*)c->d_owner.p, (const double*)c->d_wre.p,
+                           (const double*)c->d_wim.p, dt / j, (double*)c->grad_dev.p + (size_t)t * K);
+        SHIP(hipGetLastError());
+      }
+      // zbar_j = (A^H zbar_{j-1})/j = (+i dt/j) H zbar_{j-1}; accumulated into lambda_t
+      c->zbar[j & 1].ensure(sb);
+      T2* zb_new = (T2*)c->zbar[j & 1].p;
+      apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zb_prev, (const T2*)nullptr, zb_new, lam_new, 0.0,
+                   dt / j, B);
+      zb_prev = zb_new;
+    }
+    lcur ^= 1;
+    if (t % cstride == 0 && t > 0) {
+      // next iteration rebuilds psi_{t-1} from psi_t = this checkpoint
+      SHIP(hipMemcpyAsync(c->psi[cur].p, c->ck[t / cstride].p, sb, hipMemcpyDeviceToDevice, c->st));
+    }
+  }
+  if (grad_u && S > 0 && K > 0) SHIP(hipMemcpyAsync(grad_u, c->grad_dev.p, (size_t)S * K * 8, hipMemcpyDefault, c->st));
+  SHIP(hipStreamSynchronize(c->st));
+}
+
+template <class F>
+int s_guard(F&& f) {
+  try { f(); return DQ_OK; }
+  catch (const SErr& e) { s_err = e.msg; return e.code; }
+  catch (const std::exception& e) { s_err = e.what(); return DQ_ERR_HIP; }
+}
+template <class F>
+int s_with(dq_sctx* c, F&& f) {
+  return s_guard([&] {
+    if (!c) sfail(DQ_ERR_INVALID, "null context");
+    if (c->dtype == DQ_C128) f(static_cast<SCtx<double>*>(c));
+    else f(static_cast<SCtx<float>*>(c));
+  });
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dq_sctx_last_error(void) { return s_err.c_str(); }
+
+int dq_sctx_create(dq_sctx** out, int n_qubits, int n_controls, int device_id, int dtype) {
+  return s_guard([&] {
+    if (!out) sfail(DQ_ERR_INVALID, "null output");
+    *out = nullptr;
+    if (n_qubits < 1 || n_qubits > 30) sfail(DQ_ERR_INVALID, "n_qubits must be in [1, 30]");
+    if (n_controls < 0 || n_controls > 4096) sfail(DQ_ERR_INVALID, "n_controls must be in [0, 4096]");
+    if (dtype != DQ_C128 && dtype != DQ_C64) sfail(DQ_ERR_INVALID, "dtype must be DQ_C128 or DQ_C64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      (void)hipGetLastError();
+      sfail(DQ_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    }
+    if (device_id < 0 || device_id >= ndev) sfail(DQ_ERR_INVALID, "device_id out of range");
+    SHIP(hipSetDevice(device_id));
+    auto init = [&](auto* c) { c->n = n_qubits; c->d = 1u << n_qubits; c->K = n_controls; c->dev = device_id; *out = c; };
+    if (dtype == DQ_C128) init(new SCtx<double>()); else init(new SCtx<float>());
+  });
+}
+
+int dq_sctx_destroy(dq_sctx* c) {
+  if (!c) return DQ_OK;
+  return s_with(c, [&](auto* t) { (void)hipSetDevice(t->dev); (void)hipStreamSynchronize(t->st); delete t; });
+}
+
+int dq_sctx_set_stream(dq_sctx* c, void* s) {
+  return s_with(c, [&](auto* t) { SHIP(hipSetDevice(t->dev)); SHIP(hipStreamSynchronize(t->st)); t->st = (hipStream_t)s; });
+}
+
+int dq_sctx_set_terms(dq_sctx* c, int n_terms, const int* owner, const unsigned* xmask, const unsigned* zmask,
+                      const double* weight) {
+  return s_with(c, [&](auto* t) { set_terms(t, n_terms, owner, xmask, zmask, weight); });
+}
+
+int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
+  return s_with(c, [&](auto* t) {
+    if (!name) sfail(DQ_ERR_INVALID, "null option name");
+    const std::string s(name);
+    if (s == "tol") { if (!(v > 0)) sfail(DQ_ERR_INVALID, "tol must be > 0"); t->tol = v; }
+    else if (s == "force_degree") t->force_degree = (int)v;
+    else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
+    else if (s == "profile") { t->collect(); t->prof_on = v != 0; if (v < 0) { t->prof_ms = 0; t->prof_bytes = 0; t->prof_launches = 0; } }
+    else sfail(DQ_ERR_INVALID, "unknown option '" + s + "'");
+  });
+}
+
+int dq_sctx_get_info(dq_sctx* c, const char* name, double* v) {
+  return s_with(c, [&](auto* t) {
+    if (!name || !v) sfail(DQ_ERR_INVALID, "null argument");
+    const std::string s(name);
+    if (s == "degree") *v = t->last_degree;
+    else if (s == "theta") *v = t->last_theta;
+    else if (s == "groups") *v = (double)t->hgroups.size();
+    else if (s == "checkpoint_stride") *v = t->last_cstride;
+    else if (s == "passes") *v = t->last_passes;
+    else if (s == "pass_bytes") *v = t->last_bytes;
+    else if (s == "prof_ms") { t->collect(); *v = t->prof_ms; }
+    else if (s == "prof_bytes") { t->collect(); *v = t->prof_bytes; }
+    else if (s == "prof_launches") { t->collect(); *v = (double)t->prof_launches; }
+    else if (s == "dtype") *v = t->dtype;
+    else sfail(DQ_ERR_INVALID, "unknown info '" + s + "'");
+  });
+}
+
+int dq_sctx_propagate(dq_sctx* c, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out, int batch) {
+  return s_with(c, [&](auto* t) { s_propagate(t, u, n_steps, dt, psi_in, psi_out, batch); });
+}
+
+int dq_sctx_energy_grad(dq_sctx* c, const double* u, int n_steps, double dt, const void* psi0, int batch, double* loss,
+                        double* grad_u, void* psi_final, double* energies) {
+  return s_with(c, [&](auto* t) { s_energy_grad(t, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, energies); });
+}
+
+/* out = H(u_row) in  (which = 0)  or  out = M in  (which = 1): one matrix-free application, for tests. */
+int dq_sctx_apply(dq_sctx* c, int which, const double* u_row, const void* in, void* out, int batch) {
+  return s_with(c, [&](auto* t) {
+    typedef typename std::remove_pointer<decltype(t)>::type::T2 T2;
+    typedef decltype(((T2*)nullptr)->x) T;
+    s_check(t);
+    if (!in || !out || batch <= 0) sfail(DQ_ERR_INVALID, "bad arguments");
+    const size_t sb = t->state_bytes(batch);
+    t->psi[0].ensure(sb); t->psi[1].ensure(sb);
+    SHIP(hipMemcpyAsync(t->psi[0].p, in, sb, hipMemcpyDefault, t->st));
+    if (which == 0) {
+      std::vector<double> uh = s_fetch_u(t, u_row, 1);
+      step_coefficients(t, 0);
+      apply_groups(t, t->hgroups, (const T2*)t->d_coef.p, step_diag(t), (const T2*)t->psi[0].p, (const T2*)nullptr,
+                   (T2*)t->psi[1].p, (T2*)nullptr, 1.0, 0.0, batch);
+    } else {
+      apply_groups(t, t->mgroups, (const T2*)t->d_coefM.p, t->has_DM ? (const T*)t->DM.p : (const T*)nullptr,
+                   (const T2*)t->psi[0].p, (const T2*)nullptr, (T2*)t->psi[1].p, (T2*)nullptr, 1.0, 0.0, batch);
+    }
+    SHIP(hipMemcpyAsync(out, t->psi[1].p, sb, hipMemcpyDefault, t->st));
+    SHIP(hipStreamSynchronize(t->st));
+  });
+}
+
+}  // extern "C"

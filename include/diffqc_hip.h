@@ -111,6 +111,30 @@ int dq_profile_enable(dq_ctx* ctx, int on);
 int dq_profile_reset(dq_ctx* ctx);
 int dq_profile_get(dq_ctx* ctx, dq_profile* out);
 
+/* ---- Structured (matrix-free) engine for large qubit counts -----------------------
+ * H(t) = H0 + sum_k u_k(t) H_k with every operator a real-weighted sum of Pauli strings; the dense 2^n x 2^n
+ * matrices of dq_set_hamiltonians never exist. Same step as the dense engine -- psi <- exp(-i dt H(t)) psi, the
+ * exponential of the SUM (diffqc.cc:192-198, sim_plain.py:137-146) -- evaluated as a Taylor polynomial of
+ * matrix-free H.psi passes; same [2^n][batch] state layout, same pulse-table / gradient conventions.
+ * A string is (owner, xmask, zmask, weight): owner -1 = drift H0, 0..K-1 = control H_k, -2 = observable M;
+ * bit q of xmask set <=> X or Y on the qubit whose basis-index bit is q; bit q of zmask set <=> Z or Y. */
+typedef struct dq_sctx dq_sctx;
+const char* dq_sctx_last_error(void);
+int dq_sctx_create(dq_sctx** ctx, int n_qubits, int n_controls, int device_id, int dtype);
+int dq_sctx_destroy(dq_sctx* ctx);
+int dq_sctx_set_stream(dq_sctx* ctx, void* hip_stream);
+int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigned* xmask, const unsigned* zmask,
+                      const double* weight);
+/* options: "tol" (Taylor remainder bound), "force_degree", "checkpoint_bytes", "profile" (1 on, 0 off, -1 reset) */
+int dq_sctx_set_option(dq_sctx* ctx, const char* name, double value);
+int dq_sctx_get_info(dq_sctx* ctx, const char* name, double* value);
+int dq_sctx_propagate(dq_sctx* ctx, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out,
+                      int batch);
+int dq_sctx_energy_grad(dq_sctx* ctx, const double* u, int n_steps, double dt, const void* psi0, int batch,
+                        double* loss, double* grad_u, void* psi_final, double* energies);
+/* out = H(u_row) in (which = 0) or M in (which = 1): one matrix-free application (parity tests). */
+int dq_sctx_apply(dq_sctx* ctx, int which, const double* u_row, const void* in, void* out, int batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,142 @@
+"""Structured (matrix-free) engine vs the dense engine / the oracle at small qubit counts (SURVEY.md 8-F1:
+"parity only checkable at small n against the dense path")."""
+import numpy as np
+import pytest
+
+from diffquantum_amd import problems
+from diffquantum_amd.structured import DRIFT, OBSERVABLE, StructuredEngine, ising_x_terms, terms_to_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def random_terms(n, K, seed, n_drift=6, per_control=2, n_obs=4, max_weight=3):
+    rng = np.random.default_rng(seed)
+
+    def rstring():
+        s = ["I"] * n
+        for q in rng.choice(n, size=rng.integers(1, min(max_weight, n) + 1), replace=False):
+            s[q] = "XYZ"[rng.integers(3)]
+        return "".join(s)
+
+    terms = [(DRIFT, rstring(), float(rng.uniform(-1, 1))) for _ in range(n_drift)]
+    for k in range(K):
+        terms += [(k, rstring(), float(rng.uniform(-1, 1))) for _ in range(per_control)]
+    terms += [(OBSERVABLE, rstring(), float(rng.uniform(-1, 1))) for _ in range(n_obs)]
+    return terms
+
+
+@pytest.mark.parametrize("dtype,tol", [("c128", 1e-13), ("c64", 2e-5)])
+@pytest.mark.parametrize("n,K,B", [(1, 1, 1), (3, 2, 5), (6, 3, 17), (10, 4, 20), (11, 2, 3)])
+def test_apply_matches_dense(n, K, B, dtype, tol):
+    terms = random_terms(n, K, seed=n * 7 + K)
+    H0, Hs, M = terms_to_dense(terms, n, K)
+    u = np.random.default_rng(1).uniform(-2, 2, K)
+    psi = problems.random_states(1 << n, B, seed=2)
+    with StructuredEngine(n, K, dtype=dtype) as e:
+        e.set_terms(terms)
+        got = e.apply(psi, u)
+        gotM = e.apply(psi, observable=True)
+    H = H0 + np.tensordot(u, Hs, axes=1)
+    assert np.max(np.abs(got - H @ psi)) < tol * 10
+    assert np.max(np.abs(gotM - M @ psi)) < tol * 10
+
+
+@pytest.mark.parametrize("dtype,tol", [("c128", 1e-10), ("c64", 1e-4)])
+@pytest.mark.parametrize("n,K,B,S,dt", [(2, 1, 3, 6, 0.1), (4, 3, 9, 12, 0.07), (6, 2, 33, 8, -0.05), (10, 3, 4, 5, 0.04)])
+def test_chain_and_gradient_match_oracle(oracle, n, K, B, S, dt, dtype, tol):
+    terms = random_terms(n, K, seed=n + K + S)
+    H0, Hs, M = terms_to_dense(terms, n, K)
+    u = np.random.default_rng(S).uniform(-1.5, 1.5, (S, K))
+    psi0 = problems.random_states(1 << n, B, seed=5)
+    with StructuredEngine(n, K, dtype=dtype) as e:
+        e.set_terms(terms)
+        fwd = e.propagate(u, dt, psi0)
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        deg = e.info("degree")
+    if n <= 6:
+        rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    else:  # the oracle's expm_frechet is too slow at d = 1024: compare with the dense GPU engine (itself oracle-checked)
+        from diffquantum_amd.engine import Engine
+        with Engine(1 << n, K) as de:
+            de.set_hamiltonians(H0, Hs)
+            de.set_observable(M)
+            rl, rg, rf, _ = de.energy_grad(u, dt, psi0)
+    assert np.max(np.abs(fwd - rf)) < tol and np.max(np.abs(fin - rf)) < tol, deg
+    assert abs(loss - rl) < tol * B * 4
+    assert np.max(np.abs(grad - rg)) < tol * B * 4
+    assert abs(en.sum() - loss) < 1e-9 * B
+
+
+def test_ising_problem_equals_dense_builder():
+    """The string form of the D2 synthetic problem is the same operator as problems.random_ising."""
+    n = 5
+    H0, Hs, M = terms_to_dense(ising_x_terms(n, seed=3), n, n)
+    D0, Ds, DM = problems.random_ising(n, seed=3)
+    assert np.allclose(H0, D0, atol=1e-14) and np.allclose(Hs, Ds) and np.allclose(M, DM, atol=1e-14)
+
+
+def test_two_groups_and_checkpoint_stride(oracle):
+    """n = 10 in complex128 uses 2 local-bit groups (p = 8); small checkpoint budget forces psi_t rebuilds."""
+    n, K, B, S, dt = 10, 10, 6, 9, 0.03
+    terms = ising_x_terms(n, seed=1)
+    u = problems.pulse_table(K, S, S * dt, seed=2)
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    with StructuredEngine(n, K, dtype="c128") as e:
+        e.set_terms(terms)
+        assert e.info("groups") == 2
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("checkpoint_stride") == 1
+        e.set_option("checkpoint_bytes", (1 << n) * B * 16 * 2)
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("checkpoint_stride") == 5
+    assert abs(l0 - l1) < 1e-12 and np.max(np.abs(g0 - g1)) < 1e-11 and np.max(np.abs(f0 - f1)) < 1e-13
+    H0, Hs, M = terms_to_dense(terms, n, K)
+    from diffquantum_amd.engine import Engine
+    with Engine(1 << n, K) as de:
+        de.set_hamiltonians(H0, Hs)
+        de.set_observable(M)
+        rl, rg, rf, _ = de.energy_grad(u, dt, psi0)
+    assert np.max(np.abs(f0 - rf)) < 1e-10 and np.max(np.abs(g0 - rg)) < 1e-10 * B and abs(l0 - rl) < 1e-10 * B
+
+
+def test_properties_at_n16():
+    """n = 16 (d = 65536, dense H would be 64 GB): norm conservation, linearity, reversibility, directional derivative."""
+    n, B, S, dt = 16, 8, 6, 0.01
+    terms = ising_x_terms(n, seed=0)
+    u = problems.pulse_table(n, S, S * dt, seed=1)
+    psi0 = problems.random_states(1 << n, B, seed=2).astype(np.complex64)
+    with StructuredEngine(n, n, dtype="c64") as e:
+        e.set_terms(terms)
+        out = e.propagate(u, dt, psi0)
+        assert np.max(np.abs(np.linalg.norm(out.astype(np.complex128), axis=0) - 1)) < 1e-5
+        mix = (0.6 * psi0[:, :2] + (0.3 - 0.2j) * psi0[:, 2:4]).astype(np.complex64)
+        assert np.max(np.abs(e.propagate(u, dt, mix) - (0.6 * out[:, :2] + (0.3 - 0.2j) * out[:, 2:4]))) < 1e-5
+        back = e.propagate(u[::-1].copy(), -dt, out)
+        assert np.max(np.abs(back - psi0)) < 1e-5
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        v = np.random.default_rng(0).standard_normal(u.shape)
+        eps = 1e-2
+
+        def L(uu):
+            f = e.propagate(uu, dt, psi0)
+            return float(np.real(np.vdot(f.astype(np.complex128), e.apply(f, observable=True).astype(np.complex128))))
+
+        fd = (L(u + eps * v) - L(u - eps * v)) / (2 * eps)
+        assert abs(fd - float(np.sum(grad * v))) < 2e-3 * max(1.0, abs(fd))
+        assert abs(L(u) - loss) < 1e-3 * max(1.0, abs(loss))
+
+
+def test_structured_errors():
+    with StructuredEngine(3, 1) as e:
+        with pytest.raises(ValueError):
+            e.set_terms([(0, "XX", 1.0)])  # wrong string length
+        with pytest.raises(ValueError):
+            e.set_terms([(5, "XII", 1.0)])  # owner out of range
+        with pytest.raises(ValueError):
+            e.set_terms([(0, "XQI", 1.0)])
+        from diffquantum_amd._lib import DiffqcError
+        with pytest.raises(DiffqcError):
+            e.propagate(np.zeros((1, 1)), 0.1, np.ones((8, 1)))  # terms not set
+        e.set_terms([(DRIFT, "ZII", 1.0), (0, "IXI", 1.0)])
+        with pytest.raises(DiffqcError):
+            e.energy_grad(np.zeros((1, 1)), 0.1, np.ones((8, 1)))  # no observable
