@@ -67,9 +67,11 @@ hipError_t grad_contract_launch(const typename Cx<T>::type* Abar, long strideA, 
 int grad_contract_blocks(long n_elem);
 
 // e[b] = scale * sum_i Re(conj(X[i][b]) * Y[i][b]);  X, Y are d x B (ld in complex elements); fp64 accumulation
+// `part` is scratch of coldot_chunks(d) * B doubles (two-stage, fixed order)
 template <class T>
 hipError_t coldot_launch(const typename Cx<T>::type* X, long ldx, const typename Cx<T>::type* Y, long ldy, int d, int B,
-                         double scale, double* e, hipStream_t st);
+                         double scale, double* e, double* part, hipStream_t st);
+int coldot_chunks(int d);
 // out[0] = sum_b e[b]  (single block, deterministic)
 hipError_t sum_launch(const double* e, int n, double* out, hipStream_t st);
 // colsum[j] = sum_i |X[i][j]|  (for the 1-norm), d x d

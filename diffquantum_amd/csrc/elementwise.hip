@@ -166,33 +166,56 @@ template hipError_t grad_contract_launch<float>(const float2*, long, const float
 
 // ---- e[b] = scale * sum_i Re(conj(X[i][b]) Y[i][b]) ---------------------------------------
 // Energy <psi_b| M |psi_b> with Y = M Psi (sim_plain.py:281 `M.matrix_element(final, final).real`).
+// Two-stage so that tall-skinny batches (d = 2^18 rows, 64 columns) use the whole chip: stage 1 splits the rows
+// into chunks (blockIdx.y), 64 columns x 4 row-lanes per block; stage 2 adds the chunks in a fixed order.
 template <class T>
 __global__ void __launch_bounds__(256) coldot_kernel(const typename Cx<T>::type* __restrict__ X, long ldx,
                                                      const typename Cx<T>::type* __restrict__ Y, long ldy, int d,
-                                                     int B, double scale, double* __restrict__ e) {
+                                                     int B, int rows_per_chunk, double* __restrict__ part) {
   typedef typename Cx<T>::type T2;
+  __shared__ double red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(d, r0 + rows_per_chunk);
+  double s = 0.0;
+  if (b < B)
+    for (int i = r0 + rg; i < r1; i += 4) {
+      const T2 x = X[(long)i * ldx + b];
+      const T2 y = Y[(long)i * ldy + b];
+      s += (double)x.x * (double)y.x + (double)x.y * (double)y.y;
+    }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && b < B) part[(long)blockIdx.y * B + b] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+__global__ void __launch_bounds__(256) coldot_finish_kernel(const double* __restrict__ part, int nchunks, int B,
+                                                            double scale, double* __restrict__ e) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double s = 0.0;
-  for (int i = 0; i < d; ++i) {
-    const T2 x = X[(long)i * ldx + b];
-    const T2 y = Y[(long)i * ldy + b];
-    s += (double)x.x * (double)y.x + (double)x.y * (double)y.y;
-  }
+  for (int c = 0; c < nchunks; ++c) s += part[(long)c * B + b];
   e[b] = scale * s;
 }
 
+int coldot_chunks(int d) { return max(1, min(256, d / 64)); }
+
+// `part` must hold coldot_chunks(d) * B doubles
 template <class T>
 hipError_t coldot_launch(const typename Cx<T>::type* X, long ldx, const typename Cx<T>::type* Y, long ldy, int d, int B,
-                         double scale, double* e, hipStream_t st) {
+                         double scale, double* e, double* part, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(coldot_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, X, ldx, Y, ldy, d, B,
-                     scale, e);
+  const int nch = coldot_chunks(d);
+  const int rpc = (d + nch - 1) / nch;
+  hipLaunchKernelGGL(coldot_kernel<T>, dim3((unsigned)((B + 63) / 64), (unsigned)nch), dim3(256), 0, st, X, ldx, Y, ldy,
+                     d, B, rpc, part);
+  hipLaunchKernelGGL(coldot_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, part, nch, B, scale, e);
   return hipGetLastError();
 }
 template hipError_t coldot_launch<double>(const double2*, long, const double2*, long, int, int, double, double*,
-                                          hipStream_t);
-template hipError_t coldot_launch<float>(const float2*, long, const float2*, long, int, int, double, double*,
+                                          double*, hipStream_t);
+template hipError_t coldot_launch<float>(const float2*, long, const float2*, long, int, int, double, double*, double*,
                                          hipStream_t);
 
 __global__ void __launch_bounds__(256) sum_kernel(const double* __restrict__ e, int n, double* __restrict__ out) {

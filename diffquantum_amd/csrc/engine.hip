@@ -604,8 +604,9 @@ void do_energy(Ctx<T>* c, const TT* psi_dev, int B, TT* lam_out /*2 M psi*/, dou
   const int d = c->d;
   c->zgemm(0, 0, d, B, d, 2.0, (const T2*)c->M.p, d, 0, psi_dev, B, 0, 0.0, lam_out, B, 0, 1);
   c->e_dev.ensure(sizeof(double) * ((size_t)B + 1));
+  c->part.ensure(sizeof(double) * (size_t)dq::coldot_chunks(d) * B);
   c->timed(DQ_PROF_OTHER, 4.0 * d * B, 4.0 * sizeof(T) * d * B,
-           [&] { return dq::coldot_launch<T>(psi_dev, B, lam_out, B, d, B, 0.5, c->e_dev.d(), c->st); });
+           [&] { return dq::coldot_launch<T>(psi_dev, B, lam_out, B, d, B, 0.5, c->e_dev.d(), c->part.d(), c->st); });
   c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(c->e_dev.d(), B, c->e_dev.d() + B, c->st); });
   if (energies) out_copy(c, energies, c->e_dev.p, sizeof(double) * (size_t)B);
   if (total) out_copy(c, total, c->e_dev.d() + B, sizeof(double));

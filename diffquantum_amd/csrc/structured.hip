@@ -72,7 +72,7 @@ bool s_is_device_ptr(const void* p) {
 }
 
 constexpr int SBC = 16;        // batch columns per tile (128 B rows for complex64, 256 B for complex128)
-constexpr int STHREADS = 256;
+constexpr int STHREADS = 1024;  // 16 waves per 64 KB tile -> 2 workgroups = 32 waves per CU (latency hiding)
 constexpr int SMAXT = 64;      // strings per group
 
 struct DTerm {  // device view of one Pauli string inside a group
@@ -150,10 +150,10 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
     }
     for (int m = 0; m < a.nterms; ++m) {
       const T2 v = tile[(r ^ tt[m].xloc) * SBC + c];
-      const T2 cf = tc[m];
-      const T sg = (__popc((i ^ tt[m].xmask) & tt[m].zmask) & 1) ? (T)-1 : (T)1;
-      sx += sg * (cf.x * v.x - cf.y * v.y);
-      sy += sg * (cf.x * v.y + cf.y * v.x);
+      T2 cf = tc[m];
+      if (tt[m].zmask != 0 && (__popc((i ^ tt[m].xmask) & tt[m].zmask) & 1)) { cf.x = -cf.x; cf.y = -cf.y; }  // uniform branch
+      sx = fma(cf.x, v.x, sx); sx = fma(-cf.y, v.y, sx);
+      sy = fma(cf.x, v.y, sy); sy = fma(cf.y, v.x, sy);
     }
     if (a.prev) { const T2 q = a.prev[off]; sx += q.x; sy += q.y; }
     T2 o;
@@ -229,12 +229,22 @@ __global__ void __launch_bounds__(STHREADS) soverlap_kernel(SOverlap<T> a) {
 }
 
 // grad[k(slot)] += fac * Im( phase_slot * sum_blk part[blk][m] ) * weight_slot      (fixed-order sum: deterministic)
-__global__ void soverlap_finish_kernel(const double* part, int nblk, int nterms, const int* slots, const int* owner,
-                                       const double* wre, const double* wim, double fac, double* grad_row) {
-  const int m = threadIdx.x;
-  if (m >= nterms) return;
+__global__ void __launch_bounds__(256) soverlap_finish_kernel(const double* part, int nblk, int nterms, const int* slots,
+                                                              const int* owner, const double* wre, const double* wim,
+                                                              double fac, double* grad_row) {
+  // one block per string; fixed strided order + tree -> deterministic
+  __shared__ double rx[256], ry[256];
+  const int m = blockIdx.x;
   double sx = 0, sy = 0;
-  for (int b = 0; b < nblk; ++b) { sx += part[((size_t)b * nterms + m) * 2]; sy += part[((size_t)b * nterms + m) * 2 + 1]; }
+  for (int b = threadIdx.x; b < nblk; b += 256) { sx += part[((size_t)b * nterms + m) * 2]; sy += part[((size_t)b * nterms + m) * 2 + 1]; }
+  rx[threadIdx.x] = sx; ry[threadIdx.x] = sy;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) { rx[threadIdx.x] += rx[threadIdx.x + h]; ry[threadIdx.x] += ry[threadIdx.x + h]; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  sx = rx[0]; sy = ry[0];
   const int s = slots[m];
   const int k = owner[s];
   if (k < 0) return;
@@ -673,7 +683,8 @@ void s_energy(SCtx<T>* c, const typename SCtx<T>::T2* psi, typename SCtx<T>::T2*
   apply_groups(c, c->mgroups, (const T2*)c->d_coefM.p, c->has_DM ? (const T*)c->DM.p : (const T*)nullptr, psi,
                (const T2*)nullptr, lam, (T2*)nullptr, 2.0, 0.0, B);
   c->e_dev.ensure(8 * ((size_t)B + 1));
-  SHIP(dq::coldot_launch<T>(psi, B, lam, B, (int)c->d, B, 0.5, (double*)c->e_dev.p, c->st));
+  c->part.ensure(8 * (size_t)dq::coldot_chunks((int)c->d) * B);
+  SHIP(dq::coldot_launch<T>(psi, B, lam, B, (int)c->d, B, 0.5, (double*)c->e_dev.p, (double*)c->part.p, c->st));
   SHIP(dq::sum_launch((const double*)c->e_dev.p, B, (double*)c->e_dev.p + B, c->st));
   if (energies) SHIP(hipMemcpyAsync(energies, c->e_dev.p, 8 * (size_t)B, hipMemcpyDefault, c->st));
   if (total) SHIP(hipMemcpyAsync(total, (double*)c->e_dev.p + B, 8, hipMemcpyDefault, c->st));
@@ -759,7 +770,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         o.part = (double*)c->part.p;
         c->timed(2.0 * sb, [&] { hipLaunchKernelGGL(soverlap_kernel<T>, grid, dim3(STHREADS), 0, c->st, o); });
         c->last_passes += 1; c->last_bytes += 2.0 * sb;
-        hipLaunchKernelGGL(soverlap_finish_kernel, dim3(1), dim3(64), 0, c->st, (const double*)c->part.p, nblk, o.nterms,
+        hipLaunchKernelGGL(soverlap_finish_kernel, dim3(o.nterms), dim3(256), 0, c->st, (const double*)c->part.p, nblk, o.nterms,
                            (const int*)g.d_ovl_slots.p, (const int*)c->d_owner.p, (const double*)c->d_wre.p,
                            (const double*)c->d_wim.p, dt / j, (double*)c->grad_dev.p + (size_t)t * K);
         SHIP(hipGetLastError());
