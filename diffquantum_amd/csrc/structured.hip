@@ -204,17 +204,30 @@ __global__ void __launch_bounds__(STHREADS) soverlap_kernel(SOverlap<T> a) {
   __syncthreads();
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the cotangent rows of this thread stay in registers for all strings (one global read per pass)
+  constexpr int RPT = (1 << PMAX) / (STHREADS / SBC);
+  T2 u[RPT];
+  unsigned ui[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = threadIdx.x / SBC + q * (STHREADS / SBC);
+    u[q].x = 0; u[q].y = 0; ui[q] = 0;
+    if (r < R && col_ok) { ui[q] = rowidx[r]; u[q] = a.za[(size_t)ui[q] * a.B + c0 + c]; }
+  }
   for (int m = 0; m < a.nterms; ++m) {
     double sx = 0.0, sy = 0.0;
-    if (col_ok)
-      for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
-        const unsigned i = rowidx[r];
-        const T2 u = a.za[(size_t)i * a.B + c0 + c];
-        const T2 v = tile[(r ^ tt[m].xloc) * SBC + c];
-        const double sg = (__popc((i ^ tt[m].xmask) & tt[m].zmask) & 1) ? -1.0 : 1.0;
-        sx += sg * ((double)u.x * v.x + (double)u.y * v.y);   // conj(u) * v
-        sy += sg * ((double)u.x * v.y - (double)u.y * v.x);
+    const unsigned xl = tt[m].xloc, xm = tt[m].xmask, zm = tt[m].zmask;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = threadIdx.x / SBC + q * (STHREADS / SBC);
+      if (r < R) {
+        const T2 v = tile[(r ^ xl) * SBC + c];
+        T px = u[q].x * v.x + u[q].y * v.y;   // conj(u) * v
+        T py = u[q].x * v.y - u[q].y * v.x;
+        if (zm != 0 && (__popc((ui[q] ^ xm) & zm) & 1)) { px = -px; py = -py; }
+        sx += (double)px; sy += (double)py;
       }
+    }
     for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); }
     if (lane == 0) { red[0][wave] = sx; red[1][wave] = sy; }
     __syncthreads();

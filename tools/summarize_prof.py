@@ -14,7 +14,7 @@ out = []
 
 
 def short(name):
-    name = name.replace("void ", "").replace("dq::", "")
+    name = name.replace("void ", "").replace("dq::", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0][:60]
 
 
