@@ -115,8 +115,11 @@ struct SApply {
 };
 
 // out = add + (sr + i si) * ( prev + diag .* y + sum_m coef_m sign_m P'_m y )
-template <class T>
+// Which optional operands exist is a compile-time property (FLAGS bit 0 prev, 1 add, 2 acc, 3 diag): a runtime
+// "load or zero" per element makes hipcc branch around every load and drain vmcnt each time (measured 3.9 -> 2.7 TB/s).
+template <class T, int FLAGS>
 __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
+  constexpr bool HAS_PREV = FLAGS & 1, HAS_ADD = FLAGS & 2, HAS_ACC = FLAGS & 4, HAS_DIAG = FLAGS & 8;
   typedef typename dq::Cx<T>::type T2;
   constexpr int PMAX = LocalBits<T>::P;
   __shared__ T2 tile[(1 << PMAX) * SBC];
@@ -139,14 +142,31 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
   }
   __syncthreads();
   if (!col_ok) return;
-  for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
+  // every global operand of this thread's rows is requested before the LDS work starts
+  constexpr int RPT = (1 << PMAX) / (STHREADS / SBC);
+  T2 pv[RPT], ad[RPT], ac[RPT];
+  T dg[RPT];
+  const int rbase = threadIdx.x / SBC;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = min(rbase + q * (STHREADS / SBC), R - 1);  // clamped: loads stay unconditional
+    const size_t off = (size_t)rowidx[r] * a.B + c0 + c;
+    if (HAS_PREV) pv[q] = a.prev[off];
+    if (HAS_ADD) ad[q] = a.add[off];
+    if (HAS_ACC) ac[q] = a.acc[off];
+    if (HAS_DIAG) dg[q] = a.diag[rowidx[r]];
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = rbase + q * (STHREADS / SBC);
+    if (r >= R) break;
     const unsigned i = rowidx[r];
     const size_t off = (size_t)i * a.B + c0 + c;
     T sx = 0, sy = 0;
-    if (a.diag) {
-      const T dd = a.diag[i];
+    if (HAS_PREV) { sx = pv[q].x; sy = pv[q].y; }
+    if (HAS_DIAG) {
       const T2 v = tile[r * SBC + c];
-      sx = dd * v.x; sy = dd * v.y;
+      sx = fma(dg[q], v.x, sx); sy = fma(dg[q], v.y, sy);
     }
     for (int m = 0; m < a.nterms; ++m) {
       const T2 v = tile[(r ^ tt[m].xloc) * SBC + c];
@@ -155,13 +175,39 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
       sx = fma(cf.x, v.x, sx); sx = fma(-cf.y, v.y, sx);
       sy = fma(cf.x, v.y, sy); sy = fma(cf.y, v.x, sy);
     }
-    if (a.prev) { const T2 q = a.prev[off]; sx += q.x; sy += q.y; }
     T2 o;
     o.x = a.sr * sx - a.si * sy;
     o.y = a.sr * sy + a.si * sx;
-    if (a.add) { const T2 q = a.add[off]; o.x += q.x; o.y += q.y; }
+    if (HAS_ADD) { o.x += ad[q].x; o.y += ad[q].y; }
     a.out[off] = o;
-    if (a.acc) { T2 q = a.acc[off]; q.x += o.x; q.y += o.y; a.acc[off] = q; }
+    if (HAS_ACC) { T2 w; w.x = ac[q].x + o.x; w.y = ac[q].y + o.y; a.acc[off] = w; }
+  }
+}
+
+template <class T, int F>
+void sapply_launch_f(const SApply<T>& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((sapply_kernel<T, F>), grid, dim3(STHREADS), 0, st, a);
+}
+template <class T>
+void sapply_launch(const SApply<T>& a, dim3 grid, hipStream_t st) {
+  const int f = (a.prev ? 1 : 0) | (a.add ? 2 : 0) | (a.acc ? 4 : 0) | (a.diag ? 8 : 0);
+  switch (f) {
+    case 0: sapply_launch_f<T, 0>(a, grid, st); break;
+    case 1: sapply_launch_f<T, 1>(a, grid, st); break;
+    case 2: sapply_launch_f<T, 2>(a, grid, st); break;
+    case 3: sapply_launch_f<T, 3>(a, grid, st); break;
+    case 4: sapply_launch_f<T, 4>(a, grid, st); break;
+    case 5: sapply_launch_f<T, 5>(a, grid, st); break;
+    case 6: sapply_launch_f<T, 6>(a, grid, st); break;
+    case 7: sapply_launch_f<T, 7>(a, grid, st); break;
+    case 8: sapply_launch_f<T, 8>(a, grid, st); break;
+    case 9: sapply_launch_f<T, 9>(a, grid, st); break;
+    case 10: sapply_launch_f<T, 10>(a, grid, st); break;
+    case 11: sapply_launch_f<T, 11>(a, grid, st); break;
+    case 12: sapply_launch_f<T, 12>(a, grid, st); break;
+    case 13: sapply_launch_f<T, 13>(a, grid, st); break;
+    case 14: sapply_launch_f<T, 14>(a, grid, st); break;
+    default: sapply_launch_f<T, 15>(a, grid, st); break;
   }
 }
 
@@ -577,7 +623,7 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
     a.out = dst;
     dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
     const double units = 2.0 + (prev ? 1 : 0) + (a.add ? 1 : 0) + (a.acc ? 2 : 0);
-    c->timed(units * sb, [&] { hipLaunchKernelGGL(sapply_kernel<T>, grid, dim3(STHREADS), 0, c->st, a); });
+    c->timed(units * sb, [&] { sapply_launch<T>(a, grid, c->st); });
     c->last_passes += 1;
     c->last_bytes += units * sb;
     prev = dst;
