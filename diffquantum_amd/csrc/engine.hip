@@ -255,7 +255,7 @@ struct Ctx : dq_ctx {
   // workspace
   std::vector<DevBuf> pool;
   size_t pool_tc = 0;
-  DevBuf u_dev, grad_dev, part, scratch, e_dev, psi[3], lam[2], tmp_in[4];
+  DevBuf u_dev, grad_dev, part, scratch, e_dev, psi[3], lam[2], tmp_in[4];  // tmp_in[3]: staged Psi_0 of the operator-form sweep
   std::vector<DevBuf> ck;
   // profiling
   bool prof_on = false;
@@ -342,7 +342,7 @@ struct Ctx : dq_ctx {
     memset(&a, 0, sizeof(a));
     a.out = out;
     a.n_in = n_in;
-    for (int j = 0; j < n_in; ++j) { a.x[j] = x[j]; a.c[j] = c[j]; }
+    for (int j = 0; j < n_in; ++j) { a.x[j] = x[j]; a.c[j] = c[j]; }  // n_in may be 0 (x, c null): out = cI * I
     a.cI = cI;
     a.d = d;
     a.stride = (long)nn();
@@ -627,7 +627,13 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   if (!psi0) fail(DQ_ERR_INVALID, "null state pointer");
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d, K = c->K;
-  const size_t sb = (size_t)d * B * sizeof(T2);
+  const size_t sb_io = (size_t)d * B * sizeof(T2);
+  // Operator form for wide batches (B > d): L = tr(M P_S R P_S^H) with R = Psi0 Psi0^H, so the whole sweep runs on the
+  // d x d propagator product P_t (working "batch" = I, terminal costate Q = 2 M P_S R) at a cost independent of B.
+  const bool opform = (c->compose_mode == 1 || (c->compose_mode < 0 && B > d)) && S > 0;
+  c->last_composed = opform ? 1.0 : 0.0;
+  const int Bw = opform ? d : B;
+  const size_t sb = (size_t)d * Bw * sizeof(T2);
   std::vector<double> uh = fetch_u(c, u, S);
 
   // checkpoint stride from the memory budget
@@ -648,7 +654,13 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
 
   // ---- forward ----
-  HIPCK(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
+  const T2* psi0_dev = nullptr;
+  if (opform) {
+    psi0_dev = in_dev(c, psi0, sb_io, c->tmp_in[3]);
+    c->lincomb((T2*)c->psi[0].p, 0, nullptr, nullptr, 1.0, 1, false);  // P_0 = I
+  } else {
+    HIPCK(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
+  }
   int cur = 0;
   const int tc = time_chunk(c, std::max(S, 1));
   c->last_chunk = tc;
@@ -665,14 +677,29 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
         c->timed(DQ_PROF_OTHER, 0.0, 2.0 * bytes,
                  [&] { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->st); });
       }
-      c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
-               (T2*)c->psi[cur ^ 1].p, B, 0, 1);
+      c->zgemm(0, 0, d, Bw, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, Bw, 0, 0.0,
+               (T2*)c->psi[cur ^ 1].p, Bw, 0, 1);
       cur ^= 1;
     }
   }
-  // psi[cur] = Psi_S ; terminal costate Lambda_S = 2 M Psi_S, energies
-  do_energy(c, (const T2*)c->psi[cur].p, B, (T2*)c->lam[0].p, energies, loss);
-  if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
+  if (opform) {
+    // psi[cur] = P_S.  Psi_S = P_S Psi_0 (for the outputs), then Q = 2 M (P_S (Psi_0 Psi_0^H)) as terminal costate
+    c->tmp_in[1].ensure(sb_io);
+    c->tmp_in[2].ensure(sb_io);
+    T2* psiS = (T2*)c->tmp_in[1].p;
+    c->zgemm(0, 0, d, B, d, 1.0, (const T2*)c->psi[cur].p, d, 0, psi0_dev, B, 0, 0.0, psiS, B, 0, 1);
+    do_energy(c, psiS, B, (T2*)c->tmp_in[2].p, energies, loss);
+    if (psi_final) out_copy(c, psi_final, psiS, sb_io);
+    T2* R = c->mat(SLOT_TREE, 1);
+    T2* PR = c->mat(SLOT_TREE + 1, 1);
+    c->zgemm(0, 1, d, d, B, 1.0, psi0_dev, B, 0, psi0_dev, B, 0, 0.0, R, d, 0, 1);
+    c->zgemm(0, 0, d, d, d, 1.0, (const T2*)c->psi[cur].p, d, 0, R, d, 0, 0.0, PR, d, 0, 1);
+    c->zgemm(0, 0, d, d, d, 2.0, (const T2*)c->M.p, d, 0, PR, d, 0, 0.0, (T2*)c->lam[0].p, d, 0, 1);
+  } else {
+    // psi[cur] = Psi_S ; terminal costate Lambda_S = 2 M Psi_S, energies
+    do_energy(c, (const T2*)c->psi[cur].p, B, (T2*)c->lam[0].p, energies, loss);
+    if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
+  }
 
   // ---- backward ----
   const T2* psi_next = (const T2*)c->psi[cur].p;
@@ -696,14 +723,14 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
           T2* dst = nullptr;
           for (int i = 0; i < 3; ++i)
             if ((const T2*)c->psi[i].p != psi_next) { dst = (T2*)c->psi[i].p; break; }
-          c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, psi_next, B, 0, 0.0, dst, B, 0, 1);  // psi_t = U_t^H psi_{t+1}
+          c->zgemm(1, 0, d, Bw, d, 1.0, Ut, d, 0, psi_next, Bw, 0, 0.0, dst, Bw, 0, 1);  // psi_t = U_t^H psi_{t+1}
           psi_t = dst;
         }
         // G_t = Lambda_{t+1} Psi_t^H    (cotangent of U_t)
-        c->zgemm(0, 1, d, d, B, 1.0, (const T2*)c->lam[lcur].p, B, 0, psi_t, B, 0, 0.0, G + (size_t)t * c->nn(), d, 0,
+        c->zgemm(0, 1, d, d, Bw, 1.0, (const T2*)c->lam[lcur].p, Bw, 0, psi_t, Bw, 0, 0.0, G + (size_t)t * c->nn(), d, 0,
                  1);
         // Lambda_t = U_t^H Lambda_{t+1}
-        c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, (const T2*)c->lam[lcur].p, B, 0, 0.0, (T2*)c->lam[lcur ^ 1].p, B, 0, 1);
+        c->zgemm(1, 0, d, Bw, d, 1.0, Ut, d, 0, (const T2*)c->lam[lcur].p, Bw, 0, 0.0, (T2*)c->lam[lcur ^ 1].p, Bw, 0, 1);
         lcur ^= 1;
         psi_next = psi_t;
       }

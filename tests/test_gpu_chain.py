@@ -271,3 +271,25 @@ def test_operator_form_forward_for_wide_batches(oracle, n, B, S):
     ref = oracle.propagate(H0, list(Hs), u, 0.07, psi0)
     assert np.max(np.abs(auto - ref)) < TOL and np.max(np.abs(chunked - ref)) < TOL
     assert np.max(np.abs(auto - seq)) < 1e-12
+
+
+@pytest.mark.parametrize("n,K,B,S", [(2, 2, 9, 5), (3, 3, 40, 11), (4, 2, 100, 7)])
+def test_operator_form_gradient_for_wide_batches(oracle, n, K, B, S):
+    """B > d: the adjoint sweep runs on the d x d propagator product (cost independent of B)."""
+    H0, Hs, M = problems.random_hermitian_problem(n, K, seed=n + B)
+    u = np.random.default_rng(S).uniform(-1.5, 1.5, (S, K))
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    with _engine(H0, Hs, M) as e:
+        l1, g1, f1, e1 = e.energy_grad(u, 0.08, psi0)
+        assert e.info("composed") == 1
+        e.set_option("checkpoint_bytes", (1 << n) ** 2 * 16 * 3)  # force psi_t rebuilds in operator form too
+        l3, g3, f3, e3 = e.energy_grad(u, 0.08, psi0)
+        e.set_option("checkpoint_bytes", 0)
+        e.set_option("compose", 0)
+        l2, g2, f2, e2 = e.energy_grad(u, 0.08, psi0)
+        assert e.info("composed") == 0
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, 0.08, psi0)
+    for (l, g, f, en) in ((l1, g1, f1, e1), (l2, g2, f2, e2), (l3, g3, f3, e3)):
+        assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL * B and np.max(np.abs(f - rf)) < TOL
+        assert np.max(np.abs(en - oracle.energies(M, rf))) < TOL
+    assert np.max(np.abs(g1 - g2)) < 1e-11 * B
