@@ -60,6 +60,56 @@ def cpu_baseline(n, B, seed, dt, u_row):
                       "fwd+adjoint rate is lower than this".format(steps, n, 1 << n, B, el)}
 
 
+def other_configs(dev, seed):
+    """Short measurements of the other BASELINE configs on this GPU (reported as extras, outside the timed region)."""
+    import torch
+    from diffquantum_amd import problems
+    from diffquantum_amd.engine import Engine
+    from diffquantum_amd.structured import StructuredEngine, ising_x_terms
+    out = {}
+    # configs[1]: 8-qubit ring QAOA, 1000 Trotter steps, batch 1024, fp64, forward only
+    p = problems.qaoa_ring(8)
+    S, B = 1000, 1024
+    u = torch.from_numpy(problems.pulse_table(16, S, 1.0, seed=seed)).to(dev)
+    psi = torch.from_numpy(problems.random_states(256, B, seed)).to(dev)
+    with Engine(256, 16, device=dev.index or 0) as e:
+        e.use_torch_stream()
+        e.set_hamiltonians(p["H0"].astype(np.complex128), p["Hs"].astype(np.complex128))
+        e.propagate(u, 1.0 / S, psi)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fin = e.propagate(u, 1.0 / S, psi)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        out["config2_qaoa_n8_S1000_B1024_fwd"] = {
+            "steps_per_s": S / el, "wall_s": el, "operator_form": bool(e.info("composed")),
+            "max_norm_drift": float((torch.linalg.norm(fin, dim=0) - 1).abs().max().item())}
+    # configs[4] per-GPU share: 18-qubit Ising + X controls as Pauli strings, complex64, 512/8 = 64 states per GPU
+    n, B, S = 18, 64, 20
+    rng = np.random.default_rng(seed)
+    st = rng.standard_normal((1 << n, B)) + 1j * rng.standard_normal((1 << n, B))
+    st = torch.from_numpy((st / np.linalg.norm(st, axis=0)).astype(np.complex64)).to(dev)
+    us = problems.pulse_table(n, S, S * 1e-3, seed=seed)
+    with StructuredEngine(n, n, device=dev.index or 0, dtype="c64") as e:
+        e.use_torch_stream()
+        e.set_terms(ising_x_terms(n, seed))
+        e.propagate(us[:2], 1e-3, st)
+        e.set_option("profile", -1); e.set_option("profile", 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.propagate(us, 1e-3, st)
+        torch.cuda.synchronize(); el_f = time.perf_counter() - t0
+        ms, by = e.info("prof_ms"), e.info("prof_bytes")
+        e.set_option("profile", 0)
+        e.energy_grad(us[:2], 1e-3, st, want_final=False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.energy_grad(us, 1e-3, st, want_final=False)
+        torch.cuda.synchronize(); el_g = time.perf_counter() - t0
+        out["config5_pergpu_n18_B64_c64_structured"] = {
+            "fwd_steps_per_s": S / el_f, "fwd_adjoint_steps_per_s": S / el_g, "taylor_degree": int(e.info("degree")),
+            "roofline": {"bound": "hbm", "achieved": by / ms * 1e-6 if ms > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (by / ms * 1e-6 / 8000.0) if ms > 0 else 0.0,
+                         "note": "forward H.psi passes: algorithmic bytes (state-units x 2^n x B x 8 B) / HIP-event time"}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +120,7 @@ def main():
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-other-configs", action="store_true")
     a = ap.parse_args()
 
     import torch
@@ -192,6 +243,11 @@ def main():
                 "hbm_GBps": {k: (v["bytes"] / v["ms"] * 1e-6 if v["ms"] > 0 else 0.0) for k, v in prof.items() if k != "zgemm"},
             },
         }
+        if world == 1 and not a.skip_other_configs:
+            try:
+                out["other_configs"] = other_configs(dev, a.seed)
+            except Exception as e:
+                out["other_configs"] = {"error": str(e)}
         if world == 1 and not a.skip_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, B, a.seed, a.dt, u_all[0])
