@@ -114,14 +114,24 @@ struct SApply {
   T sr, si;         // complex scale of the bracket
 };
 
+template <class T2, int V>
+struct alignas(sizeof(T2) * V) CVec {
+  T2 v[V];
+};
+
 // out = add + (sr + i si) * ( prev + diag .* y + sum_m coef_m sign_m P'_m y )
 // Which optional operands exist is a compile-time property (FLAGS bit 0 prev, 1 add, 2 acc, 3 diag): a runtime
 // "load or zero" per element makes hipcc branch around every load and drain vmcnt each time (measured 3.9 -> 2.7 TB/s).
-template <class T, int FLAGS>
+// V = batch columns per lane (2 when the batch is even: 16-byte accesses for complex64, half the address math).
+template <class T, int FLAGS, int V>
 __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
   constexpr bool HAS_PREV = FLAGS & 1, HAS_ADD = FLAGS & 2, HAS_ACC = FLAGS & 4, HAS_DIAG = FLAGS & 8;
   typedef typename dq::Cx<T>::type T2;
+  typedef CVec<T2, V> VT;
   constexpr int PMAX = LocalBits<T>::P;
+  constexpr int CPL = SBC / V;              // lanes across one tile row
+  constexpr int RSTEP = STHREADS / CPL;     // rows covered by one sweep of the workgroup
+  constexpr int RPT = ((1 << PMAX) + RSTEP - 1) / RSTEP;
   __shared__ T2 tile[(1 << PMAX) * SBC];
   __shared__ unsigned rowidx[1 << PMAX];
   __shared__ DTerm tt[SMAXT];
@@ -133,60 +143,80 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
   for (int r = threadIdx.x; r < R; r += STHREADS) rowidx[r] = base | deposit_bits((unsigned)r, a.lmask);
   for (int m = threadIdx.x; m < a.nterms; m += STHREADS) { tt[m] = a.terms[m]; tc[m] = a.coef[a.terms[m].slot]; }
   __syncthreads();
-  const int c = threadIdx.x % SBC;
-  const bool col_ok = (c0 + c) < a.B;
-  for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
-    T2 v; v.x = 0; v.y = 0;
-    if (col_ok) v = a.y[(size_t)rowidx[r] * a.B + c0 + c];
-    tile[r * SBC + c] = v;
+  const int c = (threadIdx.x % CPL) * V;
+  const int rbase = threadIdx.x / CPL;
+  const bool col_ok = (c0 + c) < a.B;   // B is a multiple of V, so a lane's V columns are valid together
+  VT zero;
+#pragma unroll
+  for (int w = 0; w < V; ++w) { zero.v[w].x = 0; zero.v[w].y = 0; }
+  for (int r = rbase; r < R; r += RSTEP) {
+    VT v = zero;
+    if (col_ok) v = *(const VT*)(a.y + (size_t)rowidx[r] * a.B + c0 + c);
+    *(VT*)(tile + r * SBC + c) = v;
   }
   __syncthreads();
   if (!col_ok) return;
   // every global operand of this thread's rows is requested before the LDS work starts
-  constexpr int RPT = (1 << PMAX) / (STHREADS / SBC);
-  T2 pv[RPT], ad[RPT], ac[RPT];
+  VT pv[RPT], ad[RPT], ac[RPT];
   T dg[RPT];
-  const int rbase = threadIdx.x / SBC;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
-    const int r = min(rbase + q * (STHREADS / SBC), R - 1);  // clamped: loads stay unconditional
+    const int r = min(rbase + q * RSTEP, R - 1);  // clamped: loads stay unconditional
     const size_t off = (size_t)rowidx[r] * a.B + c0 + c;
-    if (HAS_PREV) pv[q] = a.prev[off];
-    if (HAS_ADD) ad[q] = a.add[off];
-    if (HAS_ACC) ac[q] = a.acc[off];
+    if (HAS_PREV) pv[q] = *(const VT*)(a.prev + off);
+    if (HAS_ADD) ad[q] = *(const VT*)(a.add + off);
+    if (HAS_ACC) ac[q] = *(const VT*)(a.acc + off);
     if (HAS_DIAG) dg[q] = a.diag[rowidx[r]];
   }
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
-    const int r = rbase + q * (STHREADS / SBC);
+    const int r = rbase + q * RSTEP;
     if (r >= R) break;
     const unsigned i = rowidx[r];
     const size_t off = (size_t)i * a.B + c0 + c;
-    T sx = 0, sy = 0;
-    if (HAS_PREV) { sx = pv[q].x; sy = pv[q].y; }
+    T sx[V], sy[V];
+#pragma unroll
+    for (int w = 0; w < V; ++w) { sx[w] = 0; sy[w] = 0; }
+    if (HAS_PREV) {
+#pragma unroll
+      for (int w = 0; w < V; ++w) { sx[w] = pv[q].v[w].x; sy[w] = pv[q].v[w].y; }
+    }
     if (HAS_DIAG) {
-      const T2 v = tile[r * SBC + c];
-      sx = fma(dg[q], v.x, sx); sy = fma(dg[q], v.y, sy);
+      const VT v = *(const VT*)(tile + r * SBC + c);
+#pragma unroll
+      for (int w = 0; w < V; ++w) { sx[w] = fma(dg[q], v.v[w].x, sx[w]); sy[w] = fma(dg[q], v.v[w].y, sy[w]); }
     }
     for (int m = 0; m < a.nterms; ++m) {
-      const T2 v = tile[(r ^ tt[m].xloc) * SBC + c];
+      const VT v = *(const VT*)(tile + (r ^ tt[m].xloc) * SBC + c);
       T2 cf = tc[m];
       if (tt[m].zmask != 0 && (__popc((i ^ tt[m].xmask) & tt[m].zmask) & 1)) { cf.x = -cf.x; cf.y = -cf.y; }  // uniform branch
-      sx = fma(cf.x, v.x, sx); sx = fma(-cf.y, v.y, sx);
-      sy = fma(cf.x, v.y, sy); sy = fma(cf.y, v.x, sy);
+#pragma unroll
+      for (int w = 0; w < V; ++w) {
+        sx[w] = fma(cf.x, v.v[w].x, sx[w]); sx[w] = fma(-cf.y, v.v[w].y, sx[w]);
+        sy[w] = fma(cf.x, v.v[w].y, sy[w]); sy[w] = fma(cf.y, v.v[w].x, sy[w]);
+      }
     }
-    T2 o;
-    o.x = a.sr * sx - a.si * sy;
-    o.y = a.sr * sy + a.si * sx;
-    if (HAS_ADD) { o.x += ad[q].x; o.y += ad[q].y; }
-    a.out[off] = o;
-    if (HAS_ACC) { T2 w; w.x = ac[q].x + o.x; w.y = ac[q].y + o.y; a.acc[off] = w; }
+    VT o;
+#pragma unroll
+    for (int w = 0; w < V; ++w) {
+      o.v[w].x = a.sr * sx[w] - a.si * sy[w];
+      o.v[w].y = a.sr * sy[w] + a.si * sx[w];
+      if (HAS_ADD) { o.v[w].x += ad[q].v[w].x; o.v[w].y += ad[q].v[w].y; }
+    }
+    *(VT*)(a.out + off) = o;
+    if (HAS_ACC) {
+      VT w2;
+#pragma unroll
+      for (int w = 0; w < V; ++w) { w2.v[w].x = ac[q].v[w].x + o.v[w].x; w2.v[w].y = ac[q].v[w].y + o.v[w].y; }
+      *(VT*)(a.acc + off) = w2;
+    }
   }
 }
 
 template <class T, int F>
 void sapply_launch_f(const SApply<T>& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((sapply_kernel<T, F>), grid, dim3(STHREADS), 0, st, a);
+  if ((a.B & 1) == 0) hipLaunchKernelGGL((sapply_kernel<T, F, 2>), grid, dim3(STHREADS), 0, st, a);
+  else hipLaunchKernelGGL((sapply_kernel<T, F, 1>), grid, dim3(STHREADS), 0, st, a);
 }
 template <class T>
 void sapply_launch(const SApply<T>& a, dim3 grid, hipStream_t st) {
@@ -221,67 +251,102 @@ struct SOverlap {
   int n, p;
   unsigned lmask;
   int B;
-  double* part;   // [nblocks][nterms][2]
+  unsigned ntiles;  // 2^(n-p) row tiles
+  int tpw;          // tiles walked by one workgroup
+  double* part;     // [nblocks][nterms][2]
 };
 
-// part[blk][m] = sum over the block's tile of conj(za[i][c]) * sign_m(i) * zb[i ^ x_m][c]
-template <class T>
+// part[blk][m] = sum over the workgroup's tiles of conj(za[i][c]) * sign_m(i) * zb[i ^ x_m][c]
+// A workgroup walks `tpw` tiles; per-string partial sums stay in registers (T) across them, so the wave/block
+// reduction (fp64 across waves and workgroups, fixed order) is paid once per workgroup, not once per tile.
+template <class T, int V>
 __global__ void __launch_bounds__(STHREADS) soverlap_kernel(SOverlap<T> a) {
   typedef typename dq::Cx<T>::type T2;
+  typedef CVec<T2, V> VT;
   constexpr int PMAX = LocalBits<T>::P;
+  constexpr int CPL = SBC / V;
+  constexpr int RSTEP = STHREADS / CPL;
+  constexpr int RPT = ((1 << PMAX) + RSTEP - 1) / RSTEP;
+  constexpr int TCH = 12;  // strings per register chunk
   __shared__ T2 tile[(1 << PMAX) * SBC];
   __shared__ unsigned rowidx[1 << PMAX];
   __shared__ DTerm tt[SMAXT];
-  __shared__ double red[2][STHREADS / 64];
+  __shared__ double red[2][TCH][STHREADS / 64];
   const int R = 1 << a.p;
   const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
-  const unsigned base = deposit_bits(blockIdx.x, full & ~a.lmask);
   const int c0 = blockIdx.y * SBC;
-  for (int r = threadIdx.x; r < R; r += STHREADS) rowidx[r] = base | deposit_bits((unsigned)r, a.lmask);
-  for (int m = threadIdx.x; m < a.nterms; m += STHREADS) tt[m] = a.terms[m];
-  __syncthreads();
-  const int c = threadIdx.x % SBC;
+  const int c = (threadIdx.x % CPL) * V;
+  const int rbase = threadIdx.x / CPL;
   const bool col_ok = (c0 + c) < a.B;
-  for (int r = threadIdx.x / SBC; r < R; r += STHREADS / SBC) {
-    T2 v; v.x = 0; v.y = 0;
-    if (col_ok) v = a.zb[(size_t)rowidx[r] * a.B + c0 + c];
-    tile[r * SBC + c] = v;
-  }
-  __syncthreads();
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the cotangent rows of this thread stay in registers for all strings (one global read per pass)
-  constexpr int RPT = (1 << PMAX) / (STHREADS / SBC);
-  T2 u[RPT];
-  unsigned ui[RPT];
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  VT zero;
 #pragma unroll
-  for (int q = 0; q < RPT; ++q) {
-    const int r = threadIdx.x / SBC + q * (STHREADS / SBC);
-    u[q].x = 0; u[q].y = 0; ui[q] = 0;
-    if (r < R && col_ok) { ui[q] = rowidx[r]; u[q] = a.za[(size_t)ui[q] * a.B + c0 + c]; }
-  }
-  for (int m = 0; m < a.nterms; ++m) {
-    double sx = 0.0, sy = 0.0;
-    const unsigned xl = tt[m].xloc, xm = tt[m].xmask, zm = tt[m].zmask;
+  for (int w = 0; w < V; ++w) { zero.v[w].x = 0; zero.v[w].y = 0; }
+  for (int m = threadIdx.x; m < a.nterms; m += STHREADS) tt[m] = a.terms[m];
+  for (int m0 = 0; m0 < a.nterms; m0 += TCH) {
+    const int nm = min(TCH, a.nterms - m0);
+    T px[TCH], py[TCH];
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int r = threadIdx.x / SBC + q * (STHREADS / SBC);
-      if (r < R) {
-        const T2 v = tile[(r ^ xl) * SBC + c];
-        T px = u[q].x * v.x + u[q].y * v.y;   // conj(u) * v
-        T py = u[q].x * v.y - u[q].y * v.x;
-        if (zm != 0 && (__popc((ui[q] ^ xm) & zm) & 1)) { px = -px; py = -py; }
-        sx += (double)px; sy += (double)py;
+    for (int mm = 0; mm < TCH; ++mm) { px[mm] = 0; py[mm] = 0; }
+    for (int ti = 0; ti < a.tpw; ++ti) {
+      const unsigned tix = blockIdx.x * a.tpw + ti;
+      if (tix >= a.ntiles) break;   // uniform
+      const unsigned base = deposit_bits(tix, full & ~a.lmask);
+      __syncthreads();              // previous tile fully consumed
+      for (int r = threadIdx.x; r < R; r += STHREADS) rowidx[r] = base | deposit_bits((unsigned)r, a.lmask);
+      __syncthreads();
+      for (int r = rbase; r < R; r += RSTEP) {
+        VT v = zero;
+        if (col_ok) v = *(const VT*)(a.zb + (size_t)rowidx[r] * a.B + c0 + c);
+        *(VT*)(tile + r * SBC + c) = v;
       }
+      // the cotangent rows of this thread stay in registers for all strings (one global read per pass)
+      VT u[RPT];
+      unsigned ui[RPT];
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const int r = min(rbase + q * RSTEP, R - 1);
+        ui[q] = rowidx[r];
+        u[q] = zero;
+        if (col_ok && rbase + q * RSTEP < R) u[q] = *(const VT*)(a.za + (size_t)ui[q] * a.B + c0 + c);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mm = 0; mm < TCH; ++mm)
+        if (mm < nm) {               // uniform
+          const DTerm t = tt[m0 + mm];
+#pragma unroll
+          for (int q = 0; q < RPT; ++q) {
+            const int r = rbase + q * RSTEP;
+            if (r < R) {
+              const VT v = *(const VT*)(tile + (r ^ t.xloc) * SBC + c);
+              T qx = 0, qy = 0;
+#pragma unroll
+              for (int w = 0; w < V; ++w) {
+                qx += u[q].v[w].x * v.v[w].x + u[q].v[w].y * v.v[w].y;   // conj(u) * v
+                qy += u[q].v[w].x * v.v[w].y - u[q].v[w].y * v.v[w].x;
+              }
+              if (t.zmask != 0 && (__popc((ui[q] ^ t.xmask) & t.zmask) & 1)) { qx = -qx; qy = -qy; }
+              px[mm] += qx; py[mm] += qy;
+            }
+          }
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); }
-    if (lane == 0) { red[0][wave] = sx; red[1][wave] = sy; }
+    // wave reduction in T (32-bit shuffles for complex64), fp64 across waves / workgroups
+#pragma unroll
+    for (int mm = 0; mm < TCH; ++mm)
+      if (mm < nm) {
+        T vx = px[mm], vy = py[mm];
+        for (int off = 32; off > 0; off >>= 1) { vx += __shfl_down(vx, off, 64); vy += __shfl_down(vy, off, 64); }
+        if (lane == 0) { red[0][mm][wave] = (double)vx; red[1][mm][wave] = (double)vy; }
+      }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < nm) {
       double tx = 0, ty = 0;
-      for (int w = 0; w < STHREADS / 64; ++w) { tx += red[0][w]; ty += red[1][w]; }
-      a.part[((size_t)blk * a.nterms + m) * 2 + 0] = tx;
-      a.part[((size_t)blk * a.nterms + m) * 2 + 1] = ty;
+      for (int w = 0; w < STHREADS / 64; ++w) { tx += red[0][threadIdx.x][w]; ty += red[1][threadIdx.x][w]; }
+      a.part[((size_t)blk * a.nterms + m0 + threadIdx.x) * 2 + 0] = tx;
+      a.part[((size_t)blk * a.nterms + m0 + threadIdx.x) * 2 + 1] = ty;
     }
     __syncthreads();
   }
@@ -823,11 +888,17 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         o.za = zb_prev; o.zb = z[j];
         o.terms = (const DTerm*)g.d_ovl.p; o.nterms = (int)g.ovl.size();
         o.n = c->n; o.p = g.p; o.lmask = g.lmask; o.B = B;
-        dim3 grid(c->d >> g.p, (B + SBC - 1) / SBC);
+        o.ntiles = c->d >> g.p;
+        const unsigned ychunks = (B + SBC - 1) / SBC;
+        o.tpw = (int)std::max(1u, std::min(8u, (o.ntiles * ychunks) / 512u));  // keep >= ~512 workgroups (2 per CU)
+        dim3 grid((o.ntiles + o.tpw - 1) / o.tpw, ychunks);
         const int nblk = grid.x * grid.y;
         c->part.ensure((size_t)nblk * o.nterms * 16);
         o.part = (double*)c->part.p;
-        c->timed(2.0 * sb, [&] { hipLaunchKernelGGL(soverlap_kernel<T>, grid, dim3(STHREADS), 0, c->st, o); });
+        c->timed(2.0 * sb, [&] {
+          if ((B & 1) == 0) hipLaunchKernelGGL((soverlap_kernel<T, 2>), grid, dim3(STHREADS), 0, c->st, o);
+          else hipLaunchKernelGGL((soverlap_kernel<T, 1>), grid, dim3(STHREADS), 0, c->st, o);
+        });
         c->last_passes += 1; c->last_bytes += 2.0 * sb;
         hipLaunchKernelGGL(soverlap_finish_kernel, dim3(o.nterms), dim3(256), 0, c->st, (const double*)c->part.p, nblk, o.nterms,
                            (const int*)g.d_ovl_slots.p, (const int*)c->d_owner.p, (const double*)c->d_wre.p,
