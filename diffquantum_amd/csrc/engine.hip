@@ -381,7 +381,8 @@ typename dq::Cx<T>::type* expm_forward(Ctx<T>* c, const ExpmPlan& p, int n) {
 // Where the caller must put Ubar (cotangent of U) before expm_backward.
 template <class T>
 typename dq::Cx<T>::type* ubar_slot(Ctx<T>* c, const ExpmPlan& p, int n) {
-  typedef typename dq::Cx<T>::type T2; return c->mat(SLOT_ADJ + p.out, n); }
+  return c->mat(SLOT_ADJ + p.out, n);
+}
 
 // Reverse mode through expm_forward (whose variables are still in the pool).
 // Pairing: dL = Re tr(Xbar^H dX). For C = X Y: Xbar += Cbar Y^H, Ybar += X^H Cbar; for a linear term

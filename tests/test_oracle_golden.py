@@ -242,3 +242,36 @@ def test_c_oracle_g3_demo_forward(G):
     from oracle import c_oracle
     out = c_oracle.propagate(G["demo_H0"], G["demo_Hs"], G["g3_u"], float(G["demo_T"]) / 30, G["demo_psi0"])
     assert np.max(np.abs(out[:, 0] - G["g3_final"])) < 1e-12
+
+
+# ---- host logic of the structured engine (no GPU) ------------------------------------------------------
+
+def test_pauli_masks_and_dense_strings():
+    from diffquantum_amd.structured import pauli_dense, pauli_masks, terms_to_dense, DRIFT, OBSERVABLE
+    assert pauli_masks("XIZY") == (0b1001, 0b0011)
+    assert pauli_masks("iiii") == (0, 0)
+    with pytest.raises(ValueError):
+        pauli_masks("XA")
+    # the mask action (P psi)[i] = i^{nY} (-1)^{popc((i^x)&z)} psi[i^x] reproduces the kron matrix
+    rng = np.random.default_rng(0)
+    for s in ("X", "Y", "Z", "XY", "ZYX", "IYIZ", "YYXZ"):
+        n = len(s)
+        x, z = pauli_masks(s)
+        psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+        idx = np.arange(1 << n)
+        sign = np.array([(-1) ** bin(((i ^ x) & z)).count("1") for i in idx])
+        ny = bin(x & z).count("1")
+        mine = (1j ** ny) * sign * psi[idx ^ x]
+        assert np.allclose(mine, pauli_dense(s) @ psi, atol=1e-14), s
+    H0, Hs, M = terms_to_dense([(DRIFT, "ZI", 0.5), (0, "XX", 2.0), (OBSERVABLE, "IZ", -1.0)], 2, 1)
+    assert np.allclose(H0, 0.5 * np.kron(np.diag([1, -1]), np.eye(2)))
+    assert np.allclose(Hs[0], 2.0 * np.kron([[0, 1], [1, 0]], [[0, 1], [1, 0]]))
+    assert np.allclose(M, -np.kron(np.eye(2), np.diag([1, -1])))
+
+
+def test_ising_string_form_matches_dense_generator():
+    from diffquantum_amd.structured import ising_x_terms, terms_to_dense
+    for n, seed in ((3, 0), (5, 3)):
+        H0, Hs, M = terms_to_dense(ising_x_terms(n, seed), n, n)
+        D0, Ds, DM = problems.random_ising(n, seed)
+        assert np.allclose(H0, D0, atol=1e-14) and np.allclose(Hs, Ds) and np.allclose(M, DM, atol=1e-14)
