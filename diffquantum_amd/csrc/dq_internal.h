@@ -72,6 +72,12 @@ template <class T>
 hipError_t coldot_launch(const typename Cx<T>::type* X, long ldx, const typename Cx<T>::type* Y, long ldy, int d, int B,
                          double scale, double* e, double* part, hipStream_t st);
 int coldot_chunks(int d);
+// fidelity objective: c[b] = <phi_b|psi_b>, fid[b] = |c[b]|^2, lam = scale * phi .* c (lam may be null)
+// part: coldot_chunks(d) * B * 2 doubles; cvals: 2 B doubles
+template <class T>
+hipError_t fidelity_costate_launch(const typename Cx<T>::type* phi, const typename Cx<T>::type* psi, int d, int B,
+                                   double scale, double* part, double* cvals, double* fid,
+                                   typename Cx<T>::type* lam, hipStream_t st);
 // out[0] = sum_b e[b]  (single block, deterministic)
 hipError_t sum_launch(const double* e, int n, double* out, hipStream_t st);
 // colsum[j] = sum_i |X[i][j]|  (for the 1-norm), d x d

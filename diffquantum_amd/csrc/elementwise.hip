@@ -218,6 +218,89 @@ template hipError_t coldot_launch<double>(const double2*, long, const double2*, 
 template hipError_t coldot_launch<float>(const float2*, long, const float2*, long, int, int, double, double*, double*,
                                          hipStream_t);
 
+// ---- column-wise complex overlaps c[b] = sum_i conj(X[i][b]) Y[i][b] and the fidelity costate -----------------
+// Fidelity objective (the batched form of train_fidelity, sim_plain.py:414-475: M = |psi1><psi1|):
+//   F_b = |<phi_b|psi_b>|^2,  L = sum_b (1 - F_b),  lambda_b = dL/dpsi_b^* * 2 = -2 phi_b <phi_b|psi_b>.
+template <class T>
+__global__ void __launch_bounds__(256) colcdot_kernel(const typename Cx<T>::type* __restrict__ X, long ldx,
+                                                      const typename Cx<T>::type* __restrict__ Y, long ldy, int d,
+                                                      int B, int rows_per_chunk, double* __restrict__ part) {
+  typedef typename Cx<T>::type T2;
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(d, r0 + rows_per_chunk);
+  double sx = 0.0, sy = 0.0;
+  if (b < B)
+    for (int i = r0 + rg; i < r1; i += 4) {
+      const T2 x = X[(long)i * ldx + b];
+      const T2 y = Y[(long)i * ldy + b];
+      sx += (double)x.x * (double)y.x + (double)x.y * (double)y.y;
+      sy += (double)x.x * (double)y.y - (double)x.y * (double)y.x;
+    }
+  red[0][rg][cl] = sx;
+  red[1][rg][cl] = sy;
+  __syncthreads();
+  if (rg == 0 && b < B) {
+    part[((long)blockIdx.y * B + b) * 2 + 0] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    part[((long)blockIdx.y * B + b) * 2 + 1] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+}
+
+// c[b] = sum of chunks; fid[b] = |c[b]|^2
+__global__ void __launch_bounds__(256) colcdot_finish_kernel(const double* __restrict__ part, int nchunks, int B,
+                                                             double* __restrict__ cvals, double* __restrict__ fid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double sx = 0.0, sy = 0.0;
+  for (int c = 0; c < nchunks; ++c) { sx += part[((long)c * B + b) * 2]; sy += part[((long)c * B + b) * 2 + 1]; }
+  cvals[2 * b] = sx;
+  cvals[2 * b + 1] = sy;
+  fid[b] = sx * sx + sy * sy;
+}
+
+// lam[i][b] = scale * phi[i][b] * c[b]
+template <class T>
+__global__ void __launch_bounds__(256) scale_columns_kernel(const typename Cx<T>::type* __restrict__ phi,
+                                                            const double* __restrict__ cvals, double scale,
+                                                            typename Cx<T>::type* __restrict__ lam, long n_elem, int B) {
+  typedef typename Cx<T>::type T2;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e % B);
+    const T cx = (T)(scale * cvals[2 * b]), cy = (T)(scale * cvals[2 * b + 1]);
+    const T2 p = phi[e];
+    T2 o;
+    o.x = p.x * cx - p.y * cy;
+    o.y = p.x * cy + p.y * cx;
+    lam[e] = o;
+  }
+}
+
+// part: coldot_chunks(d) * B * 2 doubles; cvals: 2 B doubles; fid: B doubles; lam = scale * phi .* c (may be null)
+template <class T>
+hipError_t fidelity_costate_launch(const typename Cx<T>::type* phi, const typename Cx<T>::type* psi, int d, int B,
+                                   double scale, double* part, double* cvals, double* fid,
+                                   typename Cx<T>::type* lam, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  const int nch = coldot_chunks(d);
+  const int rpc = (d + nch - 1) / nch;
+  hipLaunchKernelGGL(colcdot_kernel<T>, dim3((unsigned)((B + 63) / 64), (unsigned)nch), dim3(256), 0, st, phi, (long)B,
+                     psi, (long)B, d, B, rpc, part);
+  hipLaunchKernelGGL(colcdot_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, part, nch, B, cvals, fid);
+  if (lam) {
+    const long n_elem = (long)d * B;
+    long nb = (n_elem + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(scale_columns_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, phi, cvals, scale, lam, n_elem, B);
+  }
+  return hipGetLastError();
+}
+template hipError_t fidelity_costate_launch<double>(const double2*, const double2*, int, int, double, double*, double*,
+                                                    double*, double2*, hipStream_t);
+template hipError_t fidelity_costate_launch<float>(const float2*, const float2*, int, int, double, double*, double*,
+                                                   double*, float2*, hipStream_t);
+
 __global__ void __launch_bounds__(256) sum_kernel(const double* __restrict__ e, int n, double* __restrict__ out) {
   __shared__ double red[256];
   double v = 0.0;

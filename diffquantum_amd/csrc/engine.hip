@@ -615,11 +615,13 @@ void do_energy(Ctx<T>* c, const TT* psi_dev, int B, TT* lam_out /*2 M psi*/, dou
 
 template <class T>
 void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* psi0, int B, double* loss,
-                    double* grad_u, void* psi_final, double* energies) {
+                    double* grad_u, void* psi_final, double* energies, const void* targets = nullptr) {
+  // targets == null: energy objective L = sum_b <psi_b|M|psi_b>;  else fidelity objective
+  // L = sum_b (1 - |<phi_b|psi_b(T)>|^2) with phi = targets ([dim][batch]); `energies` then receives the fidelities.
   typedef TT T2;
   check_ctx(c);
   require_H(c);
-  if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
+  if (!targets && !c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
   if (!c->hermitian)
     fail(DQ_ERR_UNSUPPORTED,
          "adjoint sweep needs Hermitian H0/H_k (it rebuilds psi_t = U_t^H psi_{t+1} between checkpoints)");
@@ -631,7 +633,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   const size_t sb_io = (size_t)d * B * sizeof(T2);
   // Operator form for wide batches (B > d): L = tr(M P_S R P_S^H) with R = Psi0 Psi0^H, so the whole sweep runs on the
   // d x d propagator product P_t (working "batch" = I, terminal costate Q = 2 M P_S R) at a cost independent of B.
-  const bool opform = (c->compose_mode == 1 || (c->compose_mode < 0 && B > d)) && S > 0;
+  const bool opform = !targets && (c->compose_mode == 1 || (c->compose_mode < 0 && B > d)) && S > 0;
   c->last_composed = opform ? 1.0 : 0.0;
   const int Bw = opform ? d : B;
   const size_t sb = (size_t)d * Bw * sizeof(T2);
@@ -696,6 +698,28 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
     c->zgemm(0, 1, d, d, B, 1.0, psi0_dev, B, 0, psi0_dev, B, 0, 0.0, R, d, 0, 1);
     c->zgemm(0, 0, d, d, d, 1.0, (const T2*)c->psi[cur].p, d, 0, R, d, 0, 0.0, PR, d, 0, 1);
     c->zgemm(0, 0, d, d, d, 2.0, (const T2*)c->M.p, d, 0, PR, d, 0, 0.0, (T2*)c->lam[0].p, d, 0, 1);
+  } else if (targets) {
+    // fidelity objective: c_b = <phi_b|psi_b>, F_b = |c_b|^2, Lambda_S = -2 phi .* c, L = B - sum F
+    const T2* phi = in_dev(c, targets, sb_io, c->tmp_in[3]);
+    c->e_dev.ensure(sizeof(double) * (3 * (size_t)B + 2));
+    c->part.ensure(sizeof(double) * 2 * (size_t)dq::coldot_chunks(d) * B);
+    double* fid = c->e_dev.d();
+    double* cvals = c->e_dev.d() + B + 1;
+    c->timed(DQ_PROF_OTHER, 8.0 * d * B, 6.0 * sizeof(T) * d * B, [&] {
+      return dq::fidelity_costate_launch<T>(phi, (const T2*)c->psi[cur].p, d, B, -2.0, c->part.d(), cvals, fid,
+                                            (T2*)c->lam[0].p, c->st);
+    });
+    c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(fid, B, fid + B, c->st); });
+    if (energies) out_copy(c, energies, fid, sizeof(double) * (size_t)B);
+    if (loss) {
+      double fsum = 0.0;
+      HIPCK(hipMemcpyAsync(&fsum, fid + B, sizeof(double), hipMemcpyDeviceToHost, c->st));
+      HIPCK(hipStreamSynchronize(c->st));
+      const double l = (double)B - fsum;
+      HIPCK(hipMemcpyAsync(loss, &l, sizeof(double), hipMemcpyDefault, c->st));
+      HIPCK(hipStreamSynchronize(c->st));
+    }
+    if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
   } else {
     // psi[cur] = Psi_S ; terminal costate Lambda_S = 2 M Psi_S, energies
     do_energy(c, (const T2*)c->psi[cur].p, B, (T2*)c->lam[0].p, energies, loss);
@@ -1042,6 +1066,14 @@ int dq_energy(dq_ctx* c, const void* psi, int batch, double* energies, double* t
 int dq_energy_grad(dq_ctx* c, const double* u, int n_steps, double dt, const void* psi0, int batch, double* loss,
                    double* grad_u, void* psi_final, double* energies) {
   return with_ctx(c, [&](auto* t) { do_energy_grad(t, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, energies); });
+}
+
+int dq_fidelity_grad(dq_ctx* c, const double* u, int n_steps, double dt, const void* psi0, const void* targets, int batch,
+                     double* loss, double* grad_u, void* psi_final, double* fidelities) {
+  return with_ctx(c, [&](auto* t) {
+    if (!targets) fail(DQ_ERR_INVALID, "null target states");
+    do_energy_grad(t, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, fidelities, targets);
+  });
 }
 
 int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,

@@ -75,6 +75,38 @@ def trotter(psi0, T0, T, per_step, vv):
     return [complex(z) for z in out[:, 0]]
 
 
+def energy_grad(psi0, T0, T, per_step, vv, M):
+    """Extension: the channel model made end-to-end differentiable.
+
+    Returns (loss, dL/dvv with the shape of vv, psi_final) for L = sum_b <psi_b(T)|M|psi_b(T)>; psi0 is [dim] or
+    [dim][batch]. The time chain and its adjoint run on the GPU, the chain rule through f_u (diffqc.cc:95-135) on the host."""
+    if _state["engine"] is None:
+        raise RuntimeError("set_H must be called before energy_grad")
+    n_steps = pulse.n_steps_diffqc(int(per_step), float(T0), float(T))
+    ts, dt = pulse.time_grid(float(T0), float(T), n_steps)
+    u = pulse.f_u_table(vv, _state["channels"], _state["duration"], _state["func_type"], ts)
+    eng = _state["engine"]
+    eng.set_observable(np.asarray(M, dtype=np.complex128))
+    psi = np.asarray(psi0, dtype=np.complex128)
+    loss, grad_u, fin, _ = eng.energy_grad(u, dt, psi.reshape(_state["dim"], -1))
+    gvv = pulse.grad_vv_from_grad_u(grad_u, vv, _state["channels"], _state["duration"], _state["func_type"], ts)
+    return loss, gvv, fin
+
+
+def fidelity_grad(psi0, targets, T0, T, per_step, vv):
+    """Extension: L = sum_b (1 - |<target_b|psi_b(T)>|^2) and dL/dvv for a batch of (initial, target) pairs."""
+    if _state["engine"] is None:
+        raise RuntimeError("set_H must be called before fidelity_grad")
+    n_steps = pulse.n_steps_diffqc(int(per_step), float(T0), float(T))
+    ts, dt = pulse.time_grid(float(T0), float(T), n_steps)
+    u = pulse.f_u_table(vv, _state["channels"], _state["duration"], _state["func_type"], ts)
+    d = _state["dim"]
+    loss, grad_u, fin, fid = _state["engine"].fidelity_grad(u, dt, np.asarray(psi0, dtype=np.complex128).reshape(d, -1),
+                                                            np.asarray(targets, dtype=np.complex128).reshape(d, -1))
+    gvv = pulse.grad_vv_from_grad_u(grad_u, vv, _state["channels"], _state["duration"], _state["func_type"], ts)
+    return loss, gvv, fin, fid
+
+
 def trotter_batch(psi0, T0, T, per_step, vv):
     """Extension: psi0 is [dim][batch] (numpy or CUDA torch complex128); returns the same kind."""
     u, dt = _table(T0, T, per_step, vv)

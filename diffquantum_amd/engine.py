@@ -208,6 +208,31 @@ class Engine:
         _lib.check(self._lib.dq_energy_grad(self._ctx, pu, S, float(dt), pp, B, C.addressof(loss), pg, pf, pe))
         return loss.value, grad, fin, en
 
+    def fidelity_grad(self, u, dt: float, psi0, targets, want_final=True):
+        """Forward chain + adjoint sweep of L = sum_b (1 - |<target_b|psi_b(T)>|^2).
+
+        Returns (loss, grad_u[n_steps][n_controls], psi_final or None, fidelities[batch])."""
+        pu, ku, S = self._u(u)
+        pp, kp, B = self._psi(psi0)
+        pt, kt, Bt = self._psi(targets, "targets")
+        if Bt != B:
+            raise ValueError("targets must have the same batch width as psi0")
+        grad = np.zeros((S, self.n_controls), dtype=np.float64)
+        loss = C.c_double()
+        fid = np.empty(B, dtype=np.float64)
+        fin, pf = None, 0
+        if want_final:
+            if _is_torch(psi0):
+                import torch
+                fin = torch.empty_like(psi0)
+                pf = fin.data_ptr()
+            else:
+                fin = np.empty((self.dim, B), dtype=self.cdtype)
+                pf = fin.ctypes.data
+        _lib.check(self._lib.dq_fidelity_grad(self._ctx, pu, S, float(dt), pp, pt, B, C.addressof(loss),
+                                              grad.ctypes.data, pf, fid.ctypes.data))
+        return loss.value, grad, fin, fid
+
     # -- building blocks ----------------------------------------------------
     def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None):
         """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host)."""

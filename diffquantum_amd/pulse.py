@@ -153,3 +153,36 @@ def f_u_table(vv, channels, duration: float, func_type: int, ts):
             Ns = np.where(live, N, 1.0)
             out[:, h] += np.where(live, omega * (2 * _expit32(N) - 1) / Ns * (np.cos(w * ts) * A + np.sin(w * ts) * B), 0.0)
     return out
+
+
+def grad_vv_from_grad_u(grad_u, vv, channels, duration: float, func_type: int, ts):
+    """Chain rule through the channel model of diffqc.cc:95-135: dL/dvv[c][p][j] = sum_{a,h} dL/du[a][h] du[a][h]/dvv.
+
+    With A = vv[0][idx].phi, B = vv[1][idx].phi, N = sqrt(A^2+B^2), g(N) = omega (2 expit(N) - 1)/N and
+    f = g(N) (cos(wt) A + sin(wt) B):  df/dA = g'(N) (A/N)(cos A + sin B) + g cos,  df/dB likewise with sin.
+    Inside the reference's |N| < 1e-6 cutoff the function is identically 0, so is the derivative."""
+    vv = np.asarray(vv, dtype=np.float64)
+    grad_u = np.asarray(grad_u, dtype=np.float64)
+    ts = np.asarray(ts, dtype=np.float64)
+    n_basis = vv.shape[2]
+    phi = legendre_table(n_basis, 2 * ts / duration - 1) if func_type == 0 else bump_table(n_basis, ts / duration)
+    out = np.zeros_like(vv)
+    for h, chans in enumerate(channels):
+        for chan in chans:
+            omega, w, idx = float(chan[1]), float(chan[2]), int(round(chan[3]))
+            A = vv[0, idx] @ phi
+            B = vv[1, idx] @ phi
+            N = np.sqrt(A * A + B * B)
+            live = np.abs(N) >= 0.000001
+            Ns = np.where(live, N, 1.0)
+            sg = _expit32(Ns)
+            g = omega * (2 * sg - 1) / Ns
+            gp = omega * (2 * sg * (1 - sg) * Ns - (2 * sg - 1)) / (Ns * Ns)
+            gp = np.where(np.abs(Ns) > 32.0, -omega * (2 * sg - 1) / (Ns * Ns), gp)  # expit is clamped beyond +-32
+            cs, sn = np.cos(w * ts), np.sin(w * ts)
+            mix = cs * A + sn * B
+            dfdA = np.where(live, gp * (A / Ns) * mix + g * cs, 0.0)
+            dfdB = np.where(live, gp * (B / Ns) * mix + g * sn, 0.0)
+            out[0, idx] += phi @ (grad_u[:, h] * dfdA)
+            out[1, idx] += phi @ (grad_u[:, h] * dfdB)
+    return out

@@ -14,8 +14,10 @@ Changed on purpose:
     propagators) instead of 2K separate solves.
   * ``gradient='adjoint'`` (new) replaces the one-sample Monte-Carlo estimator by the exact
     adjoint gradient of the discrete chain (``compute_energy_grad_adjoint``).
-Out of scope: ``train_energy_FD``, ``compute_energy_grad_FD`` and
-``train_fidelity`` integrate with ``qutip.mesolve`` -- not the Trotter path -- and raise NotImplementedError.
+  * ``train_fidelity`` (sim_plain.py:414-475 integrates with qutip.mesolve) is re-based on the Trotter chain
+    (SURVEY.md section 8-F4); with ``gradient='adjoint'`` all (initial, target) pairs run as one batch.
+Out of scope: ``train_energy_FD`` and ``compute_energy_grad_FD`` integrate with
+``qutip.mesolve`` -- not the Trotter path -- and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -273,9 +275,62 @@ class SimulatorPlain(object):
         raise NotImplementedError("train_energy_FD integrates with qutip.mesolve, not the Trotter path "
                                   "(SURVEY.md section 2 row 5)")
 
-    def train_fidelity(self, *a, **k):
-        raise NotImplementedError("train_fidelity integrates with qutip.mesolve, not the Trotter path "
-                                  "(SURVEY.md section 2 row 5; section 8-F4 lists it as a later row)")
+    def train_fidelity(self, H0, Hs, initial_states, target_states):
+        """Maximise |<target_i|psi_i(T)>|^2 over the spectral coefficients.
+
+        Engine-based counterpart of the reference's train_fidelity (sim_plain.py:414-475), which integrates with
+        qutip.mesolve: here the forward solve is the Trotter chain (`my_solver`), like train_energy.
+          gradient='mc'      -- the reference's loop: for every pair, M = |target><target|, loss 1 - <M>, one-sample
+                                compute_energy_grad_MC(M, H, psi0, coeff=-1.0), one Adam step per pair (:436-460).
+          gradient='adjoint' -- all pairs as ONE batch: exact gradient of sum_i (1 - F_i) from the engine's adjoint
+                                sweep (dq_fidelity_grad), one Adam step per epoch.
+        Appends the mean infidelity per epoch to `losses_energy` and returns the coefficients."""
+        import torch
+        self.n_Hs = len(Hs)
+        init = np.random.normal(0, 1, [self.n_Hs, self.n_basis])
+        self.spectral_coeff = torch.tensor(init, requires_grad=True)
+        optimizer = torch.optim.Adam([self.spectral_coeff], lr=self.lr)
+        Q = _qobj_type()
+        self.losses_energy = []
+        for epoch in range(1, self.n_epoch + 1):
+            if self.gradient == 'adjoint':
+                frozen = self.spectral_coeff.detach().numpy().copy()
+                H = [H0] + [[Hs[j], self.generate_u(j, frozen)] for j in range(self.n_Hs)]
+                H0n, Hsn, fns = self._split_H(H)
+                eng = self._get_engine(H0n, Hsn)
+                n_steps = pulse.n_steps_sim_plain(self.per_step, 0, self.T)
+                ts, dt = pulse.time_grid(0, self.T, n_steps)
+                u = self._pulse_table(fns, ts)
+                psi0 = np.concatenate([_dense(p) for p in initial_states], axis=1)
+                tgt = np.concatenate([_dense(p) for p in target_states], axis=1)
+                loss, grad_u, fin, fid = eng.fidelity_grad(u, dt, psi0, tgt)
+                g = pulse.grad_coeff_from_grad_u(grad_u, frozen, self.omegas, self.T, ts, self.basis)
+                optimizer.zero_grad()
+                self.spectral_coeff.grad = torch.from_numpy(g / len(initial_states))
+                optimizer.step()
+                mean_loss = float(loss) / len(initial_states)
+                self.final_state = Q(fin)
+            else:
+                batch_losses = []
+                for i in range(len(initial_states)):
+                    frozen = self.spectral_coeff.detach().numpy().copy()
+                    H = [H0] + [[Hs[j], self.generate_u(j, frozen)] for j in range(self.n_Hs)]
+                    psi0, psi1 = initial_states[i], target_states[i]
+                    M = psi1 * psi1.dag()
+                    final_state = self.my_solver(H, psi0, 0, self.T)
+                    inner_product_norm = M.matrix_element(final_state, final_state)
+                    if self.is_noisy:
+                        inner_product_norm += np.random.normal(scale=np.abs(inner_product_norm.real) / 5)
+                    loss_fidelity = 1 - inner_product_norm
+                    optimizer.zero_grad()
+                    self.spectral_coeff.grad = self.compute_energy_grad_MC(M, H, psi0, coeff=-1.0)
+                    optimizer.step()
+                    batch_losses.append(loss_fidelity.real)
+                    self.final_state = final_state
+                mean_loss = float(np.array(batch_losses).mean())
+            print("epoch: {:04d}, loss: {:.4f}, loss_fidelity: {:.4f}".format(epoch, mean_loss, mean_loss))
+            self.losses_energy.append(mean_loss)
+        return self.spectral_coeff
 
     # ---- helpers -------------------------------------------------------------------------------
     @staticmethod

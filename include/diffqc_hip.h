@@ -97,6 +97,12 @@ int dq_energy(dq_ctx* ctx, const void* psi, int batch, double* energies, double*
 int dq_energy_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* psi0, int batch, double* loss,
                    double* grad_u, void* psi_final, double* energies);
 
+/* Fidelity objective for a batch of (initial, target) pairs -- the batched form of train_fidelity's
+ * M = |psi1><psi1| (sim_plain.py:436-455): loss = sum_b (1 - |<target_b|psi_b(T)>|^2), grad_u as above,
+ * fidelities[b] = |<target_b|psi_b(T)>|^2.  targets is [dim][batch] like psi0. */
+int dq_fidelity_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* psi0, const void* targets,
+                     int batch, double* loss, double* grad_u, void* psi_final, double* fidelities);
+
 /* Building blocks, exported for parity tests and reuse. */
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */
 int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,

@@ -260,6 +260,51 @@ def energy_grad(H0, Hs, M, u, dt: float, psi0):
     return loss, grad, states[-1]
 
 
+def fidelity_grad(H0, Hs, u, dt: float, psi0, targets):
+    """L = sum_b (1 - |<phi_b|psi_b(S)>|^2) and its exact derivative w.r.t. u[t][k] (expm_frechet).
+
+    The batched, Trotter-chain form of train_fidelity's objective (sim_plain.py:436-455, M = |psi1><psi1|).
+    Returns (loss, grad[S][K], psi_S, fidelities[B])."""
+    H0 = np.asarray(H0, dtype=np.complex128)
+    Hs = [np.asarray(h, dtype=np.complex128) for h in Hs]
+    d = len(H0)
+    S, K = len(u), len(Hs)
+    psi = np.array(psi0, dtype=np.complex128).reshape(d, -1)
+    phi = np.array(targets, dtype=np.complex128).reshape(d, -1)
+    states, As, Us = [psi], [], []
+    for t in range(S):
+        A = step_generator(H0, Hs, u[t], dt)
+        U = scipy.linalg.expm(A)
+        As.append(A)
+        Us.append(U)
+        psi = U @ psi
+        states.append(psi)
+    c = np.sum(phi.conj() * psi, axis=0)
+    fid = np.abs(c) ** 2
+    loss = float(np.sum(1.0 - fid))
+    lam = -2.0 * phi * c[None, :]
+    grad = np.zeros((S, K))
+    for t in range(S - 1, -1, -1):
+        for k in range(K):
+            dU = scipy.linalg.expm_frechet(As[t], -1.0j * dt * Hs[k], compute_expm=False)
+            grad[t, k] = np.real(np.sum(lam.conj() * (dU @ states[t])))
+        lam = Us[t].conj().T @ lam
+    return loss, grad, states[-1], fid
+
+
+def df_u_dvv_fd(vv, channels, duration, func_type, ts, eps=1e-6):
+    """Central differences of f_u_table w.r.t. every vv entry: [S][K][2][n_param][n_basis]."""
+    vv = np.array(vv, dtype=np.float64)
+    out = np.zeros((len(ts), len(channels)) + vv.shape)
+    for idx in np.ndindex(*vv.shape):
+        vp, vm = vv.copy(), vv.copy()
+        vp[idx] += eps
+        vm[idx] -= eps
+        out[(slice(None), slice(None)) + idx] = (np.asarray(f_u_table(vp, channels, duration, func_type, ts)) -
+                                                 np.asarray(f_u_table(vm, channels, duration, func_type, ts))) / (2 * eps)
+    return out
+
+
 def energy_grad_fd(H0, Hs, M, u, dt: float, psi0, eps: float = 1e-6):
     """Central finite differences of the forward oracle w.r.t. every u[t][k]."""
     u = np.array(u, dtype=np.float64)

@@ -146,7 +146,7 @@ def test_adjoint_training_converges_faster(tmp_path):
 
 def test_out_of_scope_methods_say_so(demo):
     sim = demo[0]
-    for name in ("train_energy_FD", "train_fidelity", "compute_energy_grad_FD"):
+    for name in ("train_energy_FD", "compute_energy_grad_FD"):
         with pytest.raises(NotImplementedError):
             getattr(sim, name)()
 
