@@ -260,6 +260,36 @@ def energy_grad(H0, Hs, M, u, dt: float, psi0):
     return loss, grad, states[-1]
 
 
+def energy_grad_one_frechet(H0, Hs, M, u, dt: float, psi0):
+    """Same quantity as energy_grad, organised for large d: ONE scipy.linalg.expm_frechet per step.
+
+    Adjoint-Frechet identity: <G, L_exp(A, E)> = <L_exp(A^H, G), E>, so with
+    G_t = Lambda_{t+1} Psi_t^H the K control gradients of a step are K contractions of Abar_t = L_exp(A_t^H, G_t).
+    Per step: expm (forward), expm_frechet (also returns exp(A^H) = U^H), three (d x d)(d x B) products.
+    This is the CPU baseline of bench.py for the fwd+adjoint metric.  Returns (loss, grad[S][K], psi_S)."""
+    H0 = np.asarray(H0, dtype=np.complex128)
+    Hs = [np.asarray(h, dtype=np.complex128) for h in Hs]
+    M = np.asarray(M, dtype=np.complex128)
+    d = len(H0)
+    S, K = len(u), len(Hs)
+    psi = np.array(psi0, dtype=np.complex128).reshape(d, -1)
+    states = [psi]
+    for t in range(S):
+        psi = np.matmul(scipy.linalg.expm(step_generator(H0, Hs, u[t], dt)), psi)
+        states.append(psi)
+    loss = float(np.sum(energies(M, psi)))
+    lam = 2.0 * (M @ psi)
+    grad = np.zeros((S, K))
+    for t in range(S - 1, -1, -1):
+        A = step_generator(H0, Hs, u[t], dt)
+        G = lam @ states[t].conj().T
+        Uh, Abar = scipy.linalg.expm_frechet(A.conj().T, G, compute_expm=True)
+        for k in range(K):
+            grad[t, k] = dt * float(np.sum(np.imag(Abar.conj() * Hs[k])))  # Re<Abar, -i dt H_k>
+        lam = Uh @ lam
+    return loss, grad, states[-1]
+
+
 def fidelity_grad(H0, Hs, u, dt: float, psi0, targets):
     """L = sum_b (1 - |<phi_b|psi_b(S)>|^2) and its exact derivative w.r.t. u[t][k] (expm_frechet).
 

@@ -275,3 +275,14 @@ def test_ising_string_form_matches_dense_generator():
         H0, Hs, M = terms_to_dense(ising_x_terms(n, seed), n, n)
         D0, Ds, DM = problems.random_ising(n, seed)
         assert np.allclose(H0, D0, atol=1e-14) and np.allclose(Hs, Ds) and np.allclose(M, DM, atol=1e-14)
+
+
+def test_one_frechet_adjoint_equals_per_control_oracle(oracle):
+    """The large-d organisation of the adjoint oracle (one expm_frechet per step; bench.py's CPU baseline)."""
+    for n, K, B, S in ((2, 2, 3, 5), (3, 3, 9, 4)):
+        H0, Hs, M = problems.random_hermitian_problem(n, K, seed=n + S)
+        u = np.random.default_rng(S).uniform(-2, 2, (S, K))
+        psi0 = problems.random_states(1 << n, B, seed=2)
+        l0, g0, f0 = oracle.energy_grad(H0, list(Hs), M, u, 0.1, psi0)
+        l1, g1, f1 = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, 0.1, psi0)
+        assert abs(l0 - l1) < 1e-12 and np.max(np.abs(g0 - g1)) < 1e-12 and np.max(np.abs(f0 - f1)) < 1e-13
