@@ -59,6 +59,11 @@ struct LincombArgs {
 template <class T>
 hipError_t lincomb_launch(const LincombArgs<T>& a, hipStream_t st);
 
+// out[z] = (accumulate ? out[z] : 0) + a * X[z] + b * X[z]^H      (d x d, batched, out != X)
+template <class T>
+hipError_t tcombine_launch(typename Cx<T>::type* out, const typename Cx<T>::type* X, int d, double a, double b,
+                           int accumulate, long stride, int batch, hipStream_t st);
+
 // part[z][blk][k] = sum over the block's elements of Im(conj(Abar[z][e]) * Hs[k][e]) (accumulated in fp64);
 // grad[z][k] = scale * sum_blk part   (deterministic two-stage reduction)
 template <class T>

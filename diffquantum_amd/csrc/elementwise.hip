@@ -88,6 +88,52 @@ hipError_t lincomb_launch(const LincombArgs<T>& a, hipStream_t st) {
 template hipError_t lincomb_launch<double>(const LincombArgs<double>&, hipStream_t);
 template hipError_t lincomb_launch<float>(const LincombArgs<float>&, hipStream_t);
 
+// ---- out = [out +] a * X + b * X^H   (d x d, batched; LDS-tiled transpose so both accesses are coalesced) ------
+// Used by the reverse mode of v1 = A A for anti-Hermitian A: S = herm(v1bar) (a = b = 1/2) and
+// Abar += X^H - X (a = -1, b = 1) -- only the skew part of Abar reaches Re<Abar, -i dt H_k>.
+template <class T>
+__global__ void __launch_bounds__(256) tcombine_kernel(typename Cx<T>::type* __restrict__ out,
+                                                       const typename Cx<T>::type* __restrict__ X, int d, double a_,
+                                                       double b_, int accumulate, long stride) {
+  typedef typename Cx<T>::type T2;
+  __shared__ T2 tl[32][33];
+  const long base = (long)blockIdx.z * stride;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const T a = (T)a_, b = (T)b_;
+  // transposed operand: tile X[j0 + r][i0 + c]
+  for (int r = ty; r < 32; r += 8) {
+    T2 v; v.x = 0; v.y = 0;
+    if (j0 + r < d && i0 + tx < d) v = X[base + (long)(j0 + r) * d + i0 + tx];
+    tl[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, j = j0 + tx;
+    if (i < d && j < d) {
+      const long off = base + (long)i * d + j;
+      const T2 x = X[off];
+      const T2 xt = tl[tx][r];  // X[j][i]
+      T2 o;
+      o.x = a * x.x + b * xt.x;
+      o.y = a * x.y - b * xt.y;  // conj
+      if (accumulate) { const T2 q = out[off]; o.x += q.x; o.y += q.y; }
+      out[off] = o;
+    }
+  }
+}
+
+template <class T>
+hipError_t tcombine_launch(typename Cx<T>::type* out, const typename Cx<T>::type* X, int d, double a, double b,
+                           int accumulate, long stride, int batch, hipStream_t st) {
+  if (d <= 0 || batch <= 0) return hipSuccess;
+  dim3 grid((unsigned)((d + 31) / 32), (unsigned)((d + 31) / 32), (unsigned)batch);
+  hipLaunchKernelGGL(tcombine_kernel<T>, grid, dim3(256), 0, st, out, X, d, a, b, accumulate, stride);
+  return hipGetLastError();
+}
+template hipError_t tcombine_launch<double>(double2*, const double2*, int, double, double, int, long, int, hipStream_t);
+template hipError_t tcombine_launch<float>(float2*, const float2*, int, double, double, int, long, int, hipStream_t);
+
 // ---- dL/du_k[t] = Re<Abar_t, -i dt H_k>_F = dt * sum Im(conj(Abar) .* H_k) ---------------
 // Stage 1: per-block partial sums for up to KC controls at a time; stage 2: fixed-order sum over
 // blocks (no atomics -> bitwise reproducible gradients).

@@ -249,7 +249,7 @@ struct Ctx : dq_ctx {
   std::vector<double> nHk;
   // options
   double checkpoint_bytes = 0.0, chunk_bytes = 2.0 * 1024 * 1024 * 1024, expm_tol = 0.0, herm_tol = 0.0;
-  int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1;
+  int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1, skew_trick = 1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0;
   // workspace
@@ -388,8 +388,12 @@ typename dq::Cx<T>::type* ubar_slot(Ctx<T>* c, const ExpmPlan& p, int n) {
 // Pairing: dL = Re tr(Xbar^H dX). For C = X Y: Xbar += Cbar Y^H, Ybar += X^H Cbar; for a linear term
 // C = ... + c X: Xbar += c Cbar. Linear contributions are queued per variable and applied in one streaming
 // pass when that variable's adjoint is needed. Returns the device pointer of Abar (n stacked matrices).
+// skew_only: the caller needs only the anti-Hermitian part of Abar and guarantees A^H = -A (the chain: the gradient
+// pairs Abar with -i dt H_k). Then the two products of the reverse mode of v = A A,
+//   Abar += vbar A^H + A^H vbar = -(vbar A + A vbar),  have skew part  X^H - X  with  X = herm(vbar) A :
+// ONE ZGEMM and two transpose-combine streaming passes instead of two ZGEMMs.
 template <class T>
-typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
+typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n, bool skew_only = false) {
   typedef typename dq::Cx<T>::type T2;
   struct Pending { const T2* x; double coef; };
   std::vector<std::vector<Pending>> pend(p.nvars);
@@ -414,7 +418,20 @@ typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
     flush(o.dst);
     if (!init[o.dst]) continue;  // this variable does not reach the output
     const T2* db = adj(o.dst);
-    if (o.kind == 1) {
+    if (o.kind == 1 && skew_only && o.a == 0 && o.b == 0) {
+      T2* S = c->mat(SLOT_TREE + 2, n);
+      T2* X = c->mat(SLOT_TREE + 3, n);
+      const double by = 2.0 * sizeof(T) * c->nn() * n;
+      c->timed(DQ_PROF_LINCOMB, 4.0 * c->nn() * n, 3.0 * by, [&] {
+        return dq::tcombine_launch<T>(S, db, c->d, 0.5, 0.5, 0, (long)c->nn(), n, c->st);
+      });
+      c->mm(0, 0, S, c->mat(0, n), X, 0.0, n);
+      flush(0);  // pending linear contributions first, so that `accumulate` below is well defined
+      c->timed(DQ_PROF_LINCOMB, 4.0 * c->nn() * n, (init[0] ? 4.0 : 3.0) * by, [&] {
+        return dq::tcombine_launch<T>(adj(0), X, c->d, -1.0, 1.0, init[0] ? 1 : 0, (long)c->nn(), n, c->st);
+      });
+      init[0] = 1;
+    } else if (o.kind == 1) {
       c->mm(0, 1, db, c->mat(o.b, n), adj(o.a), init[o.a] ? 1.0 : 0.0, n);
       init[o.a] = 1;
       c->mm(1, 0, c->mat(o.a, n), db, adj(o.b), init[o.b] ? 1.0 : 0.0, n);
@@ -759,7 +776,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
         lcur ^= 1;
         psi_next = psi_t;
       }
-      const T2* Abar = expm_backward(c, p, n);
+      const T2* Abar = expm_backward(c, p, n, c->skew_trick != 0);
       c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
       const double by = 2.0 * sizeof(T) * c->nn() * (K + ((K + 7) / 8)) * n;
       c->timed(DQ_PROF_GRADC, 3.0 * c->nn() * K * n, by, [&] {
@@ -898,6 +915,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->force_tile = t;
   } else if (s == "compose") {  // -1 auto (batch > dim), 0 never, 1 always
     c->compose_mode = (int)v < 0 ? -1 : ((int)v ? 1 : 0);
+  } else if (s == "skew_trick") {
+    c->skew_trick = v != 0 ? 1 : 0;
   } else if (s == "zgemm_alg") {
     const int a = (int)v;
     if (a != 0 && a != 1) fail(DQ_ERR_INVALID, "zgemm_alg must be 0 (4M) or 1 (3M)");

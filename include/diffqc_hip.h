@@ -79,7 +79,9 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  * "force_tile", "zgemm_alg" (0 = four real MFMAs per complex tile step, 1 = the three-multiplication
  * "3M" form on the 128x128 tile), "compose" (-1 auto / 0 / 1: dq_propagate multiplies the step propagators
  * together by a log-depth tree of batched products and applies the result once -- 8 d^3 instead of 8 d^2 batch
- * flops per step; auto = when batch > dim).  Unknown names -> DQ_ERR_INVALID. */
+ * flops per step; auto = when batch > dim), "skew_trick" (1 default: the adjoint sweep computes only the
+ * anti-Hermitian part of the generator cotangent, saving one ZGEMM per step; 0 = plain reverse mode).
+ * Unknown names -> DQ_ERR_INVALID. */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 

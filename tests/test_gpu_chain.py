@@ -293,3 +293,19 @@ def test_operator_form_gradient_for_wide_batches(oracle, n, K, B, S):
         assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL * B and np.max(np.abs(f - rf)) < TOL
         assert np.max(np.abs(en - oracle.energies(M, rf))) < TOL
     assert np.max(np.abs(g1 - g2)) < 1e-11 * B
+
+
+def test_skew_trick_leaves_the_gradient_unchanged():
+    """One ZGEMM fewer per step (skew part of the generator cotangent only) -- same gradient to rounding."""
+    H0, Hs, M = problems.random_hermitian_problem(4, 3, seed=50)
+    u = np.random.default_rng(4).uniform(-2, 2, (9, 3))
+    psi0 = problems.random_states(16, 7, seed=6)
+    with _engine(H0, Hs, M) as e:
+        for deg in (0, 4, 9):   # BBC-8 (auto), PS-4, PS-9 tapes
+            e.set_option("force_degree", deg)
+            e.set_option("skew_trick", 1)
+            l1, g1, f1, _ = e.energy_grad(u, 0.05, psi0)
+            e.set_option("skew_trick", 0)
+            l0, g0, f0, _ = e.energy_grad(u, 0.05, psi0)
+            assert l0 == l1 and np.array_equal(f0, f1)
+            assert np.max(np.abs(g0 - g1)) < 1e-13 * 7, deg
