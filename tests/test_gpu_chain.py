@@ -309,3 +309,38 @@ def test_skew_trick_leaves_the_gradient_unchanged():
             l0, g0, f0, _ = e.energy_grad(u, 0.05, psi0)
             assert l0 == l1 and np.array_equal(f0, f1)
             assert np.max(np.abs(g0 - g1)) < 1e-13 * 7, deg
+
+
+@pytest.mark.parametrize("dtype,tol", [("c128", 1e-11), ("c64", 2e-4)])
+def test_properties_at_n12_full_dimension(dtype, tol):
+    """BASELINE configs[2] Hilbert dimension (n = 12, d = 4096, random Ising + X controls, dt = 1e-3) at a reduced
+    batch / step count: the 128x128-tile 3M ZGEMM path. Size-independent properties + directional derivative."""
+    import torch
+    from diffquantum_amd.engine import Engine
+    n, B, S, dt = 12, 192, 3, 1e-3
+    d = 1 << n
+    dev = torch.device("cuda:0")
+    ct = torch.complex128 if dtype == "c128" else torch.complex64
+    H0, Hs, M = problems.random_ising_torch(n, 0, dev)
+    u = problems.pulse_table(n, S, S * dt, seed=0)
+    psi0 = torch.from_numpy(problems.random_states(d, B, seed=1)).to(dev).to(ct)
+    with Engine(d, n, dtype=dtype) as e:
+        e.use_torch_stream()
+        e.set_hamiltonians(H0.to(ct), Hs.to(ct))
+        e.set_observable(M.to(ct))
+        out = e.propagate(u, dt, psi0)
+        nrm = torch.linalg.norm(out.to(torch.complex128), dim=0)
+        assert float((nrm - 1).abs().max()) < tol * 10
+        mix = (0.6 * psi0[:, :64] + (0.3 - 0.2j) * psi0[:, 64:128]).contiguous()
+        lin = e.propagate(u, dt, mix) - (0.6 * out[:, :64] + (0.3 - 0.2j) * out[:, 64:128])
+        assert float(lin.abs().max()) < tol * 10
+        back = e.propagate(u[::-1].copy(), -dt, out)
+        assert float((back - psi0).abs().max()) < tol * 10
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        assert float((fin - out).abs().max()) < tol and abs(en.sum() - loss) < 1e-9 * B
+        v = np.random.default_rng(0).standard_normal(u.shape)
+        eps = 1e-3 if dtype == "c128" else 2e-2
+        lp = e.energy(e.propagate(u + eps * v, dt, psi0))[1]
+        lm = e.energy(e.propagate(u - eps * v, dt, psi0))[1]
+        fd, an = (lp - lm) / (2 * eps), float(np.sum(grad * v))
+        assert abs(fd - an) < (1e-6 if dtype == "c128" else 5e-3) * max(1.0, abs(an)), (fd, an)
