@@ -33,14 +33,21 @@ from .qobj import Qobj as _OwnQobj
 from .qobj import as_array
 
 
+_QOBJ_TYPE = None
+
+
 def _qobj_type():
-    try:  # hand back real qutip objects when the user has qutip
-        import qutip
-        if hasattr(qutip, "Qobj") and getattr(qutip.Qobj, "__module__", "").startswith("qutip"):
-            return qutip.Qobj
-    except Exception:
-        pass
-    return _OwnQobj
+    """Real qutip.Qobj when the user has qutip, this package's Qobj otherwise (resolved once)."""
+    global _QOBJ_TYPE
+    if _QOBJ_TYPE is None:
+        _QOBJ_TYPE = _OwnQobj
+        try:
+            import qutip
+            if hasattr(qutip, "Qobj") and getattr(qutip.Qobj, "__module__", "").startswith("qutip"):
+                _QOBJ_TYPE = qutip.Qobj
+        except Exception:
+            pass
+    return _QOBJ_TYPE
 
 
 def _dense(x):
@@ -139,10 +146,18 @@ class SimulatorPlain(object):
     @staticmethod
     def _pulse_table(fns, ts):
         u = np.empty((len(ts), len(fns)), dtype=np.float64)
+        ours = [k for k, f in enumerate(fns) if isinstance(f, _Pulse)]
+        if ours and all(fns[k].sim is fns[ours[0]].sim for k in ours):
+            # all of this simulator's closures in one vectorised evaluation (one basis table for every control)
+            sim = fns[ours[0]].sim
+            coeff = np.stack([fns[k].coeff_i for k in ours])
+            om = [sim.omegas[fns[k].i] for k in ours]
+            u[:, ours] = pulse.u_table(coeff, om, sim.T, ts, sim.basis)
+        else:
+            for k in ours:
+                u[:, k] = fns[k].table(ts)
         for k, f in enumerate(fns):
-            if isinstance(f, _Pulse):
-                u[:, k] = f.table(ts)
-            else:
+            if not isinstance(f, _Pulse):
                 u[:, k] = [f(float(t), None) for t in ts]
         return u
 
