@@ -580,13 +580,14 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
   c->last_chunk = tc;
   // composing propagators beats applying them one by one as soon as the batch is wider than the dimension
   const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && B > d);
+  T2* running = nullptr;  // product of the chunks composed so far (operator form)
   for (int c0 = 0; c0 < S; c0 += tc) {
     const int n = std::min(tc, S - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
     T2* U = build_propagators(c, p, c0, n, dt);
-    if (compose && n > 1) {
-      // operator form: V = U_{n-1} ... U_0 by a log-depth tree of batched products, then ONE apply.
-      // 8 d^3 flop per step instead of 8 d^2 B, and O(log n) launches instead of n.
+    if (compose) {
+      // operator form: V = U_{n-1} ... U_0 by a log-depth tree of batched products (8 d^3 flop per step instead of
+      // 8 d^2 B, O(log n) launches instead of n); across chunks a running product W <- V W; ONE apply at the end.
       T2* X = U;
       int m = n, lvl = 0;
       while (m > 1) {
@@ -601,8 +602,14 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
         m = pairs + (m & 1);
         ++lvl;
       }
-      c->zgemm(0, 0, d, B, d, 1.0, X, d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->psi[cur ^ 1].p, B, 0, 1);
-      cur ^= 1;
+      if (!running) {
+        running = c->mat(SLOT_TREE + 2, 1);
+        HIPCK(hipMemcpyAsync(running, X, c->mat_bytes(), hipMemcpyDeviceToDevice, c->st));
+      } else {
+        T2* nxt = c->mat(running == c->mat(SLOT_TREE + 2, 1) ? SLOT_TREE + 3 : SLOT_TREE + 2, 1);
+        c->zgemm(0, 0, d, d, d, 1.0, X, d, 0, running, d, 0, 0.0, nxt, d, 0, 1);
+        running = nxt;
+      }
     } else {
       for (int t = 0; t < n; ++t) {
         c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
@@ -610,6 +617,10 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
         cur ^= 1;
       }
     }
+  }
+  if (running) {
+    c->zgemm(0, 0, d, B, d, 1.0, running, d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->psi[cur ^ 1].p, B, 0, 1);
+    cur ^= 1;
   }
   c->last_composed = compose ? 1.0 : 0.0;
   out_copy(c, psi_out, c->psi[cur].p, sb);
