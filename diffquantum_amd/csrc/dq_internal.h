@@ -92,4 +92,64 @@ hipError_t colabs_launch(const typename Cx<T>::type* X, int d, double* colsum, h
 template <class T>
 hipError_t herm_defect_launch(const typename Cx<T>::type* X, int d, double* out, hipStream_t st);
 
+// ---- real-symmetric fast path (rgemm.hip, realpath.hip) -------------------------------------
+// Real GEMM C = alpha op(A) op(B) + beta C (op: 0 = N, 1 = T), row-major, strides in elements. sym != 0: the
+// product is known to be symmetric (commuting symmetric operands): only tiles on/above the diagonal are computed,
+// the mirror image is written too (M == N required; opA/opB ignored; beta != 0 needs a symmetric C on entry).
+template <class T>
+struct RgemmArgs {
+  const T* A;
+  const T* B;
+  T* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  long sA, sB, sC;
+  int batch;
+  double alpha, beta;
+  int opA, opB;
+  int sym;
+  T* ws;            // optional workspace of the symmetric form (split-K partial tiles of the tail), may be null
+  size_t ws_elems;  // its capacity in elements
+  int n_full, split_f;  // filled in by rgemm_launch
+};
+// cfg: tile configuration (0 = auto); n_cu: compute units of the device
+template <class T>
+hipError_t rgemm_launch(const RgemmArgs<T>& g, hipStream_t st, int cfg, int n_cu);
+
+// Hr = (Re H + Re H^T)/2 for `batch` stacked d x d matrices; imag_max[0] = max |Im H| (must be zeroed by the caller)
+template <class T>
+hipError_t real_part_launch(const typename Cx<T>::type* H, T* Hr, int d, int batch, double* imag_max, hipStream_t st);
+// X[z] = -dt (H0r + sum_k u[z*K + k] Hsr[k])          (diffqc.cc:192-197 without the factor i)
+template <class T>
+hipError_t rassemble_launch(T* X, const T* H0r, const T* Hsr, const double* u, int K, long n_elem, int batch, double dt,
+                            hipStream_t st);
+// out_o[z] = (accumulate ? out_o[z] : 0) + cI[o] I + sum_j c[o][j] x_j[z]   for o < n_out (inputs read once)
+template <class T>
+struct RLincombArgs {
+  T* out[2];
+  const T* x[8];
+  double c[2][8];
+  double cI[2];
+  int n_in, n_out;
+  int d;
+  long stride;
+  int batch;
+  int accumulate;
+};
+template <class T>
+hipError_t rlincomb_launch(const RLincombArgs<T>& a, hipStream_t st);
+// out[z] = (accumulate ? out[z] : 0) + a (Z[z] + Z[z]^T)
+template <class T>
+hipError_t rsym_launch(T* out, const T* Z, int d, double a, int accumulate, long stride, int batch, hipStream_t st);
+// U = C + i S   (n real elements each)
+template <class T>
+hipError_t pack_u_launch(typename Cx<T>::type* U, const T* C, const T* S, long n, hipStream_t st);
+// Cbar = (Re G + Re G^T)/2, Sbar = (Im G + Im G^T)/2
+template <class T>
+hipError_t split_g_launch(const typename Cx<T>::type* G, T* Cbar, T* Sbar, int d, long stride, int batch, hipStream_t st);
+// grad[z][k] = scale * sum_e Xbar[z][e] Hsr[k][e]  (two-stage, fixed order; part: batch * grad_contract_blocks * K)
+template <class T>
+hipError_t rgrad_contract_launch(const T* Xbar, long strideX, const T* Hsr, int K, long n_elem, int batch, double scale,
+                                 double* part, double* grad, hipStream_t st);
+
 }  // namespace dq

@@ -103,6 +103,8 @@ struct TapeOp {
 
 struct ExpmPlan {
   int m = 0, s = 0, nvars = 0, out = 0, nprod = 0;
+  int rq = 0;  // > 0: real-symmetric plan (cos/sin polynomials in Y = X^2 up to Y^rq); `ops` is empty then
+  double cc[8] = {0}, sc[8] = {0};  // cos X = sum cc[j] Y^j,  sin X = X sum sc[j] Y^j
   std::vector<TapeOp> ops;
   int products() const { return nprod; }
 };
@@ -241,10 +243,14 @@ namespace {
 template <class T>
 struct Ctx : dq_ctx {
   typedef typename dq::Cx<T>::type T2;
-  int d = 0, K = 0, dev = 0;
+  int d = 0, K = 0, dev = 0, n_cu = 256;
   hipStream_t st = nullptr;
+  DevBuf rws;  // split-K workspace of the symmetric real GEMM
   DevBuf H0, Hs, M;
-  bool have_H = false, have_M = false, hermitian = false;
+  DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
+  bool have_H = false, have_M = false, hermitian = false, real_h = false;
+  int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128;  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
+  double last_real_q = 0;
   double nH0 = 0.0;
   std::vector<double> nHk;
   // options
@@ -336,6 +342,37 @@ struct Ctx : dq_ctx {
   void mm(int opA, int opB, const T2* A, const T2* B, T2* C, double beta, int batch) {
     const long s = (long)nn();
     zgemm(opA, opB, d, d, d, 1.0, A, d, s, B, d, s, beta, C, d, s, batch);
+  }
+  // real product of `batch` stacked d x d matrices; A must be symmetric (it is read as A^T: the linear staging form)
+  void rmm(const T* A, const T* B, T* C, int batch, bool sym_out) {
+    dq::RgemmArgs<T> g;
+    g.A = A; g.B = B; g.C = C;
+    g.M = g.N = g.K = d;
+    g.lda = g.ldb = g.ldc = d;
+    g.sA = g.sB = g.sC = (long)nn();
+    g.batch = batch;
+    g.alpha = 1.0; g.beta = 0.0;
+    g.opA = 1; g.opB = 0;
+    g.sym = sym_out ? 1 : 0;
+    rgemm_workspace(g);
+    const double fl = 2.0 * d * (double)d * d * batch;
+    const double by = sizeof(T) * 3.0 * nn() * batch;
+    const int cfg = rgemm_cfg, ncu = n_cu;
+    timed(DQ_PROF_RGEMM, fl, by, [&] { return dq::rgemm_launch<T>(g, st, cfg, ncu); });
+  }
+  // workspace for the K-split tail tiles of a large symmetric product (at most one partial tile per workgroup slot)
+  void rgemm_workspace(dq::RgemmArgs<T>& g) {
+    g.ws = nullptr;
+    g.ws_elems = 0;
+    if (!g.sym || g.batch != 1 || g.M < 1024) return;
+    const size_t elems = (size_t)n_cu * 4 * 128 * 128;
+    rws.ensure(elems * sizeof(T));
+    g.ws = (T*)rws.p;
+    g.ws_elems = elems;
+  }
+  T* rmat(int slot, size_t tc) {
+    pool[slot].ensure(tc * nn() * sizeof(T));
+    return (T*)pool[slot].p;
   }
   void lincomb(T2* out, int n_in, const T2* const* x, const double* c, double cI, int batch, bool acc) {
     dq::LincombArgs<T> a;
@@ -444,6 +481,147 @@ typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n, boo
   return adj(0);
 }
 
+// ---- real-symmetric fast path -----------------------------------------------------------------
+// H0, H_k real  =>  A_t = i X_t with X_t = -dt (H0 + sum_k u_k H_k) real symmetric, and
+//   U_t = exp(A_t) = cos X_t + i sin X_t = C + i S,   C = sum_j cc_j Y^j,  S = X P,  P = sum_j sc_j Y^j,  Y = X^2
+// (the Taylor polynomial of degree 2q+1). All products are real products of commuting symmetric matrices:
+// q + 1 symmetric-output real GEMMs (d^3 flop each) instead of 3 complex ones (8 d^3 each).
+// Pool slots (real unless noted): X 0, Y_j j (j = 1..q <= 6), P 7, C 8, S 9, U 10 (complex); adjoints at SLOT_ADJ + slot,
+// G = Ubar at SLOT_ADJ + 10 (complex), product scratch Z at SLOT_ADJ + 11.
+enum { RS_X = 0, RS_P = 7, RS_C = 8, RS_S = 9, RS_U = 10, RS_Z = 11, RQ_MAX = 6 };
+
+ExpmPlan make_real_plan(int q) {
+  ExpmPlan p;
+  p.rq = q;
+  p.m = 2 * q + 1;
+  p.s = 0;
+  p.out = RS_U;
+  p.nvars = RS_U + 1;
+  p.nprod = q + 1;
+  double f = 1.0;  // (2j)!
+  for (int j = 0; j <= q; ++j) {
+    if (j > 0) f *= (2.0 * j - 1.0) * (2.0 * j);
+    const double sg = (j & 1) ? -1.0 : 1.0;
+    p.cc[j] = sg / f;
+    p.sc[j] = sg / (f * (2.0 * j + 1.0));
+  }
+  return p;
+}
+
+template <class T>
+void rlincomb2(Ctx<T>* c, T* out0, T* out1, int n_in, const T* const* x, const double* c0, const double* c1, double cI0,
+               double cI1, int batch, bool acc) {
+  dq::RLincombArgs<T> a;
+  memset(&a, 0, sizeof(a));
+  a.out[0] = out0;
+  a.out[1] = out1;
+  a.n_out = out1 ? 2 : 1;
+  a.n_in = n_in;
+  for (int j = 0; j < n_in; ++j) {
+    a.x[j] = x[j];
+    a.c[0][j] = c0[j];
+    a.c[1][j] = c1 ? c1[j] : 0.0;
+  }
+  a.cI[0] = cI0;
+  a.cI[1] = cI1;
+  a.d = c->d;
+  a.stride = (long)c->nn();
+  a.batch = batch;
+  a.accumulate = acc ? 1 : 0;
+  const double by = (double)sizeof(T) * c->nn() * (n_in + a.n_out * (acc ? 2 : 1)) * batch;
+  c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n_in * a.n_out * batch, by, [&] { return dq::rlincomb_launch<T>(a, c->st); });
+}
+
+// out (+)= a (Z + Z^T)
+template <class T>
+void rsym(Ctx<T>* c, T* out, const T* Z, double a, bool acc, int batch) {
+  const double by = (double)sizeof(T) * c->nn() * (acc ? 4.0 : 3.0) * batch;
+  c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * batch, by,
+           [&] { return dq::rsym_launch<T>(out, Z, c->d, a, acc ? 1 : 0, (long)c->nn(), batch, c->st); });
+}
+
+// assemble X and evaluate U = cos X + i sin X for `n` stacked steps; returns the complex propagators
+template <class T>
+typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
+  typedef typename dq::Cx<T>::type T2;
+  const int q = p.rq;
+  T* X = c->rmat(RS_X, n);
+  const double by = (double)sizeof(T) * c->nn() * (c->K + 2.0) * n;
+  c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->nn() * (c->K + 1.0) * n, by, [&] {
+    return dq::rassemble_launch<T>(X, (const T*)c->H0r.p, (const T*)c->Hsr.p, c->u_dev.d() + (size_t)c0 * c->K, c->K,
+                                   (long)c->nn(), n, dt, c->st);
+  });
+  const T* Y[RQ_MAX + 1];
+  for (int j = 1; j <= q; ++j) {
+    T* Yj = c->rmat(j, n);
+    c->rmm(j == 1 ? X : Y[1], j == 1 ? X : Y[j - 1], Yj, n, true);
+    Y[j] = Yj;
+  }
+  T* P = c->rmat(RS_P, n);
+  T* Cm = c->rmat(RS_C, n);
+  rlincomb2(c, Cm, P, q, Y + 1, p.cc + 1, p.sc + 1, p.cc[0], p.sc[0], n, false);
+  T* S = c->rmat(RS_S, n);
+  c->rmm(X, P, S, n, true);
+  T2* U = c->mat(RS_U, n);
+  const long ne = (long)c->nn() * n;
+  c->timed(DQ_PROF_LINCOMB, 0.0, 4.0 * sizeof(T) * ne, [&] { return dq::pack_u_launch<T>(U, Cm, S, ne, c->st); });
+  c->last_degree = p.m;
+  c->last_squarings = 0;
+  c->last_products = p.nprod;
+  c->last_real_q = q;
+  return U;
+}
+
+// Reverse mode through real_forward (whose variables are still in the pool); G = Ubar sits in ubar_slot.
+// Every variable is a symmetric function of X, so only the symmetric part of each cotangent matters:
+//   W = V1 V2 (V1 != V2):  V1bar += sym(Wbar V2), V2bar += sym(Wbar V1);     W = V V:  Vbar += 2 sym(Wbar V)
+// with sym(Z) = (Z + Z^T)/2 and Wbar symmetric: one real GEMM (full output) per cotangent, 2q in all.
+// Returns Xbar (n stacked real symmetric matrices): dL/du_k = <Xbar, -dt H_k>.
+template <class T>
+const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
+  typedef typename dq::Cx<T>::type T2;
+  const int q = p.rq;
+  const T2* G = c->mat(SLOT_ADJ + RS_U, n);
+  const T* X = c->rmat(RS_X, n);
+  const T* P = c->rmat(RS_P, n);
+  const T* Y[RQ_MAX + 1];
+  T* Yb[RQ_MAX + 1];
+  for (int j = 1; j <= q; ++j) { Y[j] = c->rmat(j, n); Yb[j] = c->rmat(SLOT_ADJ + j, n); }
+  T* Xb = c->rmat(SLOT_ADJ + RS_X, n);
+  T* Pb = c->rmat(SLOT_ADJ + RS_P, n);
+  T* Cb = c->rmat(SLOT_ADJ + RS_C, n);
+  T* Sb = c->rmat(SLOT_ADJ + RS_S, n);
+  T* Z = c->rmat(SLOT_ADJ + RS_Z, n);
+  c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n, 6.0 * sizeof(T) * c->nn() * n,
+           [&] { return dq::split_g_launch<T>(G, Cb, Sb, c->d, (long)c->nn(), n, c->st); });
+  // S = X P
+  c->rmm(Sb, P, Z, n, false);
+  rsym(c, Xb, Z, 0.5, false, n);
+  c->rmm(Sb, X, Z, n, false);
+  rsym(c, Pb, Z, 0.5, false, n);
+  // C = cc0 I + sum cc_j Y_j,  P = sc0 I + sum sc_j Y_j
+  for (int j = 1; j <= q; ++j) {
+    const T* in[2] = {Cb, Pb};
+    const double cf[2] = {p.cc[j], p.sc[j]};
+    rlincomb2<T>(c, Yb[j], nullptr, 2, in, cf, nullptr, 0.0, 0.0, n, false);
+  }
+  // Y_j = Y_1 Y_{j-1}
+  for (int j = q; j >= 3; --j) {
+    c->rmm(Yb[j], Y[j - 1], Z, n, false);
+    rsym(c, Yb[1], Z, 0.5, true, n);
+    c->rmm(Yb[j], Y[1], Z, n, false);
+    rsym(c, Yb[j - 1], Z, 0.5, true, n);
+  }
+  if (q >= 2) {  // Y_2 = Y_1 Y_1
+    c->rmm(Yb[2], Y[1], Z, n, false);
+    rsym(c, Yb[1], Z, 1.0, true, n);
+  }
+  // Y_1 = X X
+  c->rmm(Yb[1], X, Z, n, false);
+  rsym(c, Xb, Z, 1.0, true, n);
+  return Xb;
+}
+
 #define TT typename dq::Cx<T>::type
 
 template <class T>
@@ -538,6 +716,13 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
   double th = 0.0;
   for (int t = c0; t < c0 + n; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
   c->last_theta = th;
+  c->last_real_q = 0;
+  if (c->real_h && c->real_mode != 0) {
+    if (c->real_mode > 0) return make_real_plan(std::min(c->real_mode, (int)RQ_MAX));
+    if (c->force_degree <= 0 && c->force_s < 0 && c->d >= c->real_min_dim)  // (those options address the complex tape)
+      for (int q = 1; q <= RQ_MAX; ++q)
+        if (taylor_remainder(th, 2 * q + 1) <= c->expm_tol) return make_real_plan(q);
+  }
   return choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
 }
 
@@ -545,6 +730,7 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
 template <class T>
 TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
   typedef TT T2;
+  if (p.rq > 0) return real_forward(c, p, c0, n, dt);
   T2* A = c->mat(0, n);
   const double by = 2.0 * sizeof(T) * c->nn() * (c->K + 2.0) * n;
   c->timed(DQ_PROF_ASSEMBLE, 2.0 * 2 * c->nn() * (c->K + 1.0) * n, by, [&] {
@@ -787,8 +973,17 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
         lcur ^= 1;
         psi_next = psi_t;
       }
-      const T2* Abar = expm_backward(c, p, n, c->skew_trick != 0);
       c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
+      if (p.rq > 0) {
+        const T* Xbar = real_backward(c, p, n);
+        const double byr = (double)sizeof(T) * c->nn() * (K + ((K + 7) / 8)) * n;
+        c->timed(DQ_PROF_GRADC, 2.0 * c->nn() * K * n, byr, [&] {
+          return dq::rgrad_contract_launch<T>(Xbar, (long)c->nn(), (const T*)c->Hsr.p, K, (long)c->nn(), n, -dt,
+                                              c->part.d(), c->grad_dev.d() + (size_t)c0 * K, c->st);
+        });
+        continue;
+      }
+      const T2* Abar = expm_backward(c, p, n, c->skew_trick != 0);
       const double by = 2.0 * sizeof(T) * c->nn() * (K + ((K + 7) / 8)) * n;
       c->timed(DQ_PROF_GRADC, 3.0 * c->nn() * K * n, by, [&] {
         return dq::grad_contract_launch<T>(Abar, (long)c->nn(), (const T2*)c->Hs.p, K, (long)c->nn(), n, dt,
@@ -821,6 +1016,21 @@ void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
     scale = std::max(scale, c->nHk[k]);
   }
   c->hermitian = defect <= c->herm_tol * scale;
+  // real-symmetric fast path: all imaginary parts exactly zero -> keep (symmetrised) real copies
+  c->real_h = false;
+  if (c->hermitian) {
+    c->H0r.ensure(c->nn() * sizeof(T));
+    c->Hsr.ensure(std::max<size_t>(c->K, 1) * c->nn() * sizeof(T));
+    c->scratch.ensure(sizeof(double) * (size_t)std::max(c->d, 1));
+    HIPCK(hipMemsetAsync(c->scratch.p, 0, sizeof(double), c->st));
+    HIPCK(dq::real_part_launch<T>((const T2*)c->H0.p, (T*)c->H0r.p, c->d, 1, c->scratch.d(), c->st));
+    if (c->K > 0) HIPCK(dq::real_part_launch<T>((const T2*)c->Hs.p, (T*)c->Hsr.p, c->d, c->K, c->scratch.d(), c->st));
+    double im = 1.0;
+    HIPCK(hipMemcpyAsync(&im, c->scratch.p, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+    c->real_h = im == 0.0;
+    if (!c->real_h) { c->H0r.release(); c->Hsr.release(); }
+  }
   c->have_H = true;
 }
 
@@ -868,6 +1078,52 @@ void do_zgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, co
     dC = (T2*)c->tmp_in[2].p;
   }
   c->zgemm(opA, opB, M, N, K, alpha, dA, lda, strideA, dB, ldb, strideB, beta, dC, ldc, strideC, batch);
+  if (!c_dev) out_copy(c, C, dC, bcz);
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+void do_rgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch, int sym) {
+  check_ctx(c);
+  if (M < 0 || N < 0 || K < 0 || batch < 0) fail(DQ_ERR_INVALID, "negative dimension");
+  if ((opA | opB) & ~1) fail(DQ_ERR_INVALID, "op must be 0 (N) or 1 (transpose)");
+  if (sym && M != N) fail(DQ_ERR_INVALID, "symmetric-output form needs M == N");
+  if (M == 0 || N == 0 || batch == 0) return;
+  if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
+  if (sym) { opA = 1; opB = 0; }
+  const long ar = opA ? K : M, ac = opA ? M : K;  // stored shape of A
+  const long br = opB ? N : K, bc = opB ? K : N;
+  if (lda < ac || ldb < bc || ldc < N) fail(DQ_ERR_INVALID, "leading dimension smaller than the row length");
+  auto span = [&](long rows, long ld, long cols, long stride) -> size_t {
+    if (rows == 0 || cols == 0) return 0;
+    return (size_t)((batch - 1) * stride + (rows - 1) * ld + cols) * sizeof(T);
+  };
+  if (batch > 1 && strideC < (M - 1) * ldc + N) fail(DQ_ERR_INVALID, "overlapping output batch stride");
+  const size_t ba = span(ar, lda, ac, strideA), bb = span(br, ldb, bc, strideB), bcz = span(M, ldc, N, strideC);
+  const T* dA = ba ? (const T*)in_dev(c, A, ba, c->tmp_in[0]) : (const T*)c->tmp_in[0].p;
+  const T* dB = bb ? (const T*)in_dev(c, B, bb, c->tmp_in[1]) : (const T*)c->tmp_in[1].p;
+  T* dC;
+  const bool c_dev = is_device_ptr(C);
+  if (c_dev) dC = (T*)C;
+  else {
+    c->tmp_in[2].ensure(bcz);
+    stage_h2d(c, c->tmp_in[2].p, C, bcz);
+    dC = (T*)c->tmp_in[2].p;
+  }
+  dq::RgemmArgs<T> g;
+  g.A = dA; g.B = dB; g.C = dC;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.batch = batch;
+  g.alpha = alpha; g.beta = beta;
+  g.opA = opA; g.opB = opB;
+  g.sym = sym ? 1 : 0;
+  c->rgemm_workspace(g);
+  const int cfg = c->rgemm_cfg, ncu = c->n_cu;
+  c->timed(DQ_PROF_RGEMM, 2.0 * M * N * (double)K * batch, sizeof(T) * ((double)M * K + (double)K * N + (double)M * N) * batch,
+           [&] { return dq::rgemm_launch<T>(g, c->st, cfg, ncu); });
   if (!c_dev) out_copy(c, C, dC, bcz);
   HIPCK(hipStreamSynchronize(c->st));
 }
@@ -926,6 +1182,16 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->force_tile = t;
   } else if (s == "compose") {  // -1 auto (batch > dim), 0 never, 1 always
     c->compose_mode = (int)v < 0 ? -1 : ((int)v ? 1 : 0);
+  } else if (s == "real_path") {  // -1 auto (real H, no forced complex tape), 0 never, q in 1..6 forced
+    const int q = (int)v;
+    if (q < -1 || q > RQ_MAX) fail(DQ_ERR_INVALID, "real_path must be -1 (auto), 0 (off) or a polynomial size 1..6");
+    c->real_mode = q;
+  } else if (s == "real_min_dim") {  // auto mode: below this dimension the chain is launch-bound and the complex tape
+    c->real_min_dim = (int)v;         // (fewer launches) is kept
+  } else if (s == "rgemm_cfg") {
+    const int q = (int)v;
+    if (q != 0 && q != 1 && q != 2 && q != 32 && q != 64) fail(DQ_ERR_INVALID, "rgemm_cfg must be 0, 1, 2, 32 or 64");
+    c->rgemm_cfg = q;
   } else if (s == "skew_trick") {
     c->skew_trick = v != 0 ? 1 : 0;
   } else if (s == "zgemm_alg") {
@@ -946,6 +1212,8 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "hermitian") return c->hermitian ? 1.0 : 0.0;
   if (s == "zgemm_alg") return sizeof(T) == 8 ? c->zgemm_alg : 1;
   if (s == "composed") return c->last_composed;
+  if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
+  if (s == "real_path") return c->last_real_q;
   if (s == "norm_H0") return c->nH0;
   if (s == "dim") return c->d;
   if (s == "n_controls") return c->K;
@@ -983,7 +1251,7 @@ int with_ctx(dq_ctx* c, F&& f) {
 
 extern "C" {
 
-const char* dq_version(void) { return "diffqc_hip 0.2 (gfx950; complex128 + complex64)"; }
+const char* dq_version(void) { return "diffqc_hip 0.3 (gfx950; complex128 + complex64; real-symmetric fast path)"; }
 const char* dq_last_error(void) { return g_err.c_str(); }
 
 int dq_device_count(int* n) {
@@ -1015,6 +1283,9 @@ int dq_create_ex(dq_ctx** out, int dim, int n_controls, int device_id, int dtype
       c->d = dim;
       c->K = n_controls;
       c->dev = device_id;
+      int ncu = 0;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) c->n_cu = ncu;
+      else (void)hipGetLastError();
       c->nHk.assign(n_controls, 0.0);
       *out = c;
     };
@@ -1110,6 +1381,13 @@ int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, con
              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch) {
   return with_ctx(c, [&](auto* t) {
     do_zgemm(t, opA, opB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch);
+  });
+}
+
+int dq_rgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+             const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch, int sym) {
+  return with_ctx(c, [&](auto* t) {
+    do_rgemm(t, opA, opB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, sym);
   });
 }
 

@@ -257,6 +257,32 @@ class Engine:
                                       B.shape[1] * B.shape[2], float(beta), Cm.ctypes.data, N, M * N, nb))
         return Cm if batched else Cm[0]
 
+    def rgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None, sym=False):
+        """Real GEMM alpha*op(A)@op(B) + beta*C on the GPU kernel (op: 0 = N, 1 = transpose); A, B: 2-D or batched
+        3-D real arrays (host). sym=True: symmetric-output form (commuting symmetric operands)."""
+        rdtype = np.float64 if self.dtype == "c128" else np.float32
+        A = np.ascontiguousarray(A, dtype=rdtype)
+        B = np.ascontiguousarray(B, dtype=rdtype)
+        batched = A.ndim == 3
+        if not batched:
+            A, B = A[None], B[None]
+        nb = A.shape[0]
+        if B.shape[0] != nb:
+            raise ValueError("batch mismatch")
+        ta, tb = (1, 0) if sym else (int(opA), int(opB))
+        M, K = (A.shape[2], A.shape[1]) if ta else (A.shape[1], A.shape[2])
+        K2, N = (B.shape[2], B.shape[1]) if tb else (B.shape[1], B.shape[2])
+        if K != K2:
+            raise ValueError("inner dimensions differ: {} vs {}".format(K, K2))
+        if C_in is None:
+            Cm = np.zeros((nb, M, N), dtype=rdtype)
+        else:
+            Cm = np.array(C_in, dtype=rdtype, order="C").reshape(nb, M, N)
+        _lib.check(self._lib.dq_rgemm(self._ctx, ta, tb, M, N, K, float(alpha), A.ctypes.data, A.shape[2],
+                                      A.shape[1] * A.shape[2], B.ctypes.data, B.shape[2], B.shape[1] * B.shape[2],
+                                      float(beta), Cm.ctypes.data, N, M * N, nb, 1 if sym else 0))
+        return Cm if batched else Cm[0]
+
     def expm(self, A):
         A = np.ascontiguousarray(A, dtype=self.cdtype)
         batched = A.ndim == 3

@@ -80,6 +80,22 @@ def random_hermitian_problem(n: int, K: int, seed: int = 0):
     return herm(), np.stack([herm() for _ in range(K)]) if K else np.zeros((0, d, d), complex), herm()
 
 
+def random_real_symmetric_problem(n: int, K: int, seed: int = 0):
+    """Dense random REAL symmetric H0, H_k (stored complex, imaginary parts exactly zero) and a complex Hermitian M:
+    the class of Hamiltonians the engine's real-symmetric fast path (cos/sin form of the step exponential) covers --
+    the reference's own problems are of this kind (Z/ZZ drifts, X controls: demo_maxcut.py:36-79)."""
+    rng = np.random.default_rng(seed)
+    d = 1 << n
+
+    def sym():
+        a = rng.standard_normal((d, d))
+        a = a + a.T
+        return (a / np.linalg.norm(a, 2)).astype(np.complex128)
+
+    _, _, M = random_hermitian_problem(n, 0, seed + 1000)
+    return sym(), np.stack([sym() for _ in range(K)]) if K else np.zeros((0, d, d), complex), M
+
+
 def bump(b: int, n_basis: int, x):
     """The reference's "BSpline" bump (sim_plain.py:52-70 / diffqc.cc:82-93), vectorised over x."""
     tau = 1.0 / (n_basis - 2)

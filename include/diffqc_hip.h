@@ -48,12 +48,14 @@ typedef struct dq_ctx dq_ctx;
 #define DQ_PROF_LINCOMB 2   /* polynomial linear combinations             */
 #define DQ_PROF_GRADC 3     /* control-gradient contractions              */
 #define DQ_PROF_OTHER 4     /* reductions, copies                         */
-#define DQ_PROF_NCLASS 5
+#define DQ_PROF_RGEMM 5     /* batched real GEMM of the real-symmetric fast path (f64 MFMA) */
+#define DQ_PROF_NCLASS 6
 
 typedef struct dq_profile {
   long long launches[DQ_PROF_NCLASS];
   double ms[DQ_PROF_NCLASS];     /* sum of HIP-event durations of the class's launches       */
-  double flops[DQ_PROF_NCLASS];  /* algorithmic real flops (ZGEMM: 8*M*N*K per launch*batch) */
+  double flops[DQ_PROF_NCLASS];  /* algorithmic real flops (ZGEMM: 8*M*N*K, RGEMM: 2*M*N*K per launch*batch, also
+                                    for the symmetric-output form which executes about half of them) */
   double bytes[DQ_PROF_NCLASS];  /* algorithmic bytes moved (streaming classes)              */
 } dq_profile;
 
@@ -80,7 +82,14 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  * "3M" form on the 128x128 tile), "compose" (-1 auto / 0 / 1: dq_propagate multiplies the step propagators
  * together by a log-depth tree of batched products and applies the result once -- 8 d^3 instead of 8 d^2 batch
  * flops per step; auto = when batch > dim), "skew_trick" (1 default: the adjoint sweep computes only the
- * anti-Hermitian part of the generator cotangent, saving one ZGEMM per step; 0 = plain reverse mode).
+ * anti-Hermitian part of the generator cotangent, saving one ZGEMM per step; 0 = plain reverse mode),
+ * "real_path" (-1 auto / 0 off / q = 1..6 forced: when H0 and all H_k are real, exp(-i dt H) = cos X + i sin X with
+ * X = -dt H real symmetric is evaluated with q + 1 real symmetric-output products, Taylor degree 2q + 1, and
+ * differentiated with 2q real products; auto = smallest q meeting expm_tol, complex tape if none does or if
+ * force_degree / force_squarings are set or dim < "real_min_dim" (default 128: below it the chain is launch-bound and
+ * the complex tape needs fewer launches)), "rgemm_cfg" (tile configuration of the real GEMM, 0 = auto).
+ * dq_get_info names: "degree", "squarings", "products", "time_chunk", "checkpoint_stride", "theta", "hermitian",
+ * "zgemm_alg", "composed", "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), ...
  * Unknown names -> DQ_ERR_INVALID. */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
@@ -109,6 +118,12 @@ int dq_fidelity_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */
 int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch);
+/* Real GEMM of the real-symmetric fast path: C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = transpose;
+ * element type double (DQ_C128 contexts) or float (DQ_C64); strides in elements. sym != 0: the caller asserts that
+ * the product is symmetric (commuting symmetric operands; M == N): only the tiles on and above the diagonal are
+ * computed and mirrored. */
+int dq_rgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+             const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch, int sym);
 /* U[z] = exp(A[z]) for `batch` dim x dim matrices. */
 int dq_expm(dq_ctx* ctx, const void* A, void* U, int batch);
 /* Abar[z] = adjoint Frechet derivative: <Ubar, dexp_A(E)> = <Abar, E> for all E (real inner product Re tr(X^H Y)). */
