@@ -14,9 +14,14 @@ the 2000-step configuration are timed (the full 2000-step run is in DESIGN.md). 
 table) are resident in HBM before the clock starts.  N GPUs = N independent batch shards of 4096 (weak scaling):
 value = N*K / max-over-ranks wall time.
 
-Adds to the JSON line: `roofline` for the dominant kernel (batched ZGEMM on f64 MFMA; per-launch HIP events recorded
-by the library on the launch stream) and `cpu_baseline` (the oracle = the reference's scipy expm + matmul step, timed on
-this box's host cores on a bounded sample).
+The Ising Hamiltonian is real, so the engine takes its real-symmetric fast path by default (exp(-i dt H) = cos X + i sin X
+with real symmetric-output MFMA products; same results to rounding); `general_complex_path` in the JSON
+line is the same chain with that path switched off (what an arbitrary complex Hermitian H of this size costs).
+
+Adds to the JSON line: `roofline` for the dominant kernel (the class with the largest share of the timed region: the
+batched complex GEMM on f64 MFMA; per-launch HIP events recorded by the library on the launch stream), `roofline_real_gemm`
+for the real GEMM of the fast path, and `cpu_baseline` (the oracle = the reference's scipy expm + matmul step, timed on this
+box's host cores on a bounded sample).
 """
 import argparse
 import json
@@ -29,8 +34,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_BYTES_PER_LAUNCH = 3.60e9  # HBM-side bytes per ZGEMM launch from rocprofv3 PMC (profiles/r1_*_summary.txt):
-                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.33 GB + 0.27 GB at d = B = 4096
+TRAFFIC_BYTES_PER_LAUNCH = 3.53e9  # HBM-side bytes per ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_v5_realpath_
+                                   # summary.txt): 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.27 GB + 0.27 GB, d = B = 4096
+TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 1.92e9}  # same profile: real GEMM full-output; symmetric-output + its fix-up pass.
+                                                   # (8 B/lane loads: the guide calls this access width uncalibrated)
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
 
@@ -123,6 +130,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-other-configs", action="store_true")
+    ap.add_argument("--real-path", type=int, default=-1,
+                    help="-1 auto (real H -> cos/sin form on real MFMA products), 0 = general complex path only")
     a = ap.parse_args()
 
     import torch
@@ -156,6 +165,7 @@ def main():
     eng.use_torch_stream()
     eng.set_hamiltonians(H0, Hs)
     eng.set_observable(M)
+    eng.set_option("real_path", a.real_path)
     u_t = torch.from_numpy(u_all[:K].copy()).to(dev)
     grad_t = torch.zeros((K, n), dtype=torch.float64, device=dev)
 
@@ -186,10 +196,34 @@ def main():
         elapsed = float(tmax.item())
     prof = eng.profile()
     info = {k: eng.info(k) for k in ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk",
-                                     "zgemm_alg")}
+                                     "zgemm_alg", "real_path", "real_hamiltonians")}
+    general = None
+    if rank == 0 and world == 1 and info["real_path"] > 0:
+        # the same chain on the general complex path (any Hermitian H), outside the timed region, short chain
+        Kg = min(K, 4)
+        eng.profile_enable(False)
+        eng.set_option("real_path", 0)
+        ug = torch.from_numpy(u_all[:Kg].copy()).to(dev)
+        gg = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
+        eng.energy_grad(ug[:1], a.dt, psi0, want_final=False, want_energies=False)
+        torch.cuda.synchronize(); tg = time.perf_counter()
+        lg, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gg)
+        torch.cuda.synchronize(); tg = time.perf_counter() - tg
+        eng.set_option("real_path", a.real_path)
+        gr = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
+        lr, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gr)
+        general = {"steps_per_s": Kg / tg, "chain_steps": Kg, "products_per_step": "14 ZGEMMs (3M) of 8 d^3",
+                   "max_abs_grad_diff_vs_real_path": float((gg - gr).abs().max().item()),
+                   "abs_loss_diff_vs_real_path": abs(lg - lr),
+                   "note": "same inputs with real_path = 0: what a complex Hermitian H of this size costs; the two paths' "
+                           "gradients on the same {}-step chain differ by the amount shown".format(Kg)}
 
     if rank == 0:
         z = prof["zgemm"]
+        rg, rs = prof["rgemm"], prof["rsym"]
+
+        def rate(p):
+            return p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
         per_launch_flops = z["flops"] / max(1, z["launches"])
         per_launch_ms = z["ms"] / max(1, z["launches"])
         achieved = z["flops"] / (z["ms"] * 1e-3) / 1e12 if z["ms"] > 0 else 0.0
@@ -214,8 +248,11 @@ def main():
                             "2000 Trotter steps (per-step cost is chain-length independent)".format(n, d, n, B, a.dt, K),
                 "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
                 "chain_steps": K, "dt": a.dt, "parallelism": "dp{} (batch shards, one all-reduce of loss+dL/du)".format(world),
-                "expm": "Taylor degree {} ({} products, {} squarings), theta<={:.3g}".format(
-                    int(info["degree"]), int(info["products"]), int(info["squarings"]), info["theta"]),
+                "expm": ("cos X + i sin X, Taylor degree {} ({} real symmetric-output products), theta<={:.3g}".format(
+                    int(info["degree"]), int(info["products"]), info["theta"]) if info["real_path"] > 0 else
+                    "Taylor degree {} ({} complex products, {} squarings), theta<={:.3g}".format(
+                        int(info["degree"]), int(info["products"]), int(info["squarings"]), info["theta"])),
+                "path": "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path",
                 "checkpoint_stride": int(info["checkpoint_stride"]),
                 "trajectory_steps_per_s": steps_per_s * B,
                 "loss": loss, "grad_norm": float(torch.linalg.norm(grad).item()) if hasattr(grad, "norm") else float(np.linalg.norm(grad)),
@@ -235,14 +272,27 @@ def main():
                         "flops for 8*M*N*K algorithmic ones, so `frac` can exceed 1; `frac_executed` is the matrix-pipe "
                         "utilisation. traffic = PMC FETCH/WRITE per launch (profiles/, separate --pmc passes)",
             },
+            "roofline_real_gemm": {
+                "bound": "mfma", "kernel": "rgemm_kernel<128,128,16,4,4> (batched real GEMM, v_mfma_f64_16x16x4_f64; full-output "
+                                           "and symmetric-output launches)",
+                "full": {"achieved": rate(rg), "frac": rate(rg) / PEAK_F64_MFMA_TFLOPS, "launches": rg["launches"],
+                         "ms_per_launch": rg["ms"] / max(1, rg["launches"]), "traffic": TRAFFIC_RGEMM["rgemm"]},
+                "symmetric": {"achieved": rate(rs), "frac": rate(rs) / PEAK_F64_MFMA_TFLOPS, "launches": rs["launches"],
+                              "ms_per_launch": rs["ms"] / max(1, rs["launches"]), "traffic": TRAFFIC_RGEMM["rsym"],
+                              "note": "achieved = EXECUTED flops (tiles on/above the diagonal) / HIP-event time"},
+                "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+            },
+            "general_complex_path": general,
             "end_to_end": {
                 "algorithmic_flops_per_step": 3 * W_alg,
                 "algorithmic_tflops": 3 * W_alg * K / elapsed / 1e12,
                 "frac_of_peak": 3 * W_alg * K / elapsed / 1e12 / PEAK_F64_MFMA_TFLOPS,
                 "zgemm_flops_per_step": z["flops"] / max(K, 1),
+                "rgemm_flops_per_step": (rg["flops"] + rs["flops"]) / max(K, 1),
                 "kernel_ms": {k: v["ms"] for k, v in prof.items()},
                 "kernel_launches": {k: v["launches"] for k, v in prof.items()},
-                "hbm_GBps": {k: (v["bytes"] / v["ms"] * 1e-6 if v["ms"] > 0 else 0.0) for k, v in prof.items() if k != "zgemm"},
+                "hbm_GBps": {k: (v["bytes"] / v["ms"] * 1e-6 if v["ms"] > 0 else 0.0) for k, v in prof.items()
+                             if k not in ("zgemm", "rgemm", "rsym")},
             },
         }
         if world == 1 and not a.skip_other_configs:

@@ -355,10 +355,16 @@ struct Ctx : dq_ctx {
     g.opA = 1; g.opB = 0;
     g.sym = sym_out ? 1 : 0;
     rgemm_workspace(g);
-    const double fl = 2.0 * d * (double)d * d * batch;
+    const double fl = sym_out ? rsym_flops(d, d, batch) : 2.0 * d * (double)d * d * batch;
     const double by = sizeof(T) * 3.0 * nn() * batch;
     const int cfg = rgemm_cfg, ncu = n_cu;
-    timed(DQ_PROF_RGEMM, fl, by, [&] { return dq::rgemm_launch<T>(g, st, cfg, ncu); });
+    timed(sym_out ? DQ_PROF_RSYM : DQ_PROF_RGEMM, fl, by, [&] { return dq::rgemm_launch<T>(g, st, cfg, ncu); });
+  }
+  // executed flops of the symmetric-output form: tiles on/above the diagonal only
+  double rsym_flops(int n, int k, int batch) const {
+    const int t = rgemm_cfg == 32 || rgemm_cfg == 64 ? rgemm_cfg : (rgemm_cfg ? 128 : dq::zgemm_pick_tile(n, n, batch));
+    const double nt = (n + t - 1) / t;
+    return 2.0 * k * (double)t * t * (nt * (nt + 1) / 2) * batch;
   }
   // workspace for the K-split tail tiles of a large symmetric product (at most one partial tile per workgroup slot)
   void rgemm_workspace(dq::RgemmArgs<T>& g) {
@@ -1122,7 +1128,8 @@ void do_rgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, co
   g.sym = sym ? 1 : 0;
   c->rgemm_workspace(g);
   const int cfg = c->rgemm_cfg, ncu = c->n_cu;
-  c->timed(DQ_PROF_RGEMM, 2.0 * M * N * (double)K * batch, sizeof(T) * ((double)M * K + (double)K * N + (double)M * N) * batch,
+  c->timed(sym ? DQ_PROF_RSYM : DQ_PROF_RGEMM, sym ? c->rsym_flops(M, K, batch) : 2.0 * M * N * (double)K * batch,
+           sizeof(T) * ((double)M * K + (double)K * N + (double)M * N) * batch,
            [&] { return dq::rgemm_launch<T>(g, c->st, cfg, ncu); });
   if (!c_dev) out_copy(c, C, dC, bcz);
   HIPCK(hipStreamSynchronize(c->st));
@@ -1190,7 +1197,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->real_min_dim = (int)v;         // (fewer launches) is kept
   } else if (s == "rgemm_cfg") {
     const int q = (int)v;
-    if (q != 0 && q != 1 && q != 2 && q != 32 && q != 64) fail(DQ_ERR_INVALID, "rgemm_cfg must be 0, 1, 2, 32 or 64");
+    if (q != 0 && q != 1 && q != 2 && q != 3 && q != 32 && q != 64)
+      fail(DQ_ERR_INVALID, "rgemm_cfg must be 0, 1, 2, 3, 32 or 64");
     c->rgemm_cfg = q;
   } else if (s == "skew_trick") {
     c->skew_trick = v != 0 ? 1 : 0;

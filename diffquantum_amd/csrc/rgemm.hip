@@ -333,7 +333,7 @@ static void rlaunch_cfg(RgemmArgs<T> g, hipStream_t st, int n_cu) {
   }
 }
 
-// cfg: 0 = auto; 1 = 128x128 tile, 4 waves of 64x64; 2 = 128x128 tile, 8 waves of 64x32; 64 / 32 = small tiles.
+// cfg: 0 = auto; 128x128 tile with 1: 4 waves of 64x64, 2: 8 waves of 64x32, 3: 16 waves of 32x32; 64 / 32 = small tiles.
 // n_cu: compute units of the device (workgroup slots = n_cu * resident workgroups per CU of the configuration).
 template <class T>
 hipError_t rgemm_launch(const RgemmArgs<T>& g, hipStream_t st, int cfg, int n_cu) {
@@ -341,10 +341,11 @@ hipError_t rgemm_launch(const RgemmArgs<T>& g, hipStream_t st, int cfg, int n_cu
   if (g.sym && g.M != g.N) return hipErrorInvalidValue;
   if (cfg == 0) {
     const int t = zgemm_pick_tile(g.M, g.N, g.batch);
-    cfg = t == 128 ? 2 : t;
+    cfg = t == 128 ? 3 : t;
   }
   if (cfg == 1) rlaunch_cfg<T, 128, 128, 16, 2, 2, 2>(g, st, n_cu);
   else if (cfg == 2) rlaunch_cfg<T, 128, 128, 16, 2, 4, 4>(g, st, n_cu);
+  else if (cfg == 3) rlaunch_cfg<T, 128, 128, 16, 4, 4, 8>(g, st, n_cu);
   else if (cfg == 64) rlaunch_cfg<T, 64, 64, 16, 2, 2, 2>(g, st, n_cu);
   else if (cfg == 32) rlaunch_cfg<T, 32, 32, 16, 1, 1, 2>(g, st, n_cu);
   else return hipErrorInvalidValue;

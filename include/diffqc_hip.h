@@ -48,14 +48,16 @@ typedef struct dq_ctx dq_ctx;
 #define DQ_PROF_LINCOMB 2   /* polynomial linear combinations             */
 #define DQ_PROF_GRADC 3     /* control-gradient contractions              */
 #define DQ_PROF_OTHER 4     /* reductions, copies                         */
-#define DQ_PROF_RGEMM 5     /* batched real GEMM of the real-symmetric fast path (f64 MFMA) */
-#define DQ_PROF_NCLASS 6
+#define DQ_PROF_RGEMM 5     /* batched real GEMM of the real-symmetric fast path (f64 MFMA), full output   */
+#define DQ_PROF_RSYM 6      /* the same kernel in its symmetric-output form (tiles on/above the diagonal)  */
+#define DQ_PROF_NCLASS 7
 
 typedef struct dq_profile {
   long long launches[DQ_PROF_NCLASS];
   double ms[DQ_PROF_NCLASS];     /* sum of HIP-event durations of the class's launches       */
-  double flops[DQ_PROF_NCLASS];  /* algorithmic real flops (ZGEMM: 8*M*N*K, RGEMM: 2*M*N*K per launch*batch, also
-                                    for the symmetric-output form which executes about half of them) */
+  double flops[DQ_PROF_NCLASS];  /* real flops per class. ZGEMM: the algorithmic 8*M*N*K (the 3M form executes 6*M*N*K);
+                                    RGEMM: 2*M*N*K; RSYM: the EXECUTED 2*K*128*128*(tiles on/above the diagonal),
+                                    about half of the 2*M*N*K of the full product it stands for */
   double bytes[DQ_PROF_NCLASS];  /* algorithmic bytes moved (streaming classes)              */
 } dq_profile;
 

@@ -26,7 +26,7 @@ def _engine(H0, Hs, M=None, dtype="c128"):
 
 
 # ---- the real GEMM kernel -------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [0, 1, 2, 64, 32])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 64, 32])
 @pytest.mark.parametrize("M,N,K,nb", [(1, 1, 1, 1), (16, 16, 4, 2), (33, 17, 9, 3), (128, 128, 128, 1), (130, 257, 77, 2),
                                       (256, 256, 256, 1), (300, 140, 513, 1)])
 def test_rgemm_matches_numpy(cfg, M, N, K, nb):
@@ -45,7 +45,7 @@ def test_rgemm_matches_numpy(cfg, M, N, K, nb):
                 assert np.max(np.abs(got - ref)) < 1e-14 * scale, (opA, opB)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 64, 32])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 64, 32])
 @pytest.mark.parametrize("d,nb", [(5, 2), (64, 3), (128, 1), (200, 2), (384, 1), (1024, 1)])
 def test_rgemm_symmetric_output_form(cfg, d, nb):
     """Products of commuting symmetric matrices (two polynomials of one symmetric X): upper tiles + mirror."""
@@ -70,7 +70,7 @@ def test_rgemm_symmetric_output_form(cfg, d, nb):
 
 
 @pytest.mark.parametrize("d", [4096, 3970])
-@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("cfg", [1, 2, 3])
 def test_rgemm_symmetric_form_tail_split_at_full_dimension(cfg, d):
     """d = 4096: 528 triangle tiles on 512 workgroup slots -- the 16 tail tiles are split along K and summed by the
     fix-up kernel (fixed order). Same result as numpy, exactly symmetric, and reproducible bit for bit."""
@@ -249,7 +249,7 @@ def test_real_path_d256_through_the_128_tile(oracle):
     psi0 = problems.random_states(256, B, seed=2)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
     with _engine(H0, Hs, M) as e:
-        for cfg in (0, 1, 2, 64):
+        for cfg in (0, 1, 2, 3, 64):
             e.set_option("rgemm_cfg", cfg)
             loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
             assert e.info("real_path") >= 1

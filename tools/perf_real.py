@@ -25,7 +25,7 @@ lib = _lib.load()
 X = torch.randn(d, d, dtype=torch.float64, device=dev); X = (X + X.T) / (2 * d ** 0.5)
 Y = X @ X
 Cout = torch.empty_like(X)
-for cfg in (1, 2):
+for cfg in (1, 2, 3):
     e.set_option("rgemm_cfg", cfg)
     for sym in (0, 1):
         for rep in range(2):
@@ -33,17 +33,21 @@ for cfg in (1, 2):
             for _ in range(5):
                 _lib.check(lib.dq_rgemm(e._ctx, 1, 0, d, d, d, 1.0, X.data_ptr(), d, 0, Y.data_ptr(), d, 0, 0.0,
                                         Cout.data_ptr(), d, 0, 1, sym))
-            p = e.profile()["rgemm"]
+            p = e.profile()["rsym" if sym else "rgemm"]
         err = float((Cout - X @ Y).abs().max())
         print("rgemm cfg %d sym %d: %.3f ms/launch, %.1f TF/s algorithmic (2d^3), max err %.2e" % (
             cfg, sym, p["ms"] / p["launches"], p["flops"] / p["ms"] * 1e-9, err))
 e.profile_enable(False)
 
 tu = torch.from_numpy(u).to(dev)
-for cfg in (1, 2):
-  e.set_option("rgemm_cfg", cfg)
-  for rp in (-1, 0):
+import os
+combos = [(2, -1, 1), (3, -1, 1), (2, -1, 2), (2, 0, 1), (2, 0, 2)]
+for cfg, rp, alg in combos:
+  if True:
+    e.set_option("rgemm_cfg", cfg)
     e.set_option("real_path", rp)
+    e.set_option("zgemm_alg", alg)
+    print("---- rgemm_cfg %d real_path %d zgemm_alg %d" % (cfg, rp, alg))
     for mode in ("propagate", "energy_grad"):
         for rep in range(2):
             e.profile_enable(rep == 1)
@@ -59,10 +63,8 @@ for cfg in (1, 2):
             cfg, rp, e.info("real_path"), mode, S, t1 - t0, S / (t1 - t0), e.info("degree"), e.info("products")))
         if mode == "energy_grad":
             print("   loss %.12f |grad| %.12e" % (loss, float(np.linalg.norm(grad))))
-        for k in ("zgemm", "rgemm", "assemble", "lincomb", "gradc", "other"):
+        for k in ("zgemm", "rgemm", "rsym", "assemble", "lincomb", "gradc", "other"):
             p = prof[k]
             if p["launches"]:
                 print("   %s: %d launches, %.2f ms total, %.3f ms/launch, %.1f GB/s, %.1f TF/s" % (
                     k, p["launches"], p["ms"], p["ms"] / p["launches"], p["bytes"] / p["ms"] * 1e-6, p["flops"] / p["ms"] * 1e-9))
-    if cfg == 2:
-        break
