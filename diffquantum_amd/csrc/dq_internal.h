@@ -70,6 +70,8 @@ template <class T>
 hipError_t grad_contract_launch(const typename Cx<T>::type* Abar, long strideA, const typename Cx<T>::type* Hs, int K,
                                 long n_elem, int batch, double scale, double* part, double* grad, hipStream_t st);
 int grad_contract_blocks(long n_elem);
+// grad[z][k] = scale * sum over blocks of part[z][blk][k], fixed summation order
+hipError_t grad_finish_launch(const double* part, int nblk, int K, int batch, double scale, double* grad, hipStream_t st);
 
 // e[b] = scale * sum_i Re(conj(X[i][b]) * Y[i][b]);  X, Y are d x B (ld in complex elements); fp64 accumulation
 // `part` is scratch of coldot_chunks(d) * B doubles (two-stage, fixed order)
@@ -108,9 +110,11 @@ struct RgemmArgs {
   double alpha, beta;
   int opA, opB;
   int sym;
+  int two;          // with sym: C = alpha (A B + B A) + beta C for symmetric A, B (K == M == N)
   T* ws;            // optional workspace of the symmetric form (split-K partial tiles of the tail), may be null
   size_t ws_elems;  // its capacity in elements
   int n_full, split_f;  // filled in by rgemm_launch
+  int glds_ok;          // allow the LDS-DMA staged variant when shapes and alignment permit (1 = yes)
 };
 // cfg: tile configuration (0 = auto); n_cu: compute units of the device
 template <class T>
@@ -138,9 +142,6 @@ struct RLincombArgs {
 };
 template <class T>
 hipError_t rlincomb_launch(const RLincombArgs<T>& a, hipStream_t st);
-// out[z] = (accumulate ? out[z] : 0) + a (Z[z] + Z[z]^T)
-template <class T>
-hipError_t rsym_launch(T* out, const T* Z, int d, double a, int accumulate, long stride, int batch, hipStream_t st);
 // U = C + i S   (n real elements each)
 template <class T>
 hipError_t pack_u_launch(typename Cx<T>::type* U, const T* C, const T* S, long n, hipStream_t st);

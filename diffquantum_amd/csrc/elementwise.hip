@@ -176,14 +176,28 @@ __global__ void __launch_bounds__(GC_THREADS) grad_contract_kernel(const typenam
   }
 }
 
-__global__ void grad_finish_kernel(const double* __restrict__ part, int nblk, int K, double scale,
-                                   double* __restrict__ grad) {
+// grad[z][k] = scale * sum_b part[z][b][k]: one 256-thread block per (z, k); thread t adds blocks t, t + 256, ... in
+// order, then a fixed-shape tree over the 256 partial sums (same order on every run -> reproducible bits)
+__global__ void __launch_bounds__(256) grad_finish_kernel(const double* __restrict__ part, int nblk, int K, double scale,
+                                                          double* __restrict__ grad) {
+  __shared__ double red[256];
   const long z = blockIdx.x;
-  const int k = threadIdx.x;
-  if (k >= K) return;
+  const int k = blockIdx.y;
   double v = 0.0;
-  for (int b = 0; b < nblk; ++b) v += part[(z * nblk + b) * K + k];
-  grad[z * K + k] = scale * v;
+  for (int b = threadIdx.x; b < nblk; b += 256) v += part[(z * nblk + b) * K + k];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) grad[z * K + k] = scale * red[0];
+}
+
+hipError_t grad_finish_launch(const double* part, int nblk, int K, int batch, double scale, double* grad, hipStream_t st) {
+  if (K <= 0 || batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)batch, (unsigned)K), dim3(256), 0, st, part, nblk, K, scale, grad);
+  return hipGetLastError();
 }
 
 int grad_contract_blocks(long n_elem) {
@@ -201,9 +215,7 @@ hipError_t grad_contract_launch(const typename Cx<T>::type* Abar, long strideA, 
   dim3 grid((unsigned)nb, 1, (unsigned)batch);
   for (int k0 = 0; k0 < K; k0 += KC)
     hipLaunchKernelGGL(grad_contract_kernel<T>, grid, dim3(GC_THREADS), 0, st, Abar, strideA, Hs, K, k0, n_elem, part);
-  const int threads = ((K + 63) / 64) * 64;
-  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)batch), dim3(threads), 0, st, part, nb, K, scale, grad);
-  return hipGetLastError();
+  return grad_finish_launch(part, nb, K, batch, scale, grad, st);
 }
 template hipError_t grad_contract_launch<double>(const double2*, long, const double2*, int, long, int, double, double*,
                                                  double*, hipStream_t);
@@ -408,7 +420,7 @@ hipError_t herm_defect_launch(const typename Cx<T>::type* X, int d, double* out,
   hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
   if (e != hipSuccess) return e;
   long nb = ((long)d * d + 255) / 256;
-  if (nb > 4096) nb = 4096;
+  if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(herm_defect_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, X, d, (unsigned long long*)out);
   return hipGetLastError();
 }

@@ -249,7 +249,7 @@ struct Ctx : dq_ctx {
   DevBuf H0, Hs, M;
   DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
-  int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128;  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
+  int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128, rgemm_glds = 1;  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
   double last_real_q = 0;
   double nH0 = 0.0;
   std::vector<double> nHk;
@@ -344,18 +344,21 @@ struct Ctx : dq_ctx {
     zgemm(opA, opB, d, d, d, 1.0, A, d, s, B, d, s, beta, C, d, s, batch);
   }
   // real product of `batch` stacked d x d matrices; A must be symmetric (it is read as A^T: the linear staging form)
-  void rmm(const T* A, const T* B, T* C, int batch, bool sym_out) {
+  void rmm(const T* A, const T* B, T* C, int batch, bool sym_out, bool two = false, double alpha = 1.0,
+           bool accumulate = false) {
     dq::RgemmArgs<T> g;
     g.A = A; g.B = B; g.C = C;
     g.M = g.N = g.K = d;
     g.lda = g.ldb = g.ldc = d;
     g.sA = g.sB = g.sC = (long)nn();
     g.batch = batch;
-    g.alpha = 1.0; g.beta = 0.0;
+    g.alpha = alpha; g.beta = accumulate ? 1.0 : 0.0;
     g.opA = 1; g.opB = 0;
     g.sym = sym_out ? 1 : 0;
+    g.two = (sym_out && two) ? 1 : 0;
+    g.glds_ok = rgemm_glds;
     rgemm_workspace(g);
-    const double fl = sym_out ? rsym_flops(d, d, batch) : 2.0 * d * (double)d * d * batch;
+    const double fl = sym_out ? rsym_flops(d, d, batch) * (two ? 2.0 : 1.0) : 2.0 * d * (double)d * d * batch;
     const double by = sizeof(T) * 3.0 * nn() * batch;
     const int cfg = rgemm_cfg, ncu = n_cu;
     timed(sym_out ? DQ_PROF_RSYM : DQ_PROF_RGEMM, fl, by, [&] { return dq::rgemm_launch<T>(g, st, cfg, ncu); });
@@ -493,8 +496,8 @@ typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n, boo
 // (the Taylor polynomial of degree 2q+1). All products are real products of commuting symmetric matrices:
 // q + 1 symmetric-output real GEMMs (d^3 flop each) instead of 3 complex ones (8 d^3 each).
 // Pool slots (real unless noted): X 0, Y_j j (j = 1..q <= 6), P 7, C 8, S 9, U 10 (complex); adjoints at SLOT_ADJ + slot,
-// G = Ubar at SLOT_ADJ + 10 (complex), product scratch Z at SLOT_ADJ + 11.
-enum { RS_X = 0, RS_P = 7, RS_C = 8, RS_S = 9, RS_U = 10, RS_Z = 11, RQ_MAX = 6 };
+// G = Ubar at SLOT_ADJ + 10 (complex).
+enum { RS_X = 0, RS_P = 7, RS_C = 8, RS_S = 9, RS_U = 10, RQ_MAX = 6 };
 
 ExpmPlan make_real_plan(int q) {
   ExpmPlan p;
@@ -538,14 +541,6 @@ void rlincomb2(Ctx<T>* c, T* out0, T* out1, int n_in, const T* const* x, const d
   c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n_in * a.n_out * batch, by, [&] { return dq::rlincomb_launch<T>(a, c->st); });
 }
 
-// out (+)= a (Z + Z^T)
-template <class T>
-void rsym(Ctx<T>* c, T* out, const T* Z, double a, bool acc, int batch) {
-  const double by = (double)sizeof(T) * c->nn() * (acc ? 4.0 : 3.0) * batch;
-  c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * batch, by,
-           [&] { return dq::rsym_launch<T>(out, Z, c->d, a, acc ? 1 : 0, (long)c->nn(), batch, c->st); });
-}
-
 // assemble X and evaluate U = cos X + i sin X for `n` stacked steps; returns the complex propagators
 template <class T>
 typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
@@ -581,7 +576,8 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
 // Reverse mode through real_forward (whose variables are still in the pool); G = Ubar sits in ubar_slot.
 // Every variable is a symmetric function of X, so only the symmetric part of each cotangent matters:
 //   W = V1 V2 (V1 != V2):  V1bar += sym(Wbar V2), V2bar += sym(Wbar V1);     W = V V:  Vbar += 2 sym(Wbar V)
-// with sym(Z) = (Z + Z^T)/2 and Wbar symmetric: one real GEMM (full output) per cotangent, 2q in all.
+// with sym(Z) = (Z + Z^T)/2 = (Wbar V + V Wbar)/2 for symmetric Wbar, V: one two-product symmetric-output launch per
+// cotangent (the MFMA work of one full real GEMM), 2q in all.
 // Returns Xbar (n stacked real symmetric matrices): dL/du_k = <Xbar, -dt H_k>.
 template <class T>
 const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
@@ -597,14 +593,14 @@ const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
   T* Pb = c->rmat(SLOT_ADJ + RS_P, n);
   T* Cb = c->rmat(SLOT_ADJ + RS_C, n);
   T* Sb = c->rmat(SLOT_ADJ + RS_S, n);
-  T* Z = c->rmat(SLOT_ADJ + RS_Z, n);
   c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n, 6.0 * sizeof(T) * c->nn() * n,
            [&] { return dq::split_g_launch<T>(G, Cb, Sb, c->d, (long)c->nn(), n, c->st); });
+  // sym2(W, V, out, a): out (+)= a (W V + V W)  -- one symmetric-output launch with both products (no full-matrix
+  // round trip, no symmetrisation pass); a = 1/2 gives sym(W V), a = 1 gives 2 sym(W V)
+  auto sym2 = [&](const T* W, const T* V, T* out, double a, bool acc) { c->rmm(W, V, out, n, true, true, a, acc); };
   // S = X P
-  c->rmm(Sb, P, Z, n, false);
-  rsym(c, Xb, Z, 0.5, false, n);
-  c->rmm(Sb, X, Z, n, false);
-  rsym(c, Pb, Z, 0.5, false, n);
+  sym2(Sb, P, Xb, 0.5, false);
+  sym2(Sb, X, Pb, 0.5, false);
   // C = cc0 I + sum cc_j Y_j,  P = sc0 I + sum sc_j Y_j
   for (int j = 1; j <= q; ++j) {
     const T* in[2] = {Cb, Pb};
@@ -613,18 +609,11 @@ const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
   }
   // Y_j = Y_1 Y_{j-1}
   for (int j = q; j >= 3; --j) {
-    c->rmm(Yb[j], Y[j - 1], Z, n, false);
-    rsym(c, Yb[1], Z, 0.5, true, n);
-    c->rmm(Yb[j], Y[1], Z, n, false);
-    rsym(c, Yb[j - 1], Z, 0.5, true, n);
+    sym2(Yb[j], Y[j - 1], Yb[1], 0.5, true);
+    sym2(Yb[j], Y[1], Yb[j - 1], 0.5, true);
   }
-  if (q >= 2) {  // Y_2 = Y_1 Y_1
-    c->rmm(Yb[2], Y[1], Z, n, false);
-    rsym(c, Yb[1], Z, 1.0, true, n);
-  }
-  // Y_1 = X X
-  c->rmm(Yb[1], X, Z, n, false);
-  rsym(c, Xb, Z, 1.0, true, n);
+  if (q >= 2) sym2(Yb[2], Y[1], Yb[1], 1.0, true);  // Y_2 = Y_1 Y_1
+  sym2(Yb[1], X, Xb, 1.0, true);                     // Y_1 = X X
   return Xb;
 }
 
@@ -1095,6 +1084,7 @@ void do_rgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, co
   if (M < 0 || N < 0 || K < 0 || batch < 0) fail(DQ_ERR_INVALID, "negative dimension");
   if ((opA | opB) & ~1) fail(DQ_ERR_INVALID, "op must be 0 (N) or 1 (transpose)");
   if (sym && M != N) fail(DQ_ERR_INVALID, "symmetric-output form needs M == N");
+  if (sym == 2 && K != M) fail(DQ_ERR_INVALID, "the two-product form A B + B A needs square operands");
   if (M == 0 || N == 0 || batch == 0) return;
   if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
   if (sym) { opA = 1; opB = 0; }
@@ -1126,9 +1116,11 @@ void do_rgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, co
   g.alpha = alpha; g.beta = beta;
   g.opA = opA; g.opB = opB;
   g.sym = sym ? 1 : 0;
+  g.two = sym == 2 ? 1 : 0;
+  g.glds_ok = c->rgemm_glds;
   c->rgemm_workspace(g);
   const int cfg = c->rgemm_cfg, ncu = c->n_cu;
-  c->timed(sym ? DQ_PROF_RSYM : DQ_PROF_RGEMM, sym ? c->rsym_flops(M, K, batch) : 2.0 * M * N * (double)K * batch,
+  c->timed(sym ? DQ_PROF_RSYM : DQ_PROF_RGEMM, sym ? c->rsym_flops(M, K, batch) * (sym == 2 ? 2.0 : 1.0) : 2.0 * M * N * (double)K * batch,
            sizeof(T) * ((double)M * K + (double)K * N + (double)M * N) * batch,
            [&] { return dq::rgemm_launch<T>(g, c->st, cfg, ncu); });
   if (!c_dev) out_copy(c, C, dC, bcz);
@@ -1193,6 +1185,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     const int q = (int)v;
     if (q < -1 || q > RQ_MAX) fail(DQ_ERR_INVALID, "real_path must be -1 (auto), 0 (off) or a polynomial size 1..6");
     c->real_mode = q;
+  } else if (s == "rgemm_glds") {  // 1: direct global -> LDS staging in the real GEMM where shapes/alignment allow
+    c->rgemm_glds = v != 0 ? 1 : 0;
   } else if (s == "real_min_dim") {  // auto mode: below this dimension the chain is launch-bound and the complex tape
     c->real_min_dim = (int)v;         // (fewer launches) is kept
   } else if (s == "rgemm_cfg") {

@@ -119,42 +119,6 @@ hipError_t rlincomb_launch(const RLincombArgs<T>& a, hipStream_t st) {
 template hipError_t rlincomb_launch<double>(const RLincombArgs<double>&, hipStream_t);
 template hipError_t rlincomb_launch<float>(const RLincombArgs<float>&, hipStream_t);
 
-// ---- out = [out +] a (Z + Z^T) --------------------------------------------------------------
-template <class T>
-__global__ void __launch_bounds__(256) rsym_kernel(T* __restrict__ out, const T* __restrict__ Z, int d, double a_,
-                                                   int accumulate, long stride) {
-  __shared__ T tl[32][33];
-  const long base = (long)blockIdx.z * stride;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const T a = (T)a_;
-  for (int r = ty; r < 32; r += 8) {
-    T v = 0;
-    if (j0 + r < d && i0 + tx < d) v = Z[base + (long)(j0 + r) * d + i0 + tx];
-    tl[r][tx] = v;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int i = i0 + r, j = j0 + tx;
-    if (i < d && j < d) {
-      const long off = base + (long)i * d + j;
-      T o = a * (Z[off] + tl[tx][r]);
-      if (accumulate) o += out[off];
-      out[off] = o;
-    }
-  }
-}
-
-template <class T>
-hipError_t rsym_launch(T* out, const T* Z, int d, double a, int accumulate, long stride, int batch, hipStream_t st) {
-  if (d <= 0 || batch <= 0) return hipSuccess;
-  dim3 grid((unsigned)((d + 31) / 32), (unsigned)((d + 31) / 32), (unsigned)batch);
-  hipLaunchKernelGGL(rsym_kernel<T>, grid, dim3(256), 0, st, out, Z, d, a, accumulate, stride);
-  return hipGetLastError();
-}
-template hipError_t rsym_launch<double>(double*, const double*, int, double, int, long, int, hipStream_t);
-template hipError_t rsym_launch<float>(float*, const float*, int, double, int, long, int, hipStream_t);
-
 // ---- U = C + i S ------------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(256) pack_u_kernel(typename Cx<T>::type* __restrict__ U, const T* __restrict__ C,
@@ -220,7 +184,7 @@ template hipError_t split_g_launch<double>(const double2*, double*, double*, int
 template hipError_t split_g_launch<float>(const float2*, float*, float*, int, long, int, hipStream_t);
 
 // ---- grad[z][k] = scale * <Xbar[z], Hsr[k]> -------------------------------------------------------
-constexpr int RKC = 8;
+constexpr int RKC = 16;  // controls per pass (one pass over Xbar for K <= 16)
 constexpr int RGC_THREADS = 256;
 
 template <class T>
@@ -254,16 +218,6 @@ __global__ void __launch_bounds__(RGC_THREADS) rgrad_contract_kernel(const T* __
   }
 }
 
-__global__ void rgrad_finish_kernel(const double* __restrict__ part, int nblk, int K, double scale,
-                                    double* __restrict__ grad) {
-  const long z = blockIdx.x;
-  const int k = threadIdx.x;
-  if (k >= K) return;
-  double v = 0.0;
-  for (int b = 0; b < nblk; ++b) v += part[(z * nblk + b) * K + k];
-  grad[z * K + k] = scale * v;
-}
-
 template <class T>
 hipError_t rgrad_contract_launch(const T* Xbar, long strideX, const T* Hsr, int K, long n_elem, int batch, double scale,
                                  double* part, double* grad, hipStream_t st) {
@@ -272,9 +226,7 @@ hipError_t rgrad_contract_launch(const T* Xbar, long strideX, const T* Hsr, int 
   dim3 grid((unsigned)nb, 1, (unsigned)batch);
   for (int k0 = 0; k0 < K; k0 += RKC)
     hipLaunchKernelGGL(rgrad_contract_kernel<T>, grid, dim3(RGC_THREADS), 0, st, Xbar, strideX, Hsr, K, k0, n_elem, part);
-  const int threads = ((K + 63) / 64) * 64;
-  hipLaunchKernelGGL(rgrad_finish_kernel, dim3((unsigned)batch), dim3(threads), 0, st, part, nb, K, scale, grad);
-  return hipGetLastError();
+  return grad_finish_launch(part, nb, K, batch, scale, grad, st);
 }
 template hipError_t rgrad_contract_launch<double>(const double*, long, const double*, int, long, int, double, double*,
                                                   double*, hipStream_t);

@@ -10,6 +10,9 @@
 //   the mirror image is written by the same workgroup).
 //
 //   C[z] = alpha * op(A[z]) * op(B[z]) + beta * C[z]        op in {N, T};  row-major, explicit leading dimensions
+//   C[z] = alpha * (A[z] B[z] + B[z] A[z]) + beta * C[z]     symmetric A, B (not necessarily commuting), symmetric
+//                                                              output form only (`two`): the reverse mode's
+//                                                              sym(Wbar V) products without a full-matrix round trip
 //
 // Tiling follows zgemm.hip: BM x BN tile per workgroup, WGM x WGN waves, 16x16 MFMA tiles, K streamed in
 // BK-deep slabs through double-buffered LDS images stored k-major; next slab's global loads in flight during
@@ -27,6 +30,14 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "dq_internal.h"
+
+// Ablation switches for tools/rgemm_probe.hip only (never set in the library build): 1 = no barriers in the K loop,
+// 2 = no global loads / LDS stores after the prologue, 4 = fragments read from LDS once, 8 = no global loads (stale
+// registers are stored), 16 = no LDS stores (loads are issued and waited for). Results are then wrong;
+// the timings say what each part of the loop costs next to the MFMAs.
+#ifndef DQ_RGEMM_ABLATE
+#define DQ_RGEMM_ABLATE 0
+#endif
 
 namespace dq {
 
@@ -63,7 +74,7 @@ __device__ __forceinline__ void tri_tile(int pid, int nt, int& tile_m, int& tile
   tile_n = i + (pid - (i * nt - i * (i - 1) / 2));
 }
 
-template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int SYM, int MINW>
+template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int SYM, int MINW, int GLDS = 0>
 __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T> g) {
   typedef typename RMfma<T>::acc_t acc_t;
   constexpr int NT = WGM * WGN * 64;
@@ -77,6 +88,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
   static_assert((BM * BK) % NT == 0 && (BN * BK) % NT == 0, "tile/threads mismatch");
   static_assert(NT % BM == 0 && NT % BN == 0, "linear staging needs whole k-rows per pass");
   static_assert(!SYM || (BM == BN && LINEAR), "the symmetric-output form needs square tiles and the linear form");
+  // GLDS: the slabs go global -> LDS directly (global_load_lds_dwordx4: 16 B per lane, one wave instruction fills one
+  // 1-KiB k-row of the image; no staging registers, no ds_write). Needs whole tiles and 16-B aligned rows (host checks).
+  static_assert(!GLDS || (LINEAR && BM * sizeof(T) == 1024 && BN * sizeof(T) == 1024), "LDS-DMA staging: 1-KiB rows only");
+  constexpr int NW = NT / 64;
 
   __shared__ T lds[2 * BK * (PA + PB)];
   T* As = lds;                // [2][BK][PA]
@@ -90,7 +105,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
   // ---- workgroup -> tile (and, for tail pieces of the symmetric form, a K range) ---------------
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   const int nkt = (g.K + BK - 1) / BK;
-  int tile_m, tile_n, kt0 = 0, kt1 = nkt, piece = -1;
+  const int nk_all = (SYM && g.two) ? 2 * nkt : nkt;  // two-product form: slabs nkt.. are those of B A
+  int tile_m, tile_n, kt0 = 0, kt1 = nk_all, piece = -1;
   if (SYM) {
     const int ntri = ntm * (ntm + 1) / 2;
     const int nfull = g.n_full >= 0 ? g.n_full : ntri;
@@ -98,9 +114,9 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
     if (pid >= nfull) {
       piece = pid - nfull;
       pid = nfull + piece / g.split_f;
-      const int per = (nkt + g.split_f - 1) / g.split_f;
+      const int per = (nk_all + g.split_f - 1) / g.split_f;
       kt0 = (piece % g.split_f) * per;
-      kt1 = min(nkt, kt0 + per);
+      kt1 = min(nk_all, kt0 + per);
     } else if ((nfull & 7) == 0) {
       pid = (pid & 7) * (nfull >> 3) + (pid >> 3);
     }
@@ -120,8 +136,14 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const long z = blockIdx.z;
-  const T* __restrict__ A = g.A + z * g.sA;
-  const T* __restrict__ B = g.B + z * g.sB;
+  // current operand pair: (A, B) for slabs < nkt, (B, A) from slab nkt on (two-product form)
+  const T* A = g.A + z * g.sA;
+  const T* B = g.B + z * g.sB;
+  long lda = g.lda, ldb = g.ldb;
+  int kt_shift = 0;  // slab index of the current pair's k = 0
+  if (SYM && kt0 >= nkt) {
+    A = g.B + z * g.sB; B = g.A + z * g.sA; lda = g.ldb; ldb = g.lda; kt_shift = nkt;
+  }
   T* __restrict__ C = g.C + z * g.sC;
 
   acc_t acc[MI][NI];
@@ -130,13 +152,35 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = {0, 0, 0, 0};
 
-  T ra[A_PER_T], rb[B_PER_T];
+  T ra[GLDS ? 1 : A_PER_T], rb[GLDS ? 1 : B_PER_T];
+  constexpr int EPL = 16 / sizeof(T);  // elements per lane of one LDS-DMA instruction
+  const T* ga = A + (long)((kt0 - kt_shift) * BK) * lda + m0 + lane * EPL;
+  const T* gb = B + (long)((kt0 - kt_shift) * BK) * ldb + n0 + lane * EPL;
+  // one wave instruction per k-row: row r of the slab -> LDS row r of buffer buf_ (base is wave-uniform, + lane*16 B)
+#define DQ_RGLDS(kt_, buf_)                                                                                    \
+  {                                                                                                            \
+    if (SYM && (kt_) == nkt && kt_shift == 0) { /* switch to the pair (B, A) */                                \
+      const T* t_ = A; A = B; B = t_;                                                                          \
+      const long l_ = lda; lda = ldb; ldb = l_;                                                                \
+      kt_shift = nkt;                                                                                          \
+      ga = A + m0 + lane * EPL;                                                                                \
+      gb = B + n0 + lane * EPL;                                                                                \
+    }                                                                                                          \
+    _Pragma("unroll") for (int r = wave; r < BK; r += NW) {                                                    \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (long)r * lda),    \
+                                       (__attribute__((address_space(3))) void*)(As + ((buf_) * BK + r) * PA), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long)r * ldb),    \
+                                       (__attribute__((address_space(3))) void*)(Bs + ((buf_) * BK + r) * PB), 16, 0, 0); \
+    }                                                                                                          \
+    ga += (long)BK * lda;                                                                                      \
+    gb += (long)BK * ldb;                                                                                      \
+  }
 
   // linear form: thread -> (k-row within a pass, column); columns beyond M/N are clamped (never stored)
   const int am = tid % BM, ak = tid / BM, bn = tid % BN, bk = tid / BN;
-  const T* pa = A + (long)(kt0 * BK + ak) * g.lda + min(m0 + am, g.M - 1);
-  const T* pb = B + (long)(kt0 * BK + bk) * g.ldb + min(n0 + bn, g.N - 1);
-  const long a_step = (long)KA * g.lda, b_step = (long)KB * g.ldb;
+  const T* pa = A + (long)((kt0 - kt_shift) * BK + ak) * lda + min(m0 + am, g.M - 1);
+  const T* pb = B + (long)((kt0 - kt_shift) * BK + bk) * ldb + min(n0 + bn, g.N - 1);
+  long a_step = (long)KA * lda, b_step = (long)KB * ldb;
 
   // ---- staging (macros, not lambdas: by-reference captures of ra/rb end up in scratch memory, see zgemm.hip) ----
   // fast: the slab lies inside K; pa/pb point at its first row for this thread and are advanced afterwards
@@ -144,8 +188,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
   {                                                                                          \
     _Pragma("unroll") for (int j = 0; j < A_PER_T; ++j) ra[j] = pa[j * a_step];              \
     _Pragma("unroll") for (int j = 0; j < B_PER_T; ++j) rb[j] = pb[j * b_step];              \
-    pa += (long)BK * g.lda;                                                                  \
-    pb += (long)BK * g.ldb;                                                                  \
+    pa += (long)BK * lda;                                                                    \
+    pb += (long)BK * ldb;                                                                    \
   }
   // checked: any op form, any position. op(A) is M x K:  OPA == 0: stored [m][k] (lanes along k, transposing
   // LDS write); OPA == 1: stored [k][m] (lanes along m). op(B) is K x N:  OPB == 0: stored [k][n]; 1: stored [n][k].
@@ -156,7 +200,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
       const int m = (OPA == 0) ? e / BK : e % BM;                                            \
       const int k = (OPA == 0) ? e % BK : e / BM;                                            \
       const int gm = m0 + m, gk = (k0_) + k;                                                 \
-      const long off = (OPA == 0) ? ((long)gm * g.lda + gk) : ((long)gk * g.lda + gm);       \
+      const long off = (OPA == 0) ? ((long)gm * lda + gk) : ((long)gk * lda + gm);           \
       T v = 0;                                                                               \
       if ((gm < g.M) && (gk < g.K)) v = A[off];                                              \
       ra[j] = v;                                                                             \
@@ -166,7 +210,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
       const int n = (OPB == 0) ? e % BN : e / BK;                                            \
       const int k = (OPB == 0) ? e / BN : e % BK;                                            \
       const int gn = n0 + n, gk = (k0_) + k;                                                 \
-      const long off = (OPB == 0) ? ((long)gk * g.ldb + gn) : ((long)gn * g.ldb + gk);       \
+      const long off = (OPB == 0) ? ((long)gk * ldb + gn) : ((long)gn * ldb + gk);           \
       T v = 0;                                                                               \
       if ((gn < g.N) && (gk < g.K)) v = B[off];                                              \
       rb[j] = v;                                                                             \
@@ -174,8 +218,16 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
   }
 #define DQ_RLOAD(kt_)                                                                        \
   {                                                                                          \
-    if (LINEAR && ((kt_) + 1) * BK <= g.K) DQ_RLOAD_FAST()                                   \
-    else DQ_RLOAD_CHECKED((kt_) * BK)                                                        \
+    if (SYM && (kt_) == nkt && kt_shift == 0) { /* switch to the pair (B, A) */              \
+      const T* t_ = A; A = B; B = t_;                                                        \
+      const long l_ = lda; lda = ldb; ldb = l_;                                              \
+      kt_shift = nkt;                                                                        \
+      pa = A + (long)ak * lda + min(m0 + am, g.M - 1);                                       \
+      pb = B + (long)bk * ldb + min(n0 + bn, g.N - 1);                                       \
+      a_step = (long)KA * lda; b_step = (long)KB * ldb;                                      \
+    }                                                                                        \
+    if (LINEAR && ((kt_) - kt_shift + 1) * BK <= g.K) DQ_RLOAD_FAST()                        \
+    else DQ_RLOAD_CHECKED(((kt_) - kt_shift) * BK)                                           \
   }
 #define DQ_RSTORE_SLAB(buf_)                                                                 \
   {                                                                                          \
@@ -201,26 +253,52 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
     _Pragma("unroll") for (int ks = 0; ks < BK / 4; ++ks) {                                  \
       const int kk = ks * 4 + (lane >> 4);                                                   \
       T a[MI], b[NI];                                                                        \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = as_[kk * PA + i * 16];           \
-      _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = bs_[kk * PB + j * 16];           \
+      if (!(DQ_RGEMM_ABLATE & 4) || kt == kt0) {                                             \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = as_[kk * PA + i * 16];         \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = bs_[kk * PB + j * 16];         \
+        if (DQ_RGEMM_ABLATE & 4) {                                                           \
+          _Pragma("unroll") for (int i = 0; i < MI; ++i) fa[ks][i] = a[i];                   \
+          _Pragma("unroll") for (int j = 0; j < NI; ++j) fb[ks][j] = b[j];                   \
+        }                                                                                    \
+      } else {                                                                               \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = fa[ks][i];                     \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = fb[ks][j];                     \
+      }                                                                                      \
       _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
         acc[i][j] = RMfma<T>::run(a[i], b[j], acc[i][j]);                                    \
     }                                                                                        \
   }
 
-  if (kt0 < kt1) {
+  T fa[(DQ_RGEMM_ABLATE & 4) ? BK / 4 : 1][MI], fb[(DQ_RGEMM_ABLATE & 4) ? BK / 4 : 1][NI];  // ablation only
+  if (GLDS) {
+    if (kt0 < kt1) {
+      DQ_RGLDS(kt0, 0);
+      __syncthreads();  // (hipcc drains vmcnt before the barrier: the slab has landed)
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1 && !(DQ_RGEMM_ABLATE & 2)) DQ_RGLDS(kt + 1, cur ^ 1);
+        DQ_RCOMPUTE_SLAB(cur);
+        if (!(DQ_RGEMM_ABLATE & 1)) __syncthreads();
+      }
+    }
+  } else if (kt0 < kt1) {
     DQ_RLOAD(kt0);
     DQ_RSTORE_SLAB(0);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = (kt - kt0) & 1;
-      const bool more = kt + 1 < kt1;  // uniform
-      if (more) DQ_RLOAD(kt + 1);
+      const bool more = kt + 1 < kt1 && !(DQ_RGEMM_ABLATE & 2);  // uniform
+      if (more && !(DQ_RGEMM_ABLATE & 8)) DQ_RLOAD(kt + 1);
       DQ_RCOMPUTE_SLAB(cur);
-      if (more) DQ_RSTORE_SLAB(cur ^ 1);
-      __syncthreads();
+      if (more && !(DQ_RGEMM_ABLATE & 16)) DQ_RSTORE_SLAB(cur ^ 1);
+      if (DQ_RGEMM_ABLATE & 16) {
+        _Pragma("unroll") for (int j = 0; j < A_PER_T; ++j) asm volatile("" ::"v"(ra[j]));
+        _Pragma("unroll") for (int j = 0; j < B_PER_T; ++j) asm volatile("" ::"v"(rb[j]));
+      }
+      if (!(DQ_RGEMM_ABLATE & 1)) __syncthreads();
     }
   }
+#undef DQ_RGLDS
 #undef DQ_RLOAD_FAST
 #undef DQ_RLOAD_CHECKED
 #undef DQ_RLOAD
@@ -289,6 +367,13 @@ static void rlaunch_cfg(RgemmArgs<T> g, hipStream_t st, int n_cu) {
   dim3 block(WGM * WGN * 64);
   g.n_full = -1;
   g.split_f = 1;
+  // LDS-DMA staging: whole tiles, 1-KiB tile rows, 16-B aligned row starts in every batch member
+  constexpr int GL = (BM * sizeof(T) == 1024 && BN * sizeof(T) == 1024) ? 1 : 0;
+  constexpr long EPL = 16 / sizeof(T);
+  if (g.two && !g.sym) g.two = 0;
+  const bool glds = GL && g.glds_ok && (g.sym || (g.opA == 1 && g.opB == 0)) && g.M % BM == 0 && g.N % BN == 0 &&
+                    g.K % BK == 0 && g.lda % EPL == 0 && g.ldb % EPL == 0 && g.sA % EPL == 0 && g.sB % EPL == 0 &&
+                    ((size_t)g.A % 16) == 0 && ((size_t)g.B % 16) == 0;
   if (g.sym) {
     static int wg_per_cu = 0;  // resident workgroups per CU of this configuration (registers + LDS)
     if (wg_per_cu == 0) {
@@ -303,7 +388,7 @@ static void rlaunch_cfg(RgemmArgs<T> g, hipStream_t st, int n_cu) {
     const int slots = n_cu * wg_per_cu;
     // symmetric output: the operands commute and are symmetric, so op() is irrelevant -- always the linear form
     const int ntri = ntm * (ntm + 1) / 2;
-    const int nkt = (g.K + BK - 1) / BK;
+    const int nkt = ((g.K + BK - 1) / BK) * (g.two ? 2 : 1);
     int grid_x = ntri;
     const int rem = slots > 0 ? ntri % slots : 0;
     // tail tiles that would occupy less than half of one more round are split along K
@@ -316,10 +401,14 @@ static void rlaunch_cfg(RgemmArgs<T> g, hipStream_t st, int n_cu) {
         grid_x = g.n_full + rem * f;
       }
     }
-    hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, 1, MINW>), dim3((unsigned)grid_x, 1, (unsigned)g.batch),
-                       block, 0, st, g);
+    if (glds)
+      hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, 1, MINW, GL>), dim3((unsigned)grid_x, 1, (unsigned)g.batch),
+                         block, 0, st, g);
+    else
+      hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, 1, MINW>), dim3((unsigned)grid_x, 1, (unsigned)g.batch),
+                         block, 0, st, g);
     if (g.n_full >= 0)
-      hipLaunchKernelGGL((rgemm_fixup_kernel<T, BM, BN>), dim3((unsigned)std::min(16, BM * BN / 256), (unsigned)rem), dim3(256),
+      hipLaunchKernelGGL((rgemm_fixup_kernel<T, BM, BN>), dim3((unsigned)(BM * BN / 256), (unsigned)rem), dim3(256),
                          0, st, g);
     return;
   }
@@ -328,7 +417,10 @@ static void rlaunch_cfg(RgemmArgs<T> g, hipStream_t st, int n_cu) {
   switch (op) {
     case 0: hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 0, 0, MINW>), grid, block, 0, st, g); break;
     case 1: hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 1, 0, MINW>), grid, block, 0, st, g); break;
-    case 2: hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, 0, MINW>), grid, block, 0, st, g); break;
+    case 2:
+      if (glds) hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, 0, MINW, GL>), grid, block, 0, st, g);
+      else hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, 0, MINW>), grid, block, 0, st, g);
+      break;
     default: hipLaunchKernelGGL((rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 1, 0, MINW>), grid, block, 0, st, g); break;
   }
 }

@@ -259,7 +259,8 @@ class Engine:
 
     def rgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None, sym=False):
         """Real GEMM alpha*op(A)@op(B) + beta*C on the GPU kernel (op: 0 = N, 1 = transpose); A, B: 2-D or batched
-        3-D real arrays (host). sym=True: symmetric-output form (commuting symmetric operands)."""
+        3-D real arrays (host). sym=True/1: symmetric-output form (commuting symmetric operands); sym=2: the
+        two-product form alpha*(A@B + B@A) + beta*C for symmetric A, B."""
         rdtype = np.float64 if self.dtype == "c128" else np.float32
         A = np.ascontiguousarray(A, dtype=rdtype)
         B = np.ascontiguousarray(B, dtype=rdtype)
@@ -280,7 +281,7 @@ class Engine:
             Cm = np.array(C_in, dtype=rdtype, order="C").reshape(nb, M, N)
         _lib.check(self._lib.dq_rgemm(self._ctx, ta, tb, M, N, K, float(alpha), A.ctypes.data, A.shape[2],
                                       A.shape[1] * A.shape[2], B.ctypes.data, B.shape[2], B.shape[1] * B.shape[2],
-                                      float(beta), Cm.ctypes.data, N, M * N, nb, 1 if sym else 0))
+                                      float(beta), Cm.ctypes.data, N, M * N, nb, int(sym)))
         return Cm if batched else Cm[0]
 
     def expm(self, A):

@@ -123,7 +123,8 @@ int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, c
 /* Real GEMM of the real-symmetric fast path: C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = transpose;
  * element type double (DQ_C128 contexts) or float (DQ_C64); strides in elements. sym != 0: the caller asserts that
  * the product is symmetric (commuting symmetric operands; M == N): only the tiles on and above the diagonal are
- * computed and mirrored. */
+ * computed and mirrored. sym == 2: C = alpha*(A*B + B*A) + beta*C for symmetric A, B (M == N == K; beta != 0 needs a
+ * symmetric C), same tiles, both products in one launch. */
 int dq_rgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch, int sym);
 /* U[z] = exp(A[z]) for `batch` dim x dim matrices. */

@@ -89,6 +89,40 @@ def test_rgemm_symmetric_form_tail_split_at_full_dimension(cfg, d):
     assert np.array_equal(got, got.T) and np.array_equal(got, again)
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 64, 32])
+@pytest.mark.parametrize("d,nb", [(7, 2), (64, 2), (130, 1), (256, 2), (512, 1)])
+def test_rgemm_two_product_form(cfg, d, nb):
+    """C = alpha (A B + B A) + beta C for symmetric, NON-commuting A, B: the reverse mode's sym(Wbar V) products."""
+    from diffquantum_amd.engine import Engine
+    rng = np.random.default_rng(d + cfg)
+    sym = lambda Z: (Z + Z.transpose(0, 2, 1)) / 2
+    A, B, C0 = (sym(rng.standard_normal((nb, d, d))) for _ in range(3))
+    with Engine(4, 0) as e:
+        e.set_option("rgemm_cfg", cfg)
+        got = e.rgemm(A, B, alpha=0.5, beta=-0.7, C_in=C0, sym=2)
+    ref = 0.5 * (A @ B + B @ A) - 0.7 * C0
+    assert np.max(np.abs(got - ref)) < 1e-13 * d
+    assert np.array_equal(got, got.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+def test_rgemm_two_product_form_at_full_dimension(glds):
+    """d = 4096 (528 tiles of double K on 512 slots: K-split tail + fix-up), LDS-DMA staging on and off."""
+    from diffquantum_amd.engine import Engine
+    d = 4096
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((d, d)); A = (A + A.T) / 2
+    B = rng.standard_normal((d, d)); B = (B + B.T) / 2
+    with Engine(4, 0) as e:
+        e.set_option("rgemm_glds", glds)
+        got = e.rgemm(A, B, alpha=0.5, sym=2)
+        full = e.rgemm(A, B, 1, 0)
+    ref = 0.5 * (full + full.T)
+    assert np.max(np.abs(got - ref)) < 1e-13 * d
+    assert np.max(np.abs(full - A @ B)) < 1e-13 * d
+    assert np.array_equal(got, got.T)
+
+
 def test_rgemm_fp32_and_errors():
     from diffquantum_amd.engine import Engine
     rng = np.random.default_rng(0)
