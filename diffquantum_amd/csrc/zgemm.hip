@@ -33,6 +33,13 @@
 #include <hip/hip_runtime.h>
 #include "dq_internal.h"
 
+// Ablation switches for tools/zgemm_probe.hip only (never set in the library build): 1 = no barriers in the K loop,
+// 2 = no global loads / LDS stores after the prologue, 32 = no operand sums before the third 3M product. Results are
+// then wrong; the timings say what each part of the loop costs next to the MFMAs.
+#ifndef DQ_ZGEMM_ABLATE
+#define DQ_ZGEMM_ABLATE 0
+#endif
+
 namespace dq {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -196,8 +203,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
           acci[i][j] = Mfma<T>::template run<0>(a[i].y, b[j].y, acci[i][j]);                                 \
         }                                                                                                    \
         /* sums formed after the P1/P2 issue so they can reuse the fragment registers */                     \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i].x = (OPA != 0) ? a[i].x - a[i].y : a[i].x + a[i].y; \
-        _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j].x = (OPB != 0) ? b[j].x - b[j].y : b[j].x + b[j].y; \
+        if (!(DQ_ZGEMM_ABLATE & 32)) {                                                                       \
+          _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i].x = (OPA != 0) ? a[i].x - a[i].y : a[i].x + a[i].y; \
+          _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j].x = (OPB != 0) ? b[j].x - b[j].y : b[j].x + b[j].y; \
+        }                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)        \
           acc3[i][j] = Mfma<T>::template run<0>(a[i].x, b[j].x, acc3[i][j]);                                 \
       } else {                                                                                               \
@@ -217,10 +226,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     // the tail slab (k >= K) loads zeros through the bounds check, so no branch is needed here
-    DQ_LOAD_SLAB((kt + 1) * BK);
+    if (!(DQ_ZGEMM_ABLATE & 2)) DQ_LOAD_SLAB((kt + 1) * BK);
     DQ_COMPUTE_SLAB(kt & 1);
-    DQ_STORE_SLAB((kt + 1) & 1);
-    __syncthreads();
+    if (!(DQ_ZGEMM_ABLATE & 2)) DQ_STORE_SLAB((kt + 1) & 1);
+    if (!(DQ_ZGEMM_ABLATE & 1)) __syncthreads();
   }
 #undef DQ_LOAD_SLAB
 #undef DQ_STORE_SLAB

@@ -1,0 +1,10 @@
+#!/bin/bash
+# builds (here, cross-compiled) or runs (on the GPU box) the ablation probe of the complex GEMM kernel
+mkdir -p tools/_build
+if [ "$1" = "build" ]; then
+  for a in ${ABL:-0 1 2 3 32 35}; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DDQ_ZGEMM_ABLATE=$a tools/zgemm_probe.hip -o tools/_build/zgemm_probe_$a || exit 1
+  done
+else
+  for a in ${ABL:-0 1 2 3 32 35}; do timeout 60 tools/_build/zgemm_probe_$a; done
+fi
