@@ -29,6 +29,7 @@
 // writing raw partial tiles to a workspace) and summed in a fixed order by rgemm_fixup_kernel.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include "dq_internal.h"
 
 // Ablation switches for tools/rgemm_probe.hip only (never set in the library build): 1 = no barriers in the K loop,
@@ -375,17 +376,17 @@ static void rlaunch_cfg(RgemmArgs<T> g, hipStream_t st, int n_cu) {
                     g.K % BK == 0 && g.lda % EPL == 0 && g.ldb % EPL == 0 && g.sA % EPL == 0 && g.sB % EPL == 0 &&
                     ((size_t)g.A % 16) == 0 && ((size_t)g.B % 16) == 0;
   if (g.sym) {
-    static int wg_per_cu = 0;  // resident workgroups per CU of this configuration (registers + LDS)
-    if (wg_per_cu == 0) {
+    static std::atomic<int> wg_per_cu{0};  // resident workgroups per CU of this configuration (registers + LDS)
+    if (wg_per_cu.load() == 0) {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, 1, MINW>,
                                                        WGM * WGN * 64, 0) != hipSuccess || nb <= 0) {
         (void)hipGetLastError();
         nb = 1;
       }
-      wg_per_cu = nb;
+      wg_per_cu.store(nb);
     }
-    const int slots = n_cu * wg_per_cu;
+    const int slots = n_cu * wg_per_cu.load();
     // symmetric output: the operands commute and are symmetric, so op() is irrelevant -- always the linear form
     const int ntri = ntm * (ntm + 1) / 2;
     const int nkt = ((g.K + BK - 1) / BK) * (g.two ? 2 : 1);

@@ -1,0 +1,121 @@
+"""CPU check of the mathematics behind the engine's real-symmetric fast path, in plain numpy:
+the cos/sin evaluation scheme and its hand-written reverse mode are restated here exactly as engine.hip issues them
+(same products, same symmetrisations, same coefficients) and compared with the reference's arithmetic --
+scipy.linalg.expm (sim_plain.py:145) for the propagator and scipy.linalg.expm_frechet for its derivative.
+The HIP implementation itself is tested on the GPU (tests/test_gpu_realpath.py); this file pins the algorithm.
+"""
+import math
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+
+def coeffs(q):
+    cc = [(-1.0) ** j / math.factorial(2 * j) for j in range(q + 1)]
+    sc = [(-1.0) ** j / math.factorial(2 * j + 1) for j in range(q + 1)]
+    return cc, sc
+
+
+def forward(X, q):
+    """U = cos X + i sin X by q + 1 products of commuting symmetric matrices (engine.hip real_forward)."""
+    cc, sc = coeffs(q)
+    d = len(X)
+    Y = [None, X @ X]
+    for j in range(2, q + 1):
+        Y.append(Y[1] @ Y[j - 1])
+    C = cc[0] * np.eye(d) + sum(cc[j] * Y[j] for j in range(1, q + 1))
+    P = sc[0] * np.eye(d) + sum(sc[j] * Y[j] for j in range(1, q + 1))
+    S = X @ P
+    return C + 1j * S, (Y, P)
+
+
+def sym2(W, V, a):
+    """a (W V + V W): what one two-product symmetric-output launch of rgemm.hip computes."""
+    return a * (W @ V + V @ W)
+
+
+def backward(X, q, saved, G):
+    """Xbar for dL = Re tr(G^H dU) (engine.hip real_backward): 2q two-product launches."""
+    cc, sc = coeffs(q)
+    Y, P = saved
+    Cb = 0.5 * (G.real + G.real.T)
+    Sb = 0.5 * (G.imag + G.imag.T)
+    Xb = sym2(Sb, P, 0.5)
+    Pb = sym2(Sb, X, 0.5)
+    Yb = [None] + [cc[j] * Cb + sc[j] * Pb for j in range(1, q + 1)]
+    for j in range(q, 2, -1):
+        Yb[1] = Yb[1] + sym2(Yb[j], Y[j - 1], 0.5)
+        Yb[j - 1] = Yb[j - 1] + sym2(Yb[j], Y[1], 0.5)
+    if q >= 2:
+        Yb[1] = Yb[1] + sym2(Yb[2], Y[1], 1.0)
+    return Xb + sym2(Yb[1], X, 1.0)
+
+
+def random_symmetric(d, norm, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d))
+    A = A + A.T
+    return A * (norm / np.linalg.norm(A, 1))
+
+
+@pytest.mark.parametrize("q,theta", [(1, 1e-4), (2, 3e-3), (3, 0.024), (4, 0.08), (5, 0.2), (6, 0.4)])
+def test_cos_sin_scheme_matches_expm_within_the_taylor_remainder(q, theta):
+    X = random_symmetric(24, theta, q)
+    U, _ = forward(X, q)
+    ref = scipy.linalg.expm(1j * X)
+    rem = theta ** (2 * q + 2) / math.factorial(2 * q + 2)
+    assert np.max(np.abs(U - ref)) < rem + 5e-16
+    assert rem <= 2.0 ** -53 * 1.01 or q < 3      # these (q, theta) pairs are the fp64 selection boundary of the engine
+    assert np.max(np.abs(U @ U.conj().T - np.eye(24))) < 2 * rem + 1e-14
+
+
+@pytest.mark.parametrize("q", [1, 2, 3, 4, 5, 6])
+def test_reverse_mode_is_the_exact_adjoint_of_the_scheme(q):
+    """<Xbar, E> = Re tr(G^H dU[E]) for symmetric directions E, with dU the derivative of the POLYNOMIAL (checked by
+    the complex-step-free central difference of `forward`), and = the Frechet derivative of exp up to the remainder."""
+    d = 12
+    X = random_symmetric(d, 0.3, 10 + q)
+    rng = np.random.default_rng(q)
+    G = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    U, saved = forward(X, q)
+    Xb = backward(X, q, saved, G)
+    assert np.max(np.abs(Xb - Xb.T)) < 1e-14
+    E = rng.standard_normal((d, d))
+    E = E + E.T
+    eps = 1e-6
+    dU = (forward(X + eps * E, q)[0] - forward(X - eps * E, q)[0]) / (2 * eps)
+    lhs = float(np.sum(Xb * E))
+    rhs = float(np.real(np.trace(G.conj().T @ dU)))
+    assert abs(lhs - rhs) < 1e-8 * max(1.0, abs(rhs))
+    if q >= 5:   # remainder below 1e-10 at this norm: also equals the derivative of the true exponential
+        L = scipy.linalg.expm_frechet(1j * X, 1j * E, compute_expm=False)
+        assert abs(lhs - float(np.real(np.trace(G.conj().T @ L)))) < 1e-9 * max(1.0, abs(rhs))
+
+
+def test_gradient_of_a_two_step_chain_matches_the_oracle(oracle):
+    """The whole construction on a tiny chain: dL/du_k[t] = <Xbar_t, -dt H_k> against oracle.energy_grad
+    (scipy expm + expm_frechet on the complex generator, the reference's arithmetic)."""
+    from diffquantum_amd import problems
+    n, K, B, S = 3, 2, 4, 2
+    H0, Hs, M = problems.random_real_symmetric_problem(n, K, seed=5)
+    u = np.random.default_rng(0).uniform(-1, 1, (S, K))
+    dt = 0.02
+    psi0 = problems.random_states(1 << n, B, seed=1)
+    q = 6
+    Xs = [-dt * (H0.real + sum(u[t, k] * Hs[k].real for k in range(K))) for t in range(S)]
+    fw = [forward(X, q) for X in Xs]
+    psis = [psi0]
+    for U, _ in fw:
+        psis.append(U @ psis[-1])
+    lam = 2.0 * (M @ psis[-1])
+    grad = np.zeros((S, K))
+    for t in range(S - 1, -1, -1):
+        G = lam @ psis[t].conj().T
+        Xb = backward(Xs[t], q, fw[t][1], G)
+        for k in range(K):
+            grad[t, k] = float(np.sum(Xb * (-dt * Hs[k].real)))
+        lam = fw[t][0].conj().T @ lam
+    loss = float(np.real(np.sum(psis[-1].conj() * (M @ psis[-1]))))
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    assert abs(loss - rl) < 1e-12 and np.max(np.abs(grad - rg)) < 1e-12 and np.max(np.abs(psis[-1] - rf)) < 1e-13
