@@ -249,7 +249,8 @@ struct Ctx : dq_ctx {
   DevBuf H0, Hs, M;
   DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
-  int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128, rgemm_glds = 1;  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
+  int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128, rgemm_glds = 1;
+  long plan_steps = 0;  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
   double last_real_q = 0;
   double nH0 = 0.0;
   std::vector<double> nHk;
@@ -257,7 +258,7 @@ struct Ctx : dq_ctx {
   double checkpoint_bytes = 0.0, chunk_bytes = 2.0 * 1024 * 1024 * 1024, expm_tol = 0.0, herm_tol = 0.0;
   int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1, skew_trick = 1;
   // info
-  double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0;
+  double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0;
   // workspace
   std::vector<DevBuf> pool;
   size_t pool_tc = 0;
@@ -740,35 +741,22 @@ void require_H(Ctx<T>* c) {
   if (!c->have_H) fail(DQ_ERR_STATE, "dq_set_hamiltonians has not been called");
 }
 
+// Forward chain on the states in psi[cur] (d x B): psi <- U_{S-1} ... U_0 psi, no checkpoints. Returns the buffer index
+// holding the result. compose: multiply the chunk's propagators together by a log-depth tree of batched products
+// (8 d^3 flop per step instead of 8 d^2 B, O(log n) launches instead of n), a running product across chunks, and ONE
+// apply at the end -- cheaper as soon as the batch is wider than the dimension.
 template <class T>
-void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_in, void* psi_out, int B) {
+int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B, int cur, bool compose) {
   typedef TT T2;
-  check_ctx(c);
-  require_H(c);
-  if (S < 0 || B < 0) fail(DQ_ERR_INVALID, "n_steps and batch must be >= 0");
-  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
-  if (B == 0) return;
-  if (!psi_in || !psi_out) fail(DQ_ERR_INVALID, "null state pointer");
-  if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d;
-  const size_t sb = (size_t)d * B * sizeof(T2);
-  std::vector<double> uh = fetch_u(c, u, S);
-  c->psi[0].ensure(sb);
-  c->psi[1].ensure(sb);
-  HIPCK(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
-  int cur = 0;
   const int tc = time_chunk(c, std::max(S, 1));
   c->last_chunk = tc;
-  // composing propagators beats applying them one by one as soon as the batch is wider than the dimension
-  const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && B > d);
   T2* running = nullptr;  // product of the chunks composed so far (operator form)
   for (int c0 = 0; c0 < S; c0 += tc) {
     const int n = std::min(tc, S - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
     T2* U = build_propagators(c, p, c0, n, dt);
     if (compose) {
-      // operator form: V = U_{n-1} ... U_0 by a log-depth tree of batched products (8 d^3 flop per step instead of
-      // 8 d^2 B, O(log n) launches instead of n); across chunks a running product W <- V W; ONE apply at the end.
       T2* X = U;
       int m = n, lvl = 0;
       while (m > 1) {
@@ -803,6 +791,28 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
     c->zgemm(0, 0, d, B, d, 1.0, running, d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->psi[cur ^ 1].p, B, 0, 1);
     cur ^= 1;
   }
+  return cur;
+}
+
+template <class T>
+void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_in, void* psi_out, int B) {
+  typedef TT T2;
+  check_ctx(c);
+  require_H(c);
+  if (S < 0 || B < 0) fail(DQ_ERR_INVALID, "n_steps and batch must be >= 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (B == 0) return;
+  if (!psi_in || !psi_out) fail(DQ_ERR_INVALID, "null state pointer");
+  if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
+  const int d = c->d;
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  std::vector<double> uh = fetch_u(c, u, S);
+  c->psi[0].ensure(sb);
+  c->psi[1].ensure(sb);
+  HIPCK(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
+  // composing propagators beats applying them one by one as soon as the batch is wider than the dimension
+  const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && B > d);
+  const int cur = forward_chain(c, uh, S, dt, B, 0, compose);
   c->last_composed = compose ? 1.0 : 0.0;
   out_copy(c, psi_out, c->psi[cur].p, sb);
   HIPCK(hipStreamSynchronize(c->st));
@@ -839,77 +849,79 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   if (!psi0) fail(DQ_ERR_INVALID, "null state pointer");
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d, K = c->K;
-  const size_t sb_io = (size_t)d * B * sizeof(T2);
-  // Operator form for wide batches (B > d): L = tr(M P_S R P_S^H) with R = Psi0 Psi0^H, so the whole sweep runs on the
-  // d x d propagator product P_t (working "batch" = I, terminal costate Q = 2 M P_S R) at a cost independent of B.
-  const bool opform = !targets && (c->compose_mode == 1 || (c->compose_mode < 0 && B > d)) && S > 0;
-  c->last_composed = opform ? 1.0 : 0.0;
-  const int Bw = opform ? d : B;
-  const size_t sb = (size_t)d * Bw * sizeof(T2);
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  // Operator-form backward sweep for batch >= dim. The cotangent of U_t is G_t = Lambda_{t+1} Psi_t^H; with
+  // W_t = Lambda_t Psi_t^H (d x d) and Psi_t = U_t^H Psi_{t+1}, Lambda_t = U_t^H Lambda_{t+1}:
+  //     G_t = W_{t+1} U_t,     W_t = U_t^H G_t,     W_S = Lambda_S Psi_S^H
+  // -- two d x d x d products per step instead of two d x d x B ones, and NO intermediate states: no checkpoints, no
+  // psi_t rebuilds, memory independent of the chain length. (Unitary conjugations: the drift of W over S steps is
+  // S * eps, 2e-13 relative at S = 2000.) The forward pass then needs no checkpoints either and, for batch > dim,
+  // composes the propagators (forward_chain).
+  const bool opback = S > 0 && (c->compose_mode == 1 || (c->compose_mode < 0 && B >= d));
+  const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && B > d);
+  c->last_composed = (opback && compose) ? 1.0 : 0.0;
+  c->last_opback = opback ? 1.0 : 0.0;
   std::vector<double> uh = fetch_u(c, u, S);
-
-  // checkpoint stride from the memory budget
-  double budget = c->checkpoint_bytes;
-  if (budget <= 0.0) {
-    size_t fr = 0, tot = 0;
-    HIPCK(hipMemGetInfo(&fr, &tot));
-    budget = 0.35 * (double)fr;
-  }
-  long ncp_max = std::max(1L, (long)(budget / (double)sb));
-  int cstride = (int)std::max(1L, ((long)S + ncp_max - 1) / ncp_max);
-  const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
-  c->last_cstride = cstride;
-  if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
-  for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
-  for (int i = 0; i < 3; ++i) c->psi[i].ensure(sb);
-  for (int i = 0; i < 2; ++i) c->lam[i].ensure(sb);
+  for (int i = 0; i < 2; ++i) c->psi[i].ensure(sb);
+  c->lam[0].ensure(sb);
   c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
-
-  // ---- forward ----
-  const T2* psi0_dev = nullptr;
-  if (opform) {
-    psi0_dev = in_dev(c, psi0, sb_io, c->tmp_in[3]);
-    c->lincomb((T2*)c->psi[0].p, 0, nullptr, nullptr, 1.0, 1, false);  // P_0 = I
-  } else {
-    HIPCK(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
-  }
+  HIPCK(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
   int cur = 0;
   const int tc = time_chunk(c, std::max(S, 1));
   c->last_chunk = tc;
-  for (int c0 = 0; c0 < S; c0 += tc) {
-    const int n = std::min(tc, S - c0);
-    const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
-    const T2* U = build_propagators(c, p, c0, n, dt);
-    for (int t = 0; t < n; ++t) {
-      const int tt = c0 + t;
-      if (tt % cstride == 0) {
-        const size_t bytes = sb;
-        void* dst = c->ck[tt / cstride].p;
-        const void* src = c->psi[cur].p;
-        c->timed(DQ_PROF_OTHER, 0.0, 2.0 * bytes,
-                 [&] { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->st); });
+
+  // ---- forward ----
+  int cstride = 1;
+  if (opback) {
+    c->last_cstride = 0;  // no state checkpoints
+    cur = forward_chain(c, uh, S, dt, B, 0, compose);
+  } else {
+    // checkpoint stride from the memory budget
+    double budget = c->checkpoint_bytes;
+    if (budget <= 0.0) {
+      // default: 70 % of what is free now (the checkpoints already held by this context count as free); the rest
+      // covers the workspace pool (~25 d x d matrices) and the caller's own buffers
+      size_t fr = 0, tot = 0;
+      HIPCK(hipMemGetInfo(&fr, &tot));
+      double held = 0.0;
+      for (const auto& b : c->ck) held += (double)b.bytes;
+      budget = 0.70 * ((double)fr + held);
+    }
+    long ncp_max = std::max(1L, (long)(budget / (double)sb));
+    // plan_steps: size the stride for a longer chain than this call's (bench: a slice of the full configuration runs
+    // with the checkpoint/rebuild ratio of the whole chain)
+    const long S_plan = std::max<long>(S, c->plan_steps);
+    cstride = (int)std::max(1L, (S_plan + ncp_max - 1) / ncp_max);
+    const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
+    c->last_cstride = cstride;
+    if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
+    for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
+    c->psi[2].ensure(sb);
+    c->lam[1].ensure(sb);
+    for (int c0 = 0; c0 < S; c0 += tc) {
+      const int n = std::min(tc, S - c0);
+      const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
+      const T2* U = build_propagators(c, p, c0, n, dt);
+      for (int t = 0; t < n; ++t) {
+        const int tt = c0 + t;
+        if (tt % cstride == 0) {
+          const size_t bytes = sb;
+          void* dst = c->ck[tt / cstride].p;
+          const void* src = c->psi[cur].p;
+          c->timed(DQ_PROF_OTHER, 0.0, 2.0 * bytes,
+                   [&] { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->st); });
+        }
+        c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
+                 (T2*)c->psi[cur ^ 1].p, B, 0, 1);
+        cur ^= 1;
       }
-      c->zgemm(0, 0, d, Bw, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, Bw, 0, 0.0,
-               (T2*)c->psi[cur ^ 1].p, Bw, 0, 1);
-      cur ^= 1;
     }
   }
-  if (opform) {
-    // psi[cur] = P_S.  Psi_S = P_S Psi_0 (for the outputs), then Q = 2 M (P_S (Psi_0 Psi_0^H)) as terminal costate
-    c->tmp_in[1].ensure(sb_io);
-    c->tmp_in[2].ensure(sb_io);
-    T2* psiS = (T2*)c->tmp_in[1].p;
-    c->zgemm(0, 0, d, B, d, 1.0, (const T2*)c->psi[cur].p, d, 0, psi0_dev, B, 0, 0.0, psiS, B, 0, 1);
-    do_energy(c, psiS, B, (T2*)c->tmp_in[2].p, energies, loss);
-    if (psi_final) out_copy(c, psi_final, psiS, sb_io);
-    T2* R = c->mat(SLOT_TREE, 1);
-    T2* PR = c->mat(SLOT_TREE + 1, 1);
-    c->zgemm(0, 1, d, d, B, 1.0, psi0_dev, B, 0, psi0_dev, B, 0, 0.0, R, d, 0, 1);
-    c->zgemm(0, 0, d, d, d, 1.0, (const T2*)c->psi[cur].p, d, 0, R, d, 0, 0.0, PR, d, 0, 1);
-    c->zgemm(0, 0, d, d, d, 2.0, (const T2*)c->M.p, d, 0, PR, d, 0, 0.0, (T2*)c->lam[0].p, d, 0, 1);
-  } else if (targets) {
+
+  // ---- terminal costate Lambda_S (into lam[0]) and the outputs ----
+  if (targets) {
     // fidelity objective: c_b = <phi_b|psi_b>, F_b = |c_b|^2, Lambda_S = -2 phi .* c, L = B - sum F
-    const T2* phi = in_dev(c, targets, sb_io, c->tmp_in[3]);
+    const T2* phi = in_dev(c, targets, sb, c->tmp_in[3]);
     c->e_dev.ensure(sizeof(double) * (3 * (size_t)B + 2));
     c->part.ensure(sizeof(double) * 2 * (size_t)dq::coldot_chunks(d) * B);
     double* fid = c->e_dev.d();
@@ -928,19 +940,23 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
       HIPCK(hipMemcpyAsync(loss, &l, sizeof(double), hipMemcpyDefault, c->st));
       HIPCK(hipStreamSynchronize(c->st));
     }
-    if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
   } else {
     // psi[cur] = Psi_S ; terminal costate Lambda_S = 2 M Psi_S, energies
     do_energy(c, (const T2*)c->psi[cur].p, B, (T2*)c->lam[0].p, energies, loss);
-    if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
   }
+  if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
 
   // ---- backward ----
-  const T2* psi_next = (const T2*)c->psi[cur].p;
-  int lcur = 0;
   if (S > 0) {
     const int nblk = dq::grad_contract_blocks((long)c->nn());
     const int last_c0 = ((S - 1) / tc) * tc;
+    const T2* psi_next = (const T2*)c->psi[cur].p;
+    int lcur = 0;
+    T2* W = nullptr;  // operator form: W_{t+1}
+    if (opback) {
+      W = c->mat(SLOT_TREE, 1);
+      c->zgemm(0, 1, d, d, B, 1.0, (const T2*)c->lam[0].p, B, 0, psi_next, B, 0, 0.0, W, d, 0, 1);  // W_S
+    }
     for (int c0 = last_c0; c0 >= 0; c0 -= tc) {
       const int n = std::min(tc, S - c0);
       const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
@@ -949,6 +965,14 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
       for (int t = n - 1; t >= 0; --t) {
         const int tt = c0 + t;
         const T2* Ut = U + (size_t)t * c->nn();
+        T2* Gt = G + (size_t)t * c->nn();
+        if (opback) {
+          c->zgemm(0, 0, d, d, d, 1.0, W, d, 0, Ut, d, 0, 0.0, Gt, d, 0, 1);  // G_t = W_{t+1} U_t
+          T2* Wn = c->mat(W == c->mat(SLOT_TREE, 1) ? SLOT_TREE + 1 : SLOT_TREE, 1);
+          c->zgemm(1, 0, d, d, d, 1.0, Ut, d, 0, Gt, d, 0, 0.0, Wn, d, 0, 1);  // W_t = U_t^H G_t
+          W = Wn;
+          continue;
+        }
         const T2* psi_t;
         if (tt % cstride == 0) {
           psi_t = (const T2*)c->ck[tt / cstride].p;
@@ -957,21 +981,20 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
           T2* dst = nullptr;
           for (int i = 0; i < 3; ++i)
             if ((const T2*)c->psi[i].p != psi_next) { dst = (T2*)c->psi[i].p; break; }
-          c->zgemm(1, 0, d, Bw, d, 1.0, Ut, d, 0, psi_next, Bw, 0, 0.0, dst, Bw, 0, 1);  // psi_t = U_t^H psi_{t+1}
+          c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, psi_next, B, 0, 0.0, dst, B, 0, 1);  // psi_t = U_t^H psi_{t+1}
           psi_t = dst;
         }
         // G_t = Lambda_{t+1} Psi_t^H    (cotangent of U_t)
-        c->zgemm(0, 1, d, d, Bw, 1.0, (const T2*)c->lam[lcur].p, Bw, 0, psi_t, Bw, 0, 0.0, G + (size_t)t * c->nn(), d, 0,
-                 1);
+        c->zgemm(0, 1, d, d, B, 1.0, (const T2*)c->lam[lcur].p, B, 0, psi_t, B, 0, 0.0, Gt, d, 0, 1);
         // Lambda_t = U_t^H Lambda_{t+1}
-        c->zgemm(1, 0, d, Bw, d, 1.0, Ut, d, 0, (const T2*)c->lam[lcur].p, Bw, 0, 0.0, (T2*)c->lam[lcur ^ 1].p, Bw, 0, 1);
+        c->zgemm(1, 0, d, B, d, 1.0, Ut, d, 0, (const T2*)c->lam[lcur].p, B, 0, 0.0, (T2*)c->lam[lcur ^ 1].p, B, 0, 1);
         lcur ^= 1;
         psi_next = psi_t;
       }
       c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
       if (p.rq > 0) {
         const T* Xbar = real_backward(c, p, n);
-        const double byr = (double)sizeof(T) * c->nn() * (K + ((K + 7) / 8)) * n;
+        const double byr = (double)sizeof(T) * c->nn() * (K + ((K + 15) / 16)) * n;
         c->timed(DQ_PROF_GRADC, 2.0 * c->nn() * K * n, byr, [&] {
           return dq::rgrad_contract_launch<T>(Xbar, (long)c->nn(), (const T*)c->Hsr.p, K, (long)c->nn(), n, -dt,
                                               c->part.d(), c->grad_dev.d() + (size_t)c0 * K, c->st);
@@ -1185,6 +1208,9 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     const int q = (int)v;
     if (q < -1 || q > RQ_MAX) fail(DQ_ERR_INVALID, "real_path must be -1 (auto), 0 (off) or a polynomial size 1..6");
     c->real_mode = q;
+  } else if (s == "plan_steps") {  // checkpoint stride as if the chain had this many steps (0 = this call's length)
+    if (v < 0) fail(DQ_ERR_INVALID, "plan_steps must be >= 0");
+    c->plan_steps = (long)v;
   } else if (s == "rgemm_glds") {  // 1: direct global -> LDS staging in the real GEMM where shapes/alignment allow
     c->rgemm_glds = v != 0 ? 1 : 0;
   } else if (s == "real_min_dim") {  // auto mode: below this dimension the chain is launch-bound and the complex tape
@@ -1214,6 +1240,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "hermitian") return c->hermitian ? 1.0 : 0.0;
   if (s == "zgemm_alg") return sizeof(T) == 8 ? c->zgemm_alg : 1;
   if (s == "composed") return c->last_composed;
+  if (s == "operator_backward") return c->last_opback;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;
   if (s == "norm_H0") return c->nH0;

@@ -79,7 +79,8 @@ int dq_set_hamiltonians(dq_ctx* ctx, const void* H0, const void* Hs);
 /* Observable M ([dim][dim], Hermitian) of the energy loss <psi|M|psi> (sim_plain.py:281). */
 int dq_set_observable(dq_ctx* ctx, const void* M);
 
-/* Tunables: "checkpoint_bytes", "chunk_bytes", "expm_tol", "force_degree", "force_squarings",
+/* Tunables: "checkpoint_bytes" (state checkpoints of the adjoint sweep; 0 = 70 % of the free HBM), "plan_steps" (size the
+ * checkpoint stride for a chain of this many steps even if the call is shorter), "chunk_bytes", "expm_tol", "force_degree", "force_squarings",
  * "force_tile", "zgemm_alg" (0 = four real MFMAs per complex tile step, 1 = the three-multiplication
  * "3M" form on the 128x128 tile), "compose" (-1 auto / 0 / 1: dq_propagate multiplies the step propagators
  * together by a log-depth tree of batched products and applies the result once -- 8 d^3 instead of 8 d^2 batch

@@ -275,7 +275,8 @@ def test_operator_form_forward_for_wide_batches(oracle, n, B, S):
 
 @pytest.mark.parametrize("n,K,B,S", [(2, 2, 9, 5), (3, 3, 40, 11), (4, 2, 100, 7)])
 def test_operator_form_gradient_for_wide_batches(oracle, n, K, B, S):
-    """B > d: the adjoint sweep runs on the d x d propagator product (cost independent of B)."""
+    """B > d: composed forward + the backward sweep on W_t = Lambda_t Psi_t^H (d x d; cost independent of B, no state
+    checkpoints)."""
     H0, Hs, M = problems.random_hermitian_problem(n, K, seed=n + B)
     u = np.random.default_rng(S).uniform(-1.5, 1.5, (S, K))
     psi0 = problems.random_states(1 << n, B, seed=3)
@@ -293,6 +294,34 @@ def test_operator_form_gradient_for_wide_batches(oracle, n, K, B, S):
         assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL * B and np.max(np.abs(f - rf)) < TOL
         assert np.max(np.abs(en - oracle.energies(M, rf))) < TOL
     assert np.max(np.abs(g1 - g2)) < 1e-11 * B
+
+
+@pytest.mark.parametrize("objective", ["energy", "fidelity"])
+def test_operator_form_backward_at_batch_equal_dim(oracle, objective):
+    """B = d (the BASELINE headline shape): forward on the states, backward on W_t = Lambda_t Psi_t^H with
+    G_t = W_{t+1} U_t, W_t = U_t^H G_t -- no checkpoints, no psi_t rebuilds; same gradient as the state form."""
+    n, K, S, dt = 3, 2, 23, 0.06
+    d = B = 1 << n
+    H0, Hs, M = problems.random_hermitian_problem(n, K, seed=77)
+    u = np.random.default_rng(5).uniform(-1.5, 1.5, (S, K))
+    psi0 = problems.random_states(d, B, seed=3)
+    tgt = problems.random_states(d, B, seed=4)
+    with _engine(H0, Hs, M) as e:
+        run = (lambda: e.energy_grad(u, dt, psi0)) if objective == "energy" else (lambda: e.fidelity_grad(u, dt, psi0, tgt))
+        l1, g1, f1, x1 = run()
+        assert e.info("operator_backward") == 1 and e.info("composed") == 0 and e.info("checkpoint_stride") == 0
+        e.set_option("chunk_bytes", 24 * d * d * 16 * 4)  # several time chunks
+        l3, g3, f3, x3 = run()
+        e.set_option("compose", 0)
+        l2, g2, f2, x2 = run()
+        assert e.info("operator_backward") == 0 and e.info("checkpoint_stride") >= 1
+    if objective == "energy":
+        rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    else:
+        rl, rg, rf, _ = oracle.fidelity_grad(H0, list(Hs), u, dt, psi0, tgt)
+    for l, g, f in ((l1, g1, f1), (l2, g2, f2), (l3, g3, f3)):
+        assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL * B and np.max(np.abs(f - rf)) < TOL
+    assert np.max(np.abs(g1 - g2)) < 1e-12 * B
 
 
 def test_skew_trick_leaves_the_gradient_unchanged():
