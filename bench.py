@@ -233,7 +233,7 @@ def main():
         eng.set_option("real_path", a.real_path)
         gr = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
         lr, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gr)
-        general = {"steps_per_s": Kg / tg, "chain_steps": Kg, "products_per_step": "14 ZGEMMs (3M) of 8 d^3",
+        general = {"steps_per_s": Kg / tg, "chain_steps": Kg, "products_per_step": "11 ZGEMMs (3M) of 8 d^3 + 3 (anti-)Hermitian-output ZGEMMs (half the tiles)",
                    "max_abs_grad_diff_vs_real_path": float((gg - gr).abs().max().item()),
                    "abs_loss_diff_vs_real_path": abs(lg - lr),
                    "note": "same inputs with real_path = 0: what a complex Hermitian H of this size costs; the two paths' "

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libdiffqc_hip.so")
 
 DQ_C128, DQ_C64 = 0, 1
 DQ_OK, DQ_ERR_INVALID, DQ_ERR_STATE, DQ_ERR_HIP, DQ_ERR_NO_DEVICE, DQ_ERR_UNSUPPORTED, DQ_ERR_NOMEM = range(7)
-PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other", "rgemm", "rsym")
+PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other", "rgemm", "rsym", "zherm")
 
 
 class DiffqcError(RuntimeError):
@@ -28,10 +28,10 @@ class DiffqcNoDevice(DiffqcError):
 
 class DqProfile(C.Structure):
     _fields_ = [
-        ("launches", C.c_longlong * 7),
-        ("ms", C.c_double * 7),
-        ("flops", C.c_double * 7),
-        ("bytes", C.c_double * 7),
+        ("launches", C.c_longlong * 8),
+        ("ms", C.c_double * 8),
+        ("flops", C.c_double * 8),
+        ("bytes", C.c_double * 8),
     ]
 
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "dq_fidelity_grad": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "dq_zgemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_long, C.c_long,
                            _vp, C.c_long, C.c_long, C.c_double, _vp, C.c_long, C.c_long, C.c_int]),
+    "dq_zgemm_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_long, C.c_long,
+                              _vp, C.c_long, C.c_long, C.c_double, _vp, C.c_long, C.c_long, C.c_int, C.c_int]),
     "dq_rgemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_long, C.c_long,
                            _vp, C.c_long, C.c_long, C.c_double, _vp, C.c_long, C.c_long, C.c_int, C.c_int]),
     "dq_expm": (C.c_int, [_vp, _vp, _vp, C.c_int]),

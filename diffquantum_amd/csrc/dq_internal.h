@@ -18,6 +18,18 @@ struct Cx<float> {
   typedef float2 type;
 };
 
+// linear index over the tiles on and above the diagonal (row-major over the triangle: row i holds nt - i tiles);
+// shared by the symmetric-output forms of the real and the complex GEMM
+__device__ __forceinline__ void tri_tile(int pid, int nt, int& tile_m, int& tile_n) {
+  const double w = 2.0 * nt + 1.0;
+  int i = (int)((w - sqrt(w * w - 8.0 * pid)) * 0.5);
+  if (i < 0) i = 0;
+  while (i > 0 && i * nt - i * (i - 1) / 2 > pid) --i;  // first tile of row i <= pid
+  while ((i + 1) * nt - (i + 1) * i / 2 <= pid) ++i;
+  tile_m = i;
+  tile_n = i + (pid - (i * nt - i * (i - 1) / 2));
+}
+
 template <class T>
 struct ZgemmArgs {
   typedef typename Cx<T>::type T2;
@@ -30,10 +42,17 @@ struct ZgemmArgs {
   int batch;
   double alpha, beta;
   int opA, opB;         // 0 = as stored, 1 = conjugate transpose
+  // herm: 0 = general output; +1 / -1 = the caller asserts that the product is Hermitian / anti-Hermitian (e.g. X^H W X
+  // for (anti-)Hermitian W): only the tiles on and above the diagonal are computed, the mirror image is +-conj (M == N)
+  int herm;
+  T2* ws;            // optional workspace for the K-split tail tiles of the herm form (may be null)
+  size_t ws_elems;   // its capacity in complex elements
+  int n_full, split_f;  // filled in by zgemm_launch
 };
 
+// n_cu: compute units of the device (tail splitting of the herm form)
 template <class T>
-hipError_t zgemm_launch(const ZgemmArgs<T>& g, hipStream_t st, int force_tile, int alg);
+hipError_t zgemm_launch(const ZgemmArgs<T>& g, hipStream_t st, int force_tile, int alg, int n_cu = 256);
 int zgemm_pick_tile(int M, int N, int batch);
 
 // ---- elementwise / reduction kernels (elementwise.hip) ------------------------------

@@ -94,6 +94,8 @@ bool is_device_ptr(const void* p) {
 // The same tape drives the reverse mode (tape_backward): for C = X Y, Xbar += Cbar Y^H and Ybar += X^H Cbar.
 struct TapeOp {
   int kind;  // 0 = LIN, 1 = MUL
+  int herm;  // MUL: +1 / -1 if the product is Hermitian / anti-Hermitian whenever A is anti-Hermitian (even / odd
+             // polynomial in A with real coefficients), 0 otherwise -> (anti-)Hermitian output form of the ZGEMM
   int dst, a, b;
   int nlin;
   int lsrc[6];
@@ -200,7 +202,25 @@ ExpmPlan make_plan(int m, int q, int s) {
     p.out = nx;
   }
   p.nvars = nv;
-  for (const auto& o : p.ops) p.nprod += o.kind;
+  // parity of every variable as a polynomial in A: +1 even (Hermitian for anti-Hermitian A), -1 odd (anti-Hermitian),
+  // 0 mixed. Products of two pure-parity polynomials (they commute) are pure again.
+  std::vector<int> par(nv, 0);
+  par[0] = -1;
+  for (auto& o : p.ops) {
+    int lp = 2;  // parity of the linear part (2 = empty)
+    auto merge = [&](int x) { lp = (lp == 2 || lp == x) ? x : 0; };
+    if (o.cI != 0.0) merge(+1);
+    for (int j = 0; j < o.nlin; ++j) merge(par[o.lsrc[j]]);
+    if (o.kind == 0) {
+      par[o.dst] = lp == 2 ? 0 : lp;
+    } else {
+      int pp = par[o.a] * par[o.b];
+      if (lp != 2 && lp != pp) pp = 0;
+      par[o.dst] = pp;
+      o.herm = pp;
+    }
+    p.nprod += o.kind;
+  }
   return p;
 }
 
@@ -245,7 +265,7 @@ struct Ctx : dq_ctx {
   typedef typename dq::Cx<T>::type T2;
   int d = 0, K = 0, dev = 0, n_cu = 256;
   hipStream_t st = nullptr;
-  DevBuf rws;  // split-K workspace of the symmetric real GEMM
+  DevBuf rws, zws;  // split-K workspaces of the symmetric real GEMM / the (anti-)Hermitian complex GEMM
   DevBuf H0, Hs, M;
   DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
@@ -324,8 +344,9 @@ struct Ctx : dq_ctx {
     return (T2*)pool[slot].p;
   }
 
+  // herm: 0 general output; +1 / -1 the product is known to be Hermitian / anti-Hermitian (upper tiles + mirror)
   void zgemm(int opA, int opB, int M, int N, int Kd, double alpha, const T2* A, long lda, long sA,
-             const T2* B, long ldb, long sB, double beta, T2* C, long ldc, long sC, int batch) {
+             const T2* B, long ldb, long sB, double beta, T2* C, long ldc, long sC, int batch, int herm = 0) {
     dq::ZgemmArgs<T> g;
     g.A = A; g.B = B; g.C = C;
     g.M = M; g.N = N; g.K = Kd;
@@ -334,15 +355,25 @@ struct Ctx : dq_ctx {
     g.batch = batch;
     g.alpha = alpha; g.beta = beta;
     g.opA = opA; g.opB = opB;
+    g.herm = herm;
+    g.ws = nullptr;
+    g.ws_elems = 0;
+    if (herm && batch == 1 && M >= 1024) {  // K-split tail of the triangle: at most one partial tile per workgroup slot
+      const size_t elems = (size_t)n_cu * 2 * 128 * 128;
+      zws.ensure(elems * sizeof(T2));
+      g.ws = (T2*)zws.p;
+      g.ws_elems = elems;
+    }
+    // algorithmic flops of the product that is delivered (the herm form executes about half of them)
     const double fl = 8.0 * M * N * (double)Kd * batch;
     const double by = 2.0 * sizeof(T) * ((double)M * Kd + (double)Kd * N + (double)M * N * (beta != 0.0 ? 2 : 1)) * batch;
-    const int ft = force_tile, alg = zgemm_alg;
-    timed(DQ_PROF_ZGEMM, fl, by, [&] { return dq::zgemm_launch<T>(g, st, ft, alg); });
+    const int ft = force_tile, alg = zgemm_alg, ncu = n_cu;
+    timed(herm ? DQ_PROF_ZHERM : DQ_PROF_ZGEMM, fl, by, [&] { return dq::zgemm_launch<T>(g, st, ft, alg, ncu); });
   }
   // batched d x d product on pool matrices
-  void mm(int opA, int opB, const T2* A, const T2* B, T2* C, double beta, int batch) {
+  void mm(int opA, int opB, const T2* A, const T2* B, T2* C, double beta, int batch, int herm = 0) {
     const long s = (long)nn();
-    zgemm(opA, opB, d, d, d, 1.0, A, d, s, B, d, s, beta, C, d, s, batch);
+    zgemm(opA, opB, d, d, d, 1.0, A, d, s, B, d, s, beta, C, d, s, batch, herm);
   }
   // real product of `batch` stacked d x d matrices; A must be symmetric (it is read as A^T: the linear staging form)
   void rmm(const T* A, const T* B, T* C, int batch, bool sym_out, bool two = false, double alpha = 1.0,
@@ -406,7 +437,7 @@ enum { SLOT_ADJ = 44, SLOT_MAXV = 44, SLOT_TREE = 90 };
 
 // Forward exp of `n` stacked matrices sitting in slot 0 (variable 0 = A). Returns the device pointer of U.
 template <class T>
-typename dq::Cx<T>::type* expm_forward(Ctx<T>* c, const ExpmPlan& p, int n) {
+typename dq::Cx<T>::type* expm_forward(Ctx<T>* c, const ExpmPlan& p, int n, bool a_antiherm = false) {
   typedef typename dq::Cx<T>::type T2;
   if (p.nvars > SLOT_MAXV) fail(DQ_ERR_INVALID, "exp(A) plan needs too many temporaries");
   for (const TapeOp& o : p.ops) {
@@ -417,7 +448,8 @@ typename dq::Cx<T>::type* expm_forward(Ctx<T>* c, const ExpmPlan& p, int n) {
       for (int j = 0; j < o.nlin; ++j) x[j] = c->mat(o.lsrc[j], n);
       c->lincomb(dst, o.nlin, x, o.lc, o.cI, n, false);
     }
-    if (o.kind == 1) c->mm(0, 0, c->mat(o.a, n), c->mat(o.b, n), dst, has_lin ? 1.0 : 0.0, n);
+    // a_antiherm (the chain: A = -i dt H with Hermitian H): even / odd powers of A are Hermitian / anti-Hermitian
+    if (o.kind == 1) c->mm(0, 0, c->mat(o.a, n), c->mat(o.b, n), dst, has_lin ? 1.0 : 0.0, n, a_antiherm ? o.herm : 0);
   }
   c->last_degree = p.m;
   c->last_squarings = p.s;
@@ -733,7 +765,7 @@ TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
     return dq::assemble_launch<T>(A, (const T2*)c->H0.p, (const T2*)c->Hs.p, c->u_dev.d() + (size_t)c0 * c->K, c->K,
                                   (long)c->nn(), n, dt, c->st);
   });
-  return expm_forward(c, p, n);
+  return expm_forward(c, p, n, c->hermitian);
 }
 
 template <class T>
@@ -953,9 +985,20 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
     const T2* psi_next = (const T2*)c->psi[cur].p;
     int lcur = 0;
     T2* W = nullptr;  // operator form: W_{t+1}
+    // Only the anti-Hermitian part of W reaches the gradient: dU_t = U_t K with K anti-Hermitian (U_t unitary up to the
+    // Taylor remainder), and Re tr((W U)^H U K) = Re tr((U^H W U)^H K) vanishes for Hermitian W. With W anti-Hermitian,
+    // W_t = U_t^H (W_{t+1} U_t) is anti-Hermitian for ANY U_t: that product computes the upper triangle only.
+    // (Off when a polynomial degree is forced: the gradient is then the exact derivative of an under-resolved polynomial.)
+    const bool skew_w = opback && c->skew_trick != 0 && c->force_degree <= 0 && c->real_mode <= 0;
     if (opback) {
       W = c->mat(SLOT_TREE, 1);
       c->zgemm(0, 1, d, d, B, 1.0, (const T2*)c->lam[0].p, B, 0, psi_next, B, 0, 0.0, W, d, 0, 1);  // W_S
+      if (skew_w) {
+        T2* Ws = c->mat(SLOT_TREE + 1, 1);
+        c->timed(DQ_PROF_LINCOMB, 4.0 * c->nn(), 3.0 * 2.0 * sizeof(T) * c->nn(),
+                 [&] { return dq::tcombine_launch<T>(Ws, W, d, 0.5, -0.5, 0, (long)c->nn(), 1, c->st); });
+        W = Ws;
+      }
     }
     for (int c0 = last_c0; c0 >= 0; c0 -= tc) {
       const int n = std::min(tc, S - c0);
@@ -969,7 +1012,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
         if (opback) {
           c->zgemm(0, 0, d, d, d, 1.0, W, d, 0, Ut, d, 0, 0.0, Gt, d, 0, 1);  // G_t = W_{t+1} U_t
           T2* Wn = c->mat(W == c->mat(SLOT_TREE, 1) ? SLOT_TREE + 1 : SLOT_TREE, 1);
-          c->zgemm(1, 0, d, d, d, 1.0, Ut, d, 0, Gt, d, 0, 0.0, Wn, d, 0, 1);  // W_t = U_t^H G_t
+          c->zgemm(1, 0, d, d, d, 1.0, Ut, d, 0, Gt, d, 0, 0.0, Wn, d, 0, 1, skew_w ? -1 : 0);  // W_t = U_t^H G_t
           W = Wn;
           continue;
         }
@@ -1069,10 +1112,12 @@ void do_set_observable(Ctx<T>* c, const void* M) {
 
 template <class T>
 void do_zgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
-              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch) {
+              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch, int herm) {
   typedef TT T2;
   check_ctx(c);
   if (M < 0 || N < 0 || K < 0 || batch < 0) fail(DQ_ERR_INVALID, "negative dimension");
+  if (herm < -1 || herm > 1) fail(DQ_ERR_INVALID, "herm must be 0, +1 (Hermitian product) or -1 (anti-Hermitian)");
+  if (herm && M != N) fail(DQ_ERR_INVALID, "the (anti-)Hermitian output form needs M == N");
   if ((opA | opB) & ~1) fail(DQ_ERR_INVALID, "op must be 0 (N) or 1 (conjugate transpose)");
   if (M == 0 || N == 0 || batch == 0) return;
   if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
@@ -1095,7 +1140,7 @@ void do_zgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, co
     stage_h2d(c, c->tmp_in[2].p, C, bcz);  // beta*C and untouched gaps
     dC = (T2*)c->tmp_in[2].p;
   }
-  c->zgemm(opA, opB, M, N, K, alpha, dA, lda, strideA, dB, ldb, strideB, beta, dC, ldc, strideC, batch);
+  c->zgemm(opA, opB, M, N, K, alpha, dA, lda, strideA, dB, ldb, strideB, beta, dC, ldc, strideC, batch, herm);
   if (!c_dev) out_copy(c, C, dC, bcz);
   HIPCK(hipStreamSynchronize(c->st));
 }
@@ -1408,8 +1453,13 @@ int dq_fidelity_grad(dq_ctx* c, const double* u, int n_steps, double dt, const v
 
 int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch) {
+  return dq_zgemm_ex(c, opA, opB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, 0);
+}
+
+int dq_zgemm_ex(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+                const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch, int herm) {
   return with_ctx(c, [&](auto* t) {
-    do_zgemm(t, opA, opB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch);
+    do_zgemm(t, opA, opB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, herm);
   });
 }
 

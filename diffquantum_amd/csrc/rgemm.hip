@@ -64,17 +64,6 @@ struct RMfma<float> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-// linear index over the tiles on and above the diagonal (row-major over the triangle: row i holds nt - i tiles)
-__device__ __forceinline__ void tri_tile(int pid, int nt, int& tile_m, int& tile_n) {
-  const double w = 2.0 * nt + 1.0;
-  int i = (int)((w - sqrt(w * w - 8.0 * pid)) * 0.5);
-  if (i < 0) i = 0;
-  while (i > 0 && i * nt - i * (i - 1) / 2 > pid) --i;  // first tile of row i <= pid
-  while ((i + 1) * nt - (i + 1) * i / 2 <= pid) ++i;
-  tile_m = i;
-  tile_n = i + (pid - (i * nt - i * (i - 1) / 2));
-}
-
 template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int SYM, int MINW, int GLDS = 0>
 __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T> g) {
   typedef typename RMfma<T>::acc_t acc_t;

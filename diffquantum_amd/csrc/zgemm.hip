@@ -31,6 +31,8 @@
 // workgroups resident on one XCD cover a 4 x 8 block of tiles and share their A/B panels through that
 // XCD's L2.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
 #include "dq_internal.h"
 
 // Ablation switches for tools/zgemm_probe.hip only (never set in the library build): 1 = no barriers in the K loop,
@@ -74,7 +76,7 @@ struct Mfma<float> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int ALG3M>
+template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int ALG3M, int HERM = 0>
 __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g) {
   typedef typename Cx<T>::type T2;
   typedef typename Mfma<T>::acc_t acc_t;
@@ -99,16 +101,37 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
 
   // ---- workgroup -> tile mapping (XCD-aware, grouped along M) ------------------
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  const int nwg = ntm * ntn;
-  int pid = blockIdx.x;
-  if ((nwg & 7) == 0) pid = (pid & 7) * (nwg >> 3) + (pid >> 3);
-  constexpr int GROUP_M = 4;
-  const int in_group = GROUP_M * ntn;
-  const int group = pid / in_group;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(ntm - first_m, GROUP_M);
-  const int tile_m = first_m + (pid % in_group) % gsz;
-  const int tile_n = (pid % in_group) / gsz;
+  const int nkt = (g.K + BK - 1) / BK;
+  int tile_m, tile_n, kt0 = 0, kt1 = nkt, piece = -1;
+  if (HERM) {
+    // (anti-)Hermitian output: tiles on and above the diagonal only; the tiles beyond the last full round of
+    // workgroup slots are split along K (piece >= 0: raw partial tile -> workspace, summed by zgemm_fixup_kernel)
+    static_assert(!HERM || BM == BN, "the (anti-)Hermitian output form needs square tiles");
+    const int ntri = ntm * (ntm + 1) / 2;
+    const int nfull = g.n_full >= 0 ? g.n_full : ntri;
+    int pid = blockIdx.x;
+    if (pid >= nfull) {
+      piece = pid - nfull;
+      pid = nfull + piece / g.split_f;
+      const int per = (nkt + g.split_f - 1) / g.split_f;
+      kt0 = (piece % g.split_f) * per;
+      kt1 = min(nkt, kt0 + per);
+    } else if ((nfull & 7) == 0) {
+      pid = (pid & 7) * (nfull >> 3) + (pid >> 3);
+    }
+    tri_tile(pid, ntm, tile_m, tile_n);
+  } else {
+    const int nwg = ntm * ntn;
+    int pid = blockIdx.x;
+    if ((nwg & 7) == 0) pid = (pid & 7) * (nwg >> 3) + (pid >> 3);
+    constexpr int GROUP_M = 4;
+    const int in_group = GROUP_M * ntn;
+    const int group = pid / in_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(ntm - first_m, GROUP_M);
+    tile_m = first_m + (pid % in_group) % gsz;
+    tile_n = (pid % in_group) / gsz;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const long z = blockIdx.z;
@@ -220,15 +243,14 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
     }                                                                                                        \
   }
 
-  const int nkt = (g.K + BK - 1) / BK;
-  DQ_LOAD_SLAB(0);
+  DQ_LOAD_SLAB(kt0 * BK);
   DQ_STORE_SLAB(0);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     // the tail slab (k >= K) loads zeros through the bounds check, so no branch is needed here
     if (!(DQ_ZGEMM_ABLATE & 2)) DQ_LOAD_SLAB((kt + 1) * BK);
-    DQ_COMPUTE_SLAB(kt & 1);
-    if (!(DQ_ZGEMM_ABLATE & 2)) DQ_STORE_SLAB((kt + 1) & 1);
+    DQ_COMPUTE_SLAB((kt - kt0) & 1);
+    if (!(DQ_ZGEMM_ABLATE & 2)) DQ_STORE_SLAB((kt - kt0 + 1) & 1);
     if (!(DQ_ZGEMM_ABLATE & 1)) __syncthreads();
   }
 #undef DQ_LOAD_SLAB
@@ -237,25 +259,33 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
 
   // ---- epilogue: C = alpha*acc + beta*C -----------------------------------------
   const T alpha = (T)g.alpha, beta = (T)g.beta;
+  T2* __restrict__ W = (HERM && piece >= 0) ? g.ws + (long)piece * (BM * BN) : nullptr;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int col = n0 + wn * TN + j * 16 + (lane & 15);
+      const int lc = wn * TN + j * 16 + (lane & 15);
+      const int col = n0 + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * TM + i * 16 + Mfma<T>::row(lane, r);
-        if (row < g.M && col < g.N) {
+        const int lr = wm * TM + i * 16 + Mfma<T>::row(lane, r);
+        const int row = m0 + lr;
+        T cr, ci;
+        if (ALG3M) {  // Cr = P1 - s P2, Ci = P3 - P1 - s P2, s = +1 unless exactly one operand is conjugated
+          const T p2 = ((OPA != 0) != (OPB != 0)) ? -acci[i][j][r] : acci[i][j][r];
+          cr = accr[i][j][r] - p2;
+          ci = acc3[i][j][r] - accr[i][j][r] - p2;
+        } else {
+          cr = accr[i][j][r];
+          ci = acci[i][j][r];
+        }
+        if (HERM && piece >= 0) {  // raw partial tile -> workspace [piece][BM][BN]
+          T2 v;
+          v.x = cr;
+          v.y = ci;
+          W[lr * BN + lc] = v;
+        } else if (row < g.M && col < g.N && (!HERM || col >= row)) {
           const long off = (long)row * g.ldc + col;
-          T cr, ci;
-          if (ALG3M) {  // Cr = P1 - s P2, Ci = P3 - P1 - s P2, s = +1 unless exactly one operand is conjugated
-            const T p2 = ((OPA != 0) != (OPB != 0)) ? -acci[i][j][r] : acci[i][j][r];
-            cr = accr[i][j][r] - p2;
-            ci = acc3[i][j][r] - accr[i][j][r] - p2;
-          } else {
-            cr = accr[i][j][r];
-            ci = acci[i][j][r];
-          }
           T2 v;
           v.x = alpha * cr;
           v.y = alpha * ci;
@@ -264,18 +294,109 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
             v.x += beta * c0.x;
             v.y += beta * c0.y;
           }
+          if (HERM && col == row) {  // exactly (anti-)Hermitian diagonal
+            if (g.herm > 0) v.y = 0;
+            else v.x = 0;
+          }
           C[off] = v;
+          if (HERM && col != row) {  // mirror image: +-conj (beta != 0 needs an (anti-)Hermitian C on entry)
+            T2 m;
+            m.x = g.herm > 0 ? v.x : -v.x;
+            m.y = g.herm > 0 ? -v.y : v.y;
+            C[(long)col * g.ldc + row] = m;
+          }
         }
       }
     }
 }
 
+// sums the split_f partial tiles of every tail tile of the herm form in a fixed order and writes both triangles
+template <class T, int BM, int BN>
+__global__ void __launch_bounds__(256) zgemm_fixup_kernel(ZgemmArgs<T> g) {
+  typedef typename Cx<T>::type T2;
+  const int ntm = (g.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  tri_tile(g.n_full + blockIdx.y, ntm, tile_m, tile_n);
+  const T2* __restrict__ W = g.ws + (long)blockIdx.y * g.split_f * (BM * BN);
+  const T alpha = (T)g.alpha, beta = (T)g.beta;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < BM * BN; e += gridDim.x * 256) {
+    const int row = tile_m * BM + e / BN, col = tile_n * BN + e % BN;
+    if (row < g.M && col < g.N && col >= row) {
+      T sr = 0, si = 0;
+      for (int f = 0; f < g.split_f; ++f) {
+        const T2 w = W[(long)f * (BM * BN) + e];
+        sr += w.x;
+        si += w.y;
+      }
+      const long off = (long)row * g.ldc + col;
+      T2 v;
+      v.x = alpha * sr;
+      v.y = alpha * si;
+      if (g.beta != 0.0) {
+        const T2 c0 = g.C[off];
+        v.x += beta * c0.x;
+        v.y += beta * c0.y;
+      }
+      if (col == row) {
+        if (g.herm > 0) v.y = 0;
+        else v.x = 0;
+      }
+      g.C[off] = v;
+      if (col != row) {
+        T2 m;
+        m.x = g.herm > 0 ? v.x : -v.x;
+        m.y = g.herm > 0 ? -v.y : v.y;
+        g.C[(long)col * g.ldc + row] = m;
+      }
+    }
+  }
+}
+
 template <class T, int BM, int BN, int BK, int WGM, int WGN, int ALG3M>
-static void launch_cfg(const ZgemmArgs<T>& g, hipStream_t st) {
+static void launch_cfg(ZgemmArgs<T> g, hipStream_t st, int n_cu) {
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)g.batch);
   dim3 block(WGM * WGN * 64);
   const int op = (g.opA ? 2 : 0) | (g.opB ? 1 : 0);
+  g.n_full = -1;
+  g.split_f = 1;
+  if (g.herm) {
+    const int ntri = ntm * (ntm + 1) / 2;
+    const int nkt = (g.K + BK - 1) / BK;
+    static std::atomic<int> wg_per_cu{0};  // resident workgroups per CU of this configuration
+    if (wg_per_cu.load() == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, ALG3M, 1>,
+                                                       WGM * WGN * 64, 0) != hipSuccess || nb <= 0) {
+        (void)hipGetLastError();
+        nb = 1;
+      }
+      wg_per_cu.store(nb);
+    }
+    const int slots = n_cu * wg_per_cu.load();
+    const int rem = slots > 0 ? ntri % slots : 0;
+    int grid_x = ntri;
+    // tail tiles that would occupy less than half of one more round are split along K
+    if (g.batch == 1 && g.ws && ntri > slots && rem > 0 && 2 * rem <= slots) {
+      int f = std::min(std::min(slots / rem, nkt), 64);
+      while (f > 1 && (size_t)rem * f * BM * BN > g.ws_elems) --f;
+      if (f > 1) {
+        g.n_full = ntri - rem;
+        g.split_f = f;
+        grid_x = g.n_full + rem * f;
+      }
+    }
+    dim3 grid((unsigned)grid_x, 1, (unsigned)g.batch);
+    switch (op) {
+      case 0: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 0, ALG3M, 1>), grid, block, 0, st, g); break;
+      case 1: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 1, ALG3M, 1>), grid, block, 0, st, g); break;
+      case 2: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, ALG3M, 1>), grid, block, 0, st, g); break;
+      default: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 1, ALG3M, 1>), grid, block, 0, st, g); break;
+    }
+    if (g.n_full >= 0)
+      hipLaunchKernelGGL((zgemm_fixup_kernel<T, BM, BN>), dim3((unsigned)(BM * BN / 256), (unsigned)rem), dim3(256), 0, st, g);
+    return;
+  }
+  dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)g.batch);
   switch (op) {
     case 0: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 0, ALG3M>), grid, block, 0, st, g); break;
     case 1: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 1, ALG3M>), grid, block, 0, st, g); break;
@@ -295,24 +416,26 @@ int zgemm_pick_tile(int M, int N, int batch) {
 
 // alg: 0 = 4M (four real MFMAs per complex tile step), 1 = 3M (three; P3 trick, normwise-stable)
 template <>
-hipError_t zgemm_launch<double>(const ZgemmArgs<double>& g, hipStream_t st, int force_tile, int alg) {
+hipError_t zgemm_launch<double>(const ZgemmArgs<double>& g, hipStream_t st, int force_tile, int alg, int n_cu) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
+  if (g.herm && g.M != g.N) return hipErrorInvalidValue;
   const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
   if (tile == 128) {
-    if (alg == 1) launch_cfg<double, 128, 128, 8, 2, 4, 1>(g, st);
-    else launch_cfg<double, 128, 128, 8, 2, 4, 0>(g, st);
-  } else if (tile == 64) launch_cfg<double, 64, 64, 8, 2, 2, 0>(g, st);
-  else launch_cfg<double, 32, 32, 8, 1, 1, 0>(g, st);
+    if (alg == 1) launch_cfg<double, 128, 128, 8, 2, 4, 1>(g, st, n_cu);
+    else launch_cfg<double, 128, 128, 8, 2, 4, 0>(g, st, n_cu);
+  } else if (tile == 64) launch_cfg<double, 64, 64, 8, 2, 2, 0>(g, st, n_cu);
+  else launch_cfg<double, 32, 32, 8, 1, 1, 0>(g, st, n_cu);
   return hipGetLastError();
 }
 
 template <>
-hipError_t zgemm_launch<float>(const ZgemmArgs<float>& g, hipStream_t st, int force_tile, int /*alg*/) {
+hipError_t zgemm_launch<float>(const ZgemmArgs<float>& g, hipStream_t st, int force_tile, int /*alg*/, int n_cu) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
+  if (g.herm && g.M != g.N) return hipErrorInvalidValue;
   const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
-  if (tile == 128) launch_cfg<float, 128, 128, 8, 2, 4, 1>(g, st);
-  else if (tile == 64) launch_cfg<float, 64, 64, 8, 2, 2, 1>(g, st);
-  else launch_cfg<float, 32, 32, 8, 1, 1, 1>(g, st);
+  if (tile == 128) launch_cfg<float, 128, 128, 8, 2, 4, 1>(g, st, n_cu);
+  else if (tile == 64) launch_cfg<float, 64, 64, 8, 2, 2, 1>(g, st, n_cu);
+  else launch_cfg<float, 32, 32, 8, 1, 1, 1>(g, st, n_cu);
   return hipGetLastError();
 }
 

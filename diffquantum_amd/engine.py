@@ -234,8 +234,9 @@ class Engine:
         return loss.value, grad, fin, fid
 
     # -- building blocks ----------------------------------------------------
-    def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None):
-        """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host)."""
+    def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None, herm=0):
+        """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host).
+        herm=+1/-1: the product is known to be Hermitian / anti-Hermitian (upper tiles + mirror)."""
         A = np.ascontiguousarray(A, dtype=self.cdtype)
         B = np.ascontiguousarray(B, dtype=self.cdtype)
         batched = A.ndim == 3
@@ -252,9 +253,9 @@ class Engine:
             Cm = np.zeros((nb, M, N), dtype=self.cdtype)
         else:
             Cm = np.array(C_in, dtype=self.cdtype, order="C").reshape(nb, M, N)
-        _lib.check(self._lib.dq_zgemm(self._ctx, int(opA), int(opB), M, N, K, float(alpha), A.ctypes.data,
-                                      A.shape[2], A.shape[1] * A.shape[2], B.ctypes.data, B.shape[2],
-                                      B.shape[1] * B.shape[2], float(beta), Cm.ctypes.data, N, M * N, nb))
+        _lib.check(self._lib.dq_zgemm_ex(self._ctx, int(opA), int(opB), M, N, K, float(alpha), A.ctypes.data,
+                                         A.shape[2], A.shape[1] * A.shape[2], B.ctypes.data, B.shape[2],
+                                         B.shape[1] * B.shape[2], float(beta), Cm.ctypes.data, N, M * N, nb, int(herm)))
         return Cm if batched else Cm[0]
 
     def rgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None, sym=False):

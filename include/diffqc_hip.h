@@ -50,14 +50,16 @@ typedef struct dq_ctx dq_ctx;
 #define DQ_PROF_OTHER 4     /* reductions, copies                         */
 #define DQ_PROF_RGEMM 5     /* batched real GEMM of the real-symmetric fast path (f64 MFMA), full output   */
 #define DQ_PROF_RSYM 6      /* the same kernel in its symmetric-output form (tiles on/above the diagonal)  */
-#define DQ_PROF_NCLASS 7
+#define DQ_PROF_ZHERM 7     /* complex GEMM in its (anti-)Hermitian-output form (tiles on/above the diagonal) */
+#define DQ_PROF_NCLASS 8
 
 typedef struct dq_profile {
   long long launches[DQ_PROF_NCLASS];
   double ms[DQ_PROF_NCLASS];     /* sum of HIP-event durations of the class's launches       */
   double flops[DQ_PROF_NCLASS];  /* real flops per class. ZGEMM: the algorithmic 8*M*N*K (the 3M form executes 6*M*N*K);
                                     RGEMM: 2*M*N*K; RSYM: the EXECUTED 2*K*128*128*(tiles on/above the diagonal),
-                                    about half of the 2*M*N*K of the full product it stands for */
+                                    about half of the 2*M*N*K of the full product it stands for; ZHERM: the
+                                    algorithmic 8*M*N*K of the product delivered (about half of it is executed) */
   double bytes[DQ_PROF_NCLASS];  /* algorithmic bytes moved (streaming classes)              */
 } dq_profile;
 
@@ -121,6 +123,11 @@ int dq_fidelity_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */
 int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch);
+/* The same with herm = +1 / -1: the caller asserts that the product is Hermitian / anti-Hermitian (e.g. X^H W X for an
+ * (anti-)Hermitian W; M == N): only the tiles on and above the diagonal are computed, the mirror image is +-conj, the
+ * diagonal is made exactly real / imaginary. beta != 0 then needs an (anti-)Hermitian C on entry. */
+int dq_zgemm_ex(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
+                const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch, int herm);
 /* Real GEMM of the real-symmetric fast path: C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = transpose;
  * element type double (DQ_C128 contexts) or float (DQ_C64); strides in elements. sym != 0: the caller asserts that
  * the product is symmetric (commuting symmetric operands; M == N): only the tiles on and above the diagonal are

@@ -72,6 +72,51 @@ def test_zgemm_3m_variant(eng16, opA, opB, M, N, K):
     assert np.max(np.abs(got - ref)) < 4e-16 * K * np.max(np.abs(A)) * np.max(np.abs(B)) * 4
 
 
+@pytest.mark.parametrize("tile", [0, 32, 64, 128])
+@pytest.mark.parametrize("alg", [0, 1])
+@pytest.mark.parametrize("herm", [1, -1])
+@pytest.mark.parametrize("d,nb", [(5, 2), (64, 2), (130, 1), (384, 1)])
+def test_zgemm_hermitian_output_forms(eng16, tile, alg, herm, d, nb):
+    """X^H W X for (anti-)Hermitian W is (anti-)Hermitian for ANY X: upper tiles + (+-conj) mirror, exact diagonal."""
+    rng = np.random.default_rng(d + herm)
+    X = _rand(rng, nb, d, d)
+    W = _rand(rng, nb, d, d)
+    W = W + herm * W.conj().transpose(0, 2, 1)
+    G = W @ X
+    C0 = _rand(rng, nb, d, d)
+    C0 = C0 + herm * C0.conj().transpose(0, 2, 1)
+    eng16.set_option("force_tile", tile)
+    eng16.set_option("zgemm_alg", alg)
+    try:
+        got = eng16.zgemm(X, G, opA=1, opB=0, alpha=0.5, beta=0.25, C_in=C0, herm=herm)
+    finally:
+        eng16.set_option("force_tile", 0)
+        eng16.set_option("zgemm_alg", 0)
+    ref = 0.5 * (X.conj().transpose(0, 2, 1) @ G) + 0.25 * C0
+    assert np.max(np.abs(got - ref)) < 1e-13 * d * max(1.0, np.abs(ref).max())
+    assert np.array_equal(got, herm * got.conj().transpose(0, 2, 1))     # exactly (anti-)Hermitian, diagonal included
+
+
+def test_zgemm_hermitian_form_tail_split():
+    """d = 3072: 300 triangle tiles on 256 workgroup slots -- the 44 tail tiles are split along K and summed by the fix-up
+    kernel in a fixed order (reproducible bits)."""
+    from diffquantum_amd.engine import Engine
+    d = 3072
+    rng = np.random.default_rng(1)
+    X = (_rand(rng, d, d) / np.sqrt(d)).astype(np.complex128)
+    W = _rand(rng, d, d)
+    W = W - W.conj().T
+    G = W @ X
+    with Engine(4, 0) as e:
+        e.set_option("zgemm_alg", 1)
+        got = e.zgemm(X, G, opA=1, opB=0, herm=-1)
+        again = e.zgemm(X, G, opA=1, opB=0, herm=-1)
+        full = e.zgemm(X, G, opA=1, opB=0)
+    assert np.max(np.abs(got - full)) < 1e-12 * np.abs(full).max()
+    assert np.max(np.abs(full - X.conj().T @ G)) < 1e-12 * np.abs(full).max()
+    assert np.array_equal(got, -got.conj().T) and np.array_equal(got, again)
+
+
 def test_zgemm_batched(eng16):
     rng = np.random.default_rng(3)
     A = _rand(rng, 5, 40, 24)

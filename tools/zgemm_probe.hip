@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
       dq::ZgemmArgs<double> g;
       g.A = A; g.B = B; g.C = C; g.M = g.N = g.K = d; g.lda = g.ldb = g.ldc = d; g.sA = g.sB = g.sC = 0; g.batch = 1;
       g.alpha = 1.0; g.beta = 0.0; g.opA = op >> 1; g.opB = op & 1;
+      g.herm = 0; g.ws = nullptr; g.ws_elems = 0;
       (void)dq::zgemm_launch<double>(g, 0, 128, alg);
       (void)hipDeviceSynchronize();
       (void)hipEventRecord(e0, 0);
