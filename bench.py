@@ -36,10 +36,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_BYTES_PER_LAUNCH = 3.53e9  # HBM-side bytes per ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_v5_realpath_
-                                   # summary.txt): 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.27 GB + 0.27 GB, d = B = 4096
-TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 1.92e9}  # same profile: real GEMM full-output; symmetric-output + its fix-up pass.
-                                                   # (8 B/lane loads: the guide calls this access width uncalibrated)
+TRAFFIC_BYTES_PER_LAUNCH = 3.54e9  # HBM-side bytes per ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_v12_summary.txt):
+                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.27 GB + 0.27 GB, d = B = 4096
+TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 2.68e9}  # real GEMM: full-output (profiles/r1_bench_v5_realpath_summary.txt);
+                                                   # symmetric-output launches (average over one- and two-product
+                                                   # forms) + fix-up pass, LDS-DMA staged (r1_bench_v12_summary.txt)
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
 

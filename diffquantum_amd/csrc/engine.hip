@@ -275,7 +275,7 @@ struct Ctx : dq_ctx {
   double nH0 = 0.0;
   std::vector<double> nHk;
   // options
-  double checkpoint_bytes = 0.0, chunk_bytes = 2.0 * 1024 * 1024 * 1024, expm_tol = 0.0, herm_tol = 0.0;
+  double checkpoint_bytes = 0.0, chunk_bytes = 8.0 * 1024 * 1024 * 1024, expm_tol = 0.0, herm_tol = 0.0;
   int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1, skew_trick = 1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0;
