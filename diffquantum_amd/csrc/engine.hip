@@ -270,7 +270,8 @@ struct Ctx : dq_ctx {
   DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
   int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128, rgemm_glds = 1;
-  long plan_steps = 0;  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
+  long plan_steps = 0;
+  int small_dim = 512, time_parallel = -1;  // see do_energy_grad  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
   double last_real_q = 0;
   double nH0 = 0.0;
   std::vector<double> nHk;
@@ -278,7 +279,7 @@ struct Ctx : dq_ctx {
   double checkpoint_bytes = 0.0, chunk_bytes = 8.0 * 1024 * 1024 * 1024, expm_tol = 0.0, herm_tol = 0.0;
   int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1, skew_trick = 1;
   // info
-  double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0;
+  double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0, last_tpar = 0;
   // workspace
   std::vector<DevBuf> pool;
   size_t pool_tc = 0;
@@ -433,7 +434,7 @@ struct Ctx : dq_ctx {
 
 
 // pool slot map: variable v of the tape lives in slot v, its adjoint in slot SLOT_ADJ + v
-enum { SLOT_ADJ = 44, SLOT_MAXV = 44, SLOT_TREE = 90 };
+enum { SLOT_ADJ = 44, SLOT_MAXV = 44, SLOT_TP_L = 88, SLOT_TP_Z = 89, SLOT_TREE = 90, SLOT_TP_Q = 94, SLOT_TP_R = 95 };
 
 // Forward exp of `n` stacked matrices sitting in slot 0 (variable 0 = A). Returns the device pointer of U.
 template <class T>
@@ -706,7 +707,7 @@ void check_ctx(Ctx<T>* c) {
 // number of steps whose exp() is built in one batched pass
 template <class T>
 int time_chunk(Ctx<T>* c, int n_steps) {
-  const double per_step = 24.0 * (double)c->mat_bytes();  // tape variables + their adjoints
+  const double per_step = 24.0 * (double)c->mat_bytes();  // tape variables + their adjoints (nominal)
   long tc = (long)(c->chunk_bytes / per_step);
   tc = std::max(1L, std::min<long>(tc, n_steps));
   tc = std::min<long>(tc, 16384);
@@ -843,7 +844,7 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
   c->psi[1].ensure(sb);
   HIPCK(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
   // composing propagators beats applying them one by one as soon as the batch is wider than the dimension
-  const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && B > d);
+  const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && (B > d || d <= c->small_dim));
   const int cur = forward_chain(c, uh, S, dt, B, 0, compose);
   c->last_composed = compose ? 1.0 : 0.0;
   out_copy(c, psi_out, c->psi[cur].p, sb);
@@ -862,6 +863,69 @@ void do_energy(Ctx<T>* c, const TT* psi_dev, int B, TT* lam_out /*2 M psi*/, dou
   c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(c->e_dev.d(), B, c->e_dev.d() + B, c->st); });
   if (energies) out_copy(c, energies, c->e_dev.p, sizeof(double) * (size_t)B);
   if (total) out_copy(c, total, c->e_dev.d() + B, sizeof(double));
+}
+
+// Time-parallel form of the operator backward sweep for one chunk of n steps (U = n stacked propagators, W = W at the
+// chunk's end). With the suffix products Q_j = U_{n-1} ... U_j (Q_n = I):  W_{j+1} = Q_{j+1}^H W Q_{j+1}, hence
+//     G_j = W_{j+1} U_j = Q_{j+1}^H (W Q_j),      W_start = Q_0^H (W Q_0)
+// -- every G_j of the chunk from batched products instead of 2n dependent launches (at d <= 1024 one d x d product
+// neither fills the chip nor hides its own latency). The suffix products come from a two-level scan: blocks of ~sqrt(n)
+// steps (aligned to the chunk's end), local suffixes L_j built block-parallel in b - 1 batched launches, block totals
+// chained (nblk - 1 products), Q_j = R_{k-1} L_j per block. About 4n products for the chunk in ~2 sqrt(n) + 4 launches.
+// Returns the new W (anti-Hermitian output form if herm_w).
+template <class T>
+typename dq::Cx<T>::type* tp_sweep(Ctx<T>* c, const typename dq::Cx<T>::type* U, typename dq::Cx<T>::type* G,
+                                   typename dq::Cx<T>::type* W, int n, bool herm_w) {
+  typedef typename dq::Cx<T>::type T2;
+  const int d = c->d;
+  const long nn = (long)c->nn();
+  int b = (int)std::ceil(std::sqrt((double)n));
+  b = std::max(1, std::min(b, n));
+  const int nblk = (n + b - 1) / b;
+  const int len_first = n - (nblk - 1) * b;  // the earliest block (k = nblk - 1) may be shorter
+  T2* L = c->mat(SLOT_TP_L, n);
+  T2* Q = c->mat(SLOT_TP_Q, (size_t)n + 1);
+  T2* Z = c->mat(SLOT_TP_Z, n);
+  T2* R = c->mat(SLOT_TP_R, nblk);
+  // block k (k = 0 latest in time) covers j in (n-1-(k+1)b, n-1-kb] cut at 0; its end element is e_k = n-1-kb
+  // 1. L[e_k] = U[e_k]
+  {
+    const int j0 = n - 1 - (nblk - 1) * b;  // smallest end index
+    HIPCK(hipMemcpy2DAsync(L + (size_t)j0 * nn, (size_t)b * c->mat_bytes(), U + (size_t)j0 * nn, (size_t)b * c->mat_bytes(),
+                           c->mat_bytes(), (size_t)nblk, hipMemcpyDeviceToDevice, c->st));
+  }
+  // 2. L[e_k - r] = L[e_k - r + 1] U[e_k - r], batched over the blocks that are longer than r
+  for (int r = 1; r < b; ++r) {
+    const int nb_r = (r < len_first) ? nblk : nblk - 1;
+    if (nb_r <= 0) break;
+    const int j0 = n - 1 - (nb_r - 1) * b - r;  // smallest j of this launch
+    c->zgemm(0, 0, d, d, d, 1.0, L + (size_t)(j0 + 1) * nn, d, (long)b * nn, U + (size_t)j0 * nn, d, (long)b * nn, 0.0,
+             L + (size_t)j0 * nn, d, (long)b * nn, nb_r);
+  }
+  // 3. block suffixes R_k = U_{n-1} ... U_{start_k}:  R_0 = L[start_0],  R_k = R_{k-1} L[start_k]
+  auto start_of = [&](int k) { return std::max(0, n - (k + 1) * b); };
+  HIPCK(hipMemcpyAsync(R, L + (size_t)start_of(0) * nn, c->mat_bytes(), hipMemcpyDeviceToDevice, c->st));
+  for (int k = 1; k < nblk; ++k)
+    c->zgemm(0, 0, d, d, d, 1.0, R + (size_t)(k - 1) * nn, d, 0, L + (size_t)start_of(k) * nn, d, 0, 0.0,
+             R + (size_t)k * nn, d, 0, 1);
+  // 4. Q_j = L_j in the latest block, R_{k-1} L_j in block k >= 1;  Q_n = I
+  {
+    const int s0 = start_of(0);
+    HIPCK(hipMemcpyAsync(Q + (size_t)s0 * nn, L + (size_t)s0 * nn, (size_t)(n - s0) * c->mat_bytes(),
+                         hipMemcpyDeviceToDevice, c->st));
+    for (int k = 1; k < nblk; ++k) {
+      const int sk = start_of(k), len = (n - k * b) - sk;
+      c->zgemm(0, 0, d, d, d, 1.0, R + (size_t)(k - 1) * nn, d, 0, L + (size_t)sk * nn, d, nn, 0.0, Q + (size_t)sk * nn, d,
+               nn, len);
+    }
+    c->lincomb(Q + (size_t)n * nn, 0, nullptr, nullptr, 1.0, 1, false);
+  }
+  // 5. Z_j = W Q_j;  6. G_j = Q_{j+1}^H Z_j;  7. W <- Q_0^H Z_0
+  c->zgemm(0, 0, d, d, d, 1.0, W, d, 0, Q, d, nn, 0.0, Z, d, nn, n);
+  c->zgemm(1, 0, d, d, d, 1.0, Q + nn, d, nn, Z, d, nn, 0.0, G, d, nn, n);
+  T2* Wn = c->mat(W == c->mat(SLOT_TREE, 1) ? SLOT_TREE + 1 : SLOT_TREE, 1);
+  c->zgemm(1, 0, d, d, d, 1.0, Q, d, 0, Z, d, 0, 0.0, Wn, d, 0, 1, herm_w ? -1 : 0);
+  return Wn;
 }
 
 template <class T>
@@ -889,8 +953,11 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   // psi_t rebuilds, memory independent of the chain length. (Unitary conjugations: the drift of W over S steps is
   // S * eps, 2e-13 relative at S = 2000.) The forward pass then needs no checkpoints either and, for batch > dim,
   // composes the propagators (forward_chain).
-  const bool opback = S > 0 && (c->compose_mode == 1 || (c->compose_mode < 0 && B >= d));
-  const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && B > d);
+  // Small dimensions (d <= small_dim, default 512) take the operator form for ANY batch: a d x d x B product per step is
+  // launch-latency bound there, while the operator form batches over the time chunk (tree-composed forward,
+  // time-parallel backward below).
+  const bool opback = S > 0 && (c->compose_mode == 1 || (c->compose_mode < 0 && (B >= d || d <= c->small_dim)));
+  const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && (B > d || d <= c->small_dim));
   c->last_composed = (opback && compose) ? 1.0 : 0.0;
   c->last_opback = opback ? 1.0 : 0.0;
   std::vector<double> uh = fetch_u(c, u, S);
@@ -1005,7 +1072,10 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
       const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
       const T2* U = build_propagators(c, p, c0, n, dt);
       T2* G = ubar_slot(c, p, n);
-      for (int t = n - 1; t >= 0; --t) {
+      const bool tpar = opback && (c->time_parallel == 1 ? n >= 2 : (c->time_parallel < 0 && n >= 4));
+      c->last_tpar = tpar ? 1.0 : 0.0;
+      if (tpar) W = tp_sweep(c, U, G, W, n, skew_w);
+      for (int t = tpar ? -1 : n - 1; t >= 0; --t) {
         const int tt = c0 + t;
         const T2* Ut = U + (size_t)t * c->nn();
         T2* Gt = G + (size_t)t * c->nn();
@@ -1253,6 +1323,10 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     const int q = (int)v;
     if (q < -1 || q > RQ_MAX) fail(DQ_ERR_INVALID, "real_path must be -1 (auto), 0 (off) or a polynomial size 1..6");
     c->real_mode = q;
+  } else if (s == "small_dim") {  // auto mode: dimensions up to this take the operator form for any batch width
+    c->small_dim = (int)v;
+  } else if (s == "time_parallel") {  // operator backward sweep of a chunk: -1 auto (>= 4 steps), 0 sequential, 1 always
+    c->time_parallel = (int)v < 0 ? -1 : ((int)v ? 1 : 0);
   } else if (s == "plan_steps") {  // checkpoint stride as if the chain had this many steps (0 = this call's length)
     if (v < 0) fail(DQ_ERR_INVALID, "plan_steps must be >= 0");
     c->plan_steps = (long)v;
@@ -1286,6 +1360,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "zgemm_alg") return sizeof(T) == 8 ? c->zgemm_alg : 1;
   if (s == "composed") return c->last_composed;
   if (s == "operator_backward") return c->last_opback;
+  if (s == "time_parallel") return c->last_tpar;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;
   if (s == "norm_H0") return c->nH0;

@@ -93,6 +93,9 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  * differentiated with 2q real products; auto = smallest q meeting expm_tol, complex tape if none does or if
  * force_degree / force_squarings are set or dim < "real_min_dim" (default 128: below it the chain is launch-bound and
  * the complex tape needs fewer launches)), "rgemm_cfg" (tile configuration of the real GEMM, 0 = auto).
+ * "small_dim" (default 512: dimensions up to it take the operator form -- composed forward, operator backward sweep -- for
+ * any batch width), "time_parallel" (-1 auto / 0 / 1: the operator backward sweep of a time chunk from suffix products,
+ * ~4n batched products instead of 2n dependent launches; auto = chunks of >= 4 steps).
  * dq_get_info names: "degree", "squarings", "products", "time_chunk", "checkpoint_stride", "theta", "hermitian",
  * "zgemm_alg", "composed", "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), ...
  * Unknown names -> DQ_ERR_INVALID. */

@@ -21,6 +21,9 @@ def _engine(H0, Hs, M=None):
     e.set_hamiltonians(H0, Hs)
     if M is not None:
         e.set_observable(M)
+    # these tests address the state form / operator form by batch width; the default additionally sends every
+    # dimension <= 512 to the operator form (covered by test_small_dimensions_* below and by the reference-API tests)
+    e.set_option("small_dim", 0)
     return e
 
 
@@ -322,6 +325,59 @@ def test_operator_form_backward_at_batch_equal_dim(oracle, objective):
     for l, g, f in ((l1, g1, f1), (l2, g2, f2), (l3, g3, f3)):
         assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL * B and np.max(np.abs(f - rf)) < TOL
     assert np.max(np.abs(g1 - g2)) < 1e-12 * B
+
+
+@pytest.mark.parametrize("real", [False, True])
+@pytest.mark.parametrize("n,K,B,S,chunk", [(3, 2, 8, 37, 11), (3, 2, 3, 37, 11), (2, 1, 1, 16, 16), (4, 3, 20, 23, 5),
+                                            (3, 2, 5, 9, 2), (2, 2, 4, 50, 50), (3, 1, 2, 7, 3)])
+def test_time_parallel_backward_sweep(oracle, real, n, K, B, S, chunk):
+    """Operator backward sweep of a time chunk from suffix products (two-level scan, ragged blocks) against the
+    sequential recursion and the oracle; any batch width (small dimensions take the operator form by default)."""
+    from diffquantum_amd.engine import Engine
+    d = 1 << n
+    H0, Hs, M = (problems.random_real_symmetric_problem if real else problems.random_hermitian_problem)(n, K, seed=S + B)
+    u = np.random.default_rng(S).uniform(-1, 1, (S, K))
+    dt = 0.02
+    psi0 = problems.random_states(d, B, seed=3)
+    res = {}
+    with Engine(d, K) as e:
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        e.set_option("real_min_dim", 1)
+        e.set_option("chunk_bytes", 24 * d * d * 16 * chunk)
+        for tp in (1, 0, -1):
+            e.set_option("time_parallel", tp)
+            res[tp] = e.energy_grad(u, dt, psi0)
+            assert e.info("operator_backward") == 1 and e.info("time_chunk") == chunk
+            if tp >= 0:
+                assert e.info("time_parallel") == tp
+        assert (e.info("real_path") >= 1) == real
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    for tp, (l, g, f, en) in res.items():
+        assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL * B and np.max(np.abs(f - rf)) < TOL, tp
+    assert np.max(np.abs(res[1][1] - res[0][1])) < 1e-12 * max(B, 1)
+
+
+def test_small_dimensions_take_the_operator_form_for_any_batch(oracle):
+    """d <= small_dim (512): composed forward + operator backward even for a single state (the reference's batch-1 case)."""
+    from diffquantum_amd.engine import Engine
+    n, K, S, dt = 4, 3, 40, 0.03
+    H0, Hs, M = problems.random_hermitian_problem(n, K, seed=9)
+    u = np.random.default_rng(1).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(16, 1, seed=2)
+    with Engine(16, K) as e:
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        fwd = e.propagate(u, dt, psi0)
+        assert e.info("composed") == 1
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        assert e.info("operator_backward") == 1 and e.info("time_parallel") == 1 and e.info("checkpoint_stride") == 0
+        e.set_option("small_dim", 0)
+        loss2, grad2, fin2, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("operator_backward") == 0 and e.info("checkpoint_stride") >= 1
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    assert np.max(np.abs(fwd - rf)) < TOL and np.max(np.abs(fin - rf)) < TOL
+    assert abs(loss - rl) < TOL and np.max(np.abs(grad - rg)) < TOL and np.max(np.abs(grad2 - rg)) < TOL
 
 
 def test_skew_trick_leaves_the_gradient_unchanged():

@@ -22,6 +22,7 @@ def _engine(H0, Hs, M=None, dtype="c128"):
     if M is not None:
         e.set_observable(M)
     e.set_option("real_min_dim", 1)   # auto mode only takes the real path from dim 128 up (launch-bound below)
+    e.set_option("small_dim", 0)      # state form for batch < dim (the default sends dim <= 512 to the operator form)
     return e
 
 

@@ -107,7 +107,11 @@ def test_g5_training_trace_five_epochs(G, demo):
     assert np.max(np.abs(coeff.detach().numpy() - G["g5_coeff"])) < 1e-9
     assert np.max(np.abs(sim.final_state.full()[:, 0] - G["g5_final_state"])) < 1e-9
     state, prob = sim.find_state(sim.final_state)
-    assert state == int(G["g5_cut"]) and np.max(np.abs(prob - G["g5_prob"])) < 1e-9
+    # the 4-cycle's two optimal cuts 1010 / 0101 are degenerate: after 5 epochs |psi_5|^2 = |psi_10|^2 to rounding, so the
+    # argmax (sim_plain.py:494-505) may land on either; the probability itself is pinned
+    assert state in (int(G["g5_cut"]), 15 - int(G["g5_cut"])) and np.max(np.abs(prob - G["g5_prob"])) < 1e-9
+    p = np.abs(sim.final_state.full()[:, 0]) ** 2
+    assert abs(p[5] - p[10]) < 1e-12
 
 
 def test_g7_batched_legendre_vs_reference_columns(G, tmp_path):
