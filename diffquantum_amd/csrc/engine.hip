@@ -276,7 +276,7 @@ struct Ctx : dq_ctx {
   double nH0 = 0.0;
   std::vector<double> nHk;
   // options
-  double checkpoint_bytes = 0.0, chunk_bytes = 8.0 * 1024 * 1024 * 1024, expm_tol = 0.0, herm_tol = 0.0;
+  double checkpoint_bytes = 0.0, chunk_bytes = 0.0, expm_tol = 0.0, herm_tol = 0.0;
   int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1, skew_trick = 1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0, last_tpar = 0;
@@ -708,7 +708,20 @@ void check_ctx(Ctx<T>* c) {
 template <class T>
 int time_chunk(Ctx<T>* c, int n_steps) {
   const double per_step = 24.0 * (double)c->mat_bytes();  // tape variables + their adjoints (nominal)
-  long tc = (long)(c->chunk_bytes / per_step);
+  double budget = c->chunk_bytes;
+  if (budget <= 0.0) {
+    // default: 8 GiB; at dimensions where one d x d product leaves most of the chip idle (d <= 1024) batching over time
+    // is what fills it, so a tenth of the free HBM (plus what the pool already holds) if that is more
+    budget = 8.0 * 1024 * 1024 * 1024;
+    if ((long)((c->d + 127) / 128) * ((c->d + 127) / 128) < c->n_cu) {
+      size_t fr = 0, tot = 0;
+      HIPCK(hipMemGetInfo(&fr, &tot));
+      double held = 0.0;
+      for (const auto& b : c->pool) held += (double)b.bytes;
+      budget = std::max(budget, 0.10 * ((double)fr + held));
+    }
+  }
+  long tc = (long)(budget / per_step);
   tc = std::max(1L, std::min<long>(tc, n_steps));
   tc = std::min<long>(tc, 16384);
   return (int)tc;
@@ -1072,7 +1085,9 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
       const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
       const T2* U = build_propagators(c, p, c0, n, dt);
       T2* G = ubar_slot(c, p, n);
-      const bool tpar = opback && (c->time_parallel == 1 ? n >= 2 : (c->time_parallel < 0 && n >= 4));
+      // auto: chunks of >= 4 steps at dimensions where one d x d product leaves most of the chip idle (d <= 1024)
+      const bool tpar = opback && (c->time_parallel == 1 ? n >= 2
+                                                         : (c->time_parallel < 0 && n >= 4 && (d + 127) / 128 * ((d + 127) / 128) < c->n_cu));
       c->last_tpar = tpar ? 1.0 : 0.0;
       if (tpar) W = tp_sweep(c, U, G, W, n, skew_w);
       for (int t = tpar ? -1 : n - 1; t >= 0; --t) {
@@ -1309,7 +1324,7 @@ void do_expm_vjp(Ctx<T>* c, const void* A, const void* Ubar, void* Abar, int bat
 template <class T>
 void do_set_option(Ctx<T>* c, const std::string& s, double v) {
   if (s == "checkpoint_bytes") c->checkpoint_bytes = v;
-  else if (s == "chunk_bytes") { if (!(v > 0)) fail(DQ_ERR_INVALID, "chunk_bytes must be > 0"); c->chunk_bytes = v; }
+  else if (s == "chunk_bytes") { if (v < 0) fail(DQ_ERR_INVALID, "chunk_bytes must be >= 0 (0 = default)"); c->chunk_bytes = v; }
   else if (s == "expm_tol") { if (!(v > 0)) fail(DQ_ERR_INVALID, "expm_tol must be > 0"); c->expm_tol = v; }
   else if (s == "force_degree") c->force_degree = (int)v;
   else if (s == "force_squarings") c->force_s = (int)v;

@@ -82,7 +82,8 @@ int dq_set_hamiltonians(dq_ctx* ctx, const void* H0, const void* Hs);
 int dq_set_observable(dq_ctx* ctx, const void* M);
 
 /* Tunables: "checkpoint_bytes" (state checkpoints of the adjoint sweep; 0 = 70 % of the free HBM), "plan_steps" (size the
- * checkpoint stride for a chain of this many steps even if the call is shorter), "chunk_bytes", "expm_tol", "force_degree", "force_squarings",
+ * checkpoint stride for a chain of this many steps even if the call is shorter), "chunk_bytes" (workspace for the steps
+ * whose propagators are built in one batched pass; 0 = 8 GiB, or 10 % of the free HBM if that is more and dim <= 1024), "expm_tol", "force_degree", "force_squarings",
  * "force_tile", "zgemm_alg" (0 = four real MFMAs per complex tile step, 1 = the three-multiplication
  * "3M" form on the 128x128 tile), "compose" (-1 auto / 0 / 1: dq_propagate multiplies the step propagators
  * together by a log-depth tree of batched products and applies the result once -- 8 d^3 instead of 8 d^2 batch

@@ -24,6 +24,8 @@ for n, B, S, kind in ((8, 1024, 1000, "qaoa"), (8, 256, 1000, "qaoa"), (8, 64, 1
         e.use_torch_stream()
         e.set_hamiltonians(H0, Hs)
         e.set_observable(M)
+        import os
+        if os.environ.get("DQ_CHUNK"): e.set_option("chunk_bytes", float(os.environ["DQ_CHUNK"]))
         dt = 1.0 / S if kind != "herm" else 0.02
         for mode in ("propagate", "energy_grad"):
             for rep in range(2):
@@ -39,3 +41,5 @@ for n, B, S, kind in ((8, 1024, 1000, "qaoa"), (8, 256, 1000, "qaoa"), (8, 64, 1
             print("n=%d d=%d B=%d S=%d %s %s: %.1f ms -> %.0f steps/s; kernels %.1f ms in %d launches; real_path %d opback %d chunk %d" % (
                 n, d, B, S, kind, mode, (t1 - t0) * 1e3, S / (t1 - t0), tot, nl, e.info("real_path"),
                 e.info("operator_backward") if mode == "energy_grad" else -1, e.info("time_chunk")))
+            if mode == "energy_grad":
+                print("      " + ", ".join("%s %.1f ms/%d" % (k, v["ms"], v["launches"]) for k, v in prof.items() if v["launches"]))
