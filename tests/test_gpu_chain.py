@@ -358,6 +358,26 @@ def test_time_parallel_backward_sweep(oracle, real, n, K, B, S, chunk):
     assert np.max(np.abs(res[1][1] - res[0][1])) < 1e-12 * max(B, 1)
 
 
+@pytest.mark.parametrize("tp", [1, 0])
+def test_operator_backward_drift_over_a_long_chain(oracle, tp):
+    """2000 steps (BASELINE's chain length) at a small dimension: W is conjugated by 2000 unitaries (sequential form) or
+    assembled from suffix products of up to 2000 factors (time-parallel form) -- the gradient stays inside 1e-10."""
+    from diffquantum_amd.engine import Engine
+    n, K, B, S, dt = 3, 2, 3, 2000, 0.004
+    H0, Hs, M = problems.random_hermitian_problem(n, K, seed=21)
+    u = problems.pulse_table(K, S, S * dt, seed=3)
+    psi0 = problems.random_states(8, B, seed=5)
+    with Engine(8, K) as e:
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        e.set_option("time_parallel", tp)
+        loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("operator_backward") == 1 and e.info("time_parallel") == tp
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    assert abs(loss - rl) < TOL * B and np.max(np.abs(fin - rf)) < TOL
+    assert np.max(np.abs(grad - rg)) < TOL, np.max(np.abs(grad - rg))
+
+
 def test_small_dimensions_take_the_operator_form_for_any_batch(oracle):
     """d <= small_dim (512): composed forward + operator backward even for a single state (the reference's batch-1 case)."""
     from diffquantum_amd.engine import Engine
