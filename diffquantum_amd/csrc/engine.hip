@@ -529,18 +529,22 @@ typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n, boo
 //   U_t = exp(A_t) = cos X_t + i sin X_t = C + i S,   C = sum_j cc_j Y^j,  S = X P,  P = sum_j sc_j Y^j,  Y = X^2
 // (the Taylor polynomial of degree 2q+1). All products are real products of commuting symmetric matrices:
 // q + 1 symmetric-output real GEMMs (d^3 flop each) instead of 3 complex ones (8 d^3 each).
-// Pool slots (real unless noted): X 0, Y_j j (j = 1..q <= 6), P 7, C 8, S 9, U 10 (complex); adjoints at SLOT_ADJ + slot,
-// G = Ubar at SLOT_ADJ + 10 (complex).
-enum { RS_X = 0, RS_P = 7, RS_C = 8, RS_S = 9, RS_U = 10, RQ_MAX = 6 };
+// Larger steps: the polynomial is evaluated at X / 2^s and squared s times in the real algebra,
+//   (C + iS)^2 = (C^2 - S^2) + i (2 C S):   C' = C C - S S,  S' = 2 C S     (3 symmetric-output products per squaring)
+// -- the real form of the complex tape's U <- U U, with the same 2^s amplification of the rounding error.
+// Pool slots (real unless noted): X 0, Y_j j (j = 1..q <= 6), P 7, C 8, S 9, U 10 (complex), squaring level i = 1..s:
+// C_i 12 + 2(i-1), S_i 13 + 2(i-1); adjoints at SLOT_ADJ + slot, G = Ubar at SLOT_ADJ + 10 (complex), second
+// cotangent pair of the squaring reverse at SLOT_ADJ + 12/13.
+enum { RS_X = 0, RS_P = 7, RS_C = 8, RS_S = 9, RS_U = 10, RS_LVL = 12, RQ_MAX = 6, RS_SMAX = 14 };
 
-ExpmPlan make_real_plan(int q) {
+ExpmPlan make_real_plan(int q, int s = 0) {
   ExpmPlan p;
   p.rq = q;
   p.m = 2 * q + 1;
-  p.s = 0;
+  p.s = s;
   p.out = RS_U;
   p.nvars = RS_U + 1;
-  p.nprod = q + 1;
+  p.nprod = q + 1 + 3 * s;
   double f = 1.0;  // (2j)!
   for (int j = 0; j <= q; ++j) {
     if (j > 0) f *= (2.0 * j - 1.0) * (2.0 * j);
@@ -582,9 +586,10 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
   const int q = p.rq;
   T* X = c->rmat(RS_X, n);
   const double by = (double)sizeof(T) * c->nn() * (c->K + 2.0) * n;
+  const double dts = std::ldexp(dt, -p.s);  // X = -(dt / 2^s) H
   c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->nn() * (c->K + 1.0) * n, by, [&] {
     return dq::rassemble_launch<T>(X, (const T*)c->H0r.p, (const T*)c->Hsr.p, c->u_dev.d() + (size_t)c0 * c->K, c->K,
-                                   (long)c->nn(), n, dt, c->st);
+                                   (long)c->nn(), n, dts, c->st);
   });
   const T* Y[RQ_MAX + 1];
   for (int j = 1; j <= q; ++j) {
@@ -597,11 +602,20 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
   rlincomb2(c, Cm, P, q, Y + 1, p.cc + 1, p.sc + 1, p.cc[0], p.sc[0], n, false);
   T* S = c->rmat(RS_S, n);
   c->rmm(X, P, S, n, true);
+  for (int i = 1; i <= p.s; ++i) {  // (C + iS) <- (C + iS)^2
+    T* Cn = c->rmat(RS_LVL + 2 * (i - 1), n);
+    T* Sn = c->rmat(RS_LVL + 2 * (i - 1) + 1, n);
+    c->rmm(Cm, Cm, Cn, n, true, false, 1.0, false);
+    c->rmm(S, S, Cn, n, true, false, -1.0, true);
+    c->rmm(Cm, S, Sn, n, true, false, 2.0, false);
+    Cm = Cn;
+    S = Sn;
+  }
   T2* U = c->mat(RS_U, n);
   const long ne = (long)c->nn() * n;
   c->timed(DQ_PROF_LINCOMB, 0.0, 4.0 * sizeof(T) * ne, [&] { return dq::pack_u_launch<T>(U, Cm, S, ne, c->st); });
   c->last_degree = p.m;
-  c->last_squarings = 0;
+  c->last_squarings = p.s;
   c->last_products = p.nprod;
   c->last_real_q = q;
   return U;
@@ -625,13 +639,30 @@ const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
   for (int j = 1; j <= q; ++j) { Y[j] = c->rmat(j, n); Yb[j] = c->rmat(SLOT_ADJ + j, n); }
   T* Xb = c->rmat(SLOT_ADJ + RS_X, n);
   T* Pb = c->rmat(SLOT_ADJ + RS_P, n);
-  T* Cb = c->rmat(SLOT_ADJ + RS_C, n);
-  T* Sb = c->rmat(SLOT_ADJ + RS_S, n);
-  c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n, 6.0 * sizeof(T) * c->nn() * n,
-           [&] { return dq::split_g_launch<T>(G, Cb, Sb, c->d, (long)c->nn(), n, c->st); });
   // sym2(W, V, out, a): out (+)= a (W V + V W)  -- one symmetric-output launch with both products (no full-matrix
   // round trip, no symmetrisation pass); a = 1/2 gives sym(W V), a = 1 gives 2 sym(W V)
   auto sym2 = [&](const T* W, const T* V, T* out, double a, bool acc) { c->rmm(W, V, out, n, true, true, a, acc); };
+  // cotangents of (C_s, S_s) from G, then back through the squarings; two slot pairs alternate so that the cotangents of
+  // the polynomial's (C_0, S_0) end up in SLOT_ADJ + RS_C / RS_S
+  T* pairA[2] = {c->rmat(SLOT_ADJ + RS_C, n), c->rmat(SLOT_ADJ + RS_S, n)};
+  T* pairB[2] = {c->rmat(SLOT_ADJ + RS_LVL, n), c->rmat(SLOT_ADJ + RS_LVL + 1, n)};
+  T** cur = (p.s & 1) ? pairB : pairA;
+  c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n, 6.0 * sizeof(T) * c->nn() * n,
+           [&] { return dq::split_g_launch<T>(G, cur[0], cur[1], c->d, (long)c->nn(), n, c->st); });
+  for (int i = p.s; i >= 1; --i) {
+    // C_i = C C - S S,  S_i = 2 C S  with (C, S) = level i-1:
+    //   Cbar = 2 sym(Cbar_i C) + 2 sym(Sbar_i S),   Sbar = -2 sym(Cbar_i S) + 2 sym(Sbar_i C)
+    const T* Cp = i == 1 ? c->rmat(RS_C, n) : c->rmat(RS_LVL + 2 * (i - 2), n);
+    const T* Sp = i == 1 ? c->rmat(RS_S, n) : c->rmat(RS_LVL + 2 * (i - 2) + 1, n);
+    T** nxt = cur == pairA ? pairB : pairA;
+    sym2(cur[0], Cp, nxt[0], 1.0, false);
+    sym2(cur[1], Sp, nxt[0], 1.0, true);
+    sym2(cur[0], Sp, nxt[1], -1.0, false);
+    sym2(cur[1], Cp, nxt[1], 1.0, true);
+    cur = nxt;
+  }
+  T* Cb = cur[0];
+  T* Sb = cur[1];
   // S = X P
   sym2(Sb, P, Xb, 0.5, false);
   sym2(Sb, X, Pb, 0.5, false);
@@ -761,9 +792,20 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
   c->last_real_q = 0;
   if (c->real_h && c->real_mode != 0) {
     if (c->real_mode > 0) return make_real_plan(std::min(c->real_mode, (int)RQ_MAX));
-    if (c->force_degree <= 0 && c->force_s < 0 && c->d >= c->real_min_dim)  // (those options address the complex tape)
-      for (int q = 1; q <= RQ_MAX; ++q)
-        if (taylor_remainder(th, 2 * q + 1) <= c->expm_tol) return make_real_plan(q);
+    if (c->force_degree <= 0 && c->force_s < 0 && c->d >= c->real_min_dim) {  // (those options address the complex tape)
+      // cheapest (q, s): q + 1 products for the polynomial at theta / 2^s plus 3 per squaring
+      int bq = 0, bs = 0, best = 1 << 30;
+      for (int sq = 0; sq <= RS_SMAX; ++sq) {
+        const double ths = std::ldexp(th, -sq);
+        for (int q = 1; q <= RQ_MAX; ++q)
+          if (taylor_remainder(ths, 2 * q + 1) <= c->expm_tol) {
+            if (q + 1 + 3 * sq < best) { best = q + 1 + 3 * sq; bq = q; bs = sq; }
+            break;
+          }
+        if (best <= 3 * (sq + 1)) break;  // more squarings cannot win any more
+      }
+      if (bq > 0) return make_real_plan(bq, bs);
+    }
   }
   return choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
 }
@@ -1124,7 +1166,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
         const T* Xbar = real_backward(c, p, n);
         const double byr = (double)sizeof(T) * c->nn() * (K + ((K + 15) / 16)) * n;
         c->timed(DQ_PROF_GRADC, 2.0 * c->nn() * K * n, byr, [&] {
-          return dq::rgrad_contract_launch<T>(Xbar, (long)c->nn(), (const T*)c->Hsr.p, K, (long)c->nn(), n, -dt,
+          return dq::rgrad_contract_launch<T>(Xbar, (long)c->nn(), (const T*)c->Hsr.p, K, (long)c->nn(), n, -std::ldexp(dt, -p.s),
                                               c->part.d(), c->grad_dev.d() + (size_t)c0 * K, c->st);
         });
         continue;

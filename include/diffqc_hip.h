@@ -91,7 +91,8 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  * anti-Hermitian part of the generator cotangent, saving one ZGEMM per step; 0 = plain reverse mode),
  * "real_path" (-1 auto / 0 off / q = 1..6 forced: when H0 and all H_k are real, exp(-i dt H) = cos X + i sin X with
  * X = -dt H real symmetric is evaluated with q + 1 real symmetric-output products, Taylor degree 2q + 1, and
- * differentiated with 2q real products; auto = smallest q meeting expm_tol, complex tape if none does or if
+ * differentiated with 2q real products; larger steps are scaled by 2^-s and squared in the real algebra, three
+ * symmetric-output products per squaring; auto = cheapest (q, s) meeting expm_tol; complex tape if
  * force_degree / force_squarings are set or dim < "real_min_dim" (default 128: below it the chain is launch-bound and
  * the complex tape needs fewer launches)), "rgemm_cfg" (tile configuration of the real GEMM, 0 = auto).
  * "small_dim" (default 512: dimensions up to it take the operator form -- composed forward, operator backward sweep -- for

@@ -267,13 +267,37 @@ def test_complex_or_large_step_hamiltonians_take_the_complex_tape(oracle):
         assert e.info("real_path") == 0
     H0, Hs, M = problems.random_real_symmetric_problem(3, 2, seed=3)
     with _engine(H0, Hs, M) as e:
-        # theta ~ 30: no polynomial of size <= 6 meets the tolerance -> scaling and squaring on the complex tape
-        got = e.propagate(10 * u, 1.0, psi0)
-        assert e.info("real_path") == 0 and e.info("squarings") > 0
-        assert np.max(np.abs(got - oracle.propagate(H0, list(Hs), 10 * u, 1.0, psi0))) < TOL
         e.set_option("force_degree", 9)                                     # addresses the complex tape
         e.propagate(u, 0.1, psi0)
         assert e.info("real_path") == 0 and e.info("degree") == 9
+        e.set_option("force_degree", 0)
+        e.set_option("force_squarings", 2)                                  # so does this
+        e.propagate(u, 0.1, psi0)
+        assert e.info("real_path") == 0 and e.info("squarings") == 2
+
+
+@pytest.mark.parametrize("n,K,B,S,theta", [(3, 2, 2, 3, 30.0), (3, 2, 9, 5, 2.0), (4, 3, 5, 4, 0.9), (2, 1, 3, 6, 200.0),
+                                           (5, 2, 40, 3, 7.0)])
+def test_large_steps_square_in_the_real_algebra(oracle, n, K, B, S, theta):
+    """theta beyond the polynomials' range: cos/sin at X / 2^s, then s squarings (C, S) <- (C^2 - S^2, 2 C S) with real
+    symmetric-output products, and their reverse mode -- against the oracle and the complex tape."""
+    H0, Hs, M = problems.random_real_symmetric_problem(n, K, seed=n + K)
+    u = np.random.default_rng(S).uniform(-2, 2, (S, K))
+    dt = _dt(H0, Hs, 2.0, theta)
+    psi0 = problems.random_states(1 << n, B, seed=1)
+    with _engine(H0, Hs, M) as e:
+        fwd = e.propagate(u, dt, psi0)
+        assert e.info("real_path") >= 1 and e.info("squarings") >= 1
+        assert e.info("products") == e.info("real_path") + 1 + 3 * e.info("squarings")
+        loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
+        e.set_option("real_path", 0)
+        loss_c, grad_c, fin_c, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("real_path") == 0
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    scale = max(1.0, theta)   # d exp / dA grows with the step: same relative budget
+    assert np.max(np.abs(fwd - rf)) < TOL * scale and np.max(np.abs(fin - rf)) < TOL * scale
+    assert abs(loss - rl) < TOL * B * scale and np.max(np.abs(grad - rg)) < TOL * B * scale
+    assert np.max(np.abs(grad - grad_c)) < TOL * B * scale
 
 
 def test_real_path_d256_through_the_128_tile(oracle):
@@ -306,18 +330,18 @@ def test_real_path_fp32(oracle):
 
 def test_reference_demo_hamiltonians(oracle):
     """The MaxCut problem of the reference demo (ZZ drift, ZZ + X controls, demo_maxcut.py:36-79) is real. With the
-    demo's own step (per_step = 10: dt = 1/15, theta ~ 2) the exponential needs scaling and squaring -> complex tape;
-    with a finer grid the same problem runs on the real path. Both match the oracle."""
+    demo's own step (per_step = 10: dt = 1/15, theta ~ 2) the real path squares three times; with a finer grid it needs
+    no squaring. Both match the oracle. (In auto mode d = 16 stays on the complex tape: launch-bound, real_min_dim.)"""
     pr = problems.maxcut_problem()
     H0, Hs, M = pr["H0"].astype(complex), pr["Hs"].astype(complex), pr["H_cost"].astype(complex)
     T = pr["T"]
     psi0 = pr["psi0"].astype(complex).reshape(-1, 1)
     with _engine(H0, Hs, M) as e:
         assert e.info("real_hamiltonians") == 1
-        for S, real in ((30, False), (400, True)):
+        for S, squared in ((30, True), (400, False)):
             u = problems.pulse_table(len(Hs), S, T, seed=7)
             loss, grad, fin, _ = e.energy_grad(u, T / S, psi0)
-            assert (e.info("real_path") >= 1) == real
+            assert e.info("real_path") >= 1 and (e.info("squarings") > 0) == squared
             rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, T / S, psi0)
             assert np.max(np.abs(fin - rf)) < TOL and abs(loss - rl) < TOL and np.max(np.abs(grad - rg)) < TOL
 

@@ -52,6 +52,28 @@ def backward(X, q, saved, G):
     return Xb + sym2(Yb[1], X, 1.0)
 
 
+def forward_squared(X, q, s):
+    """cos/sin at X / 2^s, then s squarings in the real algebra: (C, S) <- (C C - S S, 2 C S)."""
+    U0, saved = forward(X / 2.0 ** s, q)
+    C, S = U0.real, U0.imag
+    levels = [(C, S)]
+    for _ in range(s):
+        C, S = C @ C - S @ S, 2.0 * (C @ S)
+        levels.append((C, S))
+    return C + 1j * S, (saved, levels)
+
+
+def backward_squared(X, q, s, saved, G):
+    """Xbar through the squarings (4 two-product launches per level) and the polynomial; d(X / 2^s) = dX / 2^s."""
+    poly_saved, levels = saved
+    Cb = 0.5 * (G.real + G.real.T)
+    Sb = 0.5 * (G.imag + G.imag.T)
+    for i in range(s, 0, -1):
+        C, S = levels[i - 1]
+        Cb, Sb = sym2(Cb, C, 1.0) + sym2(Sb, S, 1.0), sym2(Cb, S, -1.0) + sym2(Sb, C, 1.0)
+    return backward(X / 2.0 ** s, q, poly_saved, Cb + 1j * Sb) / 2.0 ** s
+
+
 def random_symmetric(d, norm, seed):
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((d, d))
@@ -91,6 +113,23 @@ def test_reverse_mode_is_the_exact_adjoint_of_the_scheme(q):
     if q >= 5:   # remainder below 1e-10 at this norm: also equals the derivative of the true exponential
         L = scipy.linalg.expm_frechet(1j * X, 1j * E, compute_expm=False)
         assert abs(lhs - float(np.real(np.trace(G.conj().T @ L)))) < 1e-9 * max(1.0, abs(rhs))
+
+
+@pytest.mark.parametrize("theta,s", [(1.5, 2), (6.0, 4), (40.0, 7)])
+def test_squarings_in_the_real_algebra(theta, s):
+    d, q = 10, 6
+    X = random_symmetric(d, theta, int(theta))
+    U, saved = forward_squared(X, q, s)
+    ref = scipy.linalg.expm(1j * X)
+    assert np.max(np.abs(U - ref)) < 1e-13 * 2 ** s
+    rng = np.random.default_rng(s)
+    G = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    Xb = backward_squared(X, q, s, saved, G)
+    E = rng.standard_normal((d, d))
+    E = E + E.T
+    L = scipy.linalg.expm_frechet(1j * X, 1j * E, compute_expm=False)
+    lhs, rhs = float(np.sum(Xb * E)), float(np.real(np.trace(G.conj().T @ L)))
+    assert abs(lhs - rhs) < 1e-11 * 2 ** s * max(1.0, abs(rhs))
 
 
 def test_gradient_of_a_two_step_chain_matches_the_oracle(oracle):
