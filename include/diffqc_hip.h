@@ -81,26 +81,31 @@ int dq_set_hamiltonians(dq_ctx* ctx, const void* H0, const void* Hs);
 /* Observable M ([dim][dim], Hermitian) of the energy loss <psi|M|psi> (sim_plain.py:281). */
 int dq_set_observable(dq_ctx* ctx, const void* M);
 
-/* Tunables: "checkpoint_bytes" (state checkpoints of the adjoint sweep; 0 = 70 % of the free HBM), "plan_steps" (size the
- * checkpoint stride for a chain of this many steps even if the call is shorter), "chunk_bytes" (workspace for the steps
- * whose propagators are built in one batched pass; 0 = 8 GiB, or 10 % of the free HBM if that is more and dim <= 1024), "expm_tol", "force_degree", "force_squarings",
- * "force_tile", "zgemm_alg" (0 = four real MFMAs per complex tile step, 1 = the three-multiplication
- * "3M" form on the 128x128 tile), "compose" (-1 auto / 0 / 1: dq_propagate multiplies the step propagators
- * together by a log-depth tree of batched products and applies the result once -- 8 d^3 instead of 8 d^2 batch
- * flops per step; auto = when batch > dim), "skew_trick" (1 default: the adjoint sweep computes only the
- * anti-Hermitian part of the generator cotangent, saving one ZGEMM per step; 0 = plain reverse mode),
- * "real_path" (-1 auto / 0 off / q = 1..6 forced: when H0 and all H_k are real, exp(-i dt H) = cos X + i sin X with
- * X = -dt H real symmetric is evaluated with q + 1 real symmetric-output products, Taylor degree 2q + 1, and
- * differentiated with 2q real products; larger steps are scaled by 2^-s and squared in the real algebra, three
- * symmetric-output products per squaring; auto = cheapest (q, s) meeting expm_tol; complex tape if
- * force_degree / force_squarings are set or dim < "real_min_dim" (default 128: below it the chain is launch-bound and
- * the complex tape needs fewer launches)), "rgemm_cfg" (tile configuration of the real GEMM, 0 = auto).
- * "small_dim" (default 512: dimensions up to it take the operator form -- composed forward, operator backward sweep -- for
- * any batch width), "time_parallel" (-1 auto / 0 / 1: the operator backward sweep of a time chunk from suffix products,
- * ~4n batched products instead of 2n dependent launches; auto = chunks of >= 4 steps).
- * dq_get_info names: "degree", "squarings", "products", "time_chunk", "checkpoint_stride", "theta", "hermitian",
- * "zgemm_alg", "composed", "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), ...
- * Unknown names -> DQ_ERR_INVALID. */
+/* Options (dq_set_option; unknown names -> DQ_ERR_INVALID). Defaults pick the fastest scheme for the shape at hand.
+ *   expm_tol           Taylor remainder bound of the step exponential (2^-53 fp64, 2^-24 fp32)
+ *   force_degree, force_squarings   pin the complex tape's polynomial degree / number of squarings
+ *   real_path          -1 auto / 0 off / q = 1..6 forced. H0 and all H_k real: exp(-i dt H) = cos X + i sin X with
+ *                      X = -dt H real symmetric, evaluated with q + 1 real symmetric-output products (Taylor degree 2q + 1)
+ *                      and differentiated with 2q; larger steps are scaled by 2^-s and squared in the real algebra (three
+ *                      symmetric products per squaring); auto = cheapest (q, s) meeting expm_tol
+ *   real_min_dim       auto real path only from this dimension up (128; below it the chain is launch-bound)
+ *   compose            -1 auto / 0 / 1: operator form. Forward: the step propagators are multiplied together by a
+ *                      log-depth tree of batched products and applied once (auto: batch > dim or dim <= small_dim);
+ *                      backward: the sweep runs on W = Lambda Psi^H (dim x dim) and keeps no state checkpoints
+ *                      (auto: batch >= dim or dim <= small_dim)
+ *   small_dim          512: dimensions up to it take the operator form for any batch width
+ *   time_parallel      -1 auto / 0 / 1: operator backward sweep of a time chunk from suffix products (~4n batched
+ *                      products instead of 2n dependent launches; auto: chunks of >= 4 steps at dim <= 1024)
+ *   skew_trick         1: only the anti-Hermitian parts of the generator cotangent / of W are carried (saves products)
+ *   checkpoint_bytes   state checkpoints of the state-form sweep (batch < dim); 0 = 70 % of the free HBM
+ *   plan_steps         size the checkpoint stride for a chain of this many steps even if the call is shorter
+ *   chunk_bytes        workspace for the steps whose propagators are built in one batched pass; 0 = 8 GiB, or 10 % of
+ *                      the free HBM if that is more and dim <= 1024
+ *   zgemm_alg          0 = four real MFMAs per complex tile step, 1 = the three-multiplication "3M" form (128x128 tile)
+ *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
+ * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
+ * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
+ * "time_parallel", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 
