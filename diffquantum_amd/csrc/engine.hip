@@ -1011,7 +1011,12 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   // Small dimensions (d <= small_dim, default 512) take the operator form for ANY batch: a d x d x B product per step is
   // launch-latency bound there, while the operator form batches over the time chunk (tree-composed forward,
   // time-parallel backward below).
-  const bool opback = S > 0 && (c->compose_mode == 1 || (c->compose_mode < 0 && (B >= d || d <= c->small_dim)));
+  // (state form: G and Lambda cost 2 x 3 x B/d units per step, operator form 3 + 1.5 -> the crossover is at B = 3d/4)
+  // A forced (possibly under-resolved) polynomial keeps the state form in auto mode: the operator form uses
+  // U_t^{-1} = U_t^H, exact only up to the Taylor remainder.
+  const bool forced_plan = c->force_degree > 0 || c->real_mode > 0;
+  const bool opback = S > 0 && (c->compose_mode == 1 ||
+                                (c->compose_mode < 0 && !forced_plan && (4L * B >= 3L * d || d <= c->small_dim)));
   const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && (B > d || d <= c->small_dim));
   c->last_composed = (opback && compose) ? 1.0 : 0.0;
   c->last_opback = opback ? 1.0 : 0.0;

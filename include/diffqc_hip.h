@@ -92,7 +92,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   compose            -1 auto / 0 / 1: operator form. Forward: the step propagators are multiplied together by a
  *                      log-depth tree of batched products and applied once (auto: batch > dim or dim <= small_dim);
  *                      backward: the sweep runs on W = Lambda Psi^H (dim x dim) and keeps no state checkpoints
- *                      (auto: batch >= dim or dim <= small_dim)
+ *                      (auto: batch >= 3/4 dim or dim <= small_dim)
  *   small_dim          512: dimensions up to it take the operator form for any batch width
  *   time_parallel      -1 auto / 0 / 1: operator backward sweep of a time chunk from suffix products (~4n batched
  *                      products instead of 2n dependent launches; auto: chunks of >= 4 steps at dim <= 1024)
