@@ -450,3 +450,38 @@ def test_properties_at_n12_full_dimension(dtype, tol):
         lm = e.energy(e.propagate(u - eps * v, dt, psi0))[1]
         fd, an = (lp - lm) / (2 * eps), float(np.sum(grad * v))
         assert abs(fd - an) < (1e-6 if dtype == "c128" else 5e-3) * max(1.0, abs(an)), (fd, an)
+
+
+def test_headline_shape_all_schemes_agree():
+    """BASELINE configs[2] at full size (n = 12, d = 4096, B = 4096, fp64), 3 steps: the four evaluation schemes of the
+    same chain -- real path / complex tape x operator-form / state-form backward sweep -- give the same loss and
+    gradient (the oracle needs ~45 s per step at this size: bench.py's cpu_baseline; parity with it is pinned at small
+    sizes, this test pins the schemes against each other where the 128-tile kernels, the K-split tails and the
+    LDS-DMA staging are actually exercised)."""
+    import torch
+    from diffquantum_amd.engine import Engine
+    n, B, S, dt = 12, 4096, 3, 1e-3
+    d = 1 << n
+    dev = torch.device("cuda:0")
+    H0, Hs, M = problems.random_ising_torch(n, 0, dev)
+    u = problems.pulse_table(n, S, S * dt, seed=0)
+    psi0 = torch.from_numpy(problems.random_states(d, B, seed=1)).to(dev)
+    res = {}
+    with Engine(d, n) as e:
+        e.use_torch_stream()
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        for real in (-1, 0):
+            for comp in (-1, 0):
+                e.set_option("real_path", real)
+                e.set_option("compose", comp)
+                loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+                assert (e.info("real_path") >= 1) == (real == -1) and e.info("operator_backward") == (1 if comp else 0)
+                res[(real, comp)] = (loss, grad, fin)
+                assert abs(float(en.sum()) - loss) < 1e-9
+                assert float((torch.linalg.norm(fin, dim=0) - 1).abs().max()) < 1e-12
+    l0, g0, f0 = res[(-1, -1)]
+    for key, (l, g, f) in res.items():
+        assert abs(l - l0) < 1e-10 * B, key
+        assert np.max(np.abs(g - g0)) < 1e-10, key           # gradient entries are ~5e-3
+        assert float((f - f0).abs().max()) < 1e-12, key
