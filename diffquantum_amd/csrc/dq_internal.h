@@ -104,6 +104,11 @@ template <class T>
 hipError_t fidelity_costate_launch(const typename Cx<T>::type* phi, const typename Cx<T>::type* psi, int d, int B,
                                    double scale, double* part, double* cvals, double* fid,
                                    typename Cx<T>::type* lam, hipStream_t st);
+// shifted states (phi +- i r H_k phi) / sqrt(1 + r^2) of the reference's Monte-Carlo estimator (sim_plain.py:194-199);
+// HP is [K][d][B], out is [d][B * K * 2] (column (b K + k) 2 + s, s = 0 plus / 1 minus)
+template <class T>
+hipError_t mc_shift_launch(const typename Cx<T>::type* phi, const typename Cx<T>::type* HP, int d, int B, int K, double r,
+                           typename Cx<T>::type* out, hipStream_t st);
 // out[0] = sum_b e[b]  (single block, deterministic)
 hipError_t sum_launch(const double* e, int n, double* out, hipStream_t st);
 // colsum[j] = sum_i |X[i][j]|  (for the 1-norm), d x d

@@ -359,6 +359,47 @@ template hipError_t fidelity_costate_launch<double>(const double2*, const double
 template hipError_t fidelity_costate_launch<float>(const float2*, const float2*, int, int, double, double*, double*,
                                                    double*, float2*, hipStream_t);
 
+// ---- shifted states of the reference's Monte-Carlo estimator -------------------------------------------------
+// sim_plain.py:194-199: gate_+- = (I +- i r H_k) / sqrt(1 + r^2) applied to phi. HP[k][i][b] = (H_k phi_b)_i;
+// out[i][(b K + k) 2 + s] = (phi[i][b] + sign_s i r HP[k][i][b]) / sqrt(1 + r^2), s = 0: +, s = 1: -.
+template <class T>
+__global__ void __launch_bounds__(256) mc_shift_kernel(const typename Cx<T>::type* __restrict__ phi,
+                                                       const typename Cx<T>::type* __restrict__ HP, int d, int B, int K,
+                                                       double r_, typename Cx<T>::type* __restrict__ out) {
+  typedef typename Cx<T>::type T2;
+  const long n = (long)d * B * K;
+  const T r = (T)r_, inv = (T)(1.0 / sqrt(1.0 + r_ * r_));
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    const long ib = e / K;          // i * B + b
+    const int b = (int)(ib % B);
+    const long i = ib / B;
+    const T2 p = phi[ib];
+    const T2 h = HP[((long)k * d + i) * B + b];
+    T2 plus, minus;                  // i r h = r (-h.y, h.x)
+    plus.x = (p.x - r * h.y) * inv;
+    plus.y = (p.y + r * h.x) * inv;
+    minus.x = (p.x + r * h.y) * inv;
+    minus.y = (p.y - r * h.x) * inv;
+    T2* o = out + (i * (long)B * K + (long)b * K + k) * 2;
+    o[0] = plus;
+    o[1] = minus;
+  }
+}
+
+template <class T>
+hipError_t mc_shift_launch(const typename Cx<T>::type* phi, const typename Cx<T>::type* HP, int d, int B, int K, double r,
+                           typename Cx<T>::type* out, hipStream_t st) {
+  const long n = (long)d * B * K;
+  if (n <= 0) return hipSuccess;
+  long nb = (n + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(mc_shift_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, phi, HP, d, B, K, r, out);
+  return hipGetLastError();
+}
+template hipError_t mc_shift_launch<double>(const double2*, const double2*, int, int, int, double, double2*, hipStream_t);
+template hipError_t mc_shift_launch<float>(const float2*, const float2*, int, int, int, double, float2*, hipStream_t);
+
 __global__ void __launch_bounds__(256) sum_kernel(const double* __restrict__ e, int n, double* __restrict__ out) {
   __shared__ double red[256];
   double v = 0.0;

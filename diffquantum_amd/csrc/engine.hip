@@ -1188,6 +1188,58 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   HIPCK(hipStreamSynchronize(c->st));
 }
 
+// The reference's "parameter-shift in time" Monte-Carlo estimator as one device-resident operation
+// (compute_energy_grad_MC, sim_plain.py:156-231): evolve 0 -> s on the first time grid, apply the 2K gates
+// (I +- i r H_k)/sqrt(1 + r^2), evolve all 2K shifted states s -> T on the second grid as ONE batch, measure M, and
+// return ps[b][k] = (1 + r^2)/(2 r) (<M>_- - <M>_+)  (sim_plain.py:220). The chain rule to the spectral coefficients
+// (du_k(s)/dv, sim_plain.py:170-184,227) stays on the host.
+template <class T>
+void do_mc_shift(Ctx<T>* c, const double* u_a, int n_a, double dt_a, const double* u_b, int n_b, double dt_b,
+                 const void* psi0, int B, double r, double* ps, void* phi_out) {
+  typedef TT T2;
+  check_ctx(c);
+  require_H(c);
+  if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
+  if (n_a < 0 || n_b < 0 || B <= 0) fail(DQ_ERR_INVALID, "step counts must be >= 0 and batch > 0");
+  if (!std::isfinite(dt_a) || !std::isfinite(dt_b) || !(r > 0.0) || !std::isfinite(r))
+    fail(DQ_ERR_INVALID, "dt must be finite and r > 0");
+  if (!psi0 || !ps) fail(DQ_ERR_INVALID, "null pointer");
+  if (c->K > 0 && ((n_a > 0 && !u_a) || (n_b > 0 && !u_b))) fail(DQ_ERR_INVALID, "null pulse table");
+  const int d = c->d, K = c->K;
+  const int B2 = 2 * K * B;
+  const size_t sb = (size_t)d * B * sizeof(T2), sb2 = (size_t)d * std::max(B2, 1) * sizeof(T2);
+  const bool small = d <= c->small_dim;
+  // phase 1: phi = chain_a psi0
+  std::vector<double> ua = fetch_u(c, u_a, n_a);
+  for (int i = 0; i < 2; ++i) c->psi[i].ensure(std::max(sb, sb2));
+  HIPCK(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
+  int cur = forward_chain(c, ua, n_a, dt_a, B, 0, c->compose_mode == 1 || (c->compose_mode < 0 && (B > d || small)));
+  if (phi_out) out_copy(c, phi_out, c->psi[cur].p, sb);
+  if (K == 0) { HIPCK(hipStreamSynchronize(c->st)); return; }
+  // phase 2: H_k phi for all k (one batched product), the 2K shifted states per trajectory
+  c->lam[0].ensure((size_t)K * sb);
+  c->lam[1].ensure(sb2);
+  c->zgemm(0, 0, d, B, d, 1.0, (const T2*)c->Hs.p, d, (long)c->nn(), (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->lam[0].p, B,
+           (long)d * B, K);
+  c->timed(DQ_PROF_OTHER, 8.0 * d * B * K, (double)sizeof(T2) * d * B * (1.0 + 3.0 * K), [&] {
+    return dq::mc_shift_launch<T>((const T2*)c->psi[cur].p, (const T2*)c->lam[0].p, d, B, K, r, (T2*)c->lam[1].p, c->st);
+  });
+  // phase 3: evolve the shifted batch s -> T and measure
+  std::vector<double> ub = fetch_u(c, u_b, n_b);
+  HIPCK(hipMemcpyAsync(c->psi[0].p, c->lam[1].p, sb2, hipMemcpyDeviceToDevice, c->st));
+  cur = forward_chain(c, ub, n_b, dt_b, B2, 0, c->compose_mode == 1 || (c->compose_mode < 0 && (B2 > d || small)));
+  std::vector<double> en(B2);
+  do_energy(c, (const T2*)c->psi[cur].p, B2, (T2*)c->lam[1].p, nullptr, nullptr);
+  HIPCK(hipMemcpyAsync(en.data(), c->e_dev.p, sizeof(double) * (size_t)B2, hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  std::vector<double> out((size_t)B * K);
+  const double f = (1.0 + r * r) / (2.0 * r);
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < K; ++k) out[(size_t)b * K + k] = f * (en[((size_t)b * K + k) * 2 + 1] - en[((size_t)b * K + k) * 2]);
+  HIPCK(hipMemcpyAsync(ps, out.data(), sizeof(double) * out.size(), hipMemcpyDefault, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
 template <class T>
 void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
   typedef TT T2;
@@ -1586,6 +1638,11 @@ int dq_fidelity_grad(dq_ctx* c, const double* u, int n_steps, double dt, const v
     if (!targets) fail(DQ_ERR_INVALID, "null target states");
     do_energy_grad(t, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, fidelities, targets);
   });
+}
+
+int dq_mc_shift_grad(dq_ctx* c, const double* u_a, int n_a, double dt_a, const double* u_b, int n_b, double dt_b,
+                     const void* psi0, int batch, double r, double* ps, void* phi_out) {
+  return with_ctx(c, [&](auto* t) { do_mc_shift(t, u_a, n_a, dt_a, u_b, n_b, dt_b, psi0, batch, r, ps, phi_out); });
 }
 
 int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,

@@ -233,6 +233,22 @@ class Engine:
                                               grad.ctypes.data, pf, fid.ctypes.data))
         return loss.value, grad, fin, fid
 
+    def mc_shift_grad(self, u_a, dt_a: float, u_b, dt_b: float, psi0, r: float = 0.5, want_phi=False):
+        """The reference's Monte-Carlo estimator core (sim_plain.py:186-220) in one call: evolve psi0 through chain a
+        (0 -> s), apply the 2K gates (I +- i r H_k)/sqrt(1 + r^2), evolve the shifted batch through chain b (s -> T),
+        measure M. Returns ps[batch][K] = (1 + r^2)/(2r) (<M>_- - <M>_+) (and phi = the state at s, if asked)."""
+        pa, ka, Sa = self._u(u_a)
+        pb, kb, Sb = self._u(u_b)
+        pp, kp, B = self._psi(psi0)
+        ps = np.zeros((B, self.n_controls), dtype=np.float64)
+        phi, pphi = None, 0
+        if want_phi:
+            phi = np.empty((self.dim, B), dtype=self.cdtype)
+            pphi = phi.ctypes.data
+        _lib.check(self._lib.dq_mc_shift_grad(self._ctx, pa, Sa, float(dt_a), pb, Sb, float(dt_b), pp, B, float(r),
+                                              ps.ctypes.data, pphi))
+        return (ps, phi) if want_phi else ps
+
     # -- building blocks ----------------------------------------------------
     def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None, herm=0):
         """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host).

@@ -207,8 +207,18 @@ class SimulatorPlain(object):
         H0, Hs, fns = self._split_H(H)
         K = Hs.shape[0]
         d = H0.shape[0]
-        phi = _dense(self.my_solver(H, initial_state, 0, s))
         r = 1 / 2
+        if self.my_solver == self.trotter and not self.sampling_measure and not self.is_noisy:
+            # the whole estimator core in one device-resident call (dq_mc_shift_grad): 0 -> s, the 2K gates, s -> T as one
+            # batch, <M> -- same time grids and arithmetic as the per-call path below
+            eng = self._get_engine(H0, Hs)
+            self._set_engine_observable(eng, M)
+            na, nb = pulse.n_steps_sim_plain(self.per_step, 0, s), pulse.n_steps_sim_plain(self.per_step, s, self.T)
+            (tsa, dta), (tsb, dtb) = pulse.time_grid(0, s, na), pulse.time_grid(s, self.T, nb)
+            ps = eng.mc_shift_grad(self._pulse_table(fns, tsa), dta, self._pulse_table(fns, tsb), dtb,
+                                   _dense(initial_state), r)[0]
+            return torch.from_numpy(coeff * ps[:, None] * dDdv)
+        phi = _dense(self.my_solver(H, initial_state, 0, s))
         shifted = np.empty((d, 2 * K), dtype=np.complex128)
         for i in range(K):
             hp = Hs[i] @ phi[:, 0]
@@ -224,16 +234,19 @@ class SimulatorPlain(object):
             grad[i] = ps * dDdv[i]
         return torch.from_numpy(grad)
 
-    def compute_energy_grad_adjoint(self, M, H, initial_state, coeff=1.0):
-        """Exact d<M>/dcoeff of the discrete chain by the engine's adjoint sweep (not in the reference)."""
-        import torch
-        H0, Hs, fns = self._split_H(H)
-        eng = self._get_engine(H0, Hs)
+    def _set_engine_observable(self, eng, M):
         Mn = _dense(M)
         mkey = hashlib.blake2b(Mn.tobytes(), digest_size=16).digest()
         if getattr(self, "_engine_M", None) != mkey:
             eng.set_observable(Mn)
             self._engine_M = mkey
+
+    def compute_energy_grad_adjoint(self, M, H, initial_state, coeff=1.0):
+        """Exact d<M>/dcoeff of the discrete chain by the engine's adjoint sweep (not in the reference)."""
+        import torch
+        H0, Hs, fns = self._split_H(H)
+        eng = self._get_engine(H0, Hs)
+        self._set_engine_observable(eng, M)
         n_steps = pulse.n_steps_sim_plain(self.per_step, 0, self.T)
         ts, dt = pulse.time_grid(0, self.T, n_steps)
         u = self._pulse_table(fns, ts)

@@ -129,6 +129,15 @@ int dq_energy_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const v
 int dq_fidelity_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* psi0, const void* targets,
                      int batch, double* loss, double* grad_u, void* psi_final, double* fidelities);
 
+/* The reference's Monte-Carlo "parameter shift in time" estimator (compute_energy_grad_MC, sim_plain.py:156-231) as one
+ * device-resident operation: phi = chain_a psi0 (n_a steps of dt_a: the interval 0 -> s on its own grid,
+ * sim_plain.py:190), the 2K shifted states (I +- i r H_k) phi / sqrt(1 + r^2) (sim_plain.py:194-199) evolved together as
+ * one batch through chain_b (s -> T, sim_plain.py:200,210), measured with M, and
+ *     ps[b][k] = (1 + r^2) / (2 r) * (<M>_minus - <M>_plus)      (sim_plain.py:220; r = 1/2 in the reference).
+ * The host multiplies by du_k(s)/dcoeff (sim_plain.py:170-184,227). phi_out ([dim][batch]) is optional. */
+int dq_mc_shift_grad(dq_ctx* ctx, const double* u_a, int n_a, double dt_a, const double* u_b, int n_b, double dt_b,
+                     const void* psi0, int batch, double r, double* ps, void* phi_out);
+
 /* Building blocks, exported for parity tests and reuse. */
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */
 int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,

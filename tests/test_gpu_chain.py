@@ -485,3 +485,29 @@ def test_headline_shape_all_schemes_agree():
         assert abs(l - l0) < 1e-10 * B, key
         assert np.max(np.abs(g - g0)) < 1e-10, key           # gradient entries are ~5e-3
         assert float((f - f0).abs().max()) < 1e-12, key
+
+
+@pytest.mark.parametrize("n,K,B", [(3, 2, 1), (4, 3, 5), (2, 1, 7), (3, 0, 2)])
+def test_mc_shift_gradient_op(oracle, n, K, B):
+    """dq_mc_shift_grad = the core of the reference's Monte-Carlo estimator (sim_plain.py:186-220) in one call, for a
+    batch of initial states: against the same steps done one by one with the oracle's propagate / energies."""
+    d = 1 << n
+    H0, Hs, M = problems.random_hermitian_problem(n, K, seed=n + B)
+    rng = np.random.default_rng(B)
+    ua, ub = rng.uniform(-1, 1, (7, K)), rng.uniform(-1, 1, (12, K))
+    dta, dtb, r = 0.031, 0.044, 0.5
+    psi0 = problems.random_states(d, B, seed=2)
+    with _engine(H0, Hs, M) as e:
+        ps, phi = e.mc_shift_grad(ua, dta, ub, dtb, psi0, r, want_phi=True)
+        with pytest.raises(ValueError):
+            e.mc_shift_grad(ua, dta, ub, dtb, psi0, 0.0)
+    rphi = oracle.propagate(H0, list(Hs), ua, dta, psi0)
+    assert np.max(np.abs(phi - rphi)) < TOL
+    assert ps.shape == (B, K)
+    for b in range(B):
+        for k in range(K):
+            hp = Hs[k] @ rphi[:, b]
+            kp = oracle.propagate(H0, list(Hs), ub, dtb, (rphi[:, b] + 1j * r * hp) / np.sqrt(1 + r * r))
+            km = oracle.propagate(H0, list(Hs), ub, dtb, (rphi[:, b] - 1j * r * hp) / np.sqrt(1 + r * r))
+            ref = (1 + r * r) / (2 * r) * (oracle.energies(M, km)[0] - oracle.energies(M, kp)[0])
+            assert abs(ps[b, k] - ref) < TOL, (b, k)
