@@ -827,7 +827,13 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   std::vector<double> uh = s_fetch_u(c, u, S);
   const int m = plan_degree(c, uh, S, dt);
   double budget = c->checkpoint_bytes;
-  if (budget <= 0) { size_t fr = 0, tot = 0; SHIP(hipMemGetInfo(&fr, &tot)); budget = 0.35 * (double)fr; }
+  if (budget <= 0) {  // default: 70 % of the free HBM plus the checkpoints this context already holds
+    size_t fr = 0, tot = 0;
+    SHIP(hipMemGetInfo(&fr, &tot));
+    double held = 0.0;
+    for (const auto& b : c->ck) held += (double)b.bytes;
+    budget = 0.70 * ((double)fr + held);
+  }
   const long ncp_max = std::max(1L, (long)(budget / (double)sb));
   const int cstride = (int)std::max(1L, ((long)S + ncp_max - 1) / ncp_max);
   const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
