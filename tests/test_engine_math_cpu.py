@@ -158,3 +158,54 @@ def test_gradient_of_a_two_step_chain_matches_the_oracle(oracle):
     loss = float(np.real(np.sum(psis[-1].conj() * (M @ psis[-1]))))
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
     assert abs(loss - rl) < 1e-12 and np.max(np.abs(grad - rg)) < 1e-12 and np.max(np.abs(psis[-1] - rf)) < 1e-13
+
+
+# ---- the time-parallel operator backward sweep (engine.hip tp_sweep), restated in numpy ---------------------------------
+def tp_sweep_model(U, W):
+    """All G_j = W_{j+1} U_j of a chunk and the chunk-start W from suffix products Q_j = U_{n-1} ... U_j, built with the
+    engine's two-level scan: blocks of ~sqrt(n) aligned to the chunk's end, local suffixes, chained block totals."""
+    n, d = len(U), U[0].shape[0]
+    b = max(1, min(int(math.ceil(math.sqrt(n))), n))
+    nblk = (n + b - 1) // b
+    len_first = n - (nblk - 1) * b
+    L = [None] * n
+    for k in range(nblk):                       # 1. block ends
+        e = n - 1 - k * b
+        L[e] = U[e]
+    for r in range(1, b):                       # 2. local suffixes, batched over the blocks longer than r
+        nb_r = nblk if r < len_first else nblk - 1
+        for k in range(nb_r):
+            j = n - 1 - k * b - r
+            L[j] = L[j + 1] @ U[j]
+    start = lambda k: max(0, n - (k + 1) * b)
+    R = [L[start(0)]]                           # 3. block suffix chain
+    for k in range(1, nblk):
+        R.append(R[k - 1] @ L[start(k)])
+    Q = [None] * (n + 1)                        # 4. Q_j
+    for j in range(start(0), n):
+        Q[j] = L[j]
+    for k in range(1, nblk):
+        for j in range(start(k), n - k * b):
+            Q[j] = R[k - 1] @ L[j]
+    Q[n] = np.eye(d)
+    Z = [W @ Q[j] for j in range(n)]            # 5-7
+    G = [Q[j + 1].conj().T @ Z[j] for j in range(n)]
+    return G, Q[0].conj().T @ Z[0]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 9, 11, 16, 17, 30])
+def test_time_parallel_sweep_equals_the_sequential_recursion(n):
+    d = 5
+    rng = np.random.default_rng(n)
+    U = [scipy.linalg.expm(1j * random_symmetric(d, 0.7, 100 * n + t) + 0.3 * (lambda a: a - a.T)(rng.standard_normal((d, d))))
+         for t in range(n)]                      # unitary: exp of an anti-Hermitian matrix
+    W = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    W = W - W.conj().T
+    G, Wn = tp_sweep_model(U, W)
+    Ws = W
+    for t in range(n - 1, -1, -1):               # G_t = W_{t+1} U_t, W_t = U_t^H G_t
+        Gt = Ws @ U[t]
+        assert np.max(np.abs(G[t] - Gt)) < 1e-13
+        Ws = U[t].conj().T @ Gt
+    assert np.max(np.abs(Wn - Ws)) < 1e-13
+    assert np.max(np.abs(Wn + Wn.conj().T)) < 1e-13   # stays anti-Hermitian
