@@ -265,6 +265,15 @@ struct Ctx : dq_ctx {
   typedef typename dq::Cx<T>::type T2;
   int d = 0, K = 0, dev = 0, n_cu = 256;
   hipStream_t st = nullptr;
+  // cache of the real path's per-chunk propagator intermediates (X, Y_1..Y_{q-1}, P, U): what the backward sweep would
+  // otherwise rebuild with q + 1 products per step; filled in the forward pass as far as the budget reaches
+  struct PCacheEntry { DevBuf buf; int c0 = -1, n = 0, rq = 0; bool valid = false; };
+  std::vector<PCacheEntry> pcache;
+  void* redirect[96] = {nullptr};   // pool slots currently backed by a cache entry (set per chunk by build_propagators)
+  int pc_mode = 0, pc_tc = 1;       // 0 off, 1 store (forward), 2 load (backward)
+  long pc_limit = 0;                // steps [0, pc_limit) are cached
+  double cache_bytes = 0.0;         // option: < 0 off, 0 auto (half of the free HBM), > 0 bytes
+  double last_cached = 0;
   DevBuf rws, zws;  // split-K workspaces of the symmetric real GEMM / the (anti-)Hermitian complex GEMM
   DevBuf H0, Hs, M;
   DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
@@ -341,6 +350,7 @@ struct Ctx : dq_ctx {
 
   // pool slot of `tc` stacked d x d matrices
   T2* mat(int slot, size_t tc) {
+    if (redirect[slot]) return (T2*)redirect[slot];  // this chunk's variable lives in the propagator cache
     pool[slot].ensure(tc * mat_bytes());
     return (T2*)pool[slot].p;
   }
@@ -413,6 +423,7 @@ struct Ctx : dq_ctx {
     g.ws_elems = elems;
   }
   T* rmat(int slot, size_t tc) {
+    if (redirect[slot]) return (T*)redirect[slot];
     pool[slot].ensure(tc * nn() * sizeof(T));
     return (T*)pool[slot].p;
   }
@@ -814,7 +825,38 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
 template <class T>
 TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
   typedef TT T2;
-  if (p.rq > 0) return real_forward(c, p, c0, n, dt);
+  for (auto& r : c->redirect) r = nullptr;
+  if (p.rq > 0) {
+    // Cached chunks keep X, Y_1..Y_{q-1}, P (real) and U (complex) in their cache entry: the forward pass computes them
+    // there directly (the pool slots are redirected for the duration of the chunk), the backward pass reads them there --
+    // no copies, no rebuild.
+    const bool cacheable = p.s == 0 && c->pc_mode != 0 && c0 + n <= c->pc_limit;
+    const size_t idx = (size_t)(c0 / std::max(c->pc_tc, 1));
+    const size_t mat = c->nn() * sizeof(T) * (size_t)n;  // one real variable of the chunk
+    const int q = p.rq;
+    auto real_slot = [&](int i) { return i == 0 ? (int)RS_X : (i < q ? i : (int)RS_P); };  // X, Y_1 .. Y_{q-1}, P
+    auto point_at = [&](char* base) {
+      for (int i = 0; i <= q; ++i) c->redirect[real_slot(i)] = base + (size_t)i * mat;
+      c->redirect[RS_U] = base + (size_t)(q + 1) * mat;
+    };
+    if (cacheable && c->pc_mode == 2 && idx < c->pcache.size()) {
+      auto& e = c->pcache[idx];
+      if (e.valid && e.c0 == c0 && e.n == n && e.rq == q) {
+        point_at((char*)e.buf.p);
+        c->last_degree = p.m; c->last_squarings = 0; c->last_products = p.nprod; c->last_real_q = q;
+        return c->mat(RS_U, n);
+      }
+    }
+    if (cacheable && c->pc_mode == 1) {
+      if (c->pcache.size() <= idx) c->pcache.resize(idx + 1);
+      auto& e = c->pcache[idx];
+      e.buf.ensure((size_t)(q + 3) * mat);
+      point_at((char*)e.buf.p);
+      e.c0 = c0; e.n = n; e.rq = q; e.valid = true;
+      c->last_cached += n;
+    }
+    return real_forward(c, p, c0, n, dt);
+  }
   T2* A = c->mat(0, n);
   const double by = 2.0 * sizeof(T) * c->nn() * (c->K + 2.0) * n;
   c->timed(DQ_PROF_ASSEMBLE, 2.0 * 2 * c->nn() * (c->K + 1.0) * n, by, [&] {
@@ -1029,10 +1071,44 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   const int tc = time_chunk(c, std::max(S, 1));
   c->last_chunk = tc;
 
+  // propagator-intermediate cache (real path): budget and the steps it covers. With plan_steps the covered share is that
+  // of the planned chain, so a slice pays the same share of rebuilds as the whole chain.
+  struct PcOff {  // whatever happens below, later calls must not see a half-filled cache as live
+    Ctx<T>* c;
+    ~PcOff() {
+      c->pc_mode = 0;
+      for (auto& r : c->redirect) r = nullptr;
+    }
+  } pc_off{c};
+  auto setup_pcache = [&]() {
+    for (auto& e : c->pcache) e.valid = false;
+    c->pc_mode = 0;
+    c->pc_limit = 0;
+    c->last_cached = 0;
+    c->pc_tc = tc;
+    if (!c->real_h || c->real_mode == 0 || c->cache_bytes < 0 || S == 0) return;
+    double budget = c->cache_bytes;
+    if (budget == 0.0) {
+      size_t fr = 0, tot = 0;
+      HIPCK(hipMemGetInfo(&fr, &tot));
+      double held = 0.0;
+      for (const auto& e : c->pcache) held += (double)e.buf.bytes;
+      budget = (opback ? 0.80 : 0.50) * ((double)fr + held);  // (the operator form keeps no state checkpoints)
+    }
+    const ExpmPlan p0 = chunk_plan(c, uh, 0, std::min(tc, S), dt);
+    if (p0.rq == 0 || p0.s > 0) return;
+    const double per_step = (p0.rq + 3.0) * c->nn() * sizeof(T);  // X, Y_1..Y_{q-1}, P (real) + U (complex)
+    const double S_plan = (double)std::max<long>(S, c->plan_steps);
+    const double share = std::min(1.0, budget / (per_step * S_plan));
+    c->pc_limit = (long)(share * S);
+    if (c->pc_limit > 0) c->pc_mode = 1;
+  };
+
   // ---- forward ----
   int cstride = 1;
   if (opback) {
     c->last_cstride = 0;  // no state checkpoints
+    setup_pcache();
     cur = forward_chain(c, uh, S, dt, B, 0, compose);
   } else {
     // checkpoint stride from the memory budget
@@ -1057,6 +1133,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
     for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
     c->psi[2].ensure(sb);
     c->lam[1].ensure(sb);
+    setup_pcache();  // (after the checkpoints: it takes half of what they left)
     for (int c0 = 0; c0 < S; c0 += tc) {
       const int n = std::min(tc, S - c0);
       const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
@@ -1106,6 +1183,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
 
   // ---- backward ----
+  if (c->pc_mode == 1) c->pc_mode = 2;
   if (S > 0) {
     const int nblk = dq::grad_contract_blocks((long)c->nn());
     const int last_c0 = ((S - 1) / tc) * tc;
@@ -1184,6 +1262,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
       });
     }
   }
+  c->pc_mode = 0;
   if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
   HIPCK(hipStreamSynchronize(c->st));
 }
@@ -1437,6 +1516,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     const int q = (int)v;
     if (q < -1 || q > RQ_MAX) fail(DQ_ERR_INVALID, "real_path must be -1 (auto), 0 (off) or a polynomial size 1..6");
     c->real_mode = q;
+  } else if (s == "cache_bytes") {  // real path: HBM for propagator intermediates kept from the forward pass (< 0 off, 0 auto)
+    c->cache_bytes = v;
   } else if (s == "small_dim") {  // auto mode: dimensions up to this take the operator form for any batch width
     c->small_dim = (int)v;
   } else if (s == "time_parallel") {  // operator backward sweep of a chunk: -1 auto (>= 4 steps), 0 sequential, 1 always
@@ -1475,6 +1556,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "composed") return c->last_composed;
   if (s == "operator_backward") return c->last_opback;
   if (s == "time_parallel") return c->last_tpar;
+  if (s == "cached_steps") return c->last_cached;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;
   if (s == "norm_H0") return c->nH0;

@@ -97,6 +97,9 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   time_parallel      -1 auto / 0 / 1: operator backward sweep of a time chunk from suffix products (~4n batched
  *                      products instead of 2n dependent launches; auto: chunks of >= 4 steps at dim <= 1024)
  *   skew_trick         1: only the anti-Hermitian parts of the generator cotangent / of W are carried (saves products)
+ *   cache_bytes        real path: HBM for the propagator intermediates (X, Y_j, P, U) that the forward pass leaves in place
+ *                      for the backward sweep, which then skips its q + 1 rebuild products for those steps; < 0 off,
+ *                      0 = 80 % of the free HBM (operator form) / 50 % (after the state form's checkpoints)
  *   checkpoint_bytes   state checkpoints of the state-form sweep (batch < dim); 0 = 70 % of the free HBM
  *   plan_steps         size the checkpoint stride for a chain of this many steps even if the call is shorter
  *   chunk_bytes        workspace for the steps whose propagators are built in one batched pass; 0 = 8 GiB, or 10 % of
@@ -105,7 +108,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
- * "time_parallel", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
+ * "time_parallel", "cached_steps", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 

@@ -354,3 +354,33 @@ def test_auto_mode_keeps_small_dimensions_on_the_complex_tape():
         e.set_hamiltonians(H0, Hs)
         e.propagate(0.01 * np.ones((3, 2)), 0.01, psi0)
         assert e.info("real_hamiltonians") == 1 and e.info("real_path") == 0
+
+
+@pytest.mark.parametrize("B", [3, 8, 40])
+def test_propagator_cache_reproduces_the_rebuild_bit_for_bit(oracle, B):
+    """The backward sweep takes the real path's intermediates (X, Y_j, P, U) of the cached steps from HBM instead of
+    rebuilding them: same bits, for a full, a partial and no cache, in state form (B = 3) and operator form."""
+    n, K, S = 3, 2, 21
+    H0, Hs, M = problems.random_real_symmetric_problem(n, K, seed=B)
+    u = np.random.default_rng(2).uniform(-2, 2, (S, K))
+    dt = _dt(H0, Hs, 2.0, 0.2)
+    psi0 = problems.random_states(8, B, seed=4)
+    per_step = None   # (q + 3) real 8 x 8 matrices per step; q is read back from the engine below
+    out = {}
+    with _engine(H0, Hs, M) as e:
+        e.set_option("chunk_bytes", 24 * 64 * 16 * 4)       # chunks of 4 steps
+        e.propagate(u, dt, psi0)
+        per_step = int(e.info("real_path") + 3) * 64 * 8
+        for name, cb, expect in (("auto", 0, S), ("off", -1, 0), ("partial", per_step * 10, 8), ("tiny", 1, 0)):
+            e.set_option("cache_bytes", cb)
+            out[name] = e.energy_grad(u, dt, psi0)
+            assert e.info("real_path") >= 1 and e.info("cached_steps") == expect, (name, e.info("cached_steps"))
+        e.set_option("cache_bytes", 0)
+        e.set_option("plan_steps", 10 * S)                  # a slice of a 10x longer chain caches its share only
+        e.set_option("cache_bytes", per_step * 10 * S // 2)
+        out["slice"] = e.energy_grad(u, dt, psi0)
+        assert e.info("cached_steps") == 8                  # share 1/2 -> 10 steps -> whole chunks: 8
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    for name, (l, g, f, en) in out.items():
+        assert np.array_equal(g, out["off"][1]) and l == out["off"][0], name
+    assert abs(out["auto"][0] - rl) < TOL * B and np.max(np.abs(out["auto"][1] - rg)) < TOL * B
