@@ -267,8 +267,10 @@ struct Ctx : dq_ctx {
   hipStream_t st = nullptr;
   // cache of the real path's per-chunk propagator intermediates (X, Y_1..Y_{q-1}, P, U): what the backward sweep would
   // otherwise rebuild with q + 1 products per step; filled in the forward pass as far as the budget reaches
-  struct PCacheEntry { DevBuf buf; int c0 = -1, n = 0, rq = 0; bool valid = false; };
+  struct PCacheEntry { size_t off = 0; int c0 = -1, n = 0, rq = 0; bool valid = false; };
   std::vector<PCacheEntry> pcache;
+  DevBuf pc_arena;                  // one allocation; entries are offsets into it (filled front to back each call)
+  size_t pc_used = 0;
   void* redirect[96] = {nullptr};   // pool slots currently backed by a cache entry (set per chunk by build_propagators)
   int pc_mode = 0, pc_tc = 1;       // 0 off, 1 store (forward), 2 load (backward)
   long pc_limit = 0;                // steps [0, pc_limit) are cached
@@ -842,16 +844,17 @@ TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
     if (cacheable && c->pc_mode == 2 && idx < c->pcache.size()) {
       auto& e = c->pcache[idx];
       if (e.valid && e.c0 == c0 && e.n == n && e.rq == q) {
-        point_at((char*)e.buf.p);
+        point_at((char*)c->pc_arena.p + e.off);
         c->last_degree = p.m; c->last_squarings = 0; c->last_products = p.nprod; c->last_real_q = q;
         return c->mat(RS_U, n);
       }
     }
-    if (cacheable && c->pc_mode == 1) {
+    if (cacheable && c->pc_mode == 1 && c->pc_used + (size_t)(q + 3) * mat <= c->pc_arena.bytes) {
       if (c->pcache.size() <= idx) c->pcache.resize(idx + 1);
       auto& e = c->pcache[idx];
-      e.buf.ensure((size_t)(q + 3) * mat);
-      point_at((char*)e.buf.p);
+      e.off = c->pc_used;
+      c->pc_used += (size_t)(q + 3) * mat;
+      point_at((char*)c->pc_arena.p + e.off);
       e.c0 = c0; e.n = n; e.rq = q; e.valid = true;
       c->last_cached += n;
     }
@@ -1091,9 +1094,9 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
     if (budget == 0.0) {
       size_t fr = 0, tot = 0;
       HIPCK(hipMemGetInfo(&fr, &tot));
-      double held = 0.0;
-      for (const auto& e : c->pcache) held += (double)e.buf.bytes;
-      budget = (opback ? 0.80 : 0.50) * ((double)fr + held);  // (the operator form keeps no state checkpoints)
+      // operator form: no state checkpoints compete for the HBM. Capped at 96 GiB by default: larger single allocations
+      // cost seconds on first use (measured: 80 GB free of charge, 200 GB 4 s); cache_bytes raises it.
+      budget = std::min((opback ? 0.80 : 0.50) * ((double)fr + (double)c->pc_arena.bytes), 96.0 * 1024 * 1024 * 1024);
     }
     const ExpmPlan p0 = chunk_plan(c, uh, 0, std::min(tc, S), dt);
     if (p0.rq == 0 || p0.s > 0) return;
@@ -1101,7 +1104,15 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
     const double S_plan = (double)std::max<long>(S, c->plan_steps);
     const double share = std::min(1.0, budget / (per_step * S_plan));
     c->pc_limit = (long)(share * S);
-    if (c->pc_limit > 0) c->pc_mode = 1;
+    if (c->pc_limit <= 0) return;
+    try {
+      c->pc_arena.ensure((size_t)(per_step * (double)c->pc_limit) + 4096);  // one allocation (grows only)
+    } catch (const DqError&) {
+      c->pc_limit = 0;  // no room after all: run without the cache
+      return;
+    }
+    c->pc_used = 0;
+    c->pc_mode = 1;
   };
 
   // ---- forward ----

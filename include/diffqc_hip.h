@@ -99,7 +99,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   skew_trick         1: only the anti-Hermitian parts of the generator cotangent / of W are carried (saves products)
  *   cache_bytes        real path: HBM for the propagator intermediates (X, Y_j, P, U) that the forward pass leaves in place
  *                      for the backward sweep, which then skips its q + 1 rebuild products for those steps; < 0 off,
- *                      0 = 80 % of the free HBM (operator form) / 50 % (after the state form's checkpoints)
+ *                      0 = 80 % of the free HBM (operator form) / 50 % (after the state form's checkpoints), at most 96 GiB
  *   checkpoint_bytes   state checkpoints of the state-form sweep (batch < dim); 0 = 70 % of the free HBM
  *   plan_steps         size the checkpoint stride for a chain of this many steps even if the call is shorter
  *   chunk_bytes        workspace for the steps whose propagators are built in one batched pass; 0 = 8 GiB, or 10 % of
