@@ -153,12 +153,16 @@ def main():
                     help="length of the full configuration's chain: the timed slice uses ITS checkpoint stride")
     ap.add_argument("--real-path", type=int, default=-1,
                     help="-1 auto (real H -> cos/sin form on real MFMA products), 0 = general complex path only")
+    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated"), default="auto",
+                    help="N > 1: 'sliced' = chain split over time across the ranks (operator form; three collectives), "
+                         "'replicated' = every rank runs the whole chain on its batch shard (one all-reduce); "
+                         "auto = sliced if its warm-up gradient equals the replicated one on every rank")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from diffquantum_amd import problems
-    from diffquantum_amd.distributed import allreduce_loss_grad
+    from diffquantum_amd.distributed import allreduce_loss_grad, time_sliced_energy_grad
     from diffquantum_amd.engine import Engine
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,13 +195,45 @@ def main():
     u_t = torch.from_numpy(u_all[:K].copy()).to(dev)
     grad_t = torch.zeros((K, n), dtype=torch.float64, device=dev)
 
-    def run(u_dev, grad_dev):
+    def run_replicated(u_dev, grad_dev):
+        eng.set_option("plan_steps", max(a.chain, K))
         loss, g, _, _ = eng.energy_grad(u_dev, a.dt, psi0, want_final=False, want_energies=False, grad_out=grad_dev)
         return allreduce_loss_grad(loss, g, device=dev)
 
+    def run_sliced(u_dev, grad_dev):
+        # chain split over TIME across the ranks: each rank builds and sweeps 1/world of the steps for the
+        # WHOLE batch (its own shard enters through W_S only); all-gather of the slice products, all-reduce of W_S,
+        # all-reduce of the gradient rows + loss
+        eng.set_option("plan_steps", (max(a.chain, K) + world - 1) // world)
+        loss, g, _, _ = time_sliced_energy_grad(eng, u_dev, a.dt, psi0, device=dev)
+        g = torch.from_numpy(g).to(dev)
+        grad_dev.copy_(g)
+        return loss, grad_dev
+
+    mode = "replicated"
+    sliced_check = None
+    if world > 1 and a.multi_gpu != "replicated":
+        mode = "sliced"
     if W > 0:
         uw = torch.from_numpy(u_all[:W].copy()).to(dev)
-        run(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+        lr, gr = run_replicated(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+        if mode == "sliced":
+            # the warm-up doubles as the check: same loss and gradient from both forms on every rank, or fall back
+            ok = 1.0
+            try:
+                ls, gs = run_sliced(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+                err = float((gs - gr).abs().max().item()) if W > 0 else 0.0
+                sliced_check = {"max_abs_grad_diff_vs_replicated": err, "abs_loss_diff_vs_replicated": abs(ls - lr)}
+                if not (err <= 1e-9 * (1.0 + float(gr.abs().max().item())) and abs(ls - lr) <= 1e-9 * (1.0 + abs(lr))):
+                    ok = 0.0
+            except Exception as e:  # noqa: BLE001 -- any failure of the sliced form means: use the replicated one
+                sliced_check = {"error": repr(e)}
+                ok = 0.0
+            flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0 and a.multi_gpu == "auto":
+                mode = "replicated"
+    run = run_sliced if mode == "sliced" else run_replicated
     eng.profile_enable(True)
     eng.profile_reset()
 
@@ -217,6 +253,26 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = eng.profile()
+    other_mode = None
+    if world > 1 and a.multi_gpu == "auto":
+        # the other multi-GPU form on the same inputs, outside the timed region (reported beside the headline)
+        eng.profile_enable(False)
+        alt = run_replicated if mode == "sliced" else run_sliced
+        try:
+            g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
+            fence()
+            t1 = time.perf_counter()
+            l2, g2 = alt(u_t, g2)
+            fence()
+            el2 = time.perf_counter() - t1
+            tm = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            other_mode = {"form": "replicated" if mode == "sliced" else "sliced", "value": world * K / float(tm.item()),
+                          "ms_per_step": float(tm.item()) / max(K, 1) * 1e3,
+                          "max_abs_grad_diff_vs_headline_form": float((g2 - grad).abs().max().item()),
+                          "abs_loss_diff_vs_headline_form": abs(l2 - loss)}
+        except Exception as e:  # noqa: BLE001
+            other_mode = {"error": repr(e)}
     info = {k: eng.info(k) for k in ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk",
                                      "zgemm_alg", "real_path", "real_hamiltonians")}
     general = None
@@ -271,7 +327,12 @@ def main():
                             "so the per-step cost is chain-length independent; otherwise the slice uses the checkpoint "
                             "stride of the full chain)".format(n, d, n, B, a.dt, K, max(a.chain, K)),
                 "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
-                "chain_steps": K, "dt": a.dt, "parallelism": "dp{} (batch shards, one all-reduce of loss+dL/du)".format(world),
+                "chain_steps": K, "dt": a.dt,
+                "parallelism": ("dp{} (batch shards, one all-reduce of loss+dL/du)".format(world) if mode == "replicated" else
+                                "dp{0} over the batch x {0} time slices: operator form, each rank builds and sweeps 1/{0} of "
+                                "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
+                                "(d x d) and of dL/du".format(world)),
+                "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "other_multi_gpu_form": other_mode,
                 "expm": ("cos X + i sin X, Taylor degree {} ({} real symmetric-output products), theta<={:.3g}".format(
                     int(info["degree"]), int(info["products"]), info["theta"]) if info["real_path"] > 0 else
                     "Taylor degree {} ({} complex products, {} squarings), theta<={:.3g}".format(

@@ -276,6 +276,11 @@ struct Ctx : dq_ctx {
   long pc_limit = 0;                // steps [0, pc_limit) are cached
   double cache_bytes = 0.0;         // option: < 0 off, 0 auto (half of the free HBM), > 0 bytes
   double last_cached = 0;
+  // time-sliced operator form (dq_slice_*): what dq_slice_forward left in place for dq_slice_backward
+  std::vector<double> slice_u;
+  double slice_dt = 0.0;
+  int slice_tc = 0;
+  bool slice_valid = false;
   DevBuf rws, zws;  // split-K workspaces of the symmetric real GEMM / the (anti-)Hermitian complex GEMM
   DevBuf H0, Hs, M;
   DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
@@ -874,55 +879,69 @@ void require_H(Ctx<T>* c) {
   if (!c->have_H) fail(DQ_ERR_STATE, "dq_set_hamiltonians has not been called");
 }
 
+// Operator form of a chain: the product U_{S-1} ... U_0 of the propagators of steps [0, S) of the staged pulse table, by a
+// log-depth tree of batched products per time chunk (8 d^3 flop per step, O(log n) launches instead of n) and a running
+// product across chunks. Returns the d x d product (a pool slot), or null for S = 0.
+template <class T>
+TT* compose_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int tc) {
+  typedef TT T2;
+  const int d = c->d;
+  T2* running = nullptr;
+  for (int c0 = 0; c0 < S; c0 += tc) {
+    const int n = std::min(tc, S - c0);
+    const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
+    T2* X = build_propagators(c, p, c0, n, dt);
+    int m = n, lvl = 0;
+    while (m > 1) {
+      const int pairs = m / 2;
+      T2* Y = c->mat(SLOT_TREE + (lvl & 1), (size_t)(pairs + (m & 1)));
+      const long s2 = 2 * (long)c->nn();
+      c->zgemm(0, 0, d, d, d, 1.0, X + c->nn(), d, s2, X, d, s2, 0.0, Y, d, (long)c->nn(), pairs);
+      if (m & 1)
+        HIPCK(hipMemcpyAsync(Y + (size_t)pairs * c->nn(), X + (size_t)(m - 1) * c->nn(), c->mat_bytes(),
+                             hipMemcpyDeviceToDevice, c->st));
+      X = Y;
+      m = pairs + (m & 1);
+      ++lvl;
+    }
+    if (!running) {
+      running = c->mat(SLOT_TREE + 2, 1);
+      HIPCK(hipMemcpyAsync(running, X, c->mat_bytes(), hipMemcpyDeviceToDevice, c->st));
+    } else {
+      T2* nxt = c->mat(running == c->mat(SLOT_TREE + 2, 1) ? SLOT_TREE + 3 : SLOT_TREE + 2, 1);
+      c->zgemm(0, 0, d, d, d, 1.0, X, d, 0, running, d, 0, 0.0, nxt, d, 0, 1);
+      running = nxt;
+    }
+  }
+  return running;
+}
+
 // Forward chain on the states in psi[cur] (d x B): psi <- U_{S-1} ... U_0 psi, no checkpoints. Returns the buffer index
-// holding the result. compose: multiply the chunk's propagators together by a log-depth tree of batched products
-// (8 d^3 flop per step instead of 8 d^2 B, O(log n) launches instead of n), a running product across chunks, and ONE
-// apply at the end -- cheaper as soon as the batch is wider than the dimension.
+// holding the result. compose: multiply the propagators together (compose_chain) and apply the product ONCE -- cheaper
+// as soon as the batch is wider than the dimension.
 template <class T>
 int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B, int cur, bool compose) {
   typedef TT T2;
   const int d = c->d;
   const int tc = time_chunk(c, std::max(S, 1));
   c->last_chunk = tc;
-  T2* running = nullptr;  // product of the chunks composed so far (operator form)
+  if (compose) {
+    T2* running = compose_chain(c, uh, S, dt, tc);
+    if (running) {
+      c->zgemm(0, 0, d, B, d, 1.0, running, d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->psi[cur ^ 1].p, B, 0, 1);
+      cur ^= 1;
+    }
+    return cur;
+  }
   for (int c0 = 0; c0 < S; c0 += tc) {
     const int n = std::min(tc, S - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
     T2* U = build_propagators(c, p, c0, n, dt);
-    if (compose) {
-      T2* X = U;
-      int m = n, lvl = 0;
-      while (m > 1) {
-        const int pairs = m / 2;
-        T2* Y = c->mat(SLOT_TREE + (lvl & 1), (size_t)(pairs + (m & 1)));
-        const long s2 = 2 * (long)c->nn();
-        c->zgemm(0, 0, d, d, d, 1.0, X + c->nn(), d, s2, X, d, s2, 0.0, Y, d, (long)c->nn(), pairs);
-        if (m & 1)
-          HIPCK(hipMemcpyAsync(Y + (size_t)pairs * c->nn(), X + (size_t)(m - 1) * c->nn(), c->mat_bytes(),
-                               hipMemcpyDeviceToDevice, c->st));
-        X = Y;
-        m = pairs + (m & 1);
-        ++lvl;
-      }
-      if (!running) {
-        running = c->mat(SLOT_TREE + 2, 1);
-        HIPCK(hipMemcpyAsync(running, X, c->mat_bytes(), hipMemcpyDeviceToDevice, c->st));
-      } else {
-        T2* nxt = c->mat(running == c->mat(SLOT_TREE + 2, 1) ? SLOT_TREE + 3 : SLOT_TREE + 2, 1);
-        c->zgemm(0, 0, d, d, d, 1.0, X, d, 0, running, d, 0, 0.0, nxt, d, 0, 1);
-        running = nxt;
-      }
-    } else {
-      for (int t = 0; t < n; ++t) {
-        c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
-                 (T2*)c->psi[cur ^ 1].p, B, 0, 1);
-        cur ^= 1;
-      }
+    for (int t = 0; t < n; ++t) {
+      c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
+               (T2*)c->psi[cur ^ 1].p, B, 0, 1);
+      cur ^= 1;
     }
-  }
-  if (running) {
-    c->zgemm(0, 0, d, B, d, 1.0, running, d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->psi[cur ^ 1].p, B, 0, 1);
-    cur ^= 1;
   }
   return cur;
 }
@@ -1028,6 +1047,157 @@ typename dq::Cx<T>::type* tp_sweep(Ctx<T>* c, const typename dq::Cx<T>::type* U,
   return Wn;
 }
 
+// Propagator-intermediate cache (real path): budget and the steps it covers. With plan_steps the covered share is that
+// of the planned chain, so a slice pays the same share of rebuilds as the whole chain. Leaves pc_mode = 1 (store) when
+// the cache is usable for this chain.
+template <class T>
+void setup_pcache(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int tc, bool opback) {
+  for (auto& e : c->pcache) e.valid = false;
+  c->slice_valid = false;  // whatever dq_slice_forward left in the arena is gone
+  c->pc_mode = 0;
+  c->pc_limit = 0;
+  c->last_cached = 0;
+  c->pc_tc = tc;
+  if (!c->real_h || c->real_mode == 0 || c->cache_bytes < 0 || S == 0) return;
+  double budget = c->cache_bytes;
+  if (budget == 0.0) {
+    size_t fr = 0, tot = 0;
+    HIPCK(hipMemGetInfo(&fr, &tot));
+    // operator form: no state checkpoints compete for the HBM. Capped at 96 GiB by default: larger single allocations
+    // cost seconds on first use (measured: 80 GB free of charge, 200 GB 4 s); cache_bytes raises it.
+    budget = std::min((opback ? 0.80 : 0.50) * ((double)fr + (double)c->pc_arena.bytes), 96.0 * 1024 * 1024 * 1024);
+  }
+  const ExpmPlan p0 = chunk_plan(c, uh, 0, std::min(tc, S), dt);
+  if (p0.rq == 0 || p0.s > 0) return;
+  const double per_step = (p0.rq + 3.0) * c->nn() * sizeof(T);  // X, Y_1..Y_{q-1}, P (real) + U (complex)
+  const double S_plan = (double)std::max<long>(S, c->plan_steps);
+  const double share = std::min(1.0, budget / (per_step * S_plan));
+  c->pc_limit = (long)(share * S);
+  if (c->pc_limit <= 0) return;
+  try {
+    c->pc_arena.ensure((size_t)(per_step * (double)c->pc_limit) + 4096);  // one allocation (grows only)
+  } catch (const DqError&) {
+    c->pc_limit = 0;  // no room after all: run without the cache
+    return;
+  }
+  c->pc_used = 0;
+  c->pc_mode = 1;
+}
+
+// whatever happens in a call, later calls must not see a half-filled cache as live
+template <class T>
+struct PcOff {
+  Ctx<T>* c;
+  ~PcOff() {
+    c->pc_mode = 0;
+    for (auto& r : c->redirect) r = nullptr;
+  }
+};
+
+// Terminal costate Lambda_S (into lam[0]) of the states in psi_S, and the scalar outputs.
+// targets == null: energy objective, Lambda_S = 2 M Psi_S; else fidelity objective, c_b = <phi_b|psi_b>, F_b = |c_b|^2,
+// Lambda_S = -2 phi .* c, L = B - sum F (`energies` then receives the fidelities).
+template <class T>
+void terminal_costate(Ctx<T>* c, const TT* psi_S, int B, const void* targets, double* loss, double* energies) {
+  typedef TT T2;
+  const int d = c->d;
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  if (!targets) {
+    do_energy(c, psi_S, B, (T2*)c->lam[0].p, energies, loss);
+    return;
+  }
+  const T2* phi = in_dev(c, targets, sb, c->tmp_in[3]);
+  c->e_dev.ensure(sizeof(double) * (3 * (size_t)B + 2));
+  c->part.ensure(sizeof(double) * 2 * (size_t)dq::coldot_chunks(d) * B);
+  double* fid = c->e_dev.d();
+  double* cvals = c->e_dev.d() + B + 1;
+  c->timed(DQ_PROF_OTHER, 8.0 * d * B, 6.0 * sizeof(T) * d * B, [&] {
+    return dq::fidelity_costate_launch<T>(phi, psi_S, d, B, -2.0, c->part.d(), cvals, fid, (T2*)c->lam[0].p, c->st);
+  });
+  c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(fid, B, fid + B, c->st); });
+  if (energies) out_copy(c, energies, fid, sizeof(double) * (size_t)B);
+  if (loss) {
+    double fsum = 0.0;
+    HIPCK(hipMemcpyAsync(&fsum, fid + B, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+    const double l = (double)B - fsum;
+    HIPCK(hipMemcpyAsync(loss, &l, sizeof(double), hipMemcpyDefault, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+  }
+}
+
+// Only the anti-Hermitian part of W reaches the gradient: dU_t = U_t K with K anti-Hermitian (U_t unitary up to the
+// Taylor remainder), and Re tr((W U)^H U K) = Re tr((U^H W U)^H K) vanishes for Hermitian W. With W anti-Hermitian,
+// W_t = U_t^H (W_{t+1} U_t) is anti-Hermitian for ANY U_t: that product computes the upper triangle only.
+// (Off when a polynomial degree is forced: the gradient is then the exact derivative of an under-resolved polynomial.)
+template <class T>
+bool skew_w_form(Ctx<T>* c) {
+  return c->skew_trick != 0 && c->force_degree <= 0 && c->real_mode <= 0;
+}
+
+// W_S = Lambda_S Psi_S^H (Lambda_S in lam[0]), reduced to its anti-Hermitian part if skew_w. Returns the pool matrix.
+template <class T>
+TT* terminal_w(Ctx<T>* c, const TT* psi_S, int B, bool skew_w) {
+  typedef TT T2;
+  const int d = c->d;
+  T2* W = c->mat(SLOT_TREE, 1);
+  c->zgemm(0, 1, d, d, B, 1.0, (const T2*)c->lam[0].p, B, 0, psi_S, B, 0, 0.0, W, d, 0, 1);
+  if (skew_w) {
+    T2* Ws = c->mat(SLOT_TREE + 1, 1);
+    c->timed(DQ_PROF_LINCOMB, 4.0 * c->nn(), 3.0 * 2.0 * sizeof(T) * c->nn(),
+             [&] { return dq::tcombine_launch<T>(Ws, W, d, 0.5, -0.5, 0, (long)c->nn(), 1, c->st); });
+    W = Ws;
+  }
+  return W;
+}
+
+// Operator-form backward sweep over one chunk of n built propagators U (descending in time): G_t = W_{t+1} U_t into the
+// cotangent slots G, W_t = U_t^H G_t. W must be one of the pool matrices SLOT_TREE / SLOT_TREE + 1; returns the new W.
+template <class T>
+TT* opback_chunk(Ctx<T>* c, const TT* U, TT* G, TT* W, int n, bool skew_w) {
+  typedef TT T2;
+  const int d = c->d;
+  // auto: chunks of >= 4 steps at dimensions where one d x d product leaves most of the chip idle (d <= 1024)
+  const bool tpar = c->time_parallel == 1 ? n >= 2
+                                          : (c->time_parallel < 0 && n >= 4 && (d + 127) / 128 * ((d + 127) / 128) < c->n_cu);
+  c->last_tpar = tpar ? 1.0 : 0.0;
+  if (tpar) return tp_sweep(c, U, G, W, n, skew_w);
+  for (int t = n - 1; t >= 0; --t) {
+    const T2* Ut = U + (size_t)t * c->nn();
+    T2* Gt = G + (size_t)t * c->nn();
+    c->zgemm(0, 0, d, d, d, 1.0, W, d, 0, Ut, d, 0, 0.0, Gt, d, 0, 1);  // G_t = W_{t+1} U_t
+    T2* Wn = c->mat(W == c->mat(SLOT_TREE, 1) ? SLOT_TREE + 1 : SLOT_TREE, 1);
+    c->zgemm(1, 0, d, d, d, 1.0, Ut, d, 0, Gt, d, 0, 0.0, Wn, d, 0, 1, skew_w ? -1 : 0);  // W_t = U_t^H G_t
+    W = Wn;
+  }
+  return W;
+}
+
+// Reverse mode through the chunk's exponentials (their variables are in the pool, the cotangents G_t of the propagators
+// in ubar_slot) and the contractions with the control Hamiltonians: grad_dev[c0 .. c0 + n)[K].
+template <class T>
+void chunk_vjp(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
+  typedef TT T2;
+  const int K = c->K;
+  const int nblk = dq::grad_contract_blocks((long)c->nn());
+  c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
+  if (p.rq > 0) {
+    const T* Xbar = real_backward(c, p, n);
+    const double byr = (double)sizeof(T) * c->nn() * (K + ((K + 15) / 16)) * n;
+    c->timed(DQ_PROF_GRADC, 2.0 * c->nn() * K * n, byr, [&] {
+      return dq::rgrad_contract_launch<T>(Xbar, (long)c->nn(), (const T*)c->Hsr.p, K, (long)c->nn(), n, -std::ldexp(dt, -p.s),
+                                          c->part.d(), c->grad_dev.d() + (size_t)c0 * K, c->st);
+    });
+    return;
+  }
+  const T2* Abar = expm_backward(c, p, n, c->skew_trick != 0);
+  const double by = 2.0 * sizeof(T) * c->nn() * (K + ((K + 7) / 8)) * n;
+  c->timed(DQ_PROF_GRADC, 3.0 * c->nn() * K * n, by, [&] {
+    return dq::grad_contract_launch<T>(Abar, (long)c->nn(), (const T2*)c->Hs.p, K, (long)c->nn(), n, dt, c->part.d(),
+                                       c->grad_dev.d() + (size_t)c0 * K, c->st);
+  });
+}
+
 template <class T>
 void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* psi0, int B, double* loss,
                     double* grad_u, void* psi_final, double* energies, const void* targets = nullptr) {
@@ -1073,53 +1243,13 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   int cur = 0;
   const int tc = time_chunk(c, std::max(S, 1));
   c->last_chunk = tc;
-
-  // propagator-intermediate cache (real path): budget and the steps it covers. With plan_steps the covered share is that
-  // of the planned chain, so a slice pays the same share of rebuilds as the whole chain.
-  struct PcOff {  // whatever happens below, later calls must not see a half-filled cache as live
-    Ctx<T>* c;
-    ~PcOff() {
-      c->pc_mode = 0;
-      for (auto& r : c->redirect) r = nullptr;
-    }
-  } pc_off{c};
-  auto setup_pcache = [&]() {
-    for (auto& e : c->pcache) e.valid = false;
-    c->pc_mode = 0;
-    c->pc_limit = 0;
-    c->last_cached = 0;
-    c->pc_tc = tc;
-    if (!c->real_h || c->real_mode == 0 || c->cache_bytes < 0 || S == 0) return;
-    double budget = c->cache_bytes;
-    if (budget == 0.0) {
-      size_t fr = 0, tot = 0;
-      HIPCK(hipMemGetInfo(&fr, &tot));
-      // operator form: no state checkpoints compete for the HBM. Capped at 96 GiB by default: larger single allocations
-      // cost seconds on first use (measured: 80 GB free of charge, 200 GB 4 s); cache_bytes raises it.
-      budget = std::min((opback ? 0.80 : 0.50) * ((double)fr + (double)c->pc_arena.bytes), 96.0 * 1024 * 1024 * 1024);
-    }
-    const ExpmPlan p0 = chunk_plan(c, uh, 0, std::min(tc, S), dt);
-    if (p0.rq == 0 || p0.s > 0) return;
-    const double per_step = (p0.rq + 3.0) * c->nn() * sizeof(T);  // X, Y_1..Y_{q-1}, P (real) + U (complex)
-    const double S_plan = (double)std::max<long>(S, c->plan_steps);
-    const double share = std::min(1.0, budget / (per_step * S_plan));
-    c->pc_limit = (long)(share * S);
-    if (c->pc_limit <= 0) return;
-    try {
-      c->pc_arena.ensure((size_t)(per_step * (double)c->pc_limit) + 4096);  // one allocation (grows only)
-    } catch (const DqError&) {
-      c->pc_limit = 0;  // no room after all: run without the cache
-      return;
-    }
-    c->pc_used = 0;
-    c->pc_mode = 1;
-  };
+  PcOff<T> pc_off{c};
 
   // ---- forward ----
   int cstride = 1;
   if (opback) {
     c->last_cstride = 0;  // no state checkpoints
-    setup_pcache();
+    setup_pcache(c, uh, S, dt, tc, opback);
     cur = forward_chain(c, uh, S, dt, B, 0, compose);
   } else {
     // checkpoint stride from the memory budget
@@ -1144,7 +1274,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
     for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
     c->psi[2].ensure(sb);
     c->lam[1].ensure(sb);
-    setup_pcache();  // (after the checkpoints: it takes half of what they left)
+    setup_pcache(c, uh, S, dt, tc, opback);  // (after the checkpoints: it takes half of what they left)
     for (int c0 = 0; c0 < S; c0 += tc) {
       const int n = std::min(tc, S - c0);
       const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
@@ -1165,78 +1295,28 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
     }
   }
 
-  // ---- terminal costate Lambda_S (into lam[0]) and the outputs ----
-  if (targets) {
-    // fidelity objective: c_b = <phi_b|psi_b>, F_b = |c_b|^2, Lambda_S = -2 phi .* c, L = B - sum F
-    const T2* phi = in_dev(c, targets, sb, c->tmp_in[3]);
-    c->e_dev.ensure(sizeof(double) * (3 * (size_t)B + 2));
-    c->part.ensure(sizeof(double) * 2 * (size_t)dq::coldot_chunks(d) * B);
-    double* fid = c->e_dev.d();
-    double* cvals = c->e_dev.d() + B + 1;
-    c->timed(DQ_PROF_OTHER, 8.0 * d * B, 6.0 * sizeof(T) * d * B, [&] {
-      return dq::fidelity_costate_launch<T>(phi, (const T2*)c->psi[cur].p, d, B, -2.0, c->part.d(), cvals, fid,
-                                            (T2*)c->lam[0].p, c->st);
-    });
-    c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(fid, B, fid + B, c->st); });
-    if (energies) out_copy(c, energies, fid, sizeof(double) * (size_t)B);
-    if (loss) {
-      double fsum = 0.0;
-      HIPCK(hipMemcpyAsync(&fsum, fid + B, sizeof(double), hipMemcpyDeviceToHost, c->st));
-      HIPCK(hipStreamSynchronize(c->st));
-      const double l = (double)B - fsum;
-      HIPCK(hipMemcpyAsync(loss, &l, sizeof(double), hipMemcpyDefault, c->st));
-      HIPCK(hipStreamSynchronize(c->st));
-    }
-  } else {
-    // psi[cur] = Psi_S ; terminal costate Lambda_S = 2 M Psi_S, energies
-    do_energy(c, (const T2*)c->psi[cur].p, B, (T2*)c->lam[0].p, energies, loss);
-  }
+  // ---- terminal costate Lambda_S (into lam[0]) and the outputs; psi[cur] = Psi_S ----
+  terminal_costate(c, (const T2*)c->psi[cur].p, B, targets, loss, energies);
   if (psi_final) out_copy(c, psi_final, c->psi[cur].p, sb);
 
   // ---- backward ----
   if (c->pc_mode == 1) c->pc_mode = 2;
   if (S > 0) {
-    const int nblk = dq::grad_contract_blocks((long)c->nn());
     const int last_c0 = ((S - 1) / tc) * tc;
     const T2* psi_next = (const T2*)c->psi[cur].p;
     int lcur = 0;
-    T2* W = nullptr;  // operator form: W_{t+1}
-    // Only the anti-Hermitian part of W reaches the gradient: dU_t = U_t K with K anti-Hermitian (U_t unitary up to the
-    // Taylor remainder), and Re tr((W U)^H U K) = Re tr((U^H W U)^H K) vanishes for Hermitian W. With W anti-Hermitian,
-    // W_t = U_t^H (W_{t+1} U_t) is anti-Hermitian for ANY U_t: that product computes the upper triangle only.
-    // (Off when a polynomial degree is forced: the gradient is then the exact derivative of an under-resolved polynomial.)
-    const bool skew_w = opback && c->skew_trick != 0 && c->force_degree <= 0 && c->real_mode <= 0;
-    if (opback) {
-      W = c->mat(SLOT_TREE, 1);
-      c->zgemm(0, 1, d, d, B, 1.0, (const T2*)c->lam[0].p, B, 0, psi_next, B, 0, 0.0, W, d, 0, 1);  // W_S
-      if (skew_w) {
-        T2* Ws = c->mat(SLOT_TREE + 1, 1);
-        c->timed(DQ_PROF_LINCOMB, 4.0 * c->nn(), 3.0 * 2.0 * sizeof(T) * c->nn(),
-                 [&] { return dq::tcombine_launch<T>(Ws, W, d, 0.5, -0.5, 0, (long)c->nn(), 1, c->st); });
-        W = Ws;
-      }
-    }
+    const bool skew_w = opback && skew_w_form(c);
+    T2* W = opback ? terminal_w(c, psi_next, B, skew_w) : nullptr;  // operator form: W_{t+1}
     for (int c0 = last_c0; c0 >= 0; c0 -= tc) {
       const int n = std::min(tc, S - c0);
       const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
       const T2* U = build_propagators(c, p, c0, n, dt);
       T2* G = ubar_slot(c, p, n);
-      // auto: chunks of >= 4 steps at dimensions where one d x d product leaves most of the chip idle (d <= 1024)
-      const bool tpar = opback && (c->time_parallel == 1 ? n >= 2
-                                                         : (c->time_parallel < 0 && n >= 4 && (d + 127) / 128 * ((d + 127) / 128) < c->n_cu));
-      c->last_tpar = tpar ? 1.0 : 0.0;
-      if (tpar) W = tp_sweep(c, U, G, W, n, skew_w);
-      for (int t = tpar ? -1 : n - 1; t >= 0; --t) {
+      if (opback) W = opback_chunk(c, U, G, W, n, skew_w);
+      for (int t = opback ? -1 : n - 1; t >= 0; --t) {
         const int tt = c0 + t;
         const T2* Ut = U + (size_t)t * c->nn();
         T2* Gt = G + (size_t)t * c->nn();
-        if (opback) {
-          c->zgemm(0, 0, d, d, d, 1.0, W, d, 0, Ut, d, 0, 0.0, Gt, d, 0, 1);  // G_t = W_{t+1} U_t
-          T2* Wn = c->mat(W == c->mat(SLOT_TREE, 1) ? SLOT_TREE + 1 : SLOT_TREE, 1);
-          c->zgemm(1, 0, d, d, d, 1.0, Ut, d, 0, Gt, d, 0, 0.0, Wn, d, 0, 1, skew_w ? -1 : 0);  // W_t = U_t^H G_t
-          W = Wn;
-          continue;
-        }
         const T2* psi_t;
         if (tt % cstride == 0) {
           psi_t = (const T2*)c->ck[tt / cstride].p;
@@ -1255,27 +1335,116 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
         lcur ^= 1;
         psi_next = psi_t;
       }
-      c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
-      if (p.rq > 0) {
-        const T* Xbar = real_backward(c, p, n);
-        const double byr = (double)sizeof(T) * c->nn() * (K + ((K + 15) / 16)) * n;
-        c->timed(DQ_PROF_GRADC, 2.0 * c->nn() * K * n, byr, [&] {
-          return dq::rgrad_contract_launch<T>(Xbar, (long)c->nn(), (const T*)c->Hsr.p, K, (long)c->nn(), n, -std::ldexp(dt, -p.s),
-                                              c->part.d(), c->grad_dev.d() + (size_t)c0 * K, c->st);
-        });
-        continue;
-      }
-      const T2* Abar = expm_backward(c, p, n, c->skew_trick != 0);
-      const double by = 2.0 * sizeof(T) * c->nn() * (K + ((K + 7) / 8)) * n;
-      c->timed(DQ_PROF_GRADC, 3.0 * c->nn() * K * n, by, [&] {
-        return dq::grad_contract_launch<T>(Abar, (long)c->nn(), (const T2*)c->Hs.p, K, (long)c->nn(), n, dt,
-                                           c->part.d(), c->grad_dev.d() + (size_t)c0 * K, c->st);
-      });
+      chunk_vjp(c, p, c0, n, dt);
     }
   }
   c->pc_mode = 0;
   if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
   HIPCK(hipStreamSynchronize(c->st));
+}
+
+// ---- time-sliced operator form ---------------------------------------------------------------
+// In operator form the cost of a gradient evaluation does not depend on the batch: the forward pass is the product
+// Q = U_{S-1} ... U_0 applied once, the backward sweep runs on the d x d matrix W. Both split over TIME: a rank that owns
+// the steps [a, b) builds only their propagators, contributes their product P = U_{b-1} ... U_a, and -- given W at time b,
+// W_b = R^H W_S R with R = U_{S-1} ... U_b the product of the later slices -- sweeps only its own steps. The three calls
+// below are those phases of dq_energy_grad; the host composes the slice products and conjugates W_S between them
+// (dq_zgemm), with one all-gather of the P's, one all-reduce of W_S (the batch shards' sum) and one all-gather of the
+// gradient rows (diffquantum_amd/distributed.py). The propagator cache filled by the forward call serves the backward call.
+template <class T>
+void do_slice_forward(Ctx<T>* c, const double* u, int n, double dt, void* P_out) {
+  typedef TT T2;
+  check_ctx(c);
+  require_H(c);
+  if (!c->hermitian) fail(DQ_ERR_UNSUPPORTED, "the operator form needs Hermitian H0/H_k (it uses U_t^{-1} = U_t^H)");
+  if (n < 0) fail(DQ_ERR_INVALID, "n_steps must be >= 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (!P_out) fail(DQ_ERR_INVALID, "null output");
+  if (n > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
+  std::vector<double> uh = fetch_u(c, u, n);
+  const int tc = time_chunk(c, std::max(n, 1));
+  c->last_chunk = tc;
+  PcOff<T> pc_off{c};
+  setup_pcache(c, uh, n, dt, tc, true);
+  T2* P = compose_chain(c, uh, n, dt, tc);
+  if (!P) {
+    P = c->mat(SLOT_TREE + 2, 1);
+    c->lincomb(P, 0, nullptr, nullptr, 1.0, 1, false);  // empty slice: the identity
+  }
+  out_copy(c, P_out, P, c->mat_bytes());
+  HIPCK(hipStreamSynchronize(c->st));
+  c->slice_u = uh;
+  c->slice_dt = dt;
+  c->slice_tc = tc;
+  c->slice_valid = true;
+}
+
+template <class T>
+void do_slice_terminal(Ctx<T>* c, const void* Q, const void* psi0, int B, const void* targets, double* loss,
+                       double* energies, void* psi_final, void* W_out) {
+  typedef TT T2;
+  check_ctx(c);
+  if (!targets && !c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
+  if (B <= 0) fail(DQ_ERR_INVALID, "batch must be > 0");
+  if (!Q || !psi0 || !W_out) fail(DQ_ERR_INVALID, "null argument");
+  const int d = c->d;
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  for (int i = 0; i < 2; ++i) c->psi[i].ensure(sb);
+  c->lam[0].ensure(sb);
+  const T2* Qd = in_dev(c, Q, c->mat_bytes(), c->tmp_in[0]);
+  const T2* p0 = in_dev(c, psi0, sb, c->psi[0]);
+  T2* psi_S = (T2*)c->psi[1].p;
+  c->zgemm(0, 0, d, B, d, 1.0, Qd, d, 0, p0, B, 0, 0.0, psi_S, B, 0, 1);  // Psi_S = Q Psi_0
+  terminal_costate(c, psi_S, B, targets, loss, energies);
+  if (psi_final) out_copy(c, psi_final, psi_S, sb);
+  const T2* W = terminal_w(c, psi_S, B, skew_w_form(c));
+  out_copy(c, W_out, W, c->mat_bytes());
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+void do_slice_backward(Ctx<T>* c, const double* u, int n, double dt, const void* W_end, double* grad_u, void* W_start) {
+  typedef TT T2;
+  check_ctx(c);
+  require_H(c);
+  if (!c->hermitian) fail(DQ_ERR_UNSUPPORTED, "the operator form needs Hermitian H0/H_k (it uses U_t^{-1} = U_t^H)");
+  if (n < 0) fail(DQ_ERR_INVALID, "n_steps must be >= 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (!W_end) fail(DQ_ERR_INVALID, "null W");
+  if (n > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
+  const int K = c->K;
+  std::vector<double> uh = fetch_u(c, u, n);
+  // the forward call's cache is live only for the very same slice
+  const bool same = c->slice_valid && c->slice_dt == dt && c->slice_u == uh;
+  const int tc = same ? c->slice_tc : time_chunk(c, std::max(n, 1));
+  c->last_chunk = tc;
+  PcOff<T> pc_off{c};
+  if (same) {
+    c->pc_mode = c->pc_limit > 0 ? 2 : 0;
+  } else {
+    for (auto& e : c->pcache) e.valid = false;
+    c->slice_valid = false;
+    c->pc_mode = 0;
+  }
+  c->grad_dev.ensure(std::max<size_t>((size_t)n * K, 1) * sizeof(double));
+  const bool skew_w = skew_w_form(c);
+  T2* W = c->mat(SLOT_TREE, 1);
+  HIPCK(hipMemcpyAsync(W, W_end, c->mat_bytes(), hipMemcpyDefault, c->st));
+  if (n > 0) {
+    const int last_c0 = ((n - 1) / tc) * tc;
+    for (int c0 = last_c0; c0 >= 0; c0 -= tc) {
+      const int m = std::min(tc, n - c0);
+      const ExpmPlan p = chunk_plan(c, uh, c0, m, dt);
+      const T2* U = build_propagators(c, p, c0, m, dt);
+      T2* G = ubar_slot(c, p, m);
+      W = opback_chunk(c, U, G, W, m, skew_w);
+      chunk_vjp(c, p, c0, m, dt);
+    }
+  }
+  if (grad_u && n > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)n * K);
+  if (W_start) out_copy(c, W_start, W, c->mat_bytes());
+  HIPCK(hipStreamSynchronize(c->st));
+  c->slice_valid = false;  // one backward per forward
 }
 
 // The reference's "parameter-shift in time" Monte-Carlo estimator as one device-resident operation
@@ -1568,6 +1737,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "operator_backward") return c->last_opback;
   if (s == "time_parallel") return c->last_tpar;
   if (s == "cached_steps") return c->last_cached;
+  if (s == "slice_skew") return skew_w_form(c) ? 1.0 : 0.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;
   if (s == "norm_H0") return c->nH0;
@@ -1607,7 +1777,7 @@ int with_ctx(dq_ctx* c, F&& f) {
 
 extern "C" {
 
-const char* dq_version(void) { return "diffqc_hip 0.3 (gfx950; complex128 + complex64; real-symmetric fast path)"; }
+const char* dq_version(void) { return "diffqc_hip 0.4 (gfx950; complex128 + complex64; real-symmetric fast path; time-sliced operator form)"; }
 const char* dq_last_error(void) { return g_err.c_str(); }
 
 int dq_device_count(int* n) {
@@ -1736,6 +1906,20 @@ int dq_fidelity_grad(dq_ctx* c, const double* u, int n_steps, double dt, const v
 int dq_mc_shift_grad(dq_ctx* c, const double* u_a, int n_a, double dt_a, const double* u_b, int n_b, double dt_b,
                      const void* psi0, int batch, double r, double* ps, void* phi_out) {
   return with_ctx(c, [&](auto* t) { do_mc_shift(t, u_a, n_a, dt_a, u_b, n_b, dt_b, psi0, batch, r, ps, phi_out); });
+}
+
+int dq_slice_forward(dq_ctx* c, const double* u, int n_steps, double dt, void* P_out) {
+  return with_ctx(c, [&](auto* t) { do_slice_forward(t, u, n_steps, dt, P_out); });
+}
+
+int dq_slice_terminal(dq_ctx* c, const void* Q, const void* psi0, int batch, const void* targets, double* loss,
+                      double* energies, void* psi_final, void* W_out) {
+  return with_ctx(c, [&](auto* t) { do_slice_terminal(t, Q, psi0, batch, targets, loss, energies, psi_final, W_out); });
+}
+
+int dq_slice_backward(dq_ctx* c, const double* u, int n_steps, double dt, const void* W_end, double* grad_u,
+                      void* W_start) {
+  return with_ctx(c, [&](auto* t) { do_slice_backward(t, u, n_steps, dt, W_end, grad_u, W_start); });
 }
 
 int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,

@@ -249,6 +249,81 @@ class Engine:
                                               ps.ctypes.data, pphi))
         return (ps, phi) if want_phi else ps
 
+    # -- time-sliced operator form (phases of energy_grad; see diffquantum_amd/distributed.py) ---------
+    def _mat_like(self, like):
+        """An uninitialised [dim][dim] complex matrix of the same kind as `like` (CUDA torch tensor or numpy)."""
+        if _is_torch(like):
+            import torch
+            return torch.empty((self.dim, self.dim), dtype=like.dtype if like.is_complex() else
+                               (torch.complex128 if self.dtype == "c128" else torch.complex64), device=like.device)
+        return np.empty((self.dim, self.dim), dtype=self.cdtype)
+
+    def slice_forward(self, u, dt: float, like=None):
+        """P = U_{n-1} ... U_0 of the slice's own pulse rows u[n][K] (identity for n = 0); the propagator
+        intermediates stay cached for slice_backward. Returns a [dim][dim] matrix of the kind of `like`."""
+        pu, ku, n = self._u(u)
+        P = self._mat_like(like)
+        pp, kp = self._c(P, (self.dim, self.dim), "P")
+        _lib.check(self._lib.dq_slice_forward(self._ctx, pu, n, float(dt), pp))
+        return P
+
+    def slice_terminal(self, Q, psi0, targets=None, want_final=False, want_energies=False):
+        """Psi_S = Q Psi_0 for this rank's columns; returns (loss, W_S, psi_final or None, energies or None) with
+        W_S = Lambda_S Psi_S^H (anti-Hermitian part if info('slice_skew'))."""
+        pq, kq = self._c(Q, (self.dim, self.dim), "Q")
+        pp, kp, B = self._psi(psi0)
+        pt = 0
+        if targets is not None:
+            pt, kt, Bt = self._psi(targets, "targets")
+            if Bt != B:
+                raise ValueError("targets must have the same batch width as psi0")
+        W = self._mat_like(Q)
+        pw, kw = self._c(W, (self.dim, self.dim), "W")
+        loss = C.c_double()
+        fin, pf = None, 0
+        if want_final:
+            if _is_torch(psi0):
+                import torch
+                fin = torch.empty_like(psi0)
+                pf = fin.data_ptr()
+            else:
+                fin = np.empty((self.dim, B), dtype=self.cdtype)
+                pf = fin.ctypes.data
+        en, pe = None, 0
+        if want_energies:
+            en = np.empty(B, dtype=np.float64)
+            pe = en.ctypes.data
+        _lib.check(self._lib.dq_slice_terminal(self._ctx, pq, pp, B, pt, C.addressof(loss), pe, pf, pw))
+        return loss.value, W, fin, en
+
+    def slice_backward(self, u, dt: float, W_end, want_w_start=False):
+        """Operator-form backward sweep over the slice's own steps from W at the slice's end; returns
+        grad_u[n][K] (numpy; rows of dL/du summed over the whole batch) and, if asked, W at the slice's start."""
+        pu, ku, n = self._u(u)
+        pw, kw = self._c(W_end, (self.dim, self.dim), "W_end")
+        grad = np.zeros((n, self.n_controls), dtype=np.float64)
+        Ws, ps = None, 0
+        if want_w_start:
+            Ws = self._mat_like(W_end)
+            ps, ks = self._c(Ws, (self.dim, self.dim), "W_start")
+        _lib.check(self._lib.dq_slice_backward(self._ctx, pu, n, float(dt), pw, grad.ctypes.data, ps))
+        return (grad, Ws) if want_w_start else grad
+
+    def matmul(self, A, B, opA=0, opB=0, herm=0, out=None):
+        """op(A) @ op(B) for [dim][dim] matrices of either kind (CUDA torch tensors stay on the device);
+        op 1 = conjugate transpose; herm = +1/-1: (anti-)Hermitian output form."""
+        d = self.dim
+        pa, ka = self._c(A, (d, d), "A")
+        pb, kb = self._c(B, (d, d), "B")
+        if out is None:
+            out = self._mat_like(A)
+        po, ko = self._c(out, (d, d), "out")
+        if not _is_torch(out) and ko is not out:
+            raise ValueError("out must be a contiguous [dim][dim] buffer of the engine dtype")
+        _lib.check(self._lib.dq_zgemm_ex(self._ctx, int(opA), int(opB), d, d, d, 1.0, pa, d, d * d, pb, d, d * d, 0.0,
+                                         po, d, d * d, 1, int(herm)))
+        return out
+
     # -- building blocks ----------------------------------------------------
     def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None, herm=0):
         """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host).

@@ -108,7 +108,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
- * "time_parallel", "cached_steps", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
+ * "time_parallel", "cached_steps", "slice_skew", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 
@@ -140,6 +140,28 @@ int dq_fidelity_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const
  * The host multiplies by du_k(s)/dcoeff (sim_plain.py:170-184,227). phi_out ([dim][batch]) is optional. */
 int dq_mc_shift_grad(dq_ctx* ctx, const double* u_a, int n_a, double dt_a, const double* u_b, int n_b, double dt_b,
                      const void* psi0, int batch, double r, double* ps, void* phi_out);
+
+/* ---- Time-sliced operator form: the phases of dq_energy_grad, for a chain split over TIME across GPUs
+ * (the reference's time loop diffqc.cc:190-200 / sim_plain.py:135-150 is sequential).
+ * In operator form (batch >= 3/4 dim) the work of a gradient evaluation is d x d matrix products per step, independent
+ * of the batch; a rank that owns the steps [a, b) of the chain
+ *   1. dq_slice_forward : builds their propagators and returns the slice product  P = U_{b-1} ... U_a  ([dim][dim] complex;
+ *                         the identity for an empty slice); real path: the propagator intermediates stay cached;
+ *   2. (host) all-gathers the P's, forms Q = P_{G-1} ... P_0 and R = the product of the LATER slices (dq_zgemm);
+ *   3. dq_slice_terminal: Psi_S = Q Psi_0 for its own batch shard, loss / energies (fidelities with `targets`, as
+ *                         dq_fidelity_grad), and  W_S = Lambda_S Psi_S^H  ([dim][dim]; its anti-Hermitian part when
+ *                         dq_get_info("slice_skew") is 1) -- the host sums W_S over the ranks (the only batch reduction);
+ *   4. (host)             W_b = R^H W_S R  (dq_zgemm_ex; anti-Hermitian output form if slice_skew);
+ *   5. dq_slice_backward: sweeps its own steps from W_end = W_b:  G_t = W_{t+1} U_t,  W_t = U_t^H G_t, reverse mode of
+ *                         exp and the control contractions -> grad_u[n_steps][n_controls] (its rows of dL/du, already
+ *                         summed over the WHOLE batch); W_start (optional) receives W_a.
+ * u holds the slice's own rows of the pulse table. With one slice covering the chain these three calls compute
+ * exactly what dq_energy_grad computes. */
+int dq_slice_forward(dq_ctx* ctx, const double* u, int n_steps, double dt, void* P_out);
+int dq_slice_terminal(dq_ctx* ctx, const void* Q, const void* psi0, int batch, const void* targets, double* loss,
+                      double* energies, void* psi_final, void* W_out);
+int dq_slice_backward(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* W_end, double* grad_u,
+                      void* W_start);
 
 /* Building blocks, exported for parity tests and reuse. */
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */

@@ -1,0 +1,58 @@
+"""Test infrastructure: a numpy stand-in for the three phase calls of the time-sliced operator form
+(Engine.slice_forward / slice_terminal / slice_backward / matmul), written with the ORACLE's arithmetic
+(scipy expm + expm_frechet on the reference's step generator, sim_plain.py:137-146).  It lets the CPU suite drive
+diffquantum_amd.distributed's rank program through real torch.distributed collectives (gloo) without a GPU.
+Never imported by the product."""
+import numpy as np
+import scipy.linalg as sla
+
+from oracle import trotter_oracle as orc
+
+
+class NumpySliceEngine:
+    def __init__(self, H0, Hs, M, skew=True):
+        self.H0 = np.asarray(H0, dtype=np.complex128)
+        self.Hs = [np.asarray(h, dtype=np.complex128) for h in Hs]
+        self.M = np.asarray(M, dtype=np.complex128)
+        self.dim = self.H0.shape[0]
+        self.n_controls = len(self.Hs)
+        self.skew = skew
+
+    def info(self, name):
+        if name == "slice_skew":
+            return 1.0 if self.skew else 0.0
+        raise KeyError(name)
+
+    def slice_forward(self, u, dt, like=None):
+        P = np.eye(self.dim, dtype=np.complex128)
+        for row in np.asarray(u, dtype=np.float64).reshape(-1, self.n_controls):
+            P = sla.expm(orc.step_generator(self.H0, self.Hs, row, dt)) @ P
+        return P
+
+    def matmul(self, A, B, opA=0, opB=0, herm=0, out=None):
+        A = A.conj().T if opA else A
+        B = B.conj().T if opB else B
+        return A @ B
+
+    def slice_terminal(self, Q, psi0, targets=None, want_final=False, want_energies=False):
+        psi = Q @ psi0
+        lam = 2.0 * (self.M @ psi)
+        en = np.real(np.sum(psi.conj() * (self.M @ psi), axis=0))
+        W = lam @ psi.conj().T
+        if self.skew:
+            W = 0.5 * (W - W.conj().T)
+        return float(en.sum()), W, (psi if want_final else None), (en if want_energies else None)
+
+    def slice_backward(self, u, dt, W_end, want_w_start=False):
+        u = np.asarray(u, dtype=np.float64).reshape(-1, self.n_controls)
+        W = np.array(W_end)
+        grad = np.zeros_like(u)
+        for t in range(u.shape[0] - 1, -1, -1):
+            A = orc.step_generator(self.H0, self.Hs, u[t], dt)
+            U = sla.expm(A)
+            G = W @ U
+            for k, Hk in enumerate(self.Hs):
+                dU = sla.expm_frechet(A, -1j * dt * Hk, compute_expm=False)
+                grad[t, k] = np.real(np.vdot(G, dU))  # Re tr(G^H dU)
+            W = U.conj().T @ G
+        return (grad, W) if want_w_start else grad

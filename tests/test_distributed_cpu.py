@@ -70,3 +70,82 @@ def test_two_rank_gloo_allreduce_equals_single_process():
     loss, grad, _ = orc.energy_grad(H0, list(Hs), M, u, 0.1, full)
     for rank, l, g in res:
         assert abs(l - loss) < 1e-12 and np.max(np.abs(g - grad)) < 1e-12
+
+
+# ---- time-sliced operator form: the rank program through real gloo collectives -------------------
+
+def test_virtual_ranks_time_sliced_equals_oracle():
+    """G virtual ranks in one process (numpy phase engine = oracle arithmetic): chain split over time, batch over ranks."""
+    from diffquantum_amd import problems
+    from diffquantum_amd.distributed import shard_range, virtual_time_sliced_energy_grad
+    from oracle import trotter_oracle as orc
+    from tests.np_slice_engine import NumpySliceEngine
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    dt = 0.1
+    B = 7
+    full = problems.random_states(4, B, seed=9)
+    for S in (0, 1, 6, 7):
+        u = np.random.default_rng(S).uniform(-1, 1, (S, 2))
+        loss, grad, fin = orc.energy_grad(H0, list(Hs), M, u, dt, full)
+        for world in (1, 2, 3, 8):  # world > S: ranks with empty slices; world > B would leave ranks without columns
+            if world > B:
+                continue
+            for skew in (True, False):
+                engines = [NumpySliceEngine(H0, Hs, M, skew) for _ in range(world)]
+                shards = [full[:, f:f + c] for f, c in (shard_range(B, r, world) for r in range(world))]
+                res = virtual_time_sliced_energy_grad(engines, u, dt, shards)
+                for r, (l, g, f, e) in enumerate(res):
+                    assert abs(l - loss) < 1e-12
+                    assert g.shape == (S, 2) and (S == 0 or np.max(np.abs(g - grad)) < 1e-12)
+                    f0, c0 = shard_range(B, r, world)
+                    assert np.max(np.abs(f - fin[:, f0:f0 + c0])) < 1e-12
+
+
+def _sliced_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from diffquantum_amd import problems
+    from diffquantum_amd.distributed import shard_range, time_sliced_energy_grad
+    from tests.np_slice_engine import NumpySliceEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (7, 2))
+    B = 5
+    first, count = shard_range(B, rank, world)
+    psi = problems.random_states(4, count, seed=9, first=first)
+    out = []
+    for _ in range(2):  # twice: the collectives stay matched call after call
+        loss, grad, fin, en = time_sliced_energy_grad(NumpySliceEngine(H0, Hs, M), u, 0.1, psi, want_final=True,
+                                                      want_energies=True)
+        out.append((loss, grad))
+    q.put((rank, out, fin, first, count))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_time_sliced_equals_single_process():
+    import torch.multiprocessing as mp
+    from diffquantum_amd import problems
+    from oracle import trotter_oracle as orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sliced_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (7, 2))
+    full = problems.random_states(4, 5, seed=9)
+    loss, grad, fin = orc.energy_grad(H0, list(Hs), M, u, 0.1, full)
+    for rank, out, f, first, count in res:
+        for l, g in out:
+            assert abs(l - loss) < 1e-12 and np.max(np.abs(g - grad)) < 1e-12
+        assert np.max(np.abs(f - fin[:, first:first + count])) < 1e-12
