@@ -170,6 +170,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and rank == 0:
         print("warning: --gpus {} but WORLD_SIZE {}".format(a.gpus, world), file=sys.stderr)
+    # one process per GPU. (Rehearsal on a box with fewer GPUs than ranks: DQ_DIST_BACKEND=gloo shares the devices
+    # round-robin and stages the collectives through the host -- RCCL refuses two ranks on one device.)
+    backend = os.environ.get("DQ_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "MASTER_PORT" in os.environ
@@ -178,7 +183,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce_(t, op):  # in place on a device tensor, whatever the backend
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     n, B, K, W = a.qubits, a.batch, a.steps, a.warmup
     d = 1 << n
@@ -230,7 +246,7 @@ def main():
                 sliced_check = {"error": repr(e)}
                 ok = 0.0
             flag = torch.tensor([ok], dtype=torch.float64, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            all_reduce_(flag, dist.ReduceOp.MIN)
             if float(flag.item()) < 1.0 and a.multi_gpu == "auto":
                 mode = "replicated"
     run = run_sliced if mode == "sliced" else run_replicated
@@ -250,7 +266,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce_(tmax, dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = eng.profile()
     other_mode = None
@@ -266,7 +282,7 @@ def main():
             fence()
             el2 = time.perf_counter() - t1
             tm = torch.tensor([el2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            all_reduce_(tm, dist.ReduceOp.MAX)
             other_mode = {"form": "replicated" if mode == "sliced" else "sliced", "value": world * K / float(tm.item()),
                           "ms_per_step": float(tm.item()) / max(K, 1) * 1e3,
                           "max_abs_grad_diff_vs_headline_form": float((g2 - grad).abs().max().item()),

@@ -39,7 +39,10 @@ def allreduce_loss_grad(loss: float, grad_u, group=None, device=None):
         return loss, grad_u
     is_np = isinstance(grad_u, np.ndarray)
     g = torch.from_numpy(np.ascontiguousarray(grad_u, dtype=np.float64)) if is_np else grad_u
-    buf = torch.empty(g.numel() + 1, dtype=torch.float64, device=device if device is not None else g.device)
+    where = device if device is not None else g.device
+    if dist.get_backend(group) != "nccl":
+        where = "cpu"  # gloo: stage through the host
+    buf = torch.empty(g.numel() + 1, dtype=torch.float64, device=where)
     buf[:-1].copy_(g.reshape(-1))
     buf[-1] = float(loss)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)

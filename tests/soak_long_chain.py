@@ -1,3 +1,5 @@
+"""Long-chain soak (run by hand on the GPU box: python tests/soak_long_chain.py): 20000-step chains against the oracle.
+Lives under tests/ because it calls the oracle (test infrastructure); not collected by pytest."""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 from diffquantum_amd import problems
