@@ -104,7 +104,7 @@ def _torch_collective(kind, x, group, device):
     on_dev = (not is_np) and t.is_cuda
     if backend == "nccl":
         if not t.is_cuda:
-            t = t.to(device)
+            t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     elif t.is_cuda:
         t = t.cpu()
     if t.is_complex():
@@ -158,6 +158,26 @@ def time_sliced_energy_grad(engine, u, dt, psi0_shard, group=None, device=None, 
             req = gen.send(res)
         except StopIteration as done:
             return done.value
+
+
+def time_sliced_propagate(engine, u, dt, psi_shard, group=None, device=None):
+    """Forward chain only (dq_propagate) with the propagators built 1/world per rank: all-gather of the slice products,
+    Q = P_{G-1} ... P_0, one apply to this rank's columns.  Returns Psi_S of this rank's columns."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        rank, world = 0, 1
+    else:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    first, count = shard_range(int(u.shape[0]), rank, world)
+    u_own = u[first:first + count]
+    if hasattr(u_own, "contiguous"):
+        u_own = u_own.contiguous()
+    P = engine.slice_forward(u_own, dt, like=psi_shard)
+    Ps = [P] if world == 1 else _torch_collective("all_gather", P, group, device)
+    acc = Ps[world - 1]
+    for j in range(world - 2, -1, -1):
+        acc = engine.matmul(acc, Ps[j])
+    return engine.apply(acc, psi_shard)
 
 
 def virtual_time_sliced_energy_grad(engines, u, dt, psi0_shards, targets=None):

@@ -324,6 +324,23 @@ class Engine:
                                          po, d, d * d, 1, int(herm)))
         return out
 
+    def apply(self, Q, psi, out=None):
+        """Q @ psi for a [dim][dim] operator and a [dim][batch] state batch of either kind (device tensors in place)."""
+        d = self.dim
+        pq, kq = self._c(Q, (d, d), "Q")
+        pp, kp, B = self._psi(psi)
+        if out is None:
+            if _is_torch(psi):
+                import torch
+                out = torch.empty_like(psi)
+            else:
+                out = np.empty((d, B), dtype=self.cdtype)
+        po, ko, Bo = self._psi(out, "out")
+        if Bo != B or (not _is_torch(out) and ko is not out):
+            raise ValueError("out must be a contiguous [dim][batch] buffer of the engine dtype")
+        _lib.check(self._lib.dq_zgemm_ex(self._ctx, 0, 0, d, B, d, 1.0, pq, d, d * d, pp, B, d * B, 0.0, po, B, d * B, 1, 0))
+        return out
+
     # -- building blocks ----------------------------------------------------
     def zgemm(self, A, B, opA=0, opB=0, alpha=1.0, beta=0.0, C_in=None, herm=0):
         """alpha*op(A)@op(B) + beta*C on the GPU kernel; A, B: 2-D or batched 3-D complex128 (host).

@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 from diffquantum_amd import problems
-from diffquantum_amd.distributed import shard_range, time_sliced_energy_grad, virtual_time_sliced_energy_grad
+from diffquantum_amd.distributed import (shard_range, time_sliced_energy_grad, time_sliced_propagate,
+                                         virtual_time_sliced_energy_grad)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -197,3 +198,19 @@ def test_slice_argument_errors():
         e.set_hamiltonians(A, np.zeros((0, 2, 2), dtype=complex))
         with pytest.raises(NotImplementedError):
             e.slice_forward(np.zeros((2, 0)), 0.1)
+
+
+@pytest.mark.parametrize("kind", ["complex", "real"])
+def test_sliced_propagate_single_rank_and_composed_slices(oracle, kind):
+    """Forward only: the slice products of a 3-way split of the chain, composed on the host, equal dq_propagate."""
+    n, K, dt, B, S = 4, 3, 0.04, 9, 10
+    H0, Hs, M = _problem(kind, n, K, seed=21)
+    u = np.random.default_rng(2).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(1 << n, B, seed=4)
+    ref = oracle.propagate(H0, list(Hs), u, dt, psi0)
+    with _engine(H0, Hs, M, real_min_dim=1) as e:
+        got = time_sliced_propagate(e, u, dt, psi0)
+        Ps = [e.slice_forward(u[f:f + c], dt) for f, c in (shard_range(S, r, 3) for r in range(3))]
+        Q = e.matmul(e.matmul(Ps[2], Ps[1]), Ps[0])
+        got3 = e.apply(Q, psi0)
+    assert np.max(np.abs(got - ref)) < TOL and np.max(np.abs(got3 - ref)) < TOL
