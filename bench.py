@@ -211,8 +211,16 @@ def main():
     u_t = torch.from_numpy(u_all[:K].copy()).to(dev)
     grad_t = torch.zeros((K, n), dtype=torch.float64, device=dev)
 
+    # Propagator cache of the sliced form: a rank's slice of the planned chain is short enough to be cached WHOLE
+    # ((q + 3) d^2 fp64 words per step, q <= 3 at this step size: 0.8 GB per step, 201 GB for 250 steps), so the budget is what
+    # the slice needs, capped at 72 % of the HBM (the engine's auto mode stops at 96 GiB: bigger first-use allocations cost
+    # seconds, which a 2000-step single-GPU chain does not win back but a fully cached slice does, evaluation after evaluation)
+    slice_steps = (max(a.chain, K) + world - 1) // world
+    sliced_cache_bytes = min(6.0 * d * d * 8 * slice_steps + (1 << 20), 0.72 * torch.cuda.get_device_properties(local).total_memory)
+
     def run_replicated(u_dev, grad_dev):
         eng.set_option("plan_steps", max(a.chain, K))
+        eng.set_option("cache_bytes", 0)
         loss, g, _, _ = eng.energy_grad(u_dev, a.dt, psi0, want_final=False, want_energies=False, grad_out=grad_dev)
         return allreduce_loss_grad(loss, g, device=dev)
 
@@ -221,6 +229,7 @@ def main():
         # WHOLE batch (its own shard enters through W_S only); all-gather of the slice products, all-reduce of W_S,
         # all-reduce of the gradient rows + loss
         eng.set_option("plan_steps", (max(a.chain, K) + world - 1) // world)
+        eng.set_option("cache_bytes", sliced_cache_bytes)
         loss, g, _, _ = time_sliced_energy_grad(eng, u_dev, a.dt, psi0, device=dev)
         g = torch.from_numpy(g).to(dev)
         grad_dev.copy_(g)

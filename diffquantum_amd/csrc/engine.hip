@@ -1073,13 +1073,16 @@ void setup_pcache(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
   const double S_plan = (double)std::max<long>(S, c->plan_steps);
   const double share = std::min(1.0, budget / (per_step * S_plan));
   c->pc_limit = (long)(share * S);
-  if (c->pc_limit <= 0) return;
-  try {
-    c->pc_arena.ensure((size_t)(per_step * (double)c->pc_limit) + 4096);  // one allocation (grows only)
-  } catch (const DqError&) {
-    c->pc_limit = 0;  // no room after all: run without the cache
-    return;
+  // one allocation (grows only); if the device refuses it, halve the covered steps until it fits
+  while (c->pc_limit > 0) {
+    try {
+      c->pc_arena.ensure((size_t)(per_step * (double)c->pc_limit) + 4096);
+      break;
+    } catch (const DqError&) {
+      c->pc_limit /= 2;
+    }
   }
+  if (c->pc_limit <= 0) return;  // no room at all: run without the cache
   c->pc_used = 0;
   c->pc_mode = 1;
 }

@@ -31,7 +31,11 @@ eng = Engine(d, n, device=0)
 eng.use_torch_stream()
 eng.set_hamiltonians(H0, Hs)
 eng.set_observable(M)
-eng.set_option("plan_steps", (2000 + world - 1) // world)
+slice_steps = (2000 + world - 1) // world
+eng.set_option("plan_steps", slice_steps)
+if len(sys.argv) > 6 and sys.argv[6] == "fullcache":  # as bench.py's sliced form: the whole slice of the planned chain cached
+    eng.set_option("cache_bytes", min(6.0 * d * d * 8 * slice_steps + (1 << 20),
+                                      0.72 * torch.cuda.get_device_properties(0).total_memory))
 
 
 def one():
@@ -61,6 +65,7 @@ print("n={} B={} K={} world={} rank={}: {:.1f} ms per gradient evaluation -> {:.
           n, B, K, world, rank, el * 1e3, K / el, world * K / el, [round(p * 1e3, 1) for p in ph], eng.info("cached_steps")))
 # the same chain in one call (the N = 1 form)
 eng.set_option("plan_steps", 2000)
+eng.set_option("cache_bytes", 0)
 eng.energy_grad(u[:2], dt, psi0, want_final=False, want_energies=False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
