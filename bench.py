@@ -183,10 +183,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
+        import datetime
+        tmo = datetime.timedelta(minutes=5)  # a mismatched collective fails the run instead of hanging it
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     def all_reduce_(t, op):  # in place on a device tensor, whatever the backend
         if backend == "nccl":
