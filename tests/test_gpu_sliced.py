@@ -214,3 +214,34 @@ def test_sliced_propagate_single_rank_and_composed_slices(oracle, kind):
         Q = e.matmul(e.matmul(Ps[2], Ps[1]), Ps[0])
         got3 = e.apply(Q, psi0)
     assert np.max(np.abs(got - ref)) < TOL and np.max(np.abs(got3 - ref)) < TOL
+
+
+def test_headline_shape_two_virtual_ranks():
+    """BASELINE configs[3] per-rank shape (n = 12, d = 4096, 4096 states per rank, fp64) with the chain of 5 steps split
+    over two virtual ranks (3 + 2 steps) and the batch of 8192 over the same two ranks: loss and gradient equal the single
+    call on the whole batch (which runs composed: batch > dim), final states equal its columns. One dq_ctx serves both
+    virtual ranks here (HBM: a second context would double the 3.5 GB Hamiltonian set and the cache arena), so every
+    backward call finds the cache holding the OTHER rank's slice and rebuilds -- the 128-tile kernels, the
+    anti-Hermitian-output conjugation R^H W R and the K-split tails at full size."""
+    import torch
+    from diffquantum_amd.engine import Engine
+    n, Bq, S, dt, world = 12, 4096, 5, 1e-3, 2
+    d = 1 << n
+    dev = torch.device("cuda:0")
+    H0, Hs, M = problems.random_ising_torch(n, 0, dev)
+    u = torch.from_numpy(problems.pulse_table(n, S, S * dt, seed=0)).to(dev)
+    full = torch.from_numpy(problems.random_states(d, world * Bq, seed=1)).to(dev)
+    shards = [full[:, r * Bq:(r + 1) * Bq].contiguous() for r in range(world)]
+    with Engine(d, n) as e:
+        e.use_torch_stream()
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        e.set_option("cache_bytes", 8 * 2 ** 30)
+        l0, g0, f0, _ = e.energy_grad(u, dt, full, want_energies=False)
+        assert e.info("real_path") >= 1 and e.info("operator_backward") == 1 and e.info("composed") == 1
+        res = virtual_time_sliced_energy_grad([e] * world, u, dt, shards)
+    for r, (l, g, f, en) in enumerate(res):
+        assert abs(l - l0) < 1e-10 * world * Bq, (r, l, l0)
+        assert np.max(np.abs(g - g0)) < 1e-10, r               # gradient entries are ~1e-2
+        assert float((f - f0[:, r * Bq:(r + 1) * Bq]).abs().max()) < 1e-12, r
+    assert abs(sum(float(x[3].sum()) for x in res) - l0) < 1e-9 * world
