@@ -239,8 +239,8 @@ def main():
 
     mode = "replicated"
     sliced_check = None
-    if world > 1 and a.multi_gpu != "replicated":
-        mode = "sliced"
+    if (world > 1 and a.multi_gpu != "replicated") or (use_dist and a.multi_gpu == "sliced"):
+        mode = "sliced"  # (asked for explicitly it also runs at world size 1: rehearsal of the collectives)
     if W > 0:
         uw = torch.from_numpy(u_all[:W].copy()).to(dev)
         lr, gr = run_replicated(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))

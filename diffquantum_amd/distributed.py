@@ -19,6 +19,8 @@ same sizes on every rank; per-rank work = 1/G of the chain + (G + 2) extra d x d
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -146,11 +148,13 @@ def time_sliced_energy_grad(engine, u, dt, psi0_shard, group=None, device=None, 
         rank, world = 0, 1
     else:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # DQ_FORCE_COLLECTIVES=1: issue the collectives even at world size 1 (rehearsal of the RCCL calls on a one-GPU box)
+    local_only = world == 1 and not (os.environ.get("DQ_FORCE_COLLECTIVES") and dist.is_available() and dist.is_initialized())
     gen = _sliced_phases(engine, u, dt, psi0_shard, rank, world, targets, want_final, want_energies)
     req = next(gen)
     while True:
         kind, x = req
-        if world == 1:
+        if local_only:
             res = [x] if kind == "all_gather" else x
         else:
             res = _torch_collective(kind, x, group, device)
