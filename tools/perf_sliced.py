@@ -63,6 +63,10 @@ el = time.perf_counter() - t0
 print("n={} B={} K={} world={} rank={}: {:.1f} ms per gradient evaluation -> {:.1f} steps/s per rank-chain, "
       "{:.1f} aggregate (world*K/t); phases [forward+compose, gather->terminal, reduce->backward] ms = {}; cached {}".format(
           n, B, K, world, rank, el * 1e3, K / el, world * K / el, [round(p * 1e3, 1) for p in ph], eng.info("cached_steps")))
+free, total = torch.cuda.mem_get_info()
+print("HBM in use after the run: {:.1f} GB of {:.1f}".format((total - free) / 1e9, total / 1e9))
+if os.environ.get("DQ_SKIP_SINGLE"):
+    sys.exit(0)
 # the same chain in one call (the N = 1 form)
 eng.set_option("plan_steps", 2000)
 eng.set_option("cache_bytes", 0)
