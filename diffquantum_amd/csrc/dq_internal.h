@@ -177,4 +177,21 @@ template <class T>
 hipError_t rgrad_contract_launch(const T* Xbar, long strideX, const T* Hsr, int K, long n_elem, int batch, double scale,
                                  double* part, double* grad, hipStream_t st);
 
+// ---- sparse control Hamiltonians of the real path (realpath.hip) ----
+// cnt[k*d + i] = nonzeros in row i of Hsr[k];  fill: the entries of (k, i), in column order, at base[k*d + i]
+template <class T>
+hipError_t rsp_count_launch(const T* Hsr, int d, int K, int* cnt, hipStream_t st);
+template <class T>
+hipError_t rsp_fill_launch(const T* Hsr, int d, int K, const long* base, int* col, int* kid, double* val, hipStream_t st);
+// X[z][i][col] += -dt u[z*K + kid] val over the CSR (rowptr: d + 1 entries), z < batch
+template <class T>
+hipError_t rsp_add_launch(T* X, long strideX, const long* rowptr, const int* col, const int* kid, const double* val,
+                          const double* u, int K, int d, int batch, double dt, hipStream_t st);
+// grad[z][k] = scale * sum_{e in control k} val[e] (<Sb[z][i_e,:], P[z][j_e,:]> + 2 <Yb[z][i_e,:], X[z][j_e,:]>)
+// (nzval: batch * nnz doubles of scratch; kptr/kent: the entries grouped by control)
+template <class T>
+hipError_t rsp_contract_launch(const T* Sb, const T* P, const T* Yb, const T* X, long stride, int d, const long* rowptr,
+                               const int* col, const double* val, long nnz, const long* kptr, const long* kent, int K,
+                               int batch, double scale, double* nzval, double* grad, hipStream_t st);
+
 }  // namespace dq

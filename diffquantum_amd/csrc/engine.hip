@@ -285,6 +285,13 @@ struct Ctx : dq_ctx {
   DevBuf H0, Hs, M;
   DevBuf H0r, Hsr;  // real parts (real-symmetric fast path)
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
+  // sparse control Hamiltonians (real path; realpath.hip): the nonzeros of all H_k in one CSR by row, and the same
+  // entries grouped by control; sparse_mode: -1 auto (total nonzeros <= sparse_fill * dim), 0 off
+  DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval;
+  long sp_nnz = 0;
+  bool sparse_h = false;
+  int sparse_mode = -1;
+  double sparse_fill = 32.0;
   int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128, rgemm_glds = 1;
   long plan_steps = 0;
   int small_dim = 512, time_parallel = -1;  // see do_energy_grad  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
@@ -318,6 +325,7 @@ struct Ctx : dq_ctx {
     for (auto e : ev_free) (void)hipEventDestroy(e);
   }
 
+  bool sparse_on() const { return sparse_h && sparse_mode != 0; }
   size_t nn() const { return (size_t)d * d; }
   size_t mat_bytes() const { return nn() * sizeof(T2); }
 
@@ -605,10 +613,22 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
   T* X = c->rmat(RS_X, n);
   const double by = (double)sizeof(T) * c->nn() * (c->K + 2.0) * n;
   const double dts = std::ldexp(dt, -p.s);  // X = -(dt / 2^s) H
-  c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->nn() * (c->K + 1.0) * n, by, [&] {
-    return dq::rassemble_launch<T>(X, (const T*)c->H0r.p, (const T*)c->Hsr.p, c->u_dev.d() + (size_t)c0 * c->K, c->K,
-                                   (long)c->nn(), n, dts, c->st);
-  });
+  if (c->sparse_on()) {
+    // dense pass over H0 only, then the controls' nonzeros are scattered in
+    c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->nn() * n, (double)sizeof(T) * c->nn() * 2.0 * n, [&] {
+      return dq::rassemble_launch<T>(X, (const T*)c->H0r.p, (const T*)c->Hsr.p, c->u_dev.d(), 0, (long)c->nn(), n, dts, c->st);
+    });
+    c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->sp_nnz * n, 3.0 * sizeof(double) * c->sp_nnz * n, [&] {
+      return dq::rsp_add_launch<T>(X, (long)c->nn(), (const long*)c->sp_rowptr.p, (const int*)c->sp_col.p,
+                                   (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
+                                   c->u_dev.d() + (size_t)c0 * c->K, c->K, c->d, n, dts, c->st);
+    });
+  } else {
+    c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->nn() * (c->K + 1.0) * n, by, [&] {
+      return dq::rassemble_launch<T>(X, (const T*)c->H0r.p, (const T*)c->Hsr.p, c->u_dev.d() + (size_t)c0 * c->K, c->K,
+                                     (long)c->nn(), n, dts, c->st);
+    });
+  }
   const T* Y[RQ_MAX + 1];
   for (int j = 1; j <= q; ++j) {
     T* Yj = c->rmat(j, n);
@@ -645,8 +665,11 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
 // with sym(Z) = (Z + Z^T)/2 = (Wbar V + V Wbar)/2 for symmetric Wbar, V: one two-product symmetric-output launch per
 // cotangent (the MFMA work of one full real GEMM), 2q in all.
 // Returns Xbar (n stacked real symmetric matrices): dL/du_k = <Xbar, -dt H_k>.
+// skip_x: the two products into Xbar are left out (sparse controls: chunk_vjp contracts Sbar, P, Ybar_1, X directly);
+// sb_out / yb_out then receive the cotangents of S and Y_1, and the return value is null.
 template <class T>
-const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
+const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n, bool skip_x = false, const T** sb_out = nullptr,
+                       const T** yb_out = nullptr) {
   typedef typename dq::Cx<T>::type T2;
   const int q = p.rq;
   const T2* G = c->mat(SLOT_ADJ + RS_U, n);
@@ -682,7 +705,7 @@ const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
   T* Cb = cur[0];
   T* Sb = cur[1];
   // S = X P
-  sym2(Sb, P, Xb, 0.5, false);
+  if (!skip_x) sym2(Sb, P, Xb, 0.5, false);
   sym2(Sb, X, Pb, 0.5, false);
   // C = cc0 I + sum cc_j Y_j,  P = sc0 I + sum sc_j Y_j
   for (int j = 1; j <= q; ++j) {
@@ -696,6 +719,11 @@ const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n) {
     sym2(Yb[j], Y[1], Yb[j - 1], 0.5, true);
   }
   if (q >= 2) sym2(Yb[2], Y[1], Yb[1], 1.0, true);  // Y_2 = Y_1 Y_1
+  if (skip_x) {
+    if (sb_out) *sb_out = Sb;
+    if (yb_out) *yb_out = Yb[1];
+    return nullptr;
+  }
   sym2(Yb[1], X, Xb, 1.0, true);                     // Y_1 = X X
   return Xb;
 }
@@ -1184,6 +1212,21 @@ void chunk_vjp(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
   const int K = c->K;
   const int nblk = dq::grad_contract_blocks((long)c->nn());
   c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
+  if (p.rq > 0 && c->sparse_on()) {
+    const T *Sb = nullptr, *Yb = nullptr;
+    real_backward(c, p, n, true, &Sb, &Yb);
+    c->sp_nzval.ensure(sizeof(double) * (size_t)std::max<long>(c->sp_nnz, 1) * n);
+    // bytes: the two cotangent rows once, the partner rows once per nonzero (mostly L2 hits: an upper bound)
+    const double bys = (double)sizeof(T) * c->d * (2.0 * c->d + 2.0 * c->sp_nnz) * n;
+    c->timed(DQ_PROF_GRADC, 4.0 * c->sp_nnz * c->d * n, bys, [&] {
+      return dq::rsp_contract_launch<T>(Sb, c->rmat(RS_P, n), Yb, c->rmat(RS_X, n), (long)c->nn(), c->d,
+                                        (const long*)c->sp_rowptr.p, (const int*)c->sp_col.p, (const double*)c->sp_val.p,
+                                        c->sp_nnz, (const long*)c->sp_kptr.p, (const long*)c->sp_kent.p, K, n,
+                                        -std::ldexp(dt, -p.s), (double*)c->sp_nzval.p,
+                                        c->grad_dev.d() + (size_t)c0 * K, c->st);
+    });
+    return;
+  }
   if (p.rq > 0) {
     const T* Xbar = real_backward(c, p, n);
     const double byr = (double)sizeof(T) * c->nn() * (K + ((K + 15) / 16)) * n;
@@ -1502,6 +1545,64 @@ void do_mc_shift(Ctx<T>* c, const double* u_a, int n_a, double dt_a, const doubl
   HIPCK(hipStreamSynchronize(c->st));
 }
 
+// CSR of the control Hamiltonians' nonzeros (real path), if they are sparse enough to pay: at most sparse_fill nonzeros
+// per row summed over the controls (X-type Paulis: K per row). Otherwise the dense passes stay.
+template <class T>
+void build_sparse_controls(Ctx<T>* c) {
+  c->sparse_h = false;
+  c->sp_nnz = 0;
+  const int d = c->d, K = c->K;
+  if (!c->real_h || K <= 0) return;
+  DevBuf cnt_dev, base_dev;
+  cnt_dev.ensure(sizeof(int) * (size_t)K * d);
+  HIPCK(dq::rsp_count_launch<T>((const T*)c->Hsr.p, d, K, (int*)cnt_dev.p, c->st));
+  std::vector<int> cnt((size_t)K * d);
+  HIPCK(hipMemcpyAsync(cnt.data(), cnt_dev.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  long nnz = 0;
+  for (int v : cnt) nnz += v;
+  if ((double)nnz > c->sparse_fill * d) return;
+  // combined CSR: row i holds its entries of control 0, then control 1, ... ; kent: the same entries grouped by control
+  std::vector<long> rowptr((size_t)d + 1, 0), base((size_t)K * d), kptr((size_t)K + 1, 0), kent((size_t)std::max<long>(nnz, 1));
+  long at = 0;
+  for (int i = 0; i < d; ++i) {
+    rowptr[i] = at;
+    for (int k = 0; k < K; ++k) {
+      base[(size_t)k * d + i] = at;
+      at += cnt[(size_t)k * d + i];
+    }
+  }
+  rowptr[d] = at;
+  for (int k = 0; k < K; ++k) {
+    long nk = 0;
+    for (int i = 0; i < d; ++i) nk += cnt[(size_t)k * d + i];
+    kptr[k + 1] = kptr[k] + nk;
+  }
+  {
+    std::vector<long> fill(kptr.begin(), kptr.end() - 1);
+    for (int i = 0; i < d; ++i)
+      for (int k = 0; k < K; ++k)
+        for (int q = 0; q < cnt[(size_t)k * d + i]; ++q) kent[fill[k]++] = base[(size_t)k * d + i] + q;
+  }
+  const size_t ne = (size_t)std::max<long>(nnz, 1);
+  c->sp_rowptr.ensure(sizeof(long) * rowptr.size());
+  c->sp_kptr.ensure(sizeof(long) * kptr.size());
+  c->sp_kent.ensure(sizeof(long) * ne);
+  c->sp_col.ensure(sizeof(int) * ne);
+  c->sp_kid.ensure(sizeof(int) * ne);
+  c->sp_val.ensure(sizeof(double) * ne);
+  base_dev.ensure(sizeof(long) * base.size());
+  HIPCK(hipMemcpyAsync(c->sp_rowptr.p, rowptr.data(), sizeof(long) * rowptr.size(), hipMemcpyHostToDevice, c->st));
+  HIPCK(hipMemcpyAsync(c->sp_kptr.p, kptr.data(), sizeof(long) * kptr.size(), hipMemcpyHostToDevice, c->st));
+  HIPCK(hipMemcpyAsync(c->sp_kent.p, kent.data(), sizeof(long) * ne, hipMemcpyHostToDevice, c->st));
+  HIPCK(hipMemcpyAsync(base_dev.p, base.data(), sizeof(long) * base.size(), hipMemcpyHostToDevice, c->st));
+  HIPCK(dq::rsp_fill_launch<T>((const T*)c->Hsr.p, d, K, (const long*)base_dev.p, (int*)c->sp_col.p, (int*)c->sp_kid.p,
+                               (double*)c->sp_val.p, c->st));
+  HIPCK(hipStreamSynchronize(c->st));  // the host vectors and the temporaries go out of scope
+  c->sp_nnz = nnz;
+  c->sparse_h = true;
+}
+
 template <class T>
 void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
   typedef TT T2;
@@ -1538,6 +1639,7 @@ void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
     c->real_h = im == 0.0;
     if (!c->real_h) { c->H0r.release(); c->Hsr.release(); }
   }
+  build_sparse_controls(c);
   c->have_H = true;
 }
 
@@ -1717,6 +1819,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     if (q != 0 && q != 1 && q != 2 && q != 3 && q != 32 && q != 64)
       fail(DQ_ERR_INVALID, "rgemm_cfg must be 0, 1, 2, 3, 32 or 64");
     c->rgemm_cfg = q;
+  } else if (s == "sparse_controls") {  // real path: -1 auto (use the controls' sparsity when they are sparse), 0 never
+    c->sparse_mode = (int)v != 0 ? -1 : 0;
   } else if (s == "skew_trick") {
     c->skew_trick = v != 0 ? 1 : 0;
   } else if (s == "zgemm_alg") {
@@ -1741,6 +1845,8 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "time_parallel") return c->last_tpar;
   if (s == "cached_steps") return c->last_cached;
   if (s == "slice_skew") return skew_w_form(c) ? 1.0 : 0.0;
+  if (s == "sparse_controls") return c->sparse_on() ? 1.0 : 0.0;
+  if (s == "control_nonzeros") return c->sparse_h ? (double)c->sp_nnz : -1.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;
   if (s == "norm_H0") return c->nH0;

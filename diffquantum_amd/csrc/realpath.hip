@@ -233,4 +233,199 @@ template hipError_t rgrad_contract_launch<double>(const double*, long, const dou
 template hipError_t rgrad_contract_launch<float>(const float*, long, const float*, int, long, int, double, double*,
                                                  double*, hipStream_t);
 
+// ---- sparse control Hamiltonians ----------------------------------------------------------------------------------
+// Control Hamiltonians are usually sparse (local Paulis: X_k has d nonzeros out of d^2; the reference's own problems,
+// demo_maxcut.py:36-79, are ZZ and X terms). When they are, three things on the real path need no dense d x d pass:
+//   * assembly   X = -dt H0 + sum_k (-dt u_k) H_k           : one dense pass over H0 + a scatter of the nonzeros
+//   * the last level of the reverse mode. The cotangent of X is  Xbar = (Sbar P + P Sbar)/2 + (Ybar_1 X + X Ybar_1)
+//     (S = X P, Y_1 = X X), two two-product symmetric launches -- but the gradient only needs <Xbar, H_k>, and for
+//     symmetric operands  <Sbar P + P Sbar, H>/2 = sum_{(i,j) in nnz(H)} H_ij <Sbar[i,:], P[j,:]>  (likewise for Ybar_1, X):
+//     nnz(H) row-by-row dot products instead of 2 x 2 d^3 flops; Xbar itself is never formed
+//   * the control contractions  <Xbar, H_k>                 : folded into the same dot products.
+// The nonzeros of all controls live in one CSR by row (entries of a row ordered by control, then column).
+
+// cnt[k*d + i] = number of nonzeros in row i of Hsr[k]
+template <class T>
+__global__ void __launch_bounds__(64) rsp_count_kernel(const T* __restrict__ Hsr, int d, int* __restrict__ cnt) {
+  const int i = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
+  const T* row = Hsr + ((long)k * d + i) * d;
+  int n = 0;
+  for (int j0 = 0; j0 < d; j0 += 64) {
+    const int j = j0 + lane;
+    const bool nz = j < d && row[j] != (T)0;
+    n += __popcll(__ballot(nz));
+  }
+  if (lane == 0) cnt[(long)k * d + i] = n;
+}
+
+// entries of (k, i) written in column order at base[k*d + i]
+template <class T>
+__global__ void __launch_bounds__(64) rsp_fill_kernel(const T* __restrict__ Hsr, int d, const long* __restrict__ base,
+                                                      int* __restrict__ col, int* __restrict__ kid,
+                                                      double* __restrict__ val) {
+  const int i = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
+  const T* row = Hsr + ((long)k * d + i) * d;
+  long at = base[(long)k * d + i];
+  for (int j0 = 0; j0 < d; j0 += 64) {
+    const int j = j0 + lane;
+    const T v = j < d ? row[j] : (T)0;
+    const unsigned long long m = __ballot(v != (T)0);
+    if (v != (T)0) {
+      const long e = at + __popcll(m & ((1ull << lane) - 1ull));
+      col[e] = j;
+      kid[e] = k;
+      val[e] = (double)v;
+    }
+    at += __popcll(m);
+  }
+}
+
+template <class T>
+hipError_t rsp_count_launch(const T* Hsr, int d, int K, int* cnt, hipStream_t st) {
+  if (d <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rsp_count_kernel<T>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, Hsr, d, cnt);
+  return hipGetLastError();
+}
+template hipError_t rsp_count_launch<double>(const double*, int, int, int*, hipStream_t);
+template hipError_t rsp_count_launch<float>(const float*, int, int, int*, hipStream_t);
+
+template <class T>
+hipError_t rsp_fill_launch(const T* Hsr, int d, int K, const long* base, int* col, int* kid, double* val, hipStream_t st) {
+  if (d <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rsp_fill_kernel<T>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, Hsr, d, base, col, kid, val);
+  return hipGetLastError();
+}
+template hipError_t rsp_fill_launch<double>(const double*, int, int, const long*, int*, int*, double*, hipStream_t);
+template hipError_t rsp_fill_launch<float>(const float*, int, int, const long*, int*, int*, double*, hipStream_t);
+
+// X[z][i][col] += -dt u[z][kid] val   for the nonzeros of row i: one thread per (row, step), entries in CSR order
+// (deterministic even when two controls share an entry)
+template <class T>
+__global__ void __launch_bounds__(256) rsp_add_kernel(T* __restrict__ X, long strideX, const long* __restrict__ rowptr,
+                                                      const int* __restrict__ col, const int* __restrict__ kid,
+                                                      const double* __restrict__ val, const double* __restrict__ u, int K,
+                                                      int d, double mdt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  const long z = blockIdx.z;
+  T* row = X + z * strideX + (long)i * d;
+  const double* uz = u + z * K;
+  for (long e = rowptr[i]; e < rowptr[i + 1]; ++e) row[col[e]] += (T)(mdt * uz[kid[e]] * val[e]);
+}
+
+template <class T>
+hipError_t rsp_add_launch(T* X, long strideX, const long* rowptr, const int* col, const int* kid, const double* val,
+                          const double* u, int K, int d, int batch, double dt, hipStream_t st) {
+  if (d <= 0 || batch <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rsp_add_kernel<T>, dim3((unsigned)((d + 255) / 256), 1, (unsigned)batch), dim3(256), 0, st, X, strideX,
+                     rowptr, col, kid, val, u, K, d, -dt);
+  return hipGetLastError();
+}
+template hipError_t rsp_add_launch<double>(double*, long, const long*, const int*, const int*, const double*, const double*,
+                                           int, int, int, double, hipStream_t);
+template hipError_t rsp_add_launch<float>(float*, long, const long*, const int*, const int*, const double*, const double*, int,
+                                          int, int, double, hipStream_t);
+
+// nzval[z][e] = val[e] * ( <Sb[z][i,:], P[z][j,:]> + 2 <Yb[z][i,:], X[z][j,:]> )   for the nonzeros e = (i, j) of row i.
+// One wave per row: a 512-column strip of the row's Sb and Yb entries stays in registers while the partner rows of up to
+// RSP_NZ nonzeros stream past it (partner rows come from L2: the rows of one control's partners are shared by neighbours).
+constexpr int RSP_NZ = 16, RSP_U = 8, RSP_WAVES = 4;
+
+template <class T>
+__global__ void __launch_bounds__(RSP_WAVES * 64) rsp_contract_kernel(const T* __restrict__ Sb, const T* __restrict__ P,
+                                                                      const T* __restrict__ Yb, const T* __restrict__ X,
+                                                                      long stride, int d, const long* __restrict__ rowptr,
+                                                                      const int* __restrict__ col,
+                                                                      const double* __restrict__ val, long nnz,
+                                                                      double* __restrict__ nzval) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * RSP_WAVES + wave;
+  if (i >= d) return;
+  const long z = blockIdx.z;
+  const T* s_row = Sb + z * stride + (long)i * d;
+  const T* y_row = Yb + z * stride + (long)i * d;
+  const T* Pz = P + z * stride;
+  const T* Xz = X + z * stride;
+  const long e_end = rowptr[i + 1];
+  for (long e0 = rowptr[i]; e0 < e_end; e0 += RSP_NZ) {
+    const int cnt = (int)min((long)RSP_NZ, e_end - e0);
+    double acc[RSP_NZ];
+#pragma unroll
+    for (int q = 0; q < RSP_NZ; ++q) acc[q] = 0.0;
+    for (int m0 = 0; m0 < d; m0 += 64 * RSP_U) {
+      T s[RSP_U], y[RSP_U];
+#pragma unroll
+      for (int r = 0; r < RSP_U; ++r) {
+        const int m = m0 + r * 64 + lane;
+        s[r] = m < d ? s_row[m] : (T)0;
+        y[r] = m < d ? (T)2 * y_row[m] : (T)0;
+      }
+#pragma unroll
+      for (int q = 0; q < RSP_NZ; ++q) {
+        if (q < cnt) {  // wave-uniform
+          const long j = col[e0 + q];
+          const T* p_row = Pz + j * d;
+          const T* x_row = Xz + j * d;
+          T t = 0;
+#pragma unroll
+          for (int r = 0; r < RSP_U; ++r) {
+            const int m = m0 + r * 64 + lane;
+            if (m < d) t += s[r] * p_row[m] + y[r] * x_row[m];
+          }
+          acc[q] += (double)t;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RSP_NZ; ++q) {
+      if (q < cnt) {
+        double v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) nzval[z * nnz + e0 + q] = v * val[e0 + q];
+      }
+    }
+  }
+}
+
+// grad[z][k] = scale * sum of nzval[z][e] over the entries of control k (kent[kptr[k] .. kptr[k+1]), fixed order)
+__global__ void __launch_bounds__(256) rsp_reduce_kernel(const double* __restrict__ nzval, long nnz,
+                                                         const long* __restrict__ kptr, const long* __restrict__ kent, int K,
+                                                         double scale, double* __restrict__ grad) {
+  const int k = blockIdx.x;
+  const long z = blockIdx.z;
+  const double* v = nzval + z * nnz;
+  double a = 0.0;
+  for (long q = kptr[k] + threadIdx.x; q < kptr[k + 1]; q += 256) a += v[kent[q]];
+  __shared__ double red[256];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) grad[z * K + k] = scale * red[0];
+}
+
+template <class T>
+hipError_t rsp_contract_launch(const T* Sb, const T* P, const T* Yb, const T* X, long stride, int d, const long* rowptr,
+                               const int* col, const double* val, long nnz, const long* kptr, const long* kent, int K,
+                               int batch, double scale, double* nzval, double* grad, hipStream_t st) {
+  if (d <= 0 || batch <= 0 || K <= 0) return hipSuccess;
+  if (nnz > 0) {
+    hipLaunchKernelGGL(rsp_contract_kernel<T>, dim3((unsigned)((d + RSP_WAVES - 1) / RSP_WAVES), 1, (unsigned)batch),
+                       dim3(RSP_WAVES * 64), 0, st, Sb, P, Yb, X, stride, d, rowptr, col, val, nnz, nzval);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(rsp_reduce_kernel, dim3((unsigned)K, 1, (unsigned)batch), dim3(256), 0, st, nzval, nnz, kptr, kent, K,
+                     scale, grad);
+  return hipGetLastError();
+}
+template hipError_t rsp_contract_launch<double>(const double*, const double*, const double*, const double*, long, int,
+                                                const long*, const int*, const double*, long, const long*, const long*, int,
+                                                int, double, double*, double*, hipStream_t);
+template hipError_t rsp_contract_launch<float>(const float*, const float*, const float*, const float*, long, int, const long*,
+                                               const int*, const double*, long, const long*, const long*, int, int, double,
+                                               double*, double*, hipStream_t);
+
 }  // namespace dq

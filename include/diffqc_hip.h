@@ -97,6 +97,11 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   time_parallel      -1 auto / 0 / 1: operator backward sweep of a time chunk from suffix products (~4n batched
  *                      products instead of 2n dependent launches; auto: chunks of >= 4 steps at dim <= 1024)
  *   skew_trick         1: only the anti-Hermitian parts of the generator cotangent / of W are carried (saves products)
+ *   sparse_controls    real path: 1 (default) = when the control Hamiltonians are sparse (at most 32 nonzeros per row summed
+ *                      over the controls -- local Paulis have one each), assembly scatters their nonzeros instead of
+ *                      streaming K dense matrices, and the last level of the reverse mode together with the control
+ *                      contractions <Xbar, H_k> becomes nnz(H) row dot products instead of two two-product symmetric
+ *                      launches (4 d^3 flop); 0 = always the dense passes. dq_get_info("sparse_controls") tells which
  *   cache_bytes        real path: HBM for the propagator intermediates (X, Y_j, P, U) that the forward pass leaves in place
  *                      for the backward sweep, which then skips its q + 1 rebuild products for those steps; < 0 off,
  *                      0 = 80 % of the free HBM (operator form) / 50 % (after the state form's checkpoints), at most 96 GiB
@@ -108,7 +113,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
- * "time_parallel", "cached_steps", "slice_skew", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
+ * "time_parallel", "cached_steps", "slice_skew", "sparse_controls", "control_nonzeros" (-1 = dense), "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 

@@ -1,0 +1,157 @@
+"""GPU parity of the sparse-control fast path of the real-symmetric scheme: when the control Hamiltonians H_k are sparse
+(the reference's own problems are: ZZ and X terms, demo_maxcut.py:36-79; BASELINE's X_k controls), the dH assembly
+(diffqc.cc:192-197, sim_plain.py:137-143) scatters their nonzeros and the gradient's last reverse-mode level becomes row
+dot products over nnz(H_k) (realpath.hip). Checked against the oracle and against the dense passes of the same engine.
+
+Tolerance (BASELINE.json north_star): 1e-10 on amplitudes and gradients in fp64, 1e-4 in fp32.
+"""
+import numpy as np
+import pytest
+
+from diffquantum_amd import problems
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _engine(H0, Hs, M, dtype="c128", **opts):
+    from diffquantum_amd.engine import Engine
+    e = Engine(len(H0), len(Hs), dtype=dtype)
+    e.set_hamiltonians(H0, Hs)
+    e.set_observable(M)
+    e.set_option("real_min_dim", 1)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    return e
+
+
+def _sparse_problem(d, K, seed, per_row=2, heavy_row=False):
+    """Real symmetric H0 (dense), K sparse real symmetric controls with random patterns: diagonal entries, entries shared
+    by two controls, empty rows, and optionally one row/column with many nonzeros (more than one register group)."""
+    rng = np.random.default_rng(seed)
+    H0 = rng.standard_normal((d, d))
+    H0 = (H0 + H0.T) / 2
+    Hs = np.zeros((K, d, d))
+    for k in range(K):
+        for _ in range(per_row * d // 2):
+            i, j = rng.integers(0, d, 2)
+            v = rng.standard_normal()
+            Hs[k, i, j] += v
+            if i != j:
+                Hs[k, j, i] += v
+    if K >= 2:
+        Hs[1] += 0.5 * (Hs[0] != 0)          # same pattern in two controls
+    if heavy_row:
+        v = rng.standard_normal(d)
+        Hs[0, 0, :] += v
+        Hs[0, :, 0] += v
+    Hs[:, d // 2, :] = 0                     # an empty row/column
+    Hs[:, :, d // 2] = 0
+    M = rng.standard_normal((d, d))
+    M = (M + M.T) / 2
+    return H0.astype(complex), Hs.astype(complex), M.astype(complex)
+
+
+def _states(d, B, seed):
+    rng = np.random.default_rng(seed)
+    psi = rng.standard_normal((d, B)) + 1j * rng.standard_normal((d, B))
+    return psi / np.linalg.norm(psi, axis=0)
+
+
+@pytest.mark.parametrize("n,B,S", [(3, 4, 6), (4, 20, 5), (5, 3, 4), (6, 70, 3)])
+def test_ising_x_controls_match_oracle_and_dense(oracle, n, B, S):
+    """BASELINE's problem family (random Ising drift, X_k controls): state form (B < d) and operator form (B >= d)."""
+    dt = 0.03
+    H0, Hs, M = problems.random_ising(n, seed=n)
+    u = np.random.default_rng(S).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("control_nonzeros") == n * (1 << n)
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("real_path") >= 1 and e.info("sparse_controls") == 1
+        p1 = e.propagate(u, dt, psi0)
+        e.set_option("sparse_controls", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_controls") == 0
+    assert abs(l1 - rl) < TOL and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+    assert np.max(np.abs(p1 - rf)) < TOL
+    assert abs(l1 - l0) < 1e-12 * max(1, B) and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
+
+
+@pytest.mark.parametrize("d,K,B,heavy", [(8, 1, 3, False), (24, 3, 5, True), (64, 2, 64, True), (100, 4, 7, False),
+                                         (130, 2, 131, True)])
+def test_random_sparse_controls(oracle, d, K, B, heavy):
+    """Arbitrary sparse symmetric controls and dimensions that are not powers of two (bounds of the row strips)."""
+    S, dt = 4, 0.02
+    H0, Hs, M = _sparse_problem(d, K, seed=d + K, heavy_row=heavy)
+    u = np.random.default_rng(d).uniform(-1, 1, (S, K))
+    psi0 = _states(d, B, seed=1)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        nnz = int(np.count_nonzero(Hs))
+        assert e.info("control_nonzeros") == nnz
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_controls") == 1 and e.info("real_path") >= 1
+    assert abs(l1 - rl) < TOL * max(1, B) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+
+
+def test_dense_controls_keep_the_dense_passes():
+    H0, Hs, M = problems.random_real_symmetric_problem(4, 3, seed=1)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("control_nonzeros") == -1 and e.info("sparse_controls") == 0
+    H0, Hs, M = problems.random_hermitian_problem(3, 2, seed=1)   # complex: no real path at all
+    with _engine(H0, Hs, M) as e:
+        assert e.info("control_nonzeros") == -1
+
+
+def test_sparse_controls_with_squarings(oracle):
+    """A step too large for the polynomial alone: scaled by 2^-s and squared in the real algebra; the sparse contraction
+    then pairs the cotangents with X / 2^s."""
+    n, B, S, dt = 4, 6, 3, 0.9
+    H0, Hs, M = problems.random_ising(n, seed=3)
+    u = np.random.default_rng(1).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("squarings") >= 1 and e.info("sparse_controls") == 1
+    assert abs(l1 - rl) < 1e-9 and np.max(np.abs(g1 - rg)) < 1e-9 and np.max(np.abs(f1 - rf)) < 1e-10
+
+
+def test_sparse_controls_fp32(oracle):
+    n, B, S, dt = 5, 40, 5, 0.03
+    H0, Hs, M = problems.random_ising(n, seed=5)
+    u = np.random.default_rng(2).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, dtype="c64") as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("sparse_controls") == 1 and e.info("real_path") >= 1
+    assert abs(l1 - rl) < 1e-4 * B and np.max(np.abs(g1 - rg)) < 1e-4 and np.max(np.abs(f1 - rf)) < 1e-4
+
+
+def test_sparse_controls_mid_dimension_cached_and_sliced():
+    """d = 256 with the propagator cache live and the chain split over three virtual ranks: sparse and dense passes agree."""
+    from diffquantum_amd.distributed import shard_range, virtual_time_sliced_energy_grad
+    n, B, S, dt = 8, 256, 12, 2e-3
+    p = problems.qaoa_ring(n)
+    H0, Hs = p["H0"].astype(complex), p["Hs"].astype(complex)
+    M = H0
+    u = np.random.default_rng(0).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    with _engine(H0, Hs, M, real_min_dim=128) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_controls") == 1 and e.info("cached_steps") > 0
+        e.set_option("sparse_controls", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+    assert abs(l1 - l0) < 1e-11 * B and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
+    engines = [_engine(H0, Hs, M, real_min_dim=128) for _ in range(3)]
+    try:
+        shards = [np.ascontiguousarray(psi0[:, f:f + c]) for f, c in (shard_range(B, r, 3) for r in range(3))]
+        res = virtual_time_sliced_energy_grad(engines, u, dt, shards)
+    finally:
+        for e in engines:
+            e.close()
+    for l, g, f, en in res:
+        assert abs(l - l0) < 1e-10 * B and np.max(np.abs(g - g0)) < TOL
