@@ -37,11 +37,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_BYTES_PER_LAUNCH = 3.54e9  # HBM-side bytes per ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_v12_summary.txt):
-                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.27 GB + 0.27 GB, d = B = 4096
-TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 2.68e9}  # real GEMM: full-output (profiles/r1_bench_v5_realpath_summary.txt);
-                                                   # symmetric-output launches (average over one- and two-product
-                                                   # forms) + fix-up pass, LDS-DMA staged (r1_bench_v12_summary.txt)
+TRAFFIC_BYTES_PER_LAUNCH = 3.49e9  # HBM-side bytes per full-output ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_s3_sparse_summary.txt):
+                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.22 GB + 0.27 GB, d = B = 4096
+TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 2.51e9}  # real GEMM: full-output (profiles/r1_bench_v5_realpath_summary.txt);
+                                                   # symmetric-output launches (average over the one- and two-product forms of
+                                                   # the headline step: 8 + 4 per step) + fix-up pass, LDS-DMA staged
+                                                   # (profiles/r1_bench_s3_sparse_summary.txt: 2445 + 64 MB)
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
 
