@@ -245,3 +245,31 @@ def test_headline_shape_two_virtual_ranks():
         assert np.max(np.abs(g - g0)) < 1e-10, r               # gradient entries are ~1e-2
         assert float((f - f0[:, r * Bq:(r + 1) * Bq]).abs().max()) < 1e-12, r
     assert abs(sum(float(x[3].sum()) for x in res) - l0) < 1e-9 * world
+
+
+def test_headline_dimension_eight_virtual_ranks_narrow_batch():
+    """n = 12 (d = 4096) with the chain of 10 steps split over EIGHT virtual ranks (2 or 1 steps each) and 256 states per
+    rank: the single call on the 2048-state batch runs in STATE form (batch < 3/4 dim: checkpoints, psi_t rebuilds), the
+    sliced program in operator form -- two different algorithms for the same gradient, at the full matrix size, with seven
+    slice products composed and every rank's W conjugated by its own suffix product."""
+    import torch
+    from diffquantum_amd.engine import Engine
+    n, Bq, S, dt, world = 12, 256, 10, 1e-3, 8
+    d = 1 << n
+    dev = torch.device("cuda:0")
+    H0, Hs, M = problems.random_ising_torch(n, 0, dev)
+    u = torch.from_numpy(problems.pulse_table(n, S, S * dt, seed=3)).to(dev)
+    full = torch.from_numpy(problems.random_states(d, world * Bq, seed=4)).to(dev)
+    shards = [full[:, r * Bq:(r + 1) * Bq].contiguous() for r in range(world)]
+    with Engine(d, n) as e:
+        e.use_torch_stream()
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        e.set_option("cache_bytes", 8 * 2 ** 30)
+        l0, g0, f0, _ = e.energy_grad(u, dt, full, want_energies=False)
+        assert e.info("operator_backward") == 0 and e.info("checkpoint_stride") >= 1
+        res = virtual_time_sliced_energy_grad([e] * world, u, dt, shards)
+    for r, (l, g, f, en) in enumerate(res):
+        assert abs(l - l0) < 1e-10 * world * Bq, (r, l, l0)
+        assert np.max(np.abs(g - g0)) < 1e-10, r
+        assert float((f - f0[:, r * Bq:(r + 1) * Bq]).abs().max()) < 1e-12, r
