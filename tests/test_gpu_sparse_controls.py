@@ -155,3 +155,30 @@ def test_sparse_controls_mid_dimension_cached_and_sliced():
             e.close()
     for l, g, f, en in res:
         assert abs(l - l0) < 1e-10 * B and np.max(np.abs(g - g0)) < TOL
+
+
+def test_zero_and_diagonal_controls(oracle):
+    """A control that is identically zero (no nonzeros at all), a purely diagonal one, and all controls zero."""
+    d, B, S, dt = 16, 4, 5, 0.05
+    rng = np.random.default_rng(7)
+    H0 = rng.standard_normal((d, d))
+    H0 = ((H0 + H0.T) / 2).astype(complex)
+    M = np.diag(rng.standard_normal(d)).astype(complex)
+    Hs = np.zeros((3, d, d), dtype=complex)
+    Hs[1] = np.diag(rng.standard_normal(d))
+    Hs[2, 0, 5] = Hs[2, 5, 0] = 0.7
+    u = rng.uniform(-1, 1, (S, 3))
+    psi0 = _states(d, B, seed=3)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("control_nonzeros") == d + 2
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_controls") == 1
+    assert np.all(g1[:, 0] == 0.0)
+    assert abs(l1 - rl) < TOL and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+    with _engine(H0, np.zeros((2, d, d), dtype=complex), M) as e:
+        assert e.info("control_nonzeros") == 0
+        l2, g2, f2, _ = e.energy_grad(u[:, :2], dt, psi0)
+        assert e.info("sparse_controls") == 1 and np.all(g2 == 0.0)
+    rl2, rg2, rf2 = oracle.energy_grad(H0, [np.zeros((d, d))] * 2, M, u[:, :2], dt, psi0)
+    assert abs(l2 - rl2) < TOL and np.max(np.abs(f2 - rf2)) < TOL
