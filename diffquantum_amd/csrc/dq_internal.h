@@ -182,7 +182,8 @@ hipError_t rgrad_contract_launch(const T* Xbar, long strideX, const T* Hsr, int 
 template <class T>
 hipError_t rsp_count_launch(const T* Hsr, int d, int K, int* cnt, hipStream_t st);
 template <class T>
-hipError_t rsp_fill_launch(const T* Hsr, int d, int K, const long* base, int* col, int* kid, double* val, hipStream_t st);
+hipError_t rsp_fill_launch(const T* Hsr, int d, int K, const long* base, int* col, int* kid, double* val, int kid0,
+                           hipStream_t st);
 // X[z][i][col] += -dt u[z*K + kid] val over the CSR (rowptr: d + 1 entries), z < batch
 template <class T>
 hipError_t rsp_add_launch(T* X, long strideX, const long* rowptr, const int* col, const int* kid, const double* val,
@@ -193,5 +194,20 @@ template <class T>
 hipError_t rsp_contract_launch(const T* Sb, const T* P, const T* Yb, const T* X, long stride, int d, const long* rowptr,
                                const int* col, const double* val, long nnz, const long* kptr, const long* kent, int K,
                                int batch, double scale, double* nzval, double* grad, hipStream_t st);
+
+// ---- sparse generator (drift and controls sparse; realpath.hip) ----
+// out[z][i][:] = ca * Add[z][i][:] + sum_{e in row i} w_e V[z][col_e][:],  w_e = -dt (kid_e < 0 ? 1 : u[z*K + kid_e]) val_e
+// (Add may be null)
+template <class T>
+hipError_t rsp_mm_launch(T* out, const T* V, const T* Add, double ca, long stride, int d, const long* rowptr, const int* col,
+                         const int* kid, const double* val, const double* u, int K, int batch, double dt, hipStream_t st);
+// nzval[z][e] = val_e (direct_e + sum_l <G[l][z][i,:], Xp[l][z][j,:]>) for the control entries (0 for drift entries);
+// direct_e = dc D[z][i][j] + sum_{e' in row i} w_e' G2[z][col_e'][j] if D is given
+template <class T>
+hipError_t rsp_levels_launch(const T* const* G, const T* const* Xp, int nl, const T* D, const T* G2, double dc, long stride,
+                             int d, const long* rowptr, const int* col, const int* kid, const double* val, const double* u,
+                             int K, int batch, double dt, long nnz, double* nzval, hipStream_t st);
+hipError_t rsp_reduce_launch(const double* nzval, long nnz, const long* kptr, const long* kent, int K, int batch, double scale,
+                             double* grad, hipStream_t st);
 
 }  // namespace dq

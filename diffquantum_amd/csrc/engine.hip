@@ -106,6 +106,7 @@ struct TapeOp {
 struct ExpmPlan {
   int m = 0, s = 0, nvars = 0, out = 0, nprod = 0;
   int rq = 0;  // > 0: real-symmetric plan (cos/sin polynomials in Y = X^2 up to Y^rq); `ops` is empty then
+  int spx = 0; // real plan evaluated with the sparse generator: powers X_{m+1} = X X_m by sparse x dense products
   double cc[8] = {0}, sc[8] = {0};  // cos X = sum cc[j] Y^j,  sin X = X sum sc[j] Y^j
   std::vector<TapeOp> ops;
   int products() const { return nprod; }
@@ -288,14 +289,15 @@ struct Ctx : dq_ctx {
   // sparse control Hamiltonians (real path; realpath.hip): the nonzeros of all H_k in one CSR by row, and the same
   // entries grouped by control; sparse_mode: -1 auto (total nonzeros <= sparse_fill * dim), 0 off
   DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval;
-  long sp_nnz = 0;
-  bool sparse_h = false;
-  int sparse_mode = -1;
+  long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
+  bool sparse_h = false;   // a CSR exists (controls, and the drift too if sparse_x)
+  bool sparse_x = false;   // the drift H0 is in the CSR as well (entries with kid = -1): X_t itself is sparse
+  int sparse_mode = -1, sparse_gen_mode = -1;
   double sparse_fill = 32.0;
   int real_mode = -1, rgemm_cfg = 0, real_min_dim = 128, rgemm_glds = 1;
   long plan_steps = 0;
   int small_dim = 512, time_parallel = -1;  // see do_energy_grad  // real_mode: -1 auto (dim >= real_min_dim), 0 off, q >= 1 forced
-  double last_real_q = 0;
+  double last_real_q = 0, last_spx = 0;
   double nH0 = 0.0;
   std::vector<double> nHk;
   // options
@@ -326,6 +328,7 @@ struct Ctx : dq_ctx {
   }
 
   bool sparse_on() const { return sparse_h && sparse_mode != 0; }
+  bool sparse_gen_on() const { return sparse_on() && sparse_x && sparse_gen_mode != 0; }
   size_t nn() const { return (size_t)d * d; }
   size_t mat_bytes() const { return nn() * sizeof(T2); }
 
@@ -563,6 +566,9 @@ typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n, boo
 // cotangent pair of the squaring reverse at SLOT_ADJ + 12/13.
 enum { RS_X = 0, RS_P = 7, RS_C = 8, RS_S = 9, RS_U = 10, RS_LVL = 12, RQ_MAX = 6, RS_SMAX = 14 };
 
+// sparse-generator scheme (spx plans, s = 0): the power X_m (m = 2 .. 2q + 1 <= 13) lives in the squaring-level slots
+inline int spx_slot(int m) { return m == 1 ? (int)RS_X : (int)RS_LVL + (m - 2); }
+
 ExpmPlan make_real_plan(int q, int s = 0) {
   ExpmPlan p;
   p.rq = q;
@@ -614,10 +620,15 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
   const double by = (double)sizeof(T) * c->nn() * (c->K + 2.0) * n;
   const double dts = std::ldexp(dt, -p.s);  // X = -(dt / 2^s) H
   if (c->sparse_on()) {
-    // dense pass over H0 only, then the controls' nonzeros are scattered in
-    c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->nn() * n, (double)sizeof(T) * c->nn() * 2.0 * n, [&] {
-      return dq::rassemble_launch<T>(X, (const T*)c->H0r.p, (const T*)c->Hsr.p, c->u_dev.d(), 0, (long)c->nn(), n, dts, c->st);
-    });
+    // dense pass over H0 only (or zeros, if the drift's nonzeros are in the CSR too), then the nonzeros are scattered in
+    if (c->sparse_x) {
+      c->timed(DQ_PROF_ASSEMBLE, 0.0, (double)sizeof(T) * c->nn() * n,
+               [&] { return hipMemsetAsync(X, 0, sizeof(T) * c->nn() * (size_t)n, c->st); });
+    } else {
+      c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->nn() * n, (double)sizeof(T) * c->nn() * 2.0 * n, [&] {
+        return dq::rassemble_launch<T>(X, (const T*)c->H0r.p, (const T*)c->Hsr.p, c->u_dev.d(), 0, (long)c->nn(), n, dts, c->st);
+      });
+    }
     c->timed(DQ_PROF_ASSEMBLE, 2.0 * c->sp_nnz * n, 3.0 * sizeof(double) * c->sp_nnz * n, [&] {
       return dq::rsp_add_launch<T>(X, (long)c->nn(), (const long*)c->sp_rowptr.p, (const int*)c->sp_col.p,
                                    (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
@@ -629,6 +640,40 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
                                      (long)c->nn(), n, dts, c->st);
     });
   }
+  if (p.spx) {
+    // sparse generator: X_{m+1} = X X_m (m = 1 .. 2q) by sparse x dense products; C and S are linear combinations
+    const int np = 2 * q + 1;
+    const T* Xp[2 * RQ_MAX + 2];
+    Xp[1] = X;
+    const double bym = (double)sizeof(T) * c->d * ((double)c->sp_nnz + 2.0 * c->d) * n;  // partner rows (L2) + in + out
+    for (int m = 1; m < np; ++m) {
+      T* Xn = c->rmat(spx_slot(m + 1), n);
+      c->timed(DQ_PROF_SPMM, 2.0 * c->sp_nnz * c->d * n, bym, [&] {
+        return dq::rsp_mm_launch<T>(Xn, Xp[m], (const T*)nullptr, 0.0, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
+                                    (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
+                                    c->u_dev.d() + (size_t)c0 * c->K, c->K, n, dts, c->st);
+      });
+      Xp[m + 1] = Xn;
+    }
+    T* Cm = c->rmat(RS_C, n);
+    T* S = c->rmat(RS_S, n);
+    const T* ev[RQ_MAX + 1];
+    const T* od[RQ_MAX + 1];
+    for (int j = 1; j <= q; ++j) ev[j - 1] = Xp[2 * j];
+    for (int j = 0; j <= q; ++j) od[j] = Xp[2 * j + 1];
+    rlincomb2<T>(c, Cm, nullptr, q, ev, p.cc + 1, nullptr, p.cc[0], 0.0, n, false);
+    rlincomb2<T>(c, S, nullptr, q + 1, od, p.sc, nullptr, 0.0, 0.0, n, false);
+    T2* U = c->mat(RS_U, n);
+    const long ne = (long)c->nn() * n;
+    c->timed(DQ_PROF_LINCOMB, 0.0, 4.0 * sizeof(T) * ne, [&] { return dq::pack_u_launch<T>(U, Cm, S, ne, c->st); });
+    c->last_degree = p.m;
+    c->last_squarings = 0;
+    c->last_products = 2 * q;
+    c->last_real_q = q;
+    c->last_spx = 1;
+    return U;
+  }
+  c->last_spx = 0;
   const T* Y[RQ_MAX + 1];
   for (int j = 1; j <= q; ++j) {
     T* Yj = c->rmat(j, n);
@@ -726,6 +771,60 @@ const T* real_backward(Ctx<T>* c, const ExpmPlan& p, int n, bool skip_x = false,
   }
   sym2(Yb[1], X, Xb, 1.0, true);                     // Y_1 = X X
   return Xb;
+}
+
+// Reverse mode of the sparse-generator scheme (spx plans), down to the control gradients of the chunk:
+//   Xbar_{2q+1} = sc_q Sbar;   Xbar_m = coef_m (Cbar | Sbar) + X Xbar_{m+1}   (m = 2q .. 2: sparse x dense with an AXPY)
+//   dL/du_k = scale * < Xbar_1 + sum_{m=1}^{2q} Xbar_{m+1} X_m , H_k >  over nnz(H_k)     (Xbar_1 only at those entries)
+template <class T>
+void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, double* grad_out) {
+  typedef typename dq::Cx<T>::type T2;
+  const int q = p.rq, np = 2 * q + 1, K = c->K;
+  const T2* G = c->mat(SLOT_ADJ + RS_U, n);
+  T* Cb = c->rmat(SLOT_ADJ + RS_C, n);
+  T* Sb = c->rmat(SLOT_ADJ + RS_S, n);
+  c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n, 6.0 * sizeof(T) * c->nn() * n,
+           [&] { return dq::split_g_launch<T>(G, Cb, Sb, c->d, (long)c->nn(), n, c->st); });
+  const T* Xp[2 * RQ_MAX + 2];
+  const T* Xb[2 * RQ_MAX + 2];
+  for (int m = 1; m <= np; ++m) Xp[m] = c->rmat(spx_slot(m), n);
+  auto coef = [&](int m) { return (m & 1) ? p.sc[(m - 1) / 2] : p.cc[m / 2]; };
+  {  // Xbar_{2q+1} = sc_q Sbar
+    T* top = c->rmat(SLOT_ADJ + spx_slot(np), n);
+    const T* in[1] = {Sb};
+    const double cf[1] = {coef(np)};
+    rlincomb2<T>(c, top, nullptr, 1, in, cf, nullptr, 0.0, 0.0, n, false);
+    Xb[np] = top;
+  }
+  const double dts = dt;  // spx plans have no squarings
+  const double bym = (double)sizeof(T) * c->d * ((double)c->sp_nnz + 3.0 * c->d) * n;
+  for (int m = np - 1; m >= 2; --m) {
+    T* dst = c->rmat(SLOT_ADJ + spx_slot(m), n);
+    const T* add = (m & 1) ? Sb : Cb;
+    const double ca = coef(m);
+    const T* src = Xb[m + 1];
+    c->timed(DQ_PROF_SPMM, 2.0 * c->sp_nnz * c->d * n, bym, [&] {
+      return dq::rsp_mm_launch<T>(dst, src, add, ca, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
+                                  (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
+                                  c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->st);
+    });
+    Xb[m] = dst;
+  }
+  // levels m = 1 .. 2q pair Xbar_{m+1} with X_m; the direct term is Xbar_1 = sc_0 Sbar + X Xbar_2 at the controls' nonzeros
+  const T* Gl[2 * RQ_MAX + 2];
+  const T* Xl[2 * RQ_MAX + 2];
+  for (int m = 1; m < np; ++m) { Gl[m - 1] = Xb[m + 1]; Xl[m - 1] = Xp[m]; }
+  c->sp_nzval.ensure(sizeof(double) * (size_t)std::max<long>(c->sp_nnz, 1) * n);
+  const double byl = (double)sizeof(T) * c->d * (np - 1) * ((double)c->d + 0.5 * c->sp_nnz) * n;
+  c->timed(DQ_PROF_GRADC, 2.0 * (np - 1) * 0.5 * c->sp_nnz * c->d * n, byl, [&] {
+    return dq::rsp_levels_launch<T>(Gl, Xl, np - 1, Sb, Xb[2], coef(1), (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
+                                    (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
+                                    c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->sp_nnz, (double*)c->sp_nzval.p, c->st);
+  });
+  c->timed(DQ_PROF_GRADC, (double)c->sp_nnz * n, 8.0 * c->sp_nnz * n, [&] {
+    return dq::rsp_reduce_launch((const double*)c->sp_nzval.p, c->sp_nnz, (const long*)c->sp_kptr.p, (const long*)c->sp_kent.p,
+                                 K, n, -dt, grad_out, c->st);
+  });
 }
 
 #define TT typename dq::Cx<T>::type
@@ -837,7 +936,21 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
   c->last_theta = th;
   c->last_real_q = 0;
   if (c->real_h && c->real_mode != 0) {
-    if (c->real_mode > 0) return make_real_plan(std::min(c->real_mode, (int)RQ_MAX));
+    if (c->real_mode > 0) {
+      ExpmPlan p = make_real_plan(std::min(c->real_mode, (int)RQ_MAX));
+      p.spx = c->sparse_gen_on() ? 1 : 0;
+      return p;
+    }
+    if (c->sparse_gen_on() && c->force_degree <= 0 && c->force_s < 0 && c->d >= c->real_min_dim) {
+      // sparse generator: every product is a sparse x dense pass, the polynomial alone (no squarings) whenever one fits
+      for (int q = 1; q <= RQ_MAX; ++q)
+        if (taylor_remainder(th, 2 * q + 1) <= c->expm_tol) {
+          ExpmPlan p = make_real_plan(q, 0);
+          p.spx = 1;
+          p.nprod = 2 * q;
+          return p;
+        }
+    }
     if (c->force_degree <= 0 && c->force_s < 0 && c->d >= c->real_min_dim) {  // (those options address the complex tape)
       // cheapest (q, s): q + 1 products for the polynomial at theta / 2^s plus 3 per squaring
       int bq = 0, bs = 0, best = 1 << 30;
@@ -865,7 +978,7 @@ TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
     // Cached chunks keep X, Y_1..Y_{q-1}, P (real) and U (complex) in their cache entry: the forward pass computes them
     // there directly (the pool slots are redirected for the duration of the chunk), the backward pass reads them there --
     // no copies, no rebuild.
-    const bool cacheable = p.s == 0 && c->pc_mode != 0 && c0 + n <= c->pc_limit;
+    const bool cacheable = p.s == 0 && !p.spx && c->pc_mode != 0 && c0 + n <= c->pc_limit;
     const size_t idx = (size_t)(c0 / std::max(c->pc_tc, 1));
     const size_t mat = c->nn() * sizeof(T) * (size_t)n;  // one real variable of the chunk
     const int q = p.rq;
@@ -1096,7 +1209,7 @@ void setup_pcache(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
     budget = std::min((opback ? 0.80 : 0.50) * ((double)fr + (double)c->pc_arena.bytes), 96.0 * 1024 * 1024 * 1024);
   }
   const ExpmPlan p0 = chunk_plan(c, uh, 0, std::min(tc, S), dt);
-  if (p0.rq == 0 || p0.s > 0) return;
+  if (p0.rq == 0 || p0.s > 0 || p0.spx) return;  // (the sparse-generator scheme rebuilds: its products are cheap passes)
   const double per_step = (p0.rq + 3.0) * c->nn() * sizeof(T);  // X, Y_1..Y_{q-1}, P (real) + U (complex)
   const double S_plan = (double)std::max<long>(S, c->plan_steps);
   const double share = std::min(1.0, budget / (per_step * S_plan));
@@ -1212,6 +1325,10 @@ void chunk_vjp(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
   const int K = c->K;
   const int nblk = dq::grad_contract_blocks((long)c->nn());
   c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
+  if (p.rq > 0 && p.spx) {
+    real_backward_spx(c, p, c0, n, dt, c->grad_dev.d() + (size_t)c0 * K);
+    return;
+  }
   if (p.rq > 0 && c->sparse_on()) {
     const T *Sb = nullptr, *Yb = nullptr;
     real_backward(c, p, n, true, &Sb, &Yb);
@@ -1545,62 +1662,77 @@ void do_mc_shift(Ctx<T>* c, const double* u_a, int n_a, double dt_a, const doubl
   HIPCK(hipStreamSynchronize(c->st));
 }
 
-// CSR of the control Hamiltonians' nonzeros (real path), if they are sparse enough to pay: at most sparse_fill nonzeros
-// per row summed over the controls (X-type Paulis: K per row). Otherwise the dense passes stay.
+// CSR of the Hamiltonians' nonzeros (real path), if they are sparse enough to pay: at most sparse_fill nonzeros per row
+// summed over the sources (X-type Paulis: one per control). Two tiers: controls AND drift sparse (sparse_x: the drift's
+// entries join the CSR with kid = -1, so X_t itself is sparse and the polynomial runs on sparse x dense products), or the
+// controls alone (dense drift: scatter assembly + the last reverse-mode level as row dot products). Otherwise dense passes.
+// Row i of the CSR holds its drift entries first (if any), then those of control 0, control 1, ...
 template <class T>
 void build_sparse_controls(Ctx<T>* c) {
   c->sparse_h = false;
+  c->sparse_x = false;
   c->sp_nnz = 0;
   const int d = c->d, K = c->K;
   if (!c->real_h || K <= 0) return;
+  const int NS = K + 1;  // source 0 = drift, source k + 1 = control k
   DevBuf cnt_dev, base_dev;
-  cnt_dev.ensure(sizeof(int) * (size_t)K * d);
-  HIPCK(dq::rsp_count_launch<T>((const T*)c->Hsr.p, d, K, (int*)cnt_dev.p, c->st));
-  std::vector<int> cnt((size_t)K * d);
+  cnt_dev.ensure(sizeof(int) * (size_t)NS * d);
+  HIPCK(dq::rsp_count_launch<T>((const T*)c->H0r.p, d, 1, (int*)cnt_dev.p, c->st));
+  HIPCK(dq::rsp_count_launch<T>((const T*)c->Hsr.p, d, K, (int*)cnt_dev.p + d, c->st));
+  std::vector<int> cnt((size_t)NS * d);
   HIPCK(hipMemcpyAsync(cnt.data(), cnt_dev.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->st));
   HIPCK(hipStreamSynchronize(c->st));
-  long nnz = 0;
-  for (int v : cnt) nnz += v;
-  if ((double)nnz > c->sparse_fill * d) return;
-  // combined CSR: row i holds its entries of control 0, then control 1, ... ; kent: the same entries grouped by control
-  std::vector<long> rowptr((size_t)d + 1, 0), base((size_t)K * d), kptr((size_t)K + 1, 0), kent((size_t)std::max<long>(nnz, 1));
+  long nnz_c = 0, nnz_0 = 0;
+  for (int i = 0; i < d; ++i) nnz_0 += cnt[i];
+  for (size_t q = d; q < cnt.size(); ++q) nnz_c += cnt[q];
+  const double cap = std::min(c->sparse_fill * d, 0.5 * (double)d * d);  // (and never more than half full: tiny dimensions)
+  if ((double)nnz_c > cap) return;
+  const bool with_drift = (double)(nnz_c + nnz_0) <= cap;
+  const int s0 = with_drift ? 0 : 1;  // first source in the CSR
+  const long nnz = nnz_c + (with_drift ? nnz_0 : 0);
+  std::vector<long> rowptr((size_t)d + 1, 0), base((size_t)NS * d, 0), kptr((size_t)K + 1, 0), kent((size_t)std::max<long>(nnz_c, 1));
   long at = 0;
   for (int i = 0; i < d; ++i) {
     rowptr[i] = at;
-    for (int k = 0; k < K; ++k) {
-      base[(size_t)k * d + i] = at;
-      at += cnt[(size_t)k * d + i];
+    for (int sidx = s0; sidx < NS; ++sidx) {
+      base[(size_t)sidx * d + i] = at;
+      at += cnt[(size_t)sidx * d + i];
     }
   }
   rowptr[d] = at;
   for (int k = 0; k < K; ++k) {
     long nk = 0;
-    for (int i = 0; i < d; ++i) nk += cnt[(size_t)k * d + i];
+    for (int i = 0; i < d; ++i) nk += cnt[(size_t)(k + 1) * d + i];
     kptr[k + 1] = kptr[k] + nk;
   }
-  {
+  {  // the control entries grouped by control (fixed order: by row, then column), for the per-control reduction
     std::vector<long> fill(kptr.begin(), kptr.end() - 1);
     for (int i = 0; i < d; ++i)
       for (int k = 0; k < K; ++k)
-        for (int q = 0; q < cnt[(size_t)k * d + i]; ++q) kent[fill[k]++] = base[(size_t)k * d + i] + q;
+        for (int q = 0; q < cnt[(size_t)(k + 1) * d + i]; ++q) kent[fill[k]++] = base[(size_t)(k + 1) * d + i] + q;
   }
   const size_t ne = (size_t)std::max<long>(nnz, 1);
   c->sp_rowptr.ensure(sizeof(long) * rowptr.size());
   c->sp_kptr.ensure(sizeof(long) * kptr.size());
-  c->sp_kent.ensure(sizeof(long) * ne);
+  c->sp_kent.ensure(sizeof(long) * kent.size());
   c->sp_col.ensure(sizeof(int) * ne);
   c->sp_kid.ensure(sizeof(int) * ne);
   c->sp_val.ensure(sizeof(double) * ne);
   base_dev.ensure(sizeof(long) * base.size());
   HIPCK(hipMemcpyAsync(c->sp_rowptr.p, rowptr.data(), sizeof(long) * rowptr.size(), hipMemcpyHostToDevice, c->st));
   HIPCK(hipMemcpyAsync(c->sp_kptr.p, kptr.data(), sizeof(long) * kptr.size(), hipMemcpyHostToDevice, c->st));
-  HIPCK(hipMemcpyAsync(c->sp_kent.p, kent.data(), sizeof(long) * ne, hipMemcpyHostToDevice, c->st));
+  HIPCK(hipMemcpyAsync(c->sp_kent.p, kent.data(), sizeof(long) * kent.size(), hipMemcpyHostToDevice, c->st));
   HIPCK(hipMemcpyAsync(base_dev.p, base.data(), sizeof(long) * base.size(), hipMemcpyHostToDevice, c->st));
-  HIPCK(dq::rsp_fill_launch<T>((const T*)c->Hsr.p, d, K, (const long*)base_dev.p, (int*)c->sp_col.p, (int*)c->sp_kid.p,
-                               (double*)c->sp_val.p, c->st));
+  if (with_drift)
+    HIPCK(dq::rsp_fill_launch<T>((const T*)c->H0r.p, d, 1, (const long*)base_dev.p, (int*)c->sp_col.p, (int*)c->sp_kid.p,
+                                 (double*)c->sp_val.p, -1, c->st));
+  HIPCK(dq::rsp_fill_launch<T>((const T*)c->Hsr.p, d, K, (const long*)base_dev.p + d, (int*)c->sp_col.p, (int*)c->sp_kid.p,
+                               (double*)c->sp_val.p, 0, c->st));
   HIPCK(hipStreamSynchronize(c->st));  // the host vectors and the temporaries go out of scope
   c->sp_nnz = nnz;
+  c->sp_nnz_c = nnz_c;
   c->sparse_h = true;
+  c->sparse_x = with_drift;
 }
 
 template <class T>
@@ -1821,6 +1953,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->rgemm_cfg = q;
   } else if (s == "sparse_controls") {  // real path: -1 auto (use the controls' sparsity when they are sparse), 0 never
     c->sparse_mode = (int)v != 0 ? -1 : 0;
+  } else if (s == "sparse_generator") {  // drift and controls sparse: -1 auto (sparse x dense products for every power), 0 off
+    c->sparse_gen_mode = (int)v != 0 ? -1 : 0;
   } else if (s == "skew_trick") {
     c->skew_trick = v != 0 ? 1 : 0;
   } else if (s == "zgemm_alg") {
@@ -1846,7 +1980,9 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "cached_steps") return c->last_cached;
   if (s == "slice_skew") return skew_w_form(c) ? 1.0 : 0.0;
   if (s == "sparse_controls") return c->sparse_on() ? 1.0 : 0.0;
-  if (s == "control_nonzeros") return c->sparse_h ? (double)c->sp_nnz : -1.0;
+  if (s == "control_nonzeros") return c->sparse_h ? (double)c->sp_nnz_c : -1.0;
+  if (s == "sparse_generator") return c->last_spx;
+  if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;
   if (s == "norm_H0") return c->nH0;

@@ -6,6 +6,8 @@
 //   step generator   A = -i dt (H0 + sum_k u_k H_k) = i X,  X = -dt (H0 + sum_k u_k H_k)   (diffqc.cc:192-197)
 //   propagator       U = exp(A) = cos X + i sin X = C + i S                                 (diffqc.cc:198)
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
 #include "dq_internal.h"
 
 namespace dq {
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(64) rsp_count_kernel(const T* __restrict__ Hsr
 template <class T>
 __global__ void __launch_bounds__(64) rsp_fill_kernel(const T* __restrict__ Hsr, int d, const long* __restrict__ base,
                                                       int* __restrict__ col, int* __restrict__ kid,
-                                                      double* __restrict__ val) {
+                                                      double* __restrict__ val, int kid0) {
   const int i = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
   const T* row = Hsr + ((long)k * d + i) * d;
   long at = base[(long)k * d + i];
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(64) rsp_fill_kernel(const T* __restrict__ Hsr,
     if (v != (T)0) {
       const long e = at + __popcll(m & ((1ull << lane) - 1ull));
       col[e] = j;
-      kid[e] = k;
+      kid[e] = kid0 + k;
       val[e] = (double)v;
     }
     at += __popcll(m);
@@ -290,15 +292,17 @@ template hipError_t rsp_count_launch<double>(const double*, int, int, int*, hipS
 template hipError_t rsp_count_launch<float>(const float*, int, int, int*, hipStream_t);
 
 template <class T>
-hipError_t rsp_fill_launch(const T* Hsr, int d, int K, const long* base, int* col, int* kid, double* val, hipStream_t st) {
+hipError_t rsp_fill_launch(const T* Hsr, int d, int K, const long* base, int* col, int* kid, double* val, int kid0,
+                           hipStream_t st) {
   if (d <= 0 || K <= 0) return hipSuccess;
-  hipLaunchKernelGGL(rsp_fill_kernel<T>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, Hsr, d, base, col, kid, val);
+  hipLaunchKernelGGL(rsp_fill_kernel<T>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, Hsr, d, base, col, kid, val, kid0);
   return hipGetLastError();
 }
-template hipError_t rsp_fill_launch<double>(const double*, int, int, const long*, int*, int*, double*, hipStream_t);
-template hipError_t rsp_fill_launch<float>(const float*, int, int, const long*, int*, int*, double*, hipStream_t);
+template hipError_t rsp_fill_launch<double>(const double*, int, int, const long*, int*, int*, double*, int, hipStream_t);
+template hipError_t rsp_fill_launch<float>(const float*, int, int, const long*, int*, int*, double*, int, hipStream_t);
 
-// X[z][i][col] += -dt u[z][kid] val   for the nonzeros of row i: one thread per (row, step), entries in CSR order
+// X[z][i][col] += -dt u[z][kid] val (kid < 0: a drift entry, weight -dt val)  for the nonzeros of row i: one thread per
+// (row, step), entries in CSR order
 // (deterministic even when two controls share an entry)
 template <class T>
 __global__ void __launch_bounds__(256) rsp_add_kernel(T* __restrict__ X, long strideX, const long* __restrict__ rowptr,
@@ -310,7 +314,7 @@ __global__ void __launch_bounds__(256) rsp_add_kernel(T* __restrict__ X, long st
   const long z = blockIdx.z;
   T* row = X + z * strideX + (long)i * d;
   const double* uz = u + z * K;
-  for (long e = rowptr[i]; e < rowptr[i + 1]; ++e) row[col[e]] += (T)(mdt * uz[kid[e]] * val[e]);
+  for (long e = rowptr[i]; e < rowptr[i + 1]; ++e) row[col[e]] += (T)(mdt * (kid[e] < 0 ? 1.0 : uz[kid[e]]) * val[e]);
 }
 
 template <class T>
@@ -427,5 +431,209 @@ template hipError_t rsp_contract_launch<double>(const double*, const double*, co
 template hipError_t rsp_contract_launch<float>(const float*, const float*, const float*, const float*, long, int, const long*,
                                                const int*, const double*, long, const long*, const long*, int, int, double,
                                                double*, double*, hipStream_t);
+
+// ---- sparse generator: drift AND controls sparse (e.g. a diagonal Ising drift with local-Pauli controls) --------------
+// Then X_t itself is sparse (13 nonzeros per row at n = 12) and every product of the polynomial can have X as its left
+// factor: the powers X_{m+1} = X X_m (m = 1 .. 2q) are sparse x dense products -- nnz(X) row AXPYs per output row, HBM/L2
+// bound -- instead of symmetric-output MFMA products, and cos X = sum cc_j X_{2j}, sin X = sum sc_j X_{2j+1} are linear
+// combinations of the stored powers. Reverse mode: Xbar_m = coef_m (Cbar | Sbar) + X Xbar_{m+1} (the same kernel with an
+// AXPY epilogue), and the generator's cotangent is only ever contracted with the controls:
+//   <Xi, H_k>,  Xi = Xbar_1 + sum_m Xbar_{m+1} X_m   ->   sum over nnz(H_k) of row dot products, level by level.
+
+// out[z][i][:] = ca * Add[z][i][:] + sum_{e in row i} w_e V[z][col_e][:],   w_e = mdt (kid_e < 0 ? 1 : u[z][kid_e]) val_e
+constexpr int RSPMM_U = 8, RSPMM_WAVES = 4;
+
+template <class T>
+__global__ void __launch_bounds__(RSPMM_WAVES * 64) rsp_mm_kernel(T* __restrict__ out, const T* __restrict__ V,
+                                                                  const T* __restrict__ Add, double ca, long stride, int d,
+                                                                  const long* __restrict__ rowptr, const int* __restrict__ col,
+                                                                  const int* __restrict__ kid, const double* __restrict__ val,
+                                                                  const double* __restrict__ u, int K, double mdt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * RSPMM_WAVES + wave;
+  if (i >= d) return;
+  const long z = blockIdx.z;
+  const T* Vz = V + z * stride;
+  const double* uz = u + z * K;
+  const long e0 = rowptr[i], e1 = rowptr[i + 1];
+  for (int m0 = 0; m0 < d; m0 += 64 * RSPMM_U) {
+    T acc[RSPMM_U];
+#pragma unroll
+    for (int r = 0; r < RSPMM_U; ++r) {
+      const int m = m0 + r * 64 + lane;
+      acc[r] = (Add != nullptr && m < d) ? (T)ca * Add[z * stride + (long)i * d + m] : (T)0;
+    }
+    for (long e = e0; e < e1; ++e) {
+      const int k = kid[e];
+      const T w = (T)(mdt * (k < 0 ? 1.0 : uz[k]) * val[e]);
+      const T* vrow = Vz + (long)col[e] * d;
+#pragma unroll
+      for (int r = 0; r < RSPMM_U; ++r) {
+        const int m = m0 + r * 64 + lane;
+        if (m < d) acc[r] += w * vrow[m];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RSPMM_U; ++r) {
+      const int m = m0 + r * 64 + lane;
+      if (m < d) out[z * stride + (long)i * d + m] = acc[r];
+    }
+  }
+}
+
+template <class T>
+hipError_t rsp_mm_launch(T* out, const T* V, const T* Add, double ca, long stride, int d, const long* rowptr, const int* col,
+                         const int* kid, const double* val, const double* u, int K, int batch, double dt, hipStream_t st) {
+  if (d <= 0 || batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rsp_mm_kernel<T>, dim3((unsigned)((d + RSPMM_WAVES - 1) / RSPMM_WAVES), 1, (unsigned)batch),
+                     dim3(RSPMM_WAVES * 64), 0, st, out, V, Add, ca, stride, d, rowptr, col, kid, val, u, K, -dt);
+  return hipGetLastError();
+}
+template hipError_t rsp_mm_launch<double>(double*, const double*, const double*, double, long, int, const long*, const int*,
+                                          const int*, const double*, const double*, int, int, double, hipStream_t);
+template hipError_t rsp_mm_launch<float>(float*, const float*, const float*, double, long, int, const long*, const int*,
+                                         const int*, const double*, const double*, int, int, double, hipStream_t);
+
+// nzval[z][e] (+)= val_e * ( direct_e + sum_{l < nl} <G_l[z][i,:], Xp_l[z][j,:]> )   for the CONTROL entries e = (i, j)
+// with j >= i (doubled for j > i: the total cotangent Xi is symmetric and so are the H_k; drift entries, kid < 0, and the
+// entries below the diagonal get 0), with  direct_e = dc D[z][i][j] + sum_{e' in row i} w_e' G2[z][col_e'][j]  when D is
+// given (the cotangent of the dense copy X_1: Xbar_1 = dc Sbar + X Xbar_2, needed at the controls' nonzeros only).
+// One wave per row; a 256-column strip of the row's cotangents (up to RSPL_MAX levels) stays in registers while the
+// partner rows of up to RSPL_NZ nonzeros stream past.
+constexpr int RSPL_MAX = 6, RSPL_U = 4, RSPL_WAVES = 4, RSPL_NZ = 8;
+
+template <class T>
+struct RspLevels {
+  const T* G[RSPL_MAX];   // cotangents Xbar_{m+1}
+  const T* Xp[RSPL_MAX];  // powers X_m
+  int nl;
+  const T* D;             // direct term (may be null)
+  const T* G2;
+  double dc;
+  int accumulate;
+};
+
+template <class T>
+__global__ void __launch_bounds__(RSPL_WAVES * 64) rsp_levels_kernel(RspLevels<T> a, long stride, int d,
+                                                                     const long* __restrict__ rowptr,
+                                                                     const int* __restrict__ col, const int* __restrict__ kid,
+                                                                     const double* __restrict__ val,
+                                                                     const double* __restrict__ u, int K, double mdt, long nnz,
+                                                                     double* __restrict__ nzval) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * RSPL_WAVES + wave;
+  if (i >= d) return;
+  const long z = blockIdx.z;
+  const long zo = z * stride;
+  const double* uz = u + z * K;
+  const long e0 = rowptr[i], e1 = rowptr[i + 1];
+  long e = e0;
+  while (e < e1) {
+    long ent[RSPL_NZ];
+    int cnt = 0;
+    while (e < e1 && cnt < RSPL_NZ) {  // wave-uniform
+      if (kid[e] >= 0 && col[e] >= i) ent[cnt++] = e;
+      else if (lane == 0 && !a.accumulate) nzval[z * nnz + e] = 0.0;
+      ++e;
+    }
+    if (cnt == 0) break;
+    double acc[RSPL_NZ];
+#pragma unroll
+    for (int q = 0; q < RSPL_NZ; ++q) acc[q] = 0.0;
+    for (int m0 = 0; m0 < d; m0 += 64 * RSPL_U) {
+      T g[RSPL_MAX][RSPL_U];
+#pragma unroll
+      for (int l = 0; l < RSPL_MAX; ++l)
+#pragma unroll
+        for (int r = 0; r < RSPL_U; ++r) {
+          const int m = m0 + r * 64 + lane;
+          g[l][r] = (l < a.nl && m < d) ? a.G[l][zo + (long)i * d + m] : (T)0;
+        }
+#pragma unroll
+      for (int q = 0; q < RSPL_NZ; ++q) {
+        if (q < cnt) {
+          const long j = col[ent[q]];
+          T t[RSPL_U];  // independent chains
+#pragma unroll
+          for (int r = 0; r < RSPL_U; ++r) t[r] = 0;
+#pragma unroll
+          for (int l = 0; l < RSPL_MAX; ++l) {
+            if (l < a.nl) {
+              const T* x = a.Xp[l] + zo + j * d;
+#pragma unroll
+              for (int r = 0; r < RSPL_U; ++r) {
+                const int m = m0 + r * 64 + lane;
+                if (m < d) t[r] += g[l][r] * x[m];
+              }
+            }
+          }
+          T ts = 0;
+#pragma unroll
+          for (int r = 0; r < RSPL_U; ++r) ts += t[r];
+          acc[q] += (double)ts;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RSPL_NZ; ++q) {
+      if (q < cnt) {
+        const long eq = ent[q];
+        const long j = col[eq];
+        double v = acc[q];
+        if (a.D != nullptr) {  // the nonzeros of row i of X, one per lane
+          for (long p = e0 + lane; p < e1; p += 64) {
+            const int k = kid[p];
+            v += mdt * (k < 0 ? 1.0 : uz[k]) * val[p] * (double)a.G2[zo + (long)col[p] * d + j];
+          }
+          if (lane == 0) v += a.dc * (double)a.D[zo + (long)i * d + j];
+        }
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) {
+          v *= val[eq] * (j > i ? 2.0 : 1.0);
+          if (a.accumulate) nzval[z * nnz + eq] += v;
+          else nzval[z * nnz + eq] = v;
+        }
+      }
+    }
+  }
+  // entries after the last group that were skipped were zeroed in the collecting loop
+}
+
+template <class T>
+hipError_t rsp_levels_launch(const T* const* G, const T* const* Xp, int nl, const T* D, const T* G2, double dc, long stride,
+                             int d, const long* rowptr, const int* col, const int* kid, const double* val, const double* u,
+                             int K, int batch, double dt, long nnz, double* nzval, hipStream_t st) {
+  if (d <= 0 || batch <= 0 || nnz <= 0) return hipSuccess;
+  int l0 = 0;
+  do {
+    RspLevels<T> a;
+    memset(&a, 0, sizeof(a));
+    a.nl = std::max(0, std::min((int)RSPL_MAX, nl - l0));
+    for (int l = 0; l < a.nl; ++l) { a.G[l] = G[l0 + l]; a.Xp[l] = Xp[l0 + l]; }
+    a.accumulate = l0 > 0 ? 1 : 0;
+    if (l0 == 0) { a.D = D; a.G2 = G2; a.dc = dc; }
+    hipLaunchKernelGGL(rsp_levels_kernel<T>, dim3((unsigned)((d + RSPL_WAVES - 1) / RSPL_WAVES), 1, (unsigned)batch),
+                       dim3(RSPL_WAVES * 64), 0, st, a, stride, d, rowptr, col, kid, val, u, K, -dt, nnz, nzval);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    l0 += RSPL_MAX;
+  } while (l0 < nl);
+  return hipSuccess;
+}
+template hipError_t rsp_levels_launch<double>(const double* const*, const double* const*, int, const double*, const double*,
+                                              double, long, int, const long*, const int*, const int*, const double*,
+                                              const double*, int, int, double, long, double*, hipStream_t);
+template hipError_t rsp_levels_launch<float>(const float* const*, const float* const*, int, const float*, const float*, double,
+                                             long, int, const long*, const int*, const int*, const double*, const double*, int,
+                                             int, double, long, double*, hipStream_t);
+
+// grad[z][k] = scale * sum of nzval[z][e] over the entries of control k (the reduction of rsp_contract_launch, on its own)
+hipError_t rsp_reduce_launch(const double* nzval, long nnz, const long* kptr, const long* kent, int K, int batch, double scale,
+                             double* grad, hipStream_t st) {
+  if (K <= 0 || batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rsp_reduce_kernel, dim3((unsigned)K, 1, (unsigned)batch), dim3(256), 0, st, nzval, nnz, kptr, kent, K,
+                     scale, grad);
+  return hipGetLastError();
+}
 
 }  // namespace dq

@@ -51,7 +51,8 @@ typedef struct dq_ctx dq_ctx;
 #define DQ_PROF_RGEMM 5     /* batched real GEMM of the real-symmetric fast path (f64 MFMA), full output   */
 #define DQ_PROF_RSYM 6      /* the same kernel in its symmetric-output form (tiles on/above the diagonal)  */
 #define DQ_PROF_ZHERM 7     /* complex GEMM in its (anti-)Hermitian-output form (tiles on/above the diagonal) */
-#define DQ_PROF_NCLASS 8
+#define DQ_PROF_SPMM 8      /* sparse generator x dense matrix passes (drift and controls sparse)                */
+#define DQ_PROF_NCLASS 9
 
 typedef struct dq_profile {
   long long launches[DQ_PROF_NCLASS];
@@ -102,6 +103,12 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      streaming K dense matrices, and the last level of the reverse mode together with the control
  *                      contractions <Xbar, H_k> becomes nnz(H) row dot products instead of two two-product symmetric
  *                      launches (4 d^3 flop); 0 = always the dense passes. dq_get_info("sparse_controls") tells which
+ *   sparse_generator   real path: 1 (default) = when the DRIFT is sparse as well (same bound, drift included: e.g. a diagonal
+ *                      Ising drift with local-Pauli controls), X_t itself is sparse and the whole polynomial runs on
+ *                      sparse x dense passes: powers X_{m+1} = X X_m, cos/sin as linear combinations of the powers, reverse
+ *                      mode Xbar_m = coef (Cbar | Sbar) + X Xbar_{m+1}, gradient = row dot products over nnz(H_k) level by
+ *                      level -- no real MFMA product left in the step exponential (steps that need squarings keep the
+ *                      dense scheme); 0 = off. dq_get_info("sparse_generator") / ("sparse_drift") tell what is in use
  *   cache_bytes        real path: HBM for the propagator intermediates (X, Y_j, P, U) that the forward pass leaves in place
  *                      for the backward sweep, which then skips its q + 1 rebuild products for those steps; < 0 off,
  *                      0 = 80 % of the free HBM (operator form) / 50 % (after the state form's checkpoints), at most 96 GiB
@@ -113,7 +120,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
- * "time_parallel", "cached_steps", "slice_skew", "sparse_controls", "control_nonzeros" (-1 = dense), "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
+ * "time_parallel", "cached_steps", "slice_skew", "sparse_controls", "control_nonzeros" (-1 = dense), "sparse_generator", "sparse_drift", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 

@@ -66,7 +66,7 @@ def test_ising_x_controls_match_oracle_and_dense(oracle, n, B, S):
     u = np.random.default_rng(S).uniform(-1, 1, (S, n))
     psi0 = problems.random_states(1 << n, B, seed=2)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M) as e:
+    with _engine(H0, Hs, M, sparse_generator=0) as e:   # (the drift is sparse too: see the sparse-generator tests below)
         assert e.info("control_nonzeros") == n * (1 << n)
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("real_path") >= 1 and e.info("sparse_controls") == 1
@@ -140,13 +140,13 @@ def test_sparse_controls_mid_dimension_cached_and_sliced():
     M = H0
     u = np.random.default_rng(0).uniform(-1, 1, (S, len(Hs)))
     psi0 = problems.random_states(1 << n, B, seed=3)
-    with _engine(H0, Hs, M, real_min_dim=128) as e:
+    with _engine(H0, Hs, M, real_min_dim=128, sparse_generator=0) as e:   # controls-only scheme (it is the one that caches)
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("sparse_controls") == 1 and e.info("cached_steps") > 0
         e.set_option("sparse_controls", 0)
         l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
     assert abs(l1 - l0) < 1e-11 * B and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
-    engines = [_engine(H0, Hs, M, real_min_dim=128) for _ in range(3)]
+    engines = [_engine(H0, Hs, M, real_min_dim=128, sparse_generator=0) for _ in range(3)]
     try:
         shards = [np.ascontiguousarray(psi0[:, f:f + c]) for f, c in (shard_range(B, r, 3) for r in range(3))]
         res = virtual_time_sliced_energy_grad(engines, u, dt, shards)
@@ -182,3 +182,115 @@ def test_zero_and_diagonal_controls(oracle):
         assert e.info("sparse_controls") == 1 and np.all(g2 == 0.0)
     rl2, rg2, rf2 = oracle.energy_grad(H0, [np.zeros((d, d))] * 2, M, u[:, :2], dt, psi0)
     assert abs(l2 - rl2) < TOL and np.max(np.abs(f2 - rf2)) < TOL
+
+
+# ---- sparse generator: drift AND controls sparse -> the polynomial runs on sparse x dense passes ---------------------
+
+def _sparse_drift_problem(d, K, seed, per_row=2):
+    """Sparse real symmetric drift (diagonal + a few off-diagonal pairs) and sparse controls, random patterns."""
+    H0, Hs, M = _sparse_problem(d, K, seed, per_row=per_row)
+    rng = np.random.default_rng(seed + 1000)
+    D = np.diag(rng.standard_normal(d))
+    for _ in range(d):
+        i, j = rng.integers(0, d, 2)
+        v = rng.standard_normal()
+        D[i, j] += v
+        if i != j:
+            D[j, i] += v
+    D[d // 2, :] = 0
+    D[:, d // 2] = 0
+    return D.astype(complex), Hs, M
+
+
+@pytest.mark.parametrize("n,B,S", [(3, 4, 6), (4, 20, 5), (5, 3, 4), (6, 70, 3)])
+def test_sparse_generator_ising_matches_oracle_and_other_schemes(oracle, n, B, S):
+    """BASELINE's problem family: diagonal Ising drift + X_k controls -> X_t has n + 1 nonzeros per row."""
+    dt = 0.03
+    H0, Hs, M = problems.random_ising(n, seed=n)
+    u = np.random.default_rng(S).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("sparse_drift") == 1
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("real_path") >= 1 and e.info("sparse_generator") == 1 and e.info("squarings") == 0
+        p1 = e.propagate(u, dt, psi0)
+        e.set_option("sparse_generator", 0)      # controls-only sparse scheme (dense symmetric products)
+        l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 0 and e.info("sparse_controls") == 1
+        e.set_option("sparse_controls", 0)       # dense passes throughout
+        l3, g3, f3, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_controls") == 0
+    assert abs(l1 - rl) < TOL and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+    assert np.max(np.abs(p1 - rf)) < TOL
+    for l, g, f in ((l2, g2, f2), (l3, g3, f3)):
+        assert abs(l1 - l) < 1e-12 * max(1, B) and np.max(np.abs(g1 - g)) < 1e-12 and np.max(np.abs(f1 - f)) < 1e-13
+
+
+@pytest.mark.parametrize("q", [1, 2, 3, 4, 5, 6])
+def test_sparse_generator_every_polynomial_size(oracle, q):
+    """Forced q = 1..6 (powers up to X^13: two level groups in the gradient contraction from q = 4); the step is chosen so
+    that each q resolves it, and the result is compared with the dense symmetric scheme at the SAME q (same polynomial)."""
+    n, B, S = 4, 9, 4
+    dt = {1: 1e-4, 2: 2e-3, 3: 0.01, 4: 0.03, 5: 0.06, 6: 0.1}[q]
+    H0, Hs, M = problems.random_ising(n, seed=q)
+    u = np.random.default_rng(q).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=q)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, real_path=q) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("real_path") == q
+        e.set_option("sparse_generator", 0)
+        l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
+    assert abs(l1 - l2) < 1e-12 and np.max(np.abs(g1 - g2)) < 1e-12 and np.max(np.abs(f1 - f2)) < 1e-13
+    assert abs(l1 - rl) < 1e-9 and np.max(np.abs(g1 - rg)) < 1e-9 and np.max(np.abs(f1 - rf)) < 1e-9
+
+
+@pytest.mark.parametrize("d,K,B", [(16, 1, 3), (24, 3, 5), (64, 2, 64), (100, 4, 7), (130, 2, 131)])
+def test_sparse_generator_random_patterns(oracle, d, K, B):
+    """Random sparse drift and controls: shared entries, empty rows, off-diagonal drift, dimensions that are not powers of two."""
+    S, dt = 4, (0.02 if d < 100 else 0.004)   # (small enough for a polynomial without squarings: the scheme's regime)
+    H0, Hs, M = _sparse_drift_problem(d, K, seed=d + K)
+    u = np.random.default_rng(d).uniform(-1, 1, (S, K))
+    psi0 = _states(d, B, seed=1)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("sparse_drift") == 1 and e.info("control_nonzeros") == int(np.count_nonzero(Hs))
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1
+    assert abs(l1 - rl) < TOL * max(1, B) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+
+
+def test_sparse_generator_large_step_falls_back_to_squarings(oracle):
+    n, B, S, dt = 4, 6, 3, 0.9
+    H0, Hs, M = problems.random_ising(n, seed=3)
+    u = np.random.default_rng(1).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("squarings") >= 1 and e.info("sparse_generator") == 0 and e.info("sparse_controls") == 1
+    assert abs(l1 - rl) < 1e-9 and np.max(np.abs(g1 - rg)) < 1e-9 and np.max(np.abs(f1 - rf)) < 1e-10
+
+
+def test_sparse_generator_fp32_and_sliced(oracle):
+    from diffquantum_amd.distributed import shard_range, virtual_time_sliced_energy_grad
+    n, B, S, dt = 5, 40, 6, 0.03
+    H0, Hs, M = problems.random_ising(n, seed=5)
+    u = np.random.default_rng(2).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, dtype="c64") as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("sparse_generator") == 1
+    assert abs(l1 - rl) < 1e-4 * B and np.max(np.abs(g1 - rg)) < 1e-4 and np.max(np.abs(f1 - rf)) < 1e-4
+    engines = [_engine(H0, Hs, M) for _ in range(3)]
+    try:
+        shards = [np.ascontiguousarray(psi0[:, f:f + c]) for f, c in (shard_range(B, r, 3) for r in range(3))]
+        res = virtual_time_sliced_energy_grad(engines, u, dt, shards)
+        assert all(e.info("sparse_generator") == 1 for e in engines)
+    finally:
+        for e in engines:
+            e.close()
+    for l, g, f, en in res:
+        assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL
