@@ -449,35 +449,52 @@ __global__ void __launch_bounds__(RSPMM_WAVES * 64) rsp_mm_kernel(T* __restrict_
                                                                   const long* __restrict__ rowptr, const int* __restrict__ col,
                                                                   const int* __restrict__ kid, const double* __restrict__ val,
                                                                   const double* __restrict__ u, int K, double mdt) {
+  // the row's nonzeros as (column, weight) pairs, staged once per 64 of them (one per lane) and then read wave-uniformly
+  __shared__ int s_col[RSPMM_WAVES][64];
+  __shared__ double s_w[RSPMM_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * RSPMM_WAVES + wave;
-  if (i >= d) return;
+  if (i >= d) return;  // (whole waves leave together; no block-level barrier below)
   const long z = blockIdx.z;
   const T* Vz = V + z * stride;
   const double* uz = u + z * K;
   const long e0 = rowptr[i], e1 = rowptr[i + 1];
-  for (int m0 = 0; m0 < d; m0 += 64 * RSPMM_U) {
-    T acc[RSPMM_U];
-#pragma unroll
-    for (int r = 0; r < RSPMM_U; ++r) {
-      const int m = m0 + r * 64 + lane;
-      acc[r] = (Add != nullptr && m < d) ? (T)ca * Add[z * stride + (long)i * d + m] : (T)0;
+  T* orow = out + z * stride + (long)i * d;
+  for (long eb = e0; eb < e1 || eb == e0; eb += 64) {
+    const int cnt = (int)min((long)64, e1 - eb);
+    if (lane < cnt) {
+      const int k = kid[eb + lane];
+      s_col[wave][lane] = col[eb + lane];
+      s_w[wave][lane] = mdt * (k < 0 ? 1.0 : uz[k]) * val[eb + lane];
     }
-    for (long e = e0; e < e1; ++e) {
-      const int k = kid[e];
-      const T w = (T)(mdt * (k < 0 ? 1.0 : uz[k]) * val[e]);
-      const T* vrow = Vz + (long)col[e] * d;
+    __builtin_amdgcn_wave_barrier();
+    const bool first = eb == e0;
+    for (int m0 = 0; m0 < d; m0 += 64 * RSPMM_U) {
+      T acc[RSPMM_U];
 #pragma unroll
       for (int r = 0; r < RSPMM_U; ++r) {
         const int m = m0 + r * 64 + lane;
-        if (m < d) acc[r] += w * vrow[m];
+        if (!first) acc[r] = m < d ? orow[m] : (T)0;
+        else acc[r] = (Add != nullptr && m < d) ? (T)ca * Add[z * stride + (long)i * d + m] : (T)0;
+      }
+      for (int q = 0; q < cnt; ++q) {
+        const int jc = __builtin_amdgcn_readfirstlane(s_col[wave][q]);
+        const T w = (T)s_w[wave][q];
+        const T* vrow = Vz + (long)jc * d;
+#pragma unroll
+        for (int r = 0; r < RSPMM_U; ++r) {
+          const int m = m0 + r * 64 + lane;
+          if (m < d) acc[r] += w * vrow[m];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RSPMM_U; ++r) {
+        const int m = m0 + r * 64 + lane;
+        if (m < d) orow[m] = acc[r];
       }
     }
-#pragma unroll
-    for (int r = 0; r < RSPMM_U; ++r) {
-      const int m = m0 + r * 64 + lane;
-      if (m < d) out[z * stride + (long)i * d + m] = acc[r];
-    }
+    __builtin_amdgcn_wave_barrier();
+    if (e1 - eb <= 64) break;
   }
 }
 
@@ -498,9 +515,7 @@ template hipError_t rsp_mm_launch<float>(float*, const float*, const float*, dou
 // with j >= i (doubled for j > i: the total cotangent Xi is symmetric and so are the H_k; drift entries, kid < 0, and the
 // entries below the diagonal get 0), with  direct_e = dc D[z][i][j] + sum_{e' in row i} w_e' G2[z][col_e'][j]  when D is
 // given (the cotangent of the dense copy X_1: Xbar_1 = dc Sbar + X Xbar_2, needed at the controls' nonzeros only).
-// One wave per row; a 256-column strip of the row's cotangents (up to RSPL_MAX levels) stays in registers while the
-// partner rows of up to RSPL_NZ nonzeros stream past.
-constexpr int RSPL_MAX = 6, RSPL_U = 4, RSPL_WAVES = 4, RSPL_NZ = 8;
+constexpr int RSPL_MAX = 6, RSPL_U = 8, RSPL_NZ = 8;
 
 template <class T>
 struct RspLevels {
@@ -513,90 +528,113 @@ struct RspLevels {
   int accumulate;
 };
 
+// One workgroup per row, one WAVE PER LEVEL: wave l keeps a 512-column strip of G_l[i,:] in registers while the partner rows
+// Xp_l[j,:] of up to RSPL_NZ of the row's gradient-carrying entries stream past (the loop of the sparse x dense kernel, 8
+// waves per SIMD); the per-level partial sums meet in LDS, wave 0 adds the direct term and writes one value per entry.
 template <class T>
-__global__ void __launch_bounds__(RSPL_WAVES * 64) rsp_levels_kernel(RspLevels<T> a, long stride, int d,
-                                                                     const long* __restrict__ rowptr,
-                                                                     const int* __restrict__ col, const int* __restrict__ kid,
-                                                                     const double* __restrict__ val,
-                                                                     const double* __restrict__ u, int K, double mdt, long nnz,
-                                                                     double* __restrict__ nzval) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * RSPL_WAVES + wave;
-  if (i >= d) return;
+__global__ void __launch_bounds__(RSPL_MAX * 64) rsp_levels_kernel(RspLevels<T> a, long stride, int d,
+                                                                   const long* __restrict__ rowptr,
+                                                                   const int* __restrict__ col, const int* __restrict__ kid,
+                                                                   const double* __restrict__ val,
+                                                                   const double* __restrict__ u, int K, double mdt, long nnz,
+                                                                   double* __restrict__ nzval) {
+  // the row's entries that carry gradient (a control's, on or above the diagonal), compacted once per 64 CSR entries
+  __shared__ int s_col[64];
+  __shared__ int s_ent[64];
+  __shared__ int s_nv;
+  __shared__ double s_red[RSPL_MAX][RSPL_NZ];
+  const int lane = threadIdx.x & 63, lvl = threadIdx.x >> 6;
+  const int i = blockIdx.x;
   const long z = blockIdx.z;
   const long zo = z * stride;
   const double* uz = u + z * K;
   const long e0 = rowptr[i], e1 = rowptr[i + 1];
-  long e = e0;
-  while (e < e1) {
-    long ent[RSPL_NZ];
-    int cnt = 0;
-    while (e < e1 && cnt < RSPL_NZ) {  // wave-uniform
-      if (kid[e] >= 0 && col[e] >= i) ent[cnt++] = e;
-      else if (lane == 0 && !a.accumulate) nzval[z * nnz + e] = 0.0;
-      ++e;
+  const bool active = lvl < a.nl;
+  const T* grow = active ? a.G[lvl] + zo + (long)i * d : nullptr;
+  const T* xbase = active ? a.Xp[lvl] + zo : nullptr;
+  for (long eb = e0; eb < e1; eb += 64) {
+    if (lvl == 0) {
+      const long e = eb + lane;
+      const bool in = e < e1;
+      const int cj = in ? col[e] : 0;
+      const bool valid = in && kid[e] >= 0 && cj >= i;
+      const unsigned long long mask = __ballot(valid);
+      if (valid) {
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+        s_col[pos] = cj;
+        s_ent[pos] = (int)(e - e0);
+      } else if (in && !a.accumulate) {
+        nzval[z * nnz + e] = 0.0;
+      }
+      if (lane == 0) s_nv = __popcll(mask);
     }
-    if (cnt == 0) break;
-    double acc[RSPL_NZ];
+    __syncthreads();
+    const int nv = s_nv;
+    for (int q0 = 0; q0 < nv; q0 += RSPL_NZ) {
+      const int cnt = min((int)RSPL_NZ, nv - q0);
+      double acc[RSPL_NZ];
 #pragma unroll
-    for (int q = 0; q < RSPL_NZ; ++q) acc[q] = 0.0;
-    for (int m0 = 0; m0 < d; m0 += 64 * RSPL_U) {
-      T g[RSPL_MAX][RSPL_U];
+      for (int q = 0; q < RSPL_NZ; ++q) acc[q] = 0.0;
+      if (active) {
+        for (int m0 = 0; m0 < d; m0 += 64 * RSPL_U) {
+          T g[RSPL_U];
 #pragma unroll
-      for (int l = 0; l < RSPL_MAX; ++l)
+          for (int r = 0; r < RSPL_U; ++r) {
+            const int m = m0 + r * 64 + lane;
+            g[r] = m < d ? grow[m] : (T)0;
+          }
 #pragma unroll
-        for (int r = 0; r < RSPL_U; ++r) {
-          const int m = m0 + r * 64 + lane;
-          g[l][r] = (l < a.nl && m < d) ? a.G[l][zo + (long)i * d + m] : (T)0;
-        }
-#pragma unroll
-      for (int q = 0; q < RSPL_NZ; ++q) {
-        if (q < cnt) {
-          const long j = col[ent[q]];
-          T t[RSPL_U];  // independent chains
-#pragma unroll
-          for (int r = 0; r < RSPL_U; ++r) t[r] = 0;
-#pragma unroll
-          for (int l = 0; l < RSPL_MAX; ++l) {
-            if (l < a.nl) {
-              const T* x = a.Xp[l] + zo + j * d;
+          for (int q = 0; q < RSPL_NZ; ++q) {
+            if (q < cnt) {
+              const int j = __builtin_amdgcn_readfirstlane(s_col[q0 + q]);
+              const T* x = xbase + (long)j * d;
+              T t[RSPL_U];  // independent chains
 #pragma unroll
               for (int r = 0; r < RSPL_U; ++r) {
                 const int m = m0 + r * 64 + lane;
-                if (m < d) t[r] += g[l][r] * x[m];
+                t[r] = m < d ? g[r] * x[m] : (T)0;
               }
+              T ts = 0;
+#pragma unroll
+              for (int r = 0; r < RSPL_U; ++r) ts += t[r];
+              acc[q] += (double)ts;
             }
           }
-          T ts = 0;
-#pragma unroll
-          for (int r = 0; r < RSPL_U; ++r) ts += t[r];
-          acc[q] += (double)ts;
         }
       }
-    }
 #pragma unroll
-    for (int q = 0; q < RSPL_NZ; ++q) {
-      if (q < cnt) {
-        const long eq = ent[q];
-        const long j = col[eq];
-        double v = acc[q];
-        if (a.D != nullptr) {  // the nonzeros of row i of X, one per lane
-          for (long p = e0 + lane; p < e1; p += 64) {
-            const int k = kid[p];
-            v += mdt * (k < 0 ? 1.0 : uz[k]) * val[p] * (double)a.G2[zo + (long)col[p] * d + j];
+      for (int q = 0; q < RSPL_NZ; ++q) {
+        if (q < cnt) {
+          double v = acc[q];
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+          if (lane == 0) s_red[lvl][q] = v;
+        }
+      }
+      __syncthreads();
+      if (lvl == 0) {
+        for (int q = 0; q < cnt; ++q) {
+          const int j = __builtin_amdgcn_readfirstlane(s_col[q0 + q]);
+          const long eq = e0 + __builtin_amdgcn_readfirstlane(s_ent[q0 + q]);
+          double v = 0.0;
+          if (a.D != nullptr) {  // Xbar_1[i][j] = dc D[i][j] + sum over the nonzeros of row i of X (one per lane)
+            for (long p = e0 + lane; p < e1; p += 64) {
+              const int k = kid[p];
+              v += mdt * (k < 0 ? 1.0 : uz[k]) * val[p] * (double)a.G2[zo + (long)col[p] * d + j];
+            }
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
           }
-          if (lane == 0) v += a.dc * (double)a.D[zo + (long)i * d + j];
-        }
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) {
-          v *= val[eq] * (j > i ? 2.0 : 1.0);
-          if (a.accumulate) nzval[z * nnz + eq] += v;
-          else nzval[z * nnz + eq] = v;
+          if (lane == 0) {
+            if (a.D != nullptr) v += a.dc * (double)a.D[zo + (long)i * d + j];
+            for (int l = 0; l < RSPL_MAX; ++l) v += s_red[l][q];  // (inactive levels left zeros)
+            v *= val[eq] * (j > i ? 2.0 : 1.0);
+            if (a.accumulate) nzval[z * nnz + eq] += v;
+            else nzval[z * nnz + eq] = v;
+          }
         }
       }
+      __syncthreads();
     }
   }
-  // entries after the last group that were skipped were zeroed in the collecting loop
 }
 
 template <class T>
@@ -612,8 +650,8 @@ hipError_t rsp_levels_launch(const T* const* G, const T* const* Xp, int nl, cons
     for (int l = 0; l < a.nl; ++l) { a.G[l] = G[l0 + l]; a.Xp[l] = Xp[l0 + l]; }
     a.accumulate = l0 > 0 ? 1 : 0;
     if (l0 == 0) { a.D = D; a.G2 = G2; a.dc = dc; }
-    hipLaunchKernelGGL(rsp_levels_kernel<T>, dim3((unsigned)((d + RSPL_WAVES - 1) / RSPL_WAVES), 1, (unsigned)batch),
-                       dim3(RSPL_WAVES * 64), 0, st, a, stride, d, rowptr, col, kid, val, u, K, -dt, nnz, nzval);
+    hipLaunchKernelGGL(rsp_levels_kernel<T>, dim3((unsigned)d, 1, (unsigned)batch), dim3(RSPL_MAX * 64), 0, st, a, stride, d,
+                       rowptr, col, kid, val, u, K, -dt, nnz, nzval);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     l0 += RSPL_MAX;
