@@ -43,6 +43,8 @@ TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 2.51e9}  # real GEMM: full-output (pro
                                                    # symmetric-output launches (average over the one- and two-product forms of
                                                    # the headline step: 8 + 4 per step) + fix-up pass, LDS-DMA staged
                                                    # (profiles/r1_bench_s3_sparse_summary.txt: 2445 + 64 MB)
+TRAFFIC_SPMM = 8.64e8  # fabric-side bytes per rsp_mm_kernel launch (profiles/r1_bench_s3_spx_summary.txt: 730 MB read + 134 MB
+                       # written for 134 MB in, 134 MB out: a partner row per nonzero of X, most of them L2 hits)
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
 
@@ -315,7 +317,8 @@ def main():
                           "abs_loss_diff_vs_headline_form": abs(l_o - loss),
                           "trial_of_the_headline_form_ms_per_step": trial[mode][0] / max(K, 1) * 1e3}
     info = {k: eng.info(k) for k in ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk",
-                                     "zgemm_alg", "real_path", "real_hamiltonians")}
+                                     "zgemm_alg", "real_path", "real_hamiltonians", "sparse_controls", "sparse_generator",
+                                     "control_nonzeros")}
     general = None
     if rank == 0 and world == 1 and info["real_path"] > 0 and not a.skip_general_path:
         # the same chain on the general complex path (any Hermitian H), outside the timed region, short chain
@@ -331,7 +334,24 @@ def main():
         eng.set_option("real_path", a.real_path)
         gr = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
         lr, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gr)
+        schemes = {}
+        for name, opts in (("sparse_controls_dense_drift", {"sparse_generator": 0}),
+                           ("dense_real_path", {"sparse_generator": 0, "sparse_controls": 0})):
+            # the same chain with the structure of the inputs ignored step by step: what a DENSE drift (then dense controls)
+            # of this size costs on the real path
+            for k_, v_ in opts.items():
+                eng.set_option(k_, v_)
+            gs_ = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
+            eng.energy_grad(ug[:1], a.dt, psi0, want_final=False, want_energies=False)
+            torch.cuda.synchronize(); ts_ = time.perf_counter()
+            ls_, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gs_)
+            torch.cuda.synchronize(); ts_ = time.perf_counter() - ts_
+            schemes[name] = {"steps_per_s": Kg / ts_, "max_abs_grad_diff_vs_headline_scheme": float((gs_ - gr).abs().max().item()),
+                             "abs_loss_diff_vs_headline_scheme": abs(ls_ - lr)}
+        eng.set_option("sparse_generator", 1)
+        eng.set_option("sparse_controls", 1)
         general = {"steps_per_s": Kg / tg, "chain_steps": Kg, "products_per_step": "11 ZGEMMs (3M) of 8 d^3 + 3 (anti-)Hermitian-output ZGEMMs (half the tiles)",
+                   "other_real_schemes": schemes,
                    "max_abs_grad_diff_vs_real_path": float((gg - gr).abs().max().item()),
                    "abs_loss_diff_vs_real_path": abs(lg - lr),
                    "note": "same inputs with real_path = 0: what a complex Hermitian H of this size costs; the two paths' "
@@ -374,8 +394,14 @@ def main():
                                 "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
                                 "(d x d) and of dL/du".format(world)),
                 "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "other_multi_gpu_form": other_mode,
-                "expm": ("cos X + i sin X, Taylor degree {} ({} real symmetric-output products), theta<={:.3g}".format(
-                    int(info["degree"]), int(info["products"]), info["theta"]) if info["real_path"] > 0 else
+                "expm": ("cos X + i sin X, Taylor degree {0}: drift and controls sparse, so X_t is sparse -- the powers X^2 .. X^{0} by "
+                         "{1} sparse x dense passes, cos/sin as linear combinations of them (no MFMA product in the step "
+                         "exponential), theta<={2:.3g}".format(int(info["degree"]), int(info["products"]), info["theta"])
+                         if info["sparse_generator"] > 0 else
+                         "cos X + i sin X, Taylor degree {} ({} real symmetric-output products{}), theta<={:.3g}".format(
+                    int(info["degree"]), int(info["products"]),
+                    "; sparse controls: scatter assembly, last reverse-mode level as row dot products" if info["sparse_controls"] > 0 else "",
+                    info["theta"]) if info["real_path"] > 0 else
                     "Taylor degree {} ({} complex products, {} squarings), theta<={:.3g}".format(
                         int(info["degree"]), int(info["products"]), int(info["squarings"]), info["theta"])),
                 "path": "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path",
@@ -429,8 +455,20 @@ def main():
             "full_output_form": {"achieved": rate(rg), "frac": rate(rg) / PEAK_F64_MFMA_TFLOPS, "launches": rg["launches"],
                                  "ms_per_launch": rg["ms"] / max(1, rg["launches"]), "traffic": TRAFFIC_RGEMM["rgemm"]},
         }
-        first, second = (rsy, zg) if rs["ms"] >= z["ms"] else (zg, rsy)
-        out["roofline"], out["roofline_other"] = first, second
+        sp = prof["spmm"]
+        spm = {
+            "bound": "hbm",
+            "kernel": "rsp_mm_kernel (sparse generator x dense matrix: out[i,:] = sum over nnz(X[i,:]) of w X_m[j,:]; one wave per row)",
+            "achieved": sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+            "frac": (sp["bytes"] / sp["ms"] * 1e-6 / 8000.0) if sp["ms"] > 0 else 0.0,
+            "traffic": TRAFFIC_SPMM, "launches": sp["launches"], "ms_per_launch": sp["ms"] / max(1, sp["launches"]),
+            "ms_in_timed_region": sp["ms"],
+            "note": "achieved = ALGORITHMIC bytes (operand read once, product written once: 2-3 x 8 d^2) / HIP-event time; the "
+                    "kernel re-reads a partner row per nonzero of X (13 per row at n = 12), mostly from L2 / Infinity Cache: "
+                    "`traffic` is the fabric-side PMC figure per launch",
+        }
+        ranked = sorted([(z["ms"], zg), (rs["ms"], rsy), (sp["ms"], spm)], key=lambda t: -t[0])
+        out["roofline"], out["roofline_other"] = ranked[0][1], ranked[1][1]
         if world == 1 and not a.skip_other_configs:
             try:
                 out["other_configs"] = other_configs(dev, a.seed, (n, a.dt, u_all[:K].copy(), psi0, loss))

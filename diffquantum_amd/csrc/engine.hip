@@ -645,7 +645,7 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
     const int np = 2 * q + 1;
     const T* Xp[2 * RQ_MAX + 2];
     Xp[1] = X;
-    const double bym = (double)sizeof(T) * c->d * ((double)c->sp_nnz + 2.0 * c->d) * n;  // partner rows (L2) + in + out
+    const double bym = (double)sizeof(T) * c->nn() * 2.0 * n;  // algorithmic: V read once, the product written once
     for (int m = 1; m < np; ++m) {
       T* Xn = c->rmat(spx_slot(m + 1), n);
       c->timed(DQ_PROF_SPMM, 2.0 * c->sp_nnz * c->d * n, bym, [&] {
@@ -797,7 +797,7 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
     Xb[np] = top;
   }
   const double dts = dt;  // spx plans have no squarings
-  const double bym = (double)sizeof(T) * c->d * ((double)c->sp_nnz + 3.0 * c->d) * n;
+  const double bym = (double)sizeof(T) * c->nn() * 3.0 * n;  // algorithmic: Xbar_{m+1} and Cbar|Sbar read, Xbar_m written
   for (int m = np - 1; m >= 2; --m) {
     T* dst = c->rmat(SLOT_ADJ + spx_slot(m), n);
     const T* add = (m & 1) ? Sb : Cb;
