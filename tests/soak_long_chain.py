@@ -16,7 +16,7 @@ for (n, K, B, S, dt, real) in ((4, 3, 5, 20000, 0.002, False), (4, 3, 5, 20000, 
     with Engine(1 << n, K) as e:
         e.set_hamiltonians(H0, Hs); e.set_observable(M); e.set_option("real_min_dim", 1)
         t0 = time.time(); l, g, f, en = e.energy_grad(u, dt, psi0); t1 = time.time()
-        info = (e.info("real_path"), e.info("operator_backward"), e.info("time_parallel"), e.info("time_chunk"), e.info("cached_steps"), e.info("sparse_controls"))
+        info = (e.info("real_path"), e.info("operator_backward"), e.info("time_parallel"), e.info("time_chunk"), e.info("cached_steps"), e.info("sparse_controls"), e.info("sparse_generator"))
     t2 = time.time(); rl, rg, rf = orc.energy_grad(H0, list(Hs), M, u, dt, psi0); t3 = time.time()
     print("n=%d S=%d real=%s: gpu %.2f s, oracle %.1f s; |dl| %.2e  max|dg| %.2e  max|dpsi| %.2e  info %s" % (
         n, S, real, t1 - t0, t3 - t2, abs(l - rl), np.abs(g - rg).max(), np.abs(f - rf).max(), info))
