@@ -220,11 +220,11 @@ def main():
     grad_t = torch.zeros((K, n), dtype=torch.float64, device=dev)
 
     # Propagator cache of the sliced form: a rank's slice of the planned chain is short enough to be cached WHOLE
-    # ((q + 3) d^2 fp64 words per step, q <= 3 at this step size: 0.8 GB per step, 201 GB for 250 steps), so the budget is what
-    # the slice needs, capped at 72 % of the HBM (the engine's auto mode stops at 96 GiB: bigger first-use allocations cost
+    # ((q + 3) d^2 fp64 words per step, 2q + 2 with the sparse-generator scheme: 0.8-1.07 GB per step at q = 3), so the budget is
+    # what the slice needs, capped at 72 % of the HBM (the engine's auto mode stops at 96 GiB: bigger first-use allocations cost
     # seconds, which a 2000-step single-GPU chain does not win back but a fully cached slice does, evaluation after evaluation)
     slice_steps = (max(a.chain, K) + world - 1) // world
-    sliced_cache_bytes = min(6.0 * d * d * 8 * slice_steps + (1 << 20), 0.72 * torch.cuda.get_device_properties(local).total_memory)
+    sliced_cache_bytes = min(8.0 * d * d * 8 * slice_steps + (1 << 20), 0.72 * torch.cuda.get_device_properties(local).total_memory)
 
     def run_replicated(u_dev, grad_dev):
         eng.set_option("plan_steps", max(a.chain, K))

@@ -978,30 +978,37 @@ TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
     // Cached chunks keep X, Y_1..Y_{q-1}, P (real) and U (complex) in their cache entry: the forward pass computes them
     // there directly (the pool slots are redirected for the duration of the chunk), the backward pass reads them there --
     // no copies, no rebuild.
-    const bool cacheable = p.s == 0 && !p.spx && c->pc_mode != 0 && c0 + n <= c->pc_limit;
+    // (sparse-generator plans keep the powers X_1 .. X_2q that the gradient contraction pairs with, and U)
+    const bool cacheable = p.s == 0 && c->pc_mode != 0 && c0 + n <= c->pc_limit;
     const size_t idx = (size_t)(c0 / std::max(c->pc_tc, 1));
     const size_t mat = c->nn() * sizeof(T) * (size_t)n;  // one real variable of the chunk
     const int q = p.rq;
-    auto real_slot = [&](int i) { return i == 0 ? (int)RS_X : (i < q ? i : (int)RS_P); };  // X, Y_1 .. Y_{q-1}, P
-    auto point_at = [&](char* base) {
-      for (int i = 0; i <= q; ++i) c->redirect[real_slot(i)] = base + (size_t)i * mat;
-      c->redirect[RS_U] = base + (size_t)(q + 1) * mat;
+    const int nreal = p.spx ? 2 * q : q + 1;
+    auto real_slot = [&](int i) {
+      if (p.spx) return spx_slot(i + 1);                      // X_1 .. X_2q
+      return i == 0 ? (int)RS_X : (i < q ? i : (int)RS_P);    // X, Y_1 .. Y_{q-1}, P
     };
+    auto point_at = [&](char* base) {
+      for (int i = 0; i < nreal; ++i) c->redirect[real_slot(i)] = base + (size_t)i * mat;
+      c->redirect[RS_U] = base + (size_t)nreal * mat;
+    };
+    const int tag = p.spx ? -q : q;  // which scheme filled the entry
     if (cacheable && c->pc_mode == 2 && idx < c->pcache.size()) {
       auto& e = c->pcache[idx];
-      if (e.valid && e.c0 == c0 && e.n == n && e.rq == q) {
+      if (e.valid && e.c0 == c0 && e.n == n && e.rq == tag) {
         point_at((char*)c->pc_arena.p + e.off);
         c->last_degree = p.m; c->last_squarings = 0; c->last_products = p.nprod; c->last_real_q = q;
+        c->last_spx = p.spx;
         return c->mat(RS_U, n);
       }
     }
-    if (cacheable && c->pc_mode == 1 && c->pc_used + (size_t)(q + 3) * mat <= c->pc_arena.bytes) {
+    if (cacheable && c->pc_mode == 1 && c->pc_used + (size_t)(nreal + 2) * mat <= c->pc_arena.bytes) {
       if (c->pcache.size() <= idx) c->pcache.resize(idx + 1);
       auto& e = c->pcache[idx];
       e.off = c->pc_used;
-      c->pc_used += (size_t)(q + 3) * mat;
+      c->pc_used += (size_t)(nreal + 2) * mat;
       point_at((char*)c->pc_arena.p + e.off);
-      e.c0 = c0; e.n = n; e.rq = q; e.valid = true;
+      e.c0 = c0; e.n = n; e.rq = tag; e.valid = true;
       c->last_cached += n;
     }
     return real_forward(c, p, c0, n, dt);
@@ -1209,10 +1216,14 @@ void setup_pcache(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
     budget = std::min((opback ? 0.80 : 0.50) * ((double)fr + (double)c->pc_arena.bytes), 96.0 * 1024 * 1024 * 1024);
   }
   const ExpmPlan p0 = chunk_plan(c, uh, 0, std::min(tc, S), dt);
-  if (p0.rq == 0 || p0.s > 0 || p0.spx) return;  // (the sparse-generator scheme rebuilds: its products are cheap passes)
-  const double per_step = (p0.rq + 3.0) * c->nn() * sizeof(T);  // X, Y_1..Y_{q-1}, P (real) + U (complex)
+  if (p0.rq == 0 || p0.s > 0) return;
+  // per step: X, Y_1..Y_{q-1}, P (real) + U (complex); sparse-generator scheme: X_1..X_2q + U
+  const double per_step = ((p0.spx ? 2.0 * p0.rq : p0.rq + 1.0) + 2.0) * c->nn() * sizeof(T);
   const double S_plan = (double)std::max<long>(S, c->plan_steps);
   const double share = std::min(1.0, budget / (per_step * S_plan));
+  // the sparse-generator scheme rebuilds with 2q cheap passes: holding tens of GB for a few percent of the steps is not
+  // worth it -- only a chain that is mostly cacheable (a rank's slice of a time-sliced chain) uses the cache
+  if (p0.spx && share < 0.5) return;
   c->pc_limit = (long)(share * S);
   // one allocation (grows only); if the device refuses it, halve the covered steps until it fits
   while (c->pc_limit > 0) {

@@ -294,3 +294,26 @@ def test_sparse_generator_fp32_and_sliced(oracle):
             e.close()
     for l, g, f, en in res:
         assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL
+
+
+def test_sparse_generator_with_the_propagator_cache():
+    """A chain that is mostly cacheable (explicit budget, as a rank's slice of a time-sliced chain has): the forward pass
+    leaves X_1 .. X_2q and U in the cache, the backward pass skips its 2q rebuild passes; same results as without."""
+    n, B, S, dt = 8, 256, 12, 2e-3
+    p = problems.qaoa_ring(n)
+    H0, Hs = p["H0"].astype(complex), p["Hs"].astype(complex)
+    u = np.random.default_rng(0).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    with _engine(H0, Hs, H0, real_min_dim=128, cache_bytes=2e9) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("cached_steps") == S
+        e.set_option("cache_bytes", -1)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("cached_steps") == 0
+        e.set_option("cache_bytes", 0)      # auto: a 12-step chain fits whole
+        e.energy_grad(u, dt, psi0)
+        assert e.info("cached_steps") == S
+        e.set_option("plan_steps", 10 ** 7)  # ... a chain of which only a sliver would fit does not take the cache
+        e.energy_grad(u, dt, psi0)
+        assert e.info("cached_steps") == 0
+    assert l1 == l0 and np.array_equal(g1, g0) and np.array_equal(f1, f0)   # same kernels on the same data

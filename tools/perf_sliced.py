@@ -34,7 +34,7 @@ eng.set_observable(M)
 slice_steps = (2000 + world - 1) // world
 eng.set_option("plan_steps", slice_steps)
 if len(sys.argv) > 6 and sys.argv[6] == "fullcache":  # as bench.py's sliced form: the whole slice of the planned chain cached
-    eng.set_option("cache_bytes", min(6.0 * d * d * 8 * slice_steps + (1 << 20),
+    eng.set_option("cache_bytes", min(8.0 * d * d * 8 * slice_steps + (1 << 20),
                                       0.72 * torch.cuda.get_device_properties(0).total_memory))
 
 
