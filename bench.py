@@ -348,7 +348,7 @@ def main():
             torch.cuda.synchronize(); ts_ = time.perf_counter() - ts_
             schemes[name] = {"steps_per_s": Kg / ts_, "max_abs_grad_diff_vs_headline_scheme": float((gs_ - gr).abs().max().item()),
                              "abs_loss_diff_vs_headline_scheme": abs(ls_ - lr)}
-        eng.set_option("sparse_generator", 1)
+        eng.set_option("sparse_generator", -1)
         eng.set_option("sparse_controls", 1)
         general = {"steps_per_s": Kg / tg, "chain_steps": Kg, "products_per_step": "11 ZGEMMs (3M) of 8 d^3 + 3 (anti-)Hermitian-output ZGEMMs (half the tiles)",
                    "other_real_schemes": schemes,

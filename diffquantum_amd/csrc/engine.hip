@@ -328,7 +328,13 @@ struct Ctx : dq_ctx {
   }
 
   bool sparse_on() const { return sparse_h && sparse_mode != 0; }
-  bool sparse_gen_on() const { return sparse_on() && sparse_x && sparse_gen_mode != 0; }
+  // sparse-generator scheme: forced (1), or auto (-1) where a sparse x dense pass (nnz/row partner rows per output row,
+  // HBM/L2-bound) beats a symmetric-output MFMA product: measured 0.225 vs 1.05 ms at d = 4096 with 13 nonzeros per row,
+  // break-even near d = 80 nnz/row (at d = 256 the MFMA product wins 6x)
+  bool sparse_gen_on() const {
+    if (!(sparse_on() && sparse_x) || sparse_gen_mode == 0) return false;
+    return sparse_gen_mode > 0 || (double)d * d >= 64.0 * (double)sp_nnz;
+  }
   size_t nn() const { return (size_t)d * d; }
   size_t mat_bytes() const { return nn() * sizeof(T2); }
 
@@ -1964,8 +1970,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->rgemm_cfg = q;
   } else if (s == "sparse_controls") {  // real path: -1 auto (use the controls' sparsity when they are sparse), 0 never
     c->sparse_mode = (int)v != 0 ? -1 : 0;
-  } else if (s == "sparse_generator") {  // drift and controls sparse: -1 auto (sparse x dense products for every power), 0 off
-    c->sparse_gen_mode = (int)v != 0 ? -1 : 0;
+  } else if (s == "sparse_generator") {  // drift and controls sparse: -1 auto (dim >= 64 nonzeros-per-row), 0 off, 1 whenever possible
+    c->sparse_gen_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "skew_trick") {
     c->skew_trick = v != 0 ? 1 : 0;
   } else if (s == "zgemm_alg") {

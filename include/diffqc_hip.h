@@ -103,7 +103,8 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      streaming K dense matrices, and the last level of the reverse mode together with the control
  *                      contractions <Xbar, H_k> becomes nnz(H) row dot products instead of two two-product symmetric
  *                      launches (4 d^3 flop); 0 = always the dense passes. dq_get_info("sparse_controls") tells which
- *   sparse_generator   real path: 1 (default) = when the DRIFT is sparse as well (same bound, drift included: e.g. a diagonal
+ *   sparse_generator   real path: -1 (default, auto: dim >= 64 x the nonzeros per row, where a sparse x dense pass beats an MFMA
+ *                      product) / 1 (whenever possible) = when the DRIFT is sparse as well (same bound, drift included: e.g. a diagonal
  *                      Ising drift with local-Pauli controls), X_t itself is sparse and the whole polynomial runs on
  *                      sparse x dense passes: powers X_{m+1} = X X_m, cos/sin as linear combinations of the powers, reverse
  *                      mode Xbar_m = coef (Cbar | Sbar) + X Xbar_{m+1}, gradient = row dot products over nnz(H_k) level by

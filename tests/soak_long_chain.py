@@ -14,7 +14,7 @@ for (n, K, B, S, dt, real) in ((4, 3, 5, 20000, 0.002, False), (4, 3, 5, 20000, 
     u = problems.pulse_table(K, S, S * dt, seed=5)
     psi0 = problems.random_states(1 << n, B, seed=6)
     with Engine(1 << n, K) as e:
-        e.set_hamiltonians(H0, Hs); e.set_observable(M); e.set_option("real_min_dim", 1)
+        e.set_hamiltonians(H0, Hs); e.set_observable(M); e.set_option("real_min_dim", 1); e.set_option("sparse_generator", 1)
         t0 = time.time(); l, g, f, en = e.energy_grad(u, dt, psi0); t1 = time.time()
         info = (e.info("real_path"), e.info("operator_backward"), e.info("time_parallel"), e.info("time_chunk"), e.info("cached_steps"), e.info("sparse_controls"), e.info("sparse_generator"))
     t2 = time.time(); rl, rg, rf = orc.energy_grad(H0, list(Hs), M, u, dt, psi0); t3 = time.time()

@@ -210,7 +210,7 @@ def test_sparse_generator_ising_matches_oracle_and_other_schemes(oracle, n, B, S
     u = np.random.default_rng(S).uniform(-1, 1, (S, n))
     psi0 = problems.random_states(1 << n, B, seed=2)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M) as e:
+    with _engine(H0, Hs, M, sparse_generator=1) as e:   # (auto takes the scheme from dim >= 64 nonzeros-per-row)
         assert e.info("sparse_drift") == 1
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("real_path") >= 1 and e.info("sparse_generator") == 1 and e.info("squarings") == 0
@@ -237,7 +237,7 @@ def test_sparse_generator_every_polynomial_size(oracle, q):
     u = np.random.default_rng(q).uniform(-1, 1, (S, n))
     psi0 = problems.random_states(1 << n, B, seed=q)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M, real_path=q) as e:
+    with _engine(H0, Hs, M, real_path=q, sparse_generator=1) as e:
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("sparse_generator") == 1 and e.info("real_path") == q
         e.set_option("sparse_generator", 0)
@@ -254,7 +254,7 @@ def test_sparse_generator_random_patterns(oracle, d, K, B):
     u = np.random.default_rng(d).uniform(-1, 1, (S, K))
     psi0 = _states(d, B, seed=1)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M) as e:
+    with _engine(H0, Hs, M, sparse_generator=1) as e:
         assert e.info("sparse_drift") == 1 and e.info("control_nonzeros") == int(np.count_nonzero(Hs))
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("sparse_generator") == 1
@@ -267,7 +267,7 @@ def test_sparse_generator_large_step_falls_back_to_squarings(oracle):
     u = np.random.default_rng(1).uniform(-1, 1, (S, n))
     psi0 = problems.random_states(1 << n, B, seed=2)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M) as e:
+    with _engine(H0, Hs, M, sparse_generator=1) as e:
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("squarings") >= 1 and e.info("sparse_generator") == 0 and e.info("sparse_controls") == 1
     assert abs(l1 - rl) < 1e-9 and np.max(np.abs(g1 - rg)) < 1e-9 and np.max(np.abs(f1 - rf)) < 1e-10
@@ -280,11 +280,11 @@ def test_sparse_generator_fp32_and_sliced(oracle):
     u = np.random.default_rng(2).uniform(-1, 1, (S, n))
     psi0 = problems.random_states(1 << n, B, seed=2)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M, dtype="c64") as e:
+    with _engine(H0, Hs, M, dtype="c64", sparse_generator=1) as e:
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
         assert e.info("sparse_generator") == 1
     assert abs(l1 - rl) < 1e-4 * B and np.max(np.abs(g1 - rg)) < 1e-4 and np.max(np.abs(f1 - rf)) < 1e-4
-    engines = [_engine(H0, Hs, M) for _ in range(3)]
+    engines = [_engine(H0, Hs, M, sparse_generator=1) for _ in range(3)]
     try:
         shards = [np.ascontiguousarray(psi0[:, f:f + c]) for f, c in (shard_range(B, r, 3) for r in range(3))]
         res = virtual_time_sliced_energy_grad(engines, u, dt, shards)
@@ -304,7 +304,7 @@ def test_sparse_generator_with_the_propagator_cache():
     H0, Hs = p["H0"].astype(complex), p["Hs"].astype(complex)
     u = np.random.default_rng(0).uniform(-1, 1, (S, len(Hs)))
     psi0 = problems.random_states(1 << n, B, seed=3)
-    with _engine(H0, Hs, H0, real_min_dim=128, cache_bytes=2e9) as e:
+    with _engine(H0, Hs, H0, real_min_dim=128, cache_bytes=2e9, sparse_generator=1) as e:
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("sparse_generator") == 1 and e.info("cached_steps") == S
         e.set_option("cache_bytes", -1)
@@ -317,3 +317,22 @@ def test_sparse_generator_with_the_propagator_cache():
         e.energy_grad(u, dt, psi0)
         assert e.info("cached_steps") == 0
     assert l1 == l0 and np.array_equal(g1, g0) and np.array_equal(f1, f0)   # same kernels on the same data
+
+
+def test_sparse_generator_auto_rule():
+    """auto: the scheme is taken where a sparse x dense pass beats an MFMA product (dim >= 64 nonzeros-per-row)."""
+    n = 8
+    p = problems.qaoa_ring(n)                 # d = 256, 17 nonzeros per row: the MFMA products win
+    H0, Hs = p["H0"].astype(complex), p["Hs"].astype(complex)
+    u = np.random.default_rng(0).uniform(-1, 1, (3, len(Hs)))
+    psi0 = problems.random_states(1 << n, 4, seed=3)
+    with _engine(H0, Hs, H0, real_min_dim=128) as e:
+        assert e.info("sparse_drift") == 1
+        e.energy_grad(u, 2e-3, psi0)
+        assert e.info("sparse_generator") == 0 and e.info("sparse_controls") == 1 and e.info("real_path") >= 1
+    H0, Hs, M = problems.random_ising(10, seed=1)   # d = 1024, 11 nonzeros per row: the sparse passes win
+    u = np.random.default_rng(0).uniform(-1, 1, (2, 10))
+    psi0 = problems.random_states(1024, 4, seed=3)
+    with _engine(H0, Hs, M, real_min_dim=128) as e:
+        e.energy_grad(u, 1e-3, psi0)
+        assert e.info("sparse_generator") == 1
