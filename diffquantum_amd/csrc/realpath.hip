@@ -634,6 +634,7 @@ __global__ void __launch_bounds__(RSPL_MAX * 64) rsp_levels_kernel(RspLevels<T> 
       }
       __syncthreads();
     }
+    __syncthreads();  // (rows with more than 64 entries: s_nv / s_col are rewritten by wave 0 in the next round)
   }
 }
 

@@ -336,3 +336,26 @@ def test_sparse_generator_auto_rule():
     with _engine(H0, Hs, M, real_min_dim=128) as e:
         e.energy_grad(u, 1e-3, psi0)
         assert e.info("sparse_generator") == 1
+
+
+def test_sparse_generator_row_with_more_than_64_entries(oracle):
+    """One row/column of a control with ~100 nonzeros (d = 128, still within the sparsity bound overall): the kernels'
+    64-entry staging rounds (sparse x dense passes and the level contraction) are taken more than once for that row."""
+    d, K, B, S, dt = 128, 2, 5, 3, 0.002
+    rng = np.random.default_rng(11)
+    H0 = np.diag(rng.standard_normal(d)).astype(complex)
+    Hs = np.zeros((K, d, d), dtype=complex)
+    v = rng.standard_normal(d) * (rng.random(d) < 0.8)
+    Hs[0, 3, :] += v
+    Hs[0, :, 3] += v
+    for i in range(0, d - 1, 2):
+        Hs[1, i, i + 1] = Hs[1, i + 1, i] = rng.standard_normal()
+    M = np.diag(rng.standard_normal(d)).astype(complex)
+    u = rng.uniform(-1, 1, (S, K))
+    psi0 = _states(d, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, sparse_generator=1) as e:
+        assert e.info("sparse_drift") == 1 and np.count_nonzero(Hs[0, 3]) + 1 > 64
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1
+    assert abs(l1 - rl) < TOL and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
