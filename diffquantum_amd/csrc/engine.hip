@@ -1758,6 +1758,8 @@ void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
   check_ctx(c);
   if (!H0 || (c->K > 0 && !Hs)) fail(DQ_ERR_INVALID, "null Hamiltonian pointer");
   c->have_H = false;
+  c->slice_valid = false;  // whatever a slice forward call cached belongs to the old Hamiltonians
+  for (auto& e : c->pcache) e.valid = false;
   c->H0.ensure(c->mat_bytes());
   c->Hs.ensure(std::max<size_t>(c->K, 1) * c->mat_bytes());
   HIPCK(hipMemcpyAsync(c->H0.p, H0, c->mat_bytes(), hipMemcpyDefault, c->st));

@@ -273,3 +273,23 @@ def test_headline_dimension_eight_virtual_ranks_narrow_batch():
         assert abs(l - l0) < 1e-10 * world * Bq, (r, l, l0)
         assert np.max(np.abs(g - g0)) < 1e-10, r
         assert float((f - f0[:, r * Bq:(r + 1) * Bq]).abs().max()) < 1e-12, r
+
+
+def test_new_hamiltonians_between_slice_calls_invalidate_the_cache():
+    """dq_set_hamiltonians between dq_slice_forward and dq_slice_backward: the cached intermediates of the old H are dropped."""
+    n, K, dt, B, S = 7, 3, 2e-3, 128, 5
+    H0, Hs, M = problems.random_real_symmetric_problem(n, K, seed=4)
+    H0b, Hsb, _ = problems.random_real_symmetric_problem(n, K, seed=5)
+    psi0 = problems.random_states(1 << n, B, seed=1)
+    u = np.random.default_rng(3).uniform(-1, 1, (S, K))
+    with _engine(H0b, Hsb, M) as e:
+        l0, g0, _, _ = e.energy_grad(u, dt, psi0)
+        e.set_hamiltonians(H0, Hs)
+        e.slice_forward(u, dt)                 # caches the intermediates of (H0, Hs)
+        e.set_hamiltonians(H0b, Hsb)
+        P = e.slice_forward(u, dt)
+        loss, W, _, _ = e.slice_terminal(P, psi0)
+        e.set_hamiltonians(H0, Hs)             # ... and back and forth once more before the backward call
+        e.set_hamiltonians(H0b, Hsb)
+        g1 = e.slice_backward(u, dt, W)
+    assert abs(loss - l0) < TOL * B and np.max(np.abs(g1 - g0)) < TOL
