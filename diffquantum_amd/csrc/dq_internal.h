@@ -207,6 +207,17 @@ template <class T>
 hipError_t rsp_levels_launch(const T* const* G, const T* const* Xp, int nl, const T* D, const T* G2, double dc, long stride,
                              int d, const long* rowptr, const int* col, const int* kid, const double* val, const double* u,
                              int K, int batch, double dt, long nnz, double* nzval, hipStream_t st);
+// rsp_mm_launch with the gradient level fused in: nzacc[z][e] (+)= <V[z][col_e,:], Xm[z][i,:]> for every entry e of row i
+// (out may be null: dot products only)
+template <class T>
+hipError_t rsp_mm_dot_launch(T* out, const T* V, const T* Add, double ca, const T* Xm, long stride, int d, const long* rowptr,
+                             const int* col, const int* kid, const double* val, const double* u, int K, int batch, double dt,
+                             long nnz, double* nzacc, int accumulate, hipStream_t st);
+// nzval[z][e] = val_e (nzacc[z][e] + dc D[z][j][i] + sum_{p in row j} w_p G2[z][col_p][i]) for control entries (i, j), else 0
+template <class T>
+hipError_t rsp_finish_launch(const double* nzacc, const T* D, const T* G2, double dc, long stride, int d, const long* rowptr,
+                             const int* col, const int* kid, const double* val, const double* u, int K, int batch, double dt,
+                             long nnz, double* nzval, hipStream_t st);
 hipError_t rsp_reduce_launch(const double* nzval, long nnz, const long* kptr, const long* kent, int K, int batch, double scale,
                              double* grad, hipStream_t st);
 

@@ -288,7 +288,8 @@ struct Ctx : dq_ctx {
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
   // sparse control Hamiltonians (real path; realpath.hip): the nonzeros of all H_k in one CSR by row, and the same
   // entries grouped by control; sparse_mode: -1 auto (total nonzeros <= sparse_fill * dim), 0 off
-  DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval;
+  DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval, sp_nzacc;
+  int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
   bool sparse_h = false;   // a CSR exists (controls, and the drift too if sparse_x)
   bool sparse_x = false;   // the drift H0 is in the CSR as well (entries with kid = -1): X_t itself is sparse
@@ -803,30 +804,61 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
     Xb[np] = top;
   }
   const double dts = dt;  // spx plans have no squarings
-  const double bym = (double)sizeof(T) * c->nn() * 3.0 * n;  // algorithmic: Xbar_{m+1} and Cbar|Sbar read, Xbar_m written
-  for (int m = np - 1; m >= 2; --m) {
-    T* dst = c->rmat(SLOT_ADJ + spx_slot(m), n);
-    const T* add = (m & 1) ? Sb : Cb;
-    const double ca = coef(m);
-    const T* src = Xb[m + 1];
-    c->timed(DQ_PROF_SPMM, 2.0 * c->sp_nnz * c->d * n, bym, [&] {
-      return dq::rsp_mm_launch<T>(dst, src, add, ca, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
-                                  (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
-                                  c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->st);
+  // Each reverse pass Xbar_m = coef_m (Cbar|Sbar) + X Xbar_{m+1} streams the partner rows of Xbar_{m+1}; the gradient's level
+  // <Xbar_{m+1}[j,:], X_m[i,:]> over X's pattern rides along (rsp_mm_dot_kernel). One more dot-only pass pairs Xbar_2 with
+  // X_1, and rsp_finish_kernel adds Xbar_1 = sc_0 Sbar + X Xbar_2 at the controls' nonzeros. (fuse_levels = 0: the
+  // separate level-contraction kernel, kept for comparison.)
+  const size_t nz = (size_t)std::max<long>(c->sp_nnz, 1);
+  c->sp_nzval.ensure(sizeof(double) * nz * n);
+  const double bym = (double)sizeof(T) * c->nn() * 4.0 * n;  // algorithmic: Xbar_{m+1}, Cbar|Sbar, X_m read, Xbar_m written
+  if (c->fuse_levels) {
+    c->sp_nzacc.ensure(sizeof(double) * nz * n);
+    double* nzacc = (double*)c->sp_nzacc.p;
+    bool started = false;
+    for (int m = np - 1; m >= 1; --m) {
+      T* dst = m >= 2 ? c->rmat(SLOT_ADJ + spx_slot(m), n) : nullptr;  // level 1: dot products only
+      const T* add = (m & 1) ? Sb : Cb;
+      const double ca = coef(m);
+      const T* src = Xb[m + 1];
+      const T* xm = Xp[m];
+      const int accf = started ? 1 : 0;
+      c->timed(DQ_PROF_SPMM, 4.0 * c->sp_nnz * c->d * n, m >= 2 ? bym : 0.5 * bym, [&] {
+        return dq::rsp_mm_dot_launch<T>(dst, src, add, ca, xm, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
+                                        (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
+                                        c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->sp_nnz, nzacc, accf, c->st);
+      });
+      started = true;
+      if (m >= 2) Xb[m] = dst;
+    }
+    c->timed(DQ_PROF_GRADC, 2.0 * c->sp_nnz * n, 16.0 * c->sp_nnz * n, [&] {
+      return dq::rsp_finish_launch<T>(nzacc, Sb, Xb[2], coef(1), (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
+                                      (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
+                                      c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->sp_nnz, (double*)c->sp_nzval.p, c->st);
     });
-    Xb[m] = dst;
-  }
-  // levels m = 1 .. 2q pair Xbar_{m+1} with X_m; the direct term is Xbar_1 = sc_0 Sbar + X Xbar_2 at the controls' nonzeros
-  const T* Gl[2 * RQ_MAX + 2];
-  const T* Xl[2 * RQ_MAX + 2];
-  for (int m = 1; m < np; ++m) { Gl[m - 1] = Xb[m + 1]; Xl[m - 1] = Xp[m]; }
-  c->sp_nzval.ensure(sizeof(double) * (size_t)std::max<long>(c->sp_nnz, 1) * n);
-  const double byl = (double)sizeof(T) * c->d * (np - 1) * ((double)c->d + 0.5 * c->sp_nnz) * n;
-  c->timed(DQ_PROF_GRADC, 2.0 * (np - 1) * 0.5 * c->sp_nnz * c->d * n, byl, [&] {
-    return dq::rsp_levels_launch<T>(Gl, Xl, np - 1, Sb, Xb[2], coef(1), (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
+  } else {
+    for (int m = np - 1; m >= 2; --m) {
+      T* dst = c->rmat(SLOT_ADJ + spx_slot(m), n);
+      const T* add = (m & 1) ? Sb : Cb;
+      const double ca = coef(m);
+      const T* src = Xb[m + 1];
+      c->timed(DQ_PROF_SPMM, 2.0 * c->sp_nnz * c->d * n, 0.75 * bym, [&] {
+        return dq::rsp_mm_launch<T>(dst, src, add, ca, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
                                     (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
-                                    c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->sp_nnz, (double*)c->sp_nzval.p, c->st);
-  });
+                                    c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->st);
+      });
+      Xb[m] = dst;
+    }
+    // levels m = 1 .. 2q pair Xbar_{m+1} with X_m; the direct term is Xbar_1 = sc_0 Sbar + X Xbar_2 at the controls' nonzeros
+    const T* Gl[2 * RQ_MAX + 2];
+    const T* Xl[2 * RQ_MAX + 2];
+    for (int m = 1; m < np; ++m) { Gl[m - 1] = Xb[m + 1]; Xl[m - 1] = Xp[m]; }
+    const double byl = (double)sizeof(T) * c->d * (np - 1) * ((double)c->d + 0.5 * c->sp_nnz) * n;
+    c->timed(DQ_PROF_GRADC, 2.0 * (np - 1) * 0.5 * c->sp_nnz * c->d * n, byl, [&] {
+      return dq::rsp_levels_launch<T>(Gl, Xl, np - 1, Sb, Xb[2], coef(1), (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
+                                      (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
+                                      c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->sp_nnz, (double*)c->sp_nzval.p, c->st);
+    });
+  }
   c->timed(DQ_PROF_GRADC, (double)c->sp_nnz * n, 8.0 * c->sp_nnz * n, [&] {
     return dq::rsp_reduce_launch((const double*)c->sp_nzval.p, c->sp_nnz, (const long*)c->sp_kptr.p, (const long*)c->sp_kent.p,
                                  K, n, -dt, grad_out, c->st);
@@ -1972,6 +2004,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->rgemm_cfg = q;
   } else if (s == "sparse_controls") {  // real path: -1 auto (use the controls' sparsity when they are sparse), 0 never
     c->sparse_mode = (int)v != 0 ? -1 : 0;
+  } else if (s == "fuse_levels") {  // sparse generator: gradient levels inside the reverse passes (1) or a separate kernel (0)
+    c->fuse_levels = v != 0 ? 1 : 0;
   } else if (s == "sparse_generator") {  // drift and controls sparse: -1 auto (dim >= 64 nonzeros-per-row), 0 off, 1 whenever possible
     c->sparse_gen_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "skew_trick") {

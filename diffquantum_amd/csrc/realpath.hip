@@ -511,6 +511,158 @@ template hipError_t rsp_mm_launch<double>(double*, const double*, const double*,
 template hipError_t rsp_mm_launch<float>(float*, const float*, const float*, double, long, int, const long*, const int*,
                                          const int*, const double*, const double*, int, int, double, hipStream_t);
 
+// The reverse-mode pass with the gradient level fused in:  out = ca Add + X V  as rsp_mm_kernel, and, while the partner rows
+// V[j_e,:] of row i's nonzeros stream through the registers anyway,
+//     nzacc[z][e] (+)= < V[z][j_e,:] , Xm[z][i,:] >          (the (j_e, i) entry of V Xm^T; V = Xbar_{m+1}, Xm = X_m)
+// -- the level sum of the generator's cotangent at X's own pattern, for the price of one more row read per output row
+// instead of a separate pass over 2 (2q) matrices. out may be null (dot products only: the level that has no product).
+// Rounds of RSPD_NZ entries (their accumulators live in registers); rows with more entries take several rounds over `out`.
+constexpr int RSPD_NZ = 16, RSPD_U = 8, RSPD_WAVES = 4;
+
+template <class T>
+__global__ void __launch_bounds__(RSPD_WAVES * 64) rsp_mm_dot_kernel(T* __restrict__ out, const T* __restrict__ V,
+                                                                     const T* __restrict__ Add, double ca,
+                                                                     const T* __restrict__ Xm, long stride, int d,
+                                                                     const long* __restrict__ rowptr,
+                                                                     const int* __restrict__ col, const int* __restrict__ kid,
+                                                                     const double* __restrict__ val,
+                                                                     const double* __restrict__ u, int K, double mdt, long nnz,
+                                                                     double* __restrict__ nzacc, int accumulate) {
+  __shared__ int s_col[RSPD_WAVES][RSPD_NZ];
+  __shared__ double s_w[RSPD_WAVES][RSPD_NZ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * RSPD_WAVES + wave;
+  if (i >= d) return;
+  const long z = blockIdx.z;
+  const T* Vz = V + z * stride;
+  const double* uz = u + z * K;
+  const long e0 = rowptr[i], e1 = rowptr[i + 1];
+  T* orow = out ? out + z * stride + (long)i * d : nullptr;
+  const T* xrow = Xm + z * stride + (long)i * d;
+  long eb = e0;
+  do {
+    const int cnt = (int)max(0L, min((long)RSPD_NZ, e1 - eb));
+    if (lane < cnt) {
+      const int k = kid[eb + lane];
+      s_col[wave][lane] = col[eb + lane];
+      s_w[wave][lane] = mdt * (k < 0 ? 1.0 : uz[k]) * val[eb + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool first = eb == e0;
+    double dacc[RSPD_NZ];
+#pragma unroll
+    for (int q = 0; q < RSPD_NZ; ++q) dacc[q] = 0.0;
+    for (int m0 = 0; m0 < d; m0 += 64 * RSPD_U) {
+      T acc[RSPD_U], xm[RSPD_U];
+#pragma unroll
+      for (int r = 0; r < RSPD_U; ++r) {
+        const int m = m0 + r * 64 + lane;
+        xm[r] = m < d ? xrow[m] : (T)0;
+        if (!orow) acc[r] = 0;
+        else if (!first) acc[r] = m < d ? orow[m] : (T)0;
+        else acc[r] = (Add != nullptr && m < d) ? (T)ca * Add[z * stride + (long)i * d + m] : (T)0;
+      }
+#pragma unroll
+      for (int q = 0; q < RSPD_NZ; ++q) {
+        if (q < cnt) {  // wave-uniform
+          const int jc = __builtin_amdgcn_readfirstlane(s_col[wave][q]);
+          const T w = (T)s_w[wave][q];
+          const T* vrow = Vz + (long)jc * d;
+          T t = 0;
+#pragma unroll
+          for (int r = 0; r < RSPD_U; ++r) {
+            const int m = m0 + r * 64 + lane;
+            const T v = m < d ? vrow[m] : (T)0;
+            acc[r] += w * v;
+            t += xm[r] * v;
+          }
+          dacc[q] += (double)t;
+        }
+      }
+      if (orow) {
+#pragma unroll
+        for (int r = 0; r < RSPD_U; ++r) {
+          const int m = m0 + r * 64 + lane;
+          if (m < d) orow[m] = acc[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RSPD_NZ; ++q) {
+      if (q < cnt) {
+        double v = dacc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) {
+          if (accumulate) nzacc[z * nnz + eb + q] += v;
+          else nzacc[z * nnz + eb + q] = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    eb += RSPD_NZ;
+  } while (eb < e1);
+}
+
+template <class T>
+hipError_t rsp_mm_dot_launch(T* out, const T* V, const T* Add, double ca, const T* Xm, long stride, int d, const long* rowptr,
+                             const int* col, const int* kid, const double* val, const double* u, int K, int batch, double dt,
+                             long nnz, double* nzacc, int accumulate, hipStream_t st) {
+  if (d <= 0 || batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rsp_mm_dot_kernel<T>, dim3((unsigned)((d + RSPD_WAVES - 1) / RSPD_WAVES), 1, (unsigned)batch),
+                     dim3(RSPD_WAVES * 64), 0, st, out, V, Add, ca, Xm, stride, d, rowptr, col, kid, val, u, K, -dt, nnz, nzacc,
+                     accumulate);
+  return hipGetLastError();
+}
+template hipError_t rsp_mm_dot_launch<double>(double*, const double*, const double*, double, const double*, long, int,
+                                              const long*, const int*, const int*, const double*, const double*, int, int,
+                                              double, long, double*, int, hipStream_t);
+template hipError_t rsp_mm_dot_launch<float>(float*, const float*, const float*, double, const float*, long, int, const long*,
+                                             const int*, const int*, const double*, const double*, int, int, double, long,
+                                             double*, int, hipStream_t);
+
+// nzval[z][e] = val_e (nzacc[z][e] + dc D[z][j][i] + sum_{p in row j} w_p G2[z][col_p][i])  for the control entries e = (i, j)
+// (0 for drift entries): the level sums of rsp_mm_dot_kernel, which sit at the TRANSPOSED position (j, i) of the generator's
+// cotangent, completed by Xbar_1 = dc Sbar + X Xbar_2 at that same position -- the total is symmetric, its pieces are not.
+template <class T>
+__global__ void __launch_bounds__(256) rsp_finish_kernel(const double* __restrict__ nzacc, const T* __restrict__ D,
+                                                         const T* __restrict__ G2, double dc, long stride, int d,
+                                                         const long* __restrict__ rowptr, const int* __restrict__ col,
+                                                         const int* __restrict__ kid, const double* __restrict__ val,
+                                                         const double* __restrict__ u, int K, double mdt, long nnz,
+                                                         double* __restrict__ nzval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  const long z = blockIdx.z;
+  const long zo = z * stride;
+  const double* uz = u + z * K;
+  for (long e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    if (kid[e] < 0) { nzval[z * nnz + e] = 0.0; continue; }
+    const int j = col[e];
+    double v = nzacc[z * nnz + e] + dc * (double)D[zo + (long)j * d + i];
+    for (long p = rowptr[j]; p < rowptr[j + 1]; ++p) {
+      const int k = kid[p];
+      v += mdt * (k < 0 ? 1.0 : uz[k]) * val[p] * (double)G2[zo + (long)col[p] * d + i];
+    }
+    nzval[z * nnz + e] = v * val[e];
+  }
+}
+
+template <class T>
+hipError_t rsp_finish_launch(const double* nzacc, const T* D, const T* G2, double dc, long stride, int d, const long* rowptr,
+                             const int* col, const int* kid, const double* val, const double* u, int K, int batch, double dt,
+                             long nnz, double* nzval, hipStream_t st) {
+  if (d <= 0 || batch <= 0 || nnz <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rsp_finish_kernel<T>, dim3((unsigned)((d + 255) / 256), 1, (unsigned)batch), dim3(256), 0, st, nzacc, D, G2,
+                     dc, stride, d, rowptr, col, kid, val, u, K, -dt, nnz, nzval);
+  return hipGetLastError();
+}
+template hipError_t rsp_finish_launch<double>(const double*, const double*, const double*, double, long, int, const long*,
+                                              const int*, const int*, const double*, const double*, int, int, double, long,
+                                              double*, hipStream_t);
+template hipError_t rsp_finish_launch<float>(const double*, const float*, const float*, double, long, int, const long*,
+                                             const int*, const int*, const double*, const double*, int, int, double, long, double*,
+                                             hipStream_t);
+
 // nzval[z][e] (+)= val_e * ( direct_e + sum_{l < nl} <G_l[z][i,:], Xp_l[z][j,:]> )   for the CONTROL entries e = (i, j)
 // with j >= i (doubled for j > i: the total cotangent Xi is symmetric and so are the H_k; drift entries, kid < 0, and the
 // entries below the diagonal get 0), with  direct_e = dc D[z][i][j] + sum_{e' in row i} w_e' G2[z][col_e'][j]  when D is
