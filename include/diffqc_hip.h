@@ -110,6 +110,8 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      mode Xbar_m = coef (Cbar | Sbar) + X Xbar_{m+1}, gradient = row dot products over nnz(H_k) level by
  *                      level -- no real MFMA product left in the step exponential (steps that need squarings keep the
  *                      dense scheme); 0 = off. dq_get_info("sparse_generator") / ("sparse_drift") tell what is in use
+ *   fuse_levels        sparse generator: 1 (default) = the gradient's level dot products are taken inside the reverse passes
+ *                      (the partner rows stream through the registers anyway), 0 = a separate contraction kernel (tests)
  *   cache_bytes        real path: HBM for the propagator intermediates (X, Y_j, P, U) that the forward pass leaves in place
  *                      for the backward sweep, which then skips its q + 1 rebuild products for those steps; < 0 off,
  *                      0 = 80 % of the free HBM (operator form) / 50 % (after the state form's checkpoints), at most 96 GiB

@@ -359,3 +359,19 @@ def test_sparse_generator_row_with_more_than_64_entries(oracle):
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("sparse_generator") == 1
     assert abs(l1 - rl) < TOL and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+
+
+@pytest.mark.parametrize("q", [2, 3, 5])
+def test_sparse_generator_fused_levels_equal_separate_contraction(q):
+    """The gradient's level dot products inside the reverse passes (default) against the separate level-contraction kernel."""
+    d, K, B, S = 64, 3, 16, 4
+    dt = {2: 2e-4, 3: 1e-3, 5: 0.01}[q]
+    H0, Hs, M = _sparse_drift_problem(d, K, seed=q)
+    u = np.random.default_rng(q).uniform(-1, 1, (S, K))
+    psi0 = _states(d, B, seed=4)
+    with _engine(H0, Hs, M, sparse_generator=1, real_path=q) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1
+        e.set_option("fuse_levels", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+    assert l1 == l0 and np.array_equal(f1, f0) and np.max(np.abs(g1 - g0)) < 1e-13 * max(1.0, np.abs(g0).max())
