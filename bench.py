@@ -43,7 +43,8 @@ TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 2.51e9}  # real GEMM: full-output (pro
                                                    # symmetric-output launches (average over the one- and two-product forms of
                                                    # the headline step: 8 + 4 per step) + fix-up pass, LDS-DMA staged
                                                    # (profiles/r1_bench_s3_sparse_summary.txt: 2445 + 64 MB)
-TRAFFIC_SPMM = 8.64e8  # fabric-side bytes per rsp_mm_kernel launch (profiles/r1_bench_s3_spx_summary.txt: 730 MB read + 134 MB
+TRAFFIC_SPMM = 8.96e8  # fabric-side bytes per sparse x dense launch (profiles/r1_bench_s3_spx_summary.txt: rsp_mm 831 MB, rsp_mm_dot
+                       # 1027 MB, 2 : 1 in the step; 700-900 MB read + 134 MB
                        # written for 134 MB in, 134 MB out: a partner row per nonzero of X, most of them L2 hits)
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
