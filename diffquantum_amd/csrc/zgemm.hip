@@ -27,7 +27,8 @@
 // it selects the AGPR form and brackets every MFMA with v_accvgpr copies: measured 138 vs 64 cycles per
 // f64 MFMA, tools/mfma_f64_probe.hip). K is streamed in BK-deep slabs through double-buffered LDS images
 // stored k-major ([k][m] and [k][n], pitch +1 element) so that fragment reads are 16 consecutive elements;
-// the next slab's global loads are in flight while the MFMAs run. Workgroup ids are remapped so that the 32
+// the next slab's global loads are in flight while the MFMAs run (the big fp64 3M tile keeps four slab images and takes one
+// barrier per two slabs: DEEP). Workgroup ids are remapped so that the 32
 // workgroups resident on one XCD cover a 4 x 8 block of tiles and share their A/B panels through that
 // XCD's L2.
 #include <hip/hip_runtime.h>
@@ -76,7 +77,7 @@ struct Mfma<float> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int ALG3M, int HERM = 0>
+template <class T, int BM, int BN, int BK, int WGM, int WGN, int OPA, int OPB, int ALG3M, int HERM = 0, int DEEP = 0>
 __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g) {
   typedef typename Cx<T>::type T2;
   typedef typename Mfma<T>::acc_t acc_t;
@@ -90,9 +91,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
   static_assert((BM * BK) % NT == 0 && (BN * BK) % NT == 0, "tile/threads mismatch");
   static_assert(ALG3M || sizeof(T) == 8, "fp32 uses the 3M form (no MFMA neg bits)");
 
-  __shared__ T2 lds[2 * BK * (PA + PB)];
-  T2* As = lds;                 // [2][BK][PA]
-  T2* Bs = lds + 2 * BK * PA;   // [2][BK][PB]
+  // DEEP: four slab images instead of two and ONE barrier per two slabs (the registers only allow one workgroup per CU at
+  // this tile, so the LDS is free: 132 KB); the register staging stays one slab deep
+  static_assert(!DEEP || !HERM, "the two-slabs-per-barrier loop is for full-output tiles (no K-split pieces)");
+  constexpr int NBUF = DEEP ? 4 : 2;
+  __shared__ T2 lds[NBUF * BK * (PA + PB)];
+  T2* As = lds;                    // [NBUF][BK][PA]
+  T2* Bs = lds + NBUF * BK * PA;   // [NBUF][BK][PB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -243,15 +248,35 @@ __global__ void __launch_bounds__(WGM* WGN * 64, 2) zgemm_kernel(ZgemmArgs<T> g)
     }                                                                                                        \
   }
 
-  DQ_LOAD_SLAB(kt0 * BK);
-  DQ_STORE_SLAB(0);
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    // the tail slab (k >= K) loads zeros through the bounds check, so no branch is needed here
-    if (!(DQ_ZGEMM_ABLATE & 2)) DQ_LOAD_SLAB((kt + 1) * BK);
-    DQ_COMPUTE_SLAB((kt - kt0) & 1);
-    if (!(DQ_ZGEMM_ABLATE & 2)) DQ_STORE_SLAB((kt - kt0 + 1) & 1);
-    if (!(DQ_ZGEMM_ABLATE & 1)) __syncthreads();
+  if (DEEP) {
+    // slabs in pairs: images (2p, 2p + 1) hold the pair being computed, the other two receive the next pair; slabs beyond K
+    // load zeros through the bounds check (an odd slab count computes one zero slab)
+    DQ_LOAD_SLAB(kt0 * BK);
+    DQ_STORE_SLAB(0);
+    DQ_LOAD_SLAB((kt0 + 1) * BK);
+    DQ_STORE_SLAB(1);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      const int cur = ((kt - kt0) >> 1) & 1;
+      DQ_LOAD_SLAB((kt + 2) * BK);
+      DQ_COMPUTE_SLAB(cur * 2);
+      DQ_STORE_SLAB((cur ^ 1) * 2);
+      DQ_LOAD_SLAB((kt + 3) * BK);
+      DQ_COMPUTE_SLAB(cur * 2 + 1);
+      DQ_STORE_SLAB((cur ^ 1) * 2 + 1);
+      __syncthreads();
+    }
+  } else {
+    DQ_LOAD_SLAB(kt0 * BK);
+    DQ_STORE_SLAB(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      // the tail slab (k >= K) loads zeros through the bounds check, so no branch is needed here
+      if (!(DQ_ZGEMM_ABLATE & 2)) DQ_LOAD_SLAB((kt + 1) * BK);
+      DQ_COMPUTE_SLAB((kt - kt0) & 1);
+      if (!(DQ_ZGEMM_ABLATE & 2)) DQ_STORE_SLAB((kt - kt0 + 1) & 1);
+      if (!(DQ_ZGEMM_ABLATE & 1)) __syncthreads();
+    }
   }
 #undef DQ_LOAD_SLAB
 #undef DQ_STORE_SLAB
@@ -397,11 +422,13 @@ static void launch_cfg(ZgemmArgs<T> g, hipStream_t st, int n_cu) {
     return;
   }
   dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)g.batch);
+  // two slabs per barrier on the big fp64 3M tile (its 256 VGPRs leave one workgroup per CU, so 132 KB of LDS are free)
+  constexpr int DEEP = (sizeof(T) == 8 && BM == 128 && BN == 128 && ALG3M) ? 1 : 0;
   switch (op) {
-    case 0: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 0, ALG3M>), grid, block, 0, st, g); break;
-    case 1: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 1, ALG3M>), grid, block, 0, st, g); break;
-    case 2: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, ALG3M>), grid, block, 0, st, g); break;
-    default: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 1, ALG3M>), grid, block, 0, st, g); break;
+    case 0: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 0, ALG3M, 0, DEEP>), grid, block, 0, st, g); break;
+    case 1: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 0, 1, ALG3M, 0, DEEP>), grid, block, 0, st, g); break;
+    case 2: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 0, ALG3M, 0, DEEP>), grid, block, 0, st, g); break;
+    default: hipLaunchKernelGGL((zgemm_kernel<T, BM, BN, BK, WGM, WGN, 1, 1, ALG3M, 0, DEEP>), grid, block, 0, st, g); break;
   }
 }
 
