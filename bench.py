@@ -37,8 +37,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_BYTES_PER_LAUNCH = 3.49e9  # HBM-side bytes per full-output ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_s3_sparse_summary.txt):
-                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.22 GB + 0.27 GB, d = B = 4096
+TRAFFIC_BYTES_PER_LAUNCH = 3.51e9  # HBM-side bytes per full-output ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_s3_final_summary.txt):
+                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.23 GB + 0.28 GB, d = B = 4096
 TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 2.51e9}  # real GEMM: full-output (profiles/r1_bench_v5_realpath_summary.txt);
                                                    # symmetric-output launches (average over the one- and two-product forms of
                                                    # the headline step: 8 + 4 per step) + fix-up pass, LDS-DMA staged
