@@ -2,11 +2,13 @@
 
 Run in the build container only (needs /root/reference, which does not exist on the GPU box):
 
-    python tests/golden/make_goldens.py
+    python tests/golden/make_goldens.py            # regenerate and write the .npz
+    python tests/golden/make_goldens.py --check    # regenerate, compare with the committed .npz, write nothing
 
 The reference's sim_plain.py / demo_maxcut.py are imported / executed unmodified from
-/root/reference with (i) tests/golden/qutip_stub on sys.path (qutip is not installed; the stub
-re-exports this project's numpy Qobj) and (ii) a subclass that only redirects the log directory
+/root/reference with (i) tests/golden/qutip_stub on sys.path (qutip is not installed; the stub is a
+self-contained numpy Qobj that imports nothing from diffquantum_amd, so the goldens are independent of the
+product's own Qobj) and (ii) a subclass that only redirects the log directory
 (the reference tree is read-only) and optionally shortens n_epoch.  Only inputs and outputs
 (arrays) are stored -- no reference source.
 
@@ -219,6 +221,21 @@ out.update(g7_H0=H0_7, g7_Hs=Hs_7, g7_coeff=coeff7, g7_T=1.3, g7_T0=0.2, g7_omeg
            g7_per_step=np.array(7), g7_psi0=psi7, g7_final=fin7)
 
 path = os.path.join(HERE, "reference_goldens.npz")
+if "--check" in sys.argv[1:]:
+    old = np.load(path)
+    assert sorted(old.files) == sorted(out), (sorted(set(old.files) ^ set(out)))
+    worst, same = 0.0, 0
+    for k in sorted(out):
+        a, b = np.asarray(out[k]), old[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if np.array_equal(a, b):
+            same += 1
+        else:
+            dlt = float(np.max(np.abs(a - b)))
+            worst = max(worst, dlt)
+            print("  differs: {:24s} max |new - committed| = {:.3e}".format(k, dlt))
+    print("check: {} of {} arrays bit-identical to the committed fixture, worst difference {:.3e}".format(same, len(out), worst))
+    sys.exit(0 if worst < 1e-12 else 1)
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
 print("G3 energy", float(out["g3_energy"]), "G5 losses", out["g5_losses_energy"], "cut", bin(int(out["g5_cut"])),

@@ -286,3 +286,21 @@ def test_one_frechet_adjoint_equals_per_control_oracle(oracle):
         l0, g0, f0 = oracle.energy_grad(H0, list(Hs), M, u, 0.1, psi0)
         l1, g1, f1 = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, 0.1, psi0)
         assert abs(l0 - l1) < 1e-12 and np.max(np.abs(g0 - g1)) < 1e-12 and np.max(np.abs(f0 - f1)) < 1e-13
+
+
+def test_golden_qutip_stub_is_independent_of_the_product(golden_dir):
+    """The goldens were captured by running the reference against tests/golden/qutip_stub: that stub must not route
+    through the product's own Qobj (a bug there would be baked into G3-G6 and then matched by the product)."""
+    import subprocess
+    import sys
+    stub = os.path.join(golden_dir, "qutip_stub")
+    code = ("import sys; sys.path.insert(0, {!r}); import qutip, numpy as np\n"
+            "assert not [m for m in sys.modules if m.split('.')[0] in ('diffquantum_amd', 'oracle')]\n"
+            "k = qutip.Qobj([1, 1j]) / np.sqrt(2.0); Z = qutip.Qobj([[1, 0], [0, -1]]); X = qutip.Qobj([[0, 1], [1, 0]])\n"
+            "assert k.shape == (2, 1) and abs(k.norm() - 1) < 1e-15 and abs(Z.matrix_element(k, k)) < 1e-15\n"
+            "Y = qutip.Qobj([[0, -1j], [1j, 0]]); assert abs(Y.matrix_element(k, k) - 1) < 1e-15\n"
+            "assert np.allclose(((qutip.qeye(2) + 0.5j * X) * k).full()[:, 0], (np.array([1, 1j]) + 0.5j * np.array([1j, 1])) / np.sqrt(2))\n"
+            "w, v = Z.eigenstates(); assert list(w) == [-1.0, 1.0] and abs(abs(v[0].full()[1, 0]) - 1) < 1e-15\n"
+            "assert abs((k.dag() * v[0]).norm() ** 2 - 0.5) < 1e-15 and X.eigenenergies()[0] == -1.0\n").format(stub)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
