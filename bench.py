@@ -1,34 +1,44 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Trotter steps/s (forward + adjoint gradient), n = 12 qubits, batch = 4096 per GPU.
+"""Benchmark of the propagator hot path on MI355X.  Default = the headline: Trotter steps/s (forward + adjoint gradient),
+n = 12 qubits, batch = 4096 per GPU (BASELINE.json configs[2]; configs[3] = the same per-GPU load on 8 GPUs).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1: starts N child ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               # ... or is started as one rank of N by a launcher
 
-A "step" is ONE Trotter step of the fwd+adjoint pass over one GPU's whole batch (BASELINE.json configs[2]:
-12-qubit random Ising H stored dense (d = 4096), K = 12 controls X_k, B = 4096 states, fp64 complex).  The timed
-region is one `dq_energy_grad` call over a chain of K steps -- K forward steps (assembly, exp, U.Psi), then the K-step
-adjoint sweep (rebuild U_t, Psi_t, costate, G_t, reverse-mode exp, control-gradient contractions) -- plus, for N > 1,
-the single RCCL all-reduce of (loss, dL/du).  K steps of the 2000-step configuration are timed. At this shape
-(batch >= dim) the backward sweep runs in operator form and keeps no state checkpoints, so the per-step cost does not depend
-on the chain length; for narrower batches `plan_steps` gives the slice the checkpoint stride of the FULL chain, so that it
-pays the same share of psi_t rebuilds per step as the whole run (the full 2000-step run itself is in DESIGN.md).  Inputs (H0, H_k, M, Psi0, pulse
-table) are resident in HBM before the clock starts.  N GPUs = N independent batch shards of 4096 (weak scaling):
-value = N*K / max-over-ranks wall time.
+Rank 0 prints ONE JSON line.  `--config 3` (default) is the headline; `--config 2` is BASELINE configs[1] (8-qubit ring
+QAOA, 1000 steps, batch 1024, forward); `--config 5` is configs[4] (18 qubits, complex64, batch 512 over the GPUs, the
+matrix-free engine, HBM-bound).  `--workload dense-real | dense-complex` replaces the Ising + X_k inputs of config 3 by
+dense random matrices of the same size and step norm (what `set_H`, diffqc.cc:43-67, accepts in general).
 
-The Ising Hamiltonian is real, so the engine takes its real-symmetric fast path by default (exp(-i dt H) = cos X + i sin X
-with real symmetric-output MFMA products; same results to rounding); `general_complex_path` in the JSON
-line is the same chain with that path switched off (what an arbitrary complex Hermitian H of this size costs).
+A "step" (config 3) is ONE Trotter step of the fwd+adjoint pass over one GPU's whole batch: 12-qubit random Ising H stored
+dense (d = 4096), K = 12 controls X_k, B = 4096 states, fp64 complex.  The timed region is one `dq_energy_grad` call over a
+chain of K steps -- K forward steps (assembly, exp, U.Psi), then the K-step adjoint sweep -- plus, for N > 1, the
+collectives of the multi-GPU form.  At this shape (batch >= dim) the backward sweep runs in operator form and keeps no
+state checkpoints, so the per-step cost does not depend on the chain length (`other_configs.full_chain_S2000` is the whole
+2000-step configuration in one call).  Inputs (H0, H_k, M, Psi0, pulse table) are resident in HBM before the clock starts.
+N GPUs = N batch shards of 4096 (weak scaling): value = N*K / max-over-ranks wall time.
 
-Adds to the JSON line: `roofline` for the dominant kernel = the kernel class with the largest share of the timed region,
-decided live from the per-launch HIP events the library records on the launch stream (on the real path: the real
-symmetric-output GEMM of the exp / reverse-mode products; on the general complex path: the batched complex GEMM),
-`roofline_other` for the second MFMA class, and `cpu_baseline` (the oracle = the reference's scipy expm + matmul step,
-timed on this box's host cores on a bounded sample).
+THE HEADLINE NUMBER DEPENDS ON THE STRUCTURE OF THE INPUTS.  The engine inspects H0 / H_k at `dq_set_hamiltonians`: real
+matrices take the cos X + i sin X form on real products, sparse controls their nonzeros only, a sparse drift too turns the
+whole step exponential into sparse x dense passes.  BASELINE's workload (diagonal Ising drift, X_k controls) is of the last
+kind.  `by_input_structure` in the JSON line gives, in the same run and with their own `roofline` blocks, the rates for
+dense real symmetric and dense complex Hermitian inputs of the same size (random data, 20-step chains), and for the Ising
+inputs with the structure ignored step by step (gradients equal to rounding).
+
+JSON extras: `roofline` = the kernel class with the largest share of the timed region, decided live from the per-launch
+HIP events the library records on the launch stream.  For MFMA classes `achieved` is the EXECUTED matrix-pipe rate (the
+3M complex product executes 6*M*N*K flops for 8*M*N*K algorithmic ones; the Hermitian-output form only the tiles on and
+above the diagonal), so `frac` = achieved / peak is a fraction of the matrix pipe; the algorithmic rate is
+`achieved_algorithmic`.  `traffic` = HBM-side bytes per launch from rocprofv3 PMC passes (`traffic_source` names the
+profiles/ file), `traffic_over_algorithmic` its ratio to the algorithmic bytes.  `cpu_baseline` = the oracle (the
+reference's scipy expm + matmul step) on this box's host cores, plus the single-thread C restatement of diffqc.cc.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,23 +47,123 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_BYTES_PER_LAUNCH = 3.51e9  # HBM-side bytes per full-output ZGEMM launch from rocprofv3 PMC (profiles/r1_bench_s3_final_summary.txt):
-                                   # 2*FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 3.23 GB + 0.28 GB, d = B = 4096
-TRAFFIC_RGEMM = {"rgemm": 1.81e9, "rsym": 2.51e9}  # real GEMM: full-output (profiles/r1_bench_v5_realpath_summary.txt);
-                                                   # symmetric-output launches (average over the one- and two-product forms of
-                                                   # the headline step: 8 + 4 per step) + fix-up pass, LDS-DMA staged
-                                                   # (profiles/r1_bench_s3_sparse_summary.txt: 2445 + 64 MB)
-TRAFFIC_SPMM = 8.96e8  # fabric-side bytes per sparse x dense launch (profiles/r1_bench_s3_spx_summary.txt: rsp_mm 831 MB, rsp_mm_dot
-                       # 1027 MB, 2 : 1 in the step; 700-900 MB read + 134 MB
-                       # written for 134 MB in, 134 MB out: a partner row per nonzero of X, most of them L2 hits)
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
+PEAK_HBM_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+# HBM-side bytes per launch at d = B = 4096, fp64: rocprofv3 PMC, separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+# read = 2 * FETCH_SIZE (gfx950 correction of the guide's HBM section), write = WRITE_SIZE.  (bytes, profiles/ file)
+TRAFFIC = {
+    "zgemm": (3.51e9, "profiles/r1_bench_s3_final_summary.txt"),
+    "zherm": (3.82e9, "profiles/r1_bench_s3_final_summary.txt"),   # incl. the 64 MB fix-up pass
+    "rgemm": (1.81e9, "profiles/r1_bench_v5_realpath_summary.txt"),
+    "rsym": (2.51e9, "profiles/r1_bench_s3_sparse_summary.txt"),
+    "spmm": (8.96e8, "profiles/r1_bench_s3_spx_summary.txt"),
+}
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself
+# ----------------------------------------------------------------------------------------------------------------
+
+def launch_ranks(a, argv):
+    """Start N fresh child ranks (one per GPU) BEFORE this process makes any GPU call and pass rank 0's JSON line
+    through.  The parent never initialises HIP (torch.cuda.device_count() does not, on this image), and it starts the
+    ranks as child processes -- it never re-execs itself."""
+    backend = os.environ.get("DQ_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print("bench.py: --gpus {} but this node shows {} GPU(s)".format(a.gpus, have), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [x for x in argv if x != "--launch"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
+class Dist:
+    """One process per GPU.  RCCL ("nccl") on device tensors; DQ_DIST_BACKEND=gloo stages the collectives through the host
+    and shares the devices round-robin (rehearsal on a box with fewer GPUs than ranks: RCCL refuses two ranks per device)."""
+
+    def __init__(self, a):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != a.gpus:
+            if self.rank == 0:
+                print("bench.py: --gpus {} but WORLD_SIZE {}".format(a.gpus, self.world), file=sys.stderr)
+            sys.exit(2)
+        self.backend = os.environ.get("DQ_DIST_BACKEND", "nccl")
+        if self.backend != "nccl":
+            local = local % max(1, torch.cuda.device_count())
+        self.local = local
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        self.on = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "MASTER_PORT" in os.environ
+        if self.on:  # launched by torch.distributed.run (also exercised at world size 1)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            os.environ.setdefault("RANK", str(self.rank))
+            os.environ.setdefault("WORLD_SIZE", str(self.world))
+            import datetime
+            tmo = datetime.timedelta(minutes=5)  # a mismatched collective fails the run instead of hanging it
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev, timeout=tmo)
+            else:
+                dist.init_process_group(self.backend, timeout=tmo)
+            self.world = dist.get_world_size()
+
+    def all_reduce_(self, t, op):  # in place on a device tensor, whatever the backend
+        if not self.on:
+            return
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op)
+            t.copy_(h)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.on:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if not self.on:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        self.all_reduce_(t, self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def name(self):
+        return ("nccl (RCCL over xGMI)" if self.backend == "nccl" else self.backend + " (host-staged rehearsal)") if self.on else "none (single process)"
+
+    def close(self):
+        if self.on:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle: test infrastructure, used here only as the reported baseline)
+# ----------------------------------------------------------------------------------------------------------------
 
 def cpu_baseline(n, B, seed, dt, u_row):
     """One fwd+adjoint Trotter step of the SAME workload on the host cores, through the oracle: the reference's
     per-step calls (scipy.linalg.expm + np.matmul, sim_plain.py:145-146) for the forward half, and the exact
-    adjoint with ONE scipy.linalg.expm_frechet per step (oracle.energy_grad_one_frechet) for the gradient half."""
+    adjoint with ONE scipy.linalg.expm_frechet per step (oracle.energy_grad_one_frechet) for the gradient half.
+    Beside it: the single-thread C restatement of diffqc.cc's trotter() (Eigen without OpenMP is
+    single-threaded) on a bounded sample."""
     from oracle import trotter_oracle as orc
     from diffquantum_amd import problems
     try:
@@ -65,65 +175,252 @@ def cpu_baseline(n, B, seed, dt, u_row):
     psi = problems.random_states(1 << n, min(B, 64), seed)
     psi = np.ascontiguousarray(np.tile(psi, (1, (B + psi.shape[1] - 1) // psi.shape[1]))[:, :B])
     t0 = time.perf_counter()
-    psi1 = orc.propagate(H0, list(Hs), u_row[None, :], dt, psi)
+    orc.propagate(H0, list(Hs), u_row[None, :], dt, psi)
     t_fwd = time.perf_counter() - t0
     t0 = time.perf_counter()
-    loss, grad, _ = orc.energy_grad_one_frechet(H0, list(Hs), M, u_row[None, :], dt, psi)
+    orc.energy_grad_one_frechet(H0, list(Hs), M, u_row[None, :], dt, psi)
     t_all = time.perf_counter() - t0
-    return {"value": 1.0 / t_all, "unit": "Trotter steps/s (fwd+adjoint)", "cores": int(cores), "kind": "port",
-            "forward_only_steps_per_s": 1.0 / t_fwd,
-            "sample": "1 fwd+adjoint Trotter step of the same workload (n={}, d={}, B={}) through the oracle: dH assembly, "
-                      "scipy.linalg.expm, np.matmul, one scipy.linalg.expm_frechet, 12 contractions: {:.1f} s "
-                      "(forward-only step: {:.1f} s)".format(n, 1 << n, B, t_all, t_fwd)}
+    out = {"value": 1.0 / t_all, "unit": "Trotter steps/s (fwd+adjoint)", "cores": int(cores), "kind": "port",
+           "forward_only_steps_per_s": 1.0 / t_fwd,
+           "sample": "1 fwd+adjoint Trotter step of the same workload (n={}, d={}, B={}) through the oracle: dH assembly, "
+                     "scipy.linalg.expm, np.matmul, one scipy.linalg.expm_frechet, {} contractions: {:.1f} s "
+                     "(forward-only step: {:.1f} s)".format(n, 1 << n, B, n, t_all, t_fwd)}
+    try:
+        out["c_single_thread"] = c_baseline(n, seed, dt)
+    except Exception as e:  # noqa: BLE001 -- a reported extra
+        out["c_single_thread"] = {"error": repr(e)}
+    return out
 
 
-def other_configs(dev, seed, headline=None):
-    """Short measurements of the other BASELINE configs on this GPU (reported as extras, outside the timed region)."""
+def c_baseline(n, seed, dt, n_small=9):
+    """oracle/diffqc_oracle.c (own Higham-2005 Pade + LU, plain loops, one thread): forward steps of diffqc.cc's
+    trotter() (`psi0 = dH.exp() * psi0`, diffqc.cc:192-198, batch 1).  At d = 4096 one step would take the better
+    part of an hour, so the sample is the same problem family at n = 9 (d = 512); the d = 4096 figure is the O(d^3)
+    extrapolation and is labelled as such."""
+    from oracle import c_oracle
+    from diffquantum_amd import problems
+    ns = min(n, n_small)
+    H0, Hs, _ = problems.random_ising(ns, seed)
+    u = problems.pulse_table(ns, 1, dt, seed=seed)
+    psi = problems.random_states(1 << ns, 1, seed)
+    t0 = time.perf_counter()
+    c_oracle.propagate(H0, Hs, u, dt, psi)
+    el = time.perf_counter() - t0
+    scale = float(1 << (n - ns)) ** 3
+    return {"forward_steps_per_s_at_sample": 1.0 / el, "cores": 1, "kind": "port",
+            "extrapolated_forward_steps_per_s": 1.0 / (el * scale),
+            "sample": "1 forward Trotter step, batch 1, n={} (d={}) in {:.2f} s on one thread (C restatement of diffqc.cc: "
+                      "assembly + Pade-13/LU expm + matvec); x{:.0f} (d^3) to d={}".format(ns, 1 << ns, el, scale, 1 << n)}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# roofline blocks from the library's per-launch HIP events
+# ----------------------------------------------------------------------------------------------------------------
+
+def roofline_blocks(prof, info, d):
+    """One block per kernel class of a dense-engine profile (`dq_profile_get`), each with its share of the timed region."""
+    three_m = bool(info["zgemm_alg"]) and d >= 1024          # 3M runs on the 128 tile (fp64); smaller tiles are 4M
+    f3 = 0.75 if three_m else 1.0
+    nt = (d + 127) // 128
+    tri = (nt * (nt + 1) / 2) / float(nt * nt) if d >= 1024 else 1.0   # Hermitian-output form: tiles on/above the diagonal
+
+    def rate(p, scale=1.0):
+        return p["flops"] * scale / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+
+    def per(p, key):
+        return p[key] / max(1, p["launches"])
+
+    def mfma(name, p, kernel, exec_factor, alg_bytes, note):
+        tr, src = TRAFFIC[name]
+        use_tr = d == 4096 and p["launches"] > 0
+        return {"bound": "mfma", "kernel": kernel,
+                "achieved": rate(p, exec_factor), "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": rate(p, exec_factor) / PEAK_F64_MFMA_TFLOPS,
+                "achieved_algorithmic": rate(p), "executed_over_algorithmic_flops": exec_factor,
+                "traffic": tr if use_tr else None, "traffic_source": src if use_tr else None,
+                "traffic_over_algorithmic": (tr / alg_bytes) if (use_tr and alg_bytes) else None,
+                "launches": p["launches"], "flops_per_launch": per(p, "flops"), "ms_per_launch": per(p, "ms"),
+                "ms_in_timed_region": p["ms"], "note": note}
+
+    z, zh, rg, rs, sp = prof["zgemm"], prof["zherm"], prof["rgemm"], prof["rsym"], prof["spmm"]
+    alg = "3M: 3 real MFMAs per complex tile step" if three_m else "4M"
+    blocks = {
+        "zgemm": mfma("zgemm", z, "zgemm_kernel<128,128,8,2,4,*,*,{}> (batched complex GEMM, v_mfma_f64_16x16x4_f64, {})".format(int(three_m), alg),
+                      f3, per(z, "bytes"),
+                      "achieved = EXECUTED MFMA flops (6*M*N*K per launch in the 3M form, 8*M*N*K in 4M) / sum of the launches' HIP-event "
+                      "durations (rank 0); achieved_algorithmic = 8*M*N*K / the same time (can exceed the peak in the 3M form)"),
+        "zherm": mfma("zherm", zh, "zgemm_kernel<...,HERM> ((anti-)Hermitian-output complex GEMM: tiles on/above the diagonal + mirror, K-split tail, {})".format(alg),
+                      f3 * tri, per(zh, "bytes"),
+                      "executed = the {}/{} tiles on and above the diagonal x (6 or 8)*K*128*128; algorithmic = 8*M*N*K of the delivered product".format(
+                          nt * (nt + 1) // 2, nt * nt)),
+        "rsym": mfma("rsym", rs, "rgemm_kernel<128,128,16,4,4,sym> (batched real GEMM, symmetric-output form, LDS-DMA staged; one- and two-product launches)",
+                     1.0, per(rs, "bytes"),
+                     "executed = algorithmic: 2*K*128*128 per tile on/above the diagonal (the mirror half is written, not computed)"),
+        "rgemm": mfma("rgemm", rg, "rgemm_kernel<128,128,16,4,4> (batched real GEMM, full output, LDS-DMA staged)", 1.0, per(rg, "bytes"),
+                      "executed = algorithmic = 2*M*N*K"),
+    }
+    tr, src = TRAFFIC["spmm"]
+    use_tr = d == 4096 and sp["launches"] > 0
+    gbps = sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0
+    blocks["spmm"] = {
+        "bound": "hbm", "kernel": "rsp_mm_kernel / rsp_mm_dot_kernel (sparse generator x dense matrix: out[i,:] = sum over nnz(X[i,:]) of w X_m[j,:])",
+        "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+        "traffic": tr if use_tr else None, "traffic_source": src if use_tr else None,
+        "traffic_over_algorithmic": (tr / per(sp, "bytes")) if (use_tr and sp["bytes"]) else None,
+        "launches": sp["launches"], "ms_per_launch": per(sp, "ms"), "ms_in_timed_region": sp["ms"],
+        "note": "achieved = ALGORITHMIC bytes (operand read once, product written once: 2-3 x 8 d^2) / HIP-event time; the partner "
+                "rows of a row's nonzeros are re-read from L2 / Infinity Cache: `traffic` is the fabric-side PMC figure per launch"}
+    total = sum(v["ms"] for v in prof.values())
+    for b in blocks.values():
+        b["share_of_kernel_time"] = b["ms_in_timed_region"] / total if total > 0 else 0.0
+    return blocks
+
+
+def ranked(blocks):
+    return [b for _, b in sorted(blocks.items(), key=lambda kv: -kv[1]["ms_in_timed_region"]) if b["launches"] > 0]
+
+
+def executed_tflops(blocks, seconds):
+    fl = sum(b["achieved"] * 1e12 * b["ms_in_timed_region"] * 1e-3 for b in blocks.values() if b["bound"] == "mfma")
+    return fl / seconds / 1e12 if seconds > 0 else 0.0
+
+
+INFO_KEYS = ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk", "zgemm_alg", "real_path",
+             "real_hamiltonians", "sparse_controls", "sparse_generator", "control_nonzeros")
+
+
+def describe_expm(info):
+    if info["sparse_generator"] > 0:
+        return ("cos X + i sin X, Taylor degree {0}: drift and controls sparse, so X_t is sparse -- the powers X^2 .. X^{0} by {1} sparse x dense "
+                "passes, cos/sin as linear combinations of them (no MFMA product in the step exponential), theta<={2:.3g}".format(
+                    int(info["degree"]), int(info["products"]), info["theta"]))
+    if info["real_path"] > 0:
+        return "cos X + i sin X, Taylor degree {} ({} real symmetric-output products{}), theta<={:.3g}".format(
+            int(info["degree"]), int(info["products"]),
+            "; sparse controls: scatter assembly, last reverse-mode level as row dot products" if info["sparse_controls"] > 0 else "",
+            info["theta"])
+    return "Taylor degree {} ({} complex products, {} squarings), theta<={:.3g}".format(
+        int(info["degree"]), int(info["products"]), int(info["squarings"]), info["theta"])
+
+
+def timed_chain(eng, torch, u_dev, dt, psi0, grad_dev):
+    """One profiled dq_energy_grad over the chain in u_dev (single GPU, no collective); returns (seconds, loss, profile)."""
+    eng.energy_grad(u_dev[:1].contiguous(), dt, psi0, want_final=False, want_energies=False)   # allocations, plan
+    eng.profile_enable(True)
+    eng.profile_reset()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    loss, _, _, _ = eng.energy_grad(u_dev, dt, psi0, want_final=False, want_energies=False, grad_out=grad_dev)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    prof = eng.profile()
+    eng.profile_enable(False)
+    return el, loss, prof
+
+
+def scheme_entry(eng, torch, u_dev, dt, psi0, d, K, name_note):
+    g = torch.zeros((u_dev.shape[0], eng.n_controls), dtype=torch.float64, device=u_dev.device)
+    el, loss, prof = timed_chain(eng, torch, u_dev, dt, psi0, g)
+    info = {k: eng.info(k) for k in INFO_KEYS}
+    blocks = roofline_blocks(prof, info, d)
+    rk = ranked(blocks)
+    return {"value": K / el, "unit": "Trotter steps/s (fwd+adjoint)", "ms_per_step": el / K * 1e3, "chain_steps": K,
+            "path": describe_expm(info), "loss": loss, "grad_norm": float(torch.linalg.norm(g).item()),
+            "roofline": rk[0] if rk else None, "roofline_other": rk[1] if len(rk) > 1 else None,
+            "executed_mfma_tflops": executed_tflops(blocks, el),
+            "executed_mfma_frac_of_peak": executed_tflops(blocks, el) / PEAK_F64_MFMA_TFLOPS,
+            "kernel_ms": {k: v["ms"] for k, v in prof.items()}, "kernel_launches": {k: v["launches"] for k, v in prof.items()},
+            "note": name_note}, g
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# extras of the headline run (single GPU, outside the timed region)
+# ----------------------------------------------------------------------------------------------------------------
+
+def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
+    """What the SAME chain costs for other input structures, 20-step chains each with its own roofline."""
     import torch
     from diffquantum_amd import problems
     from diffquantum_amd.engine import Engine
+    n, K = a.qubits, a.steps
+    d = 1 << n
+    u_dev = torch.from_numpy(u_all[:K].copy()).to(dev)
+    out = {}
+    # (1) the headline's own inputs with their structure ignored step by step: gradients must agree to rounding
+    for name, opts, note in (
+            ("ising_inputs_sparse_controls_dense_drift", {"sparse_generator": 0},
+             "same inputs, the drift treated as dense: real symmetric MFMA products for the step exponential, controls by their nonzeros"),
+            ("ising_inputs_dense_real_path", {"sparse_generator": 0, "sparse_controls": 0},
+             "same inputs, drift and controls treated as dense real symmetric matrices"),
+            ("ising_inputs_complex_tape", {"real_path": 0},
+             "same inputs on the general complex tape (real_path = 0): 11 full + 3 Hermitian-output complex products per step")):
+        for k_, v_ in opts.items():
+            eng.set_option(k_, v_)
+        ent, g = scheme_entry(eng, torch, u_dev, a.dt, psi0, d, K, note)
+        ent["max_abs_grad_diff_vs_headline"] = float((g - grad_ref).abs().max().item())
+        ent["abs_loss_diff_vs_headline"] = abs(ent["loss"] - loss_ref)
+        out[name] = ent
+        eng.set_option("sparse_generator", -1)
+        eng.set_option("sparse_controls", 1)
+        eng.set_option("real_path", a.real_path)
+    # (2) dense random data of the same size and step norm: what an arbitrary `set_H` caller gets
+    for name, cplx, note in (
+            ("dense_real_symmetric_H", False, "dense random real symmetric H0 and 12 dense real symmetric H_k (1-norms 12 and 1, as the Ising + X_k "
+                                              "workload): cos X + i sin X on real symmetric-output MFMA products"),
+            ("dense_complex_hermitian_H", True, "dense random complex Hermitian H0 and 12 dense complex Hermitian H_k (same 1-norms): the general "
+                                                "complex tape -- what diffqc.cc's set_H accepts in general")):
+        H0, Hs, M = problems.random_dense_torch(n, n, a.seed, dev, complex_h=cplx)
+        with Engine(d, n, device=dev.index or 0) as e2:
+            e2.use_torch_stream()
+            e2.set_hamiltonians(H0, Hs)
+            e2.set_observable(M)
+            del H0, Hs, M
+            ent, _ = scheme_entry(e2, torch, u_dev, a.dt, psi0, d, K, note)
+        out[name] = ent
+        torch.cuda.empty_cache()
+    return out
+
+
+def full_chain(eng, a, dev, psi0):
+    """BASELINE configs[2] in full: the S = 2000 chain in ONE dq_energy_grad call, with the size-independent
+    checks a driver can read: norm drift of Psi(T), sum of energies = loss, directional derivative of the gradient against central
+    differences of the forward path on a 100-step chain at full d and B."""
+    import torch
+    from diffquantum_amd import problems
+    n, S = a.qubits, a.chain
+    u = torch.from_numpy(problems.pulse_table(n, S, a.dt * S, seed=a.seed)).to(dev)
+    eng.set_option("plan_steps", 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    loss, grad, fin, en = eng.energy_grad(u, a.dt, psi0)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    free, tot = torch.cuda.mem_get_info()
+    res = {"chain_steps": S, "wall_s": el, "steps_per_s": S / el, "hbm_in_use_GB": (tot - free) / 1e9, "loss": loss,
+           "sum_of_energies_minus_loss": float(en.sum()) - loss, "grad_norm": float(np.linalg.norm(grad)),
+           "grad_finite": bool(np.isfinite(grad).all()),
+           "max_norm_drift": float((torch.linalg.norm(fin, dim=0) - 1).abs().max().item())}
+    del fin
+    S_fd = min(100, S)
+    u2 = problems.pulse_table(n, S_fd, a.dt * S_fd, seed=a.seed + 1)
+    v = np.random.default_rng(0).standard_normal(u2.shape)
+    _, g0, _, _ = eng.energy_grad(u2, a.dt, psi0, want_final=False, want_energies=False)
+    eps = 1e-4
+    lp = eng.energy(eng.propagate(torch.from_numpy(u2 + eps * v).to(dev), a.dt, psi0))[1]
+    lm = eng.energy(eng.propagate(torch.from_numpy(u2 - eps * v).to(dev), a.dt, psi0))[1]
+    fd, an = (lp - lm) / (2 * eps), float(np.sum(g0 * v))
+    res["directional_derivative_check"] = {"chain_steps": S_fd, "central_difference": fd, "adjoint": an,
+                                           "rel_diff": abs(fd - an) / max(abs(an), 1e-30)}
+    return res
+
+
+def other_configs(dev, seed, headline=None):
+    """Short measurements of the other BASELINE configs on this GPU (reported as extras, outside the timed region);
+    `--config 2` / `--config 5` make them the measured workload of a run of their own."""
+    import torch
     from diffquantum_amd.structured import StructuredEngine, ising_x_terms
     out = {}
-    # configs[1]: 8-qubit ring QAOA, 1000 Trotter steps, batch 1024, fp64, forward only
-    p = problems.qaoa_ring(8)
-    S, B = 1000, 1024
-    u = torch.from_numpy(problems.pulse_table(16, S, 1.0, seed=seed)).to(dev)
-    psi = torch.from_numpy(problems.random_states(256, B, seed)).to(dev)
-    with Engine(256, 16, device=dev.index or 0) as e:
-        e.use_torch_stream()
-        e.set_hamiltonians(p["H0"].astype(np.complex128), p["Hs"].astype(np.complex128))
-        e.propagate(u, 1.0 / S, psi)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        fin = e.propagate(u, 1.0 / S, psi)
-        torch.cuda.synchronize(); el = time.perf_counter() - t0
-        out["config2_qaoa_n8_S1000_B1024_fwd"] = {
-            "steps_per_s": S / el, "wall_s": el, "operator_form": bool(e.info("composed")),
-            "max_norm_drift": float((torch.linalg.norm(fin, dim=0) - 1).abs().max().item())}
-    # configs[4] per-GPU share: 18-qubit Ising + X controls as Pauli strings, complex64, 512/8 = 64 states per GPU
-    n, B, S = 18, 64, 20
-    rng = np.random.default_rng(seed)
-    st = rng.standard_normal((1 << n, B)) + 1j * rng.standard_normal((1 << n, B))
-    st = torch.from_numpy((st / np.linalg.norm(st, axis=0)).astype(np.complex64)).to(dev)
-    us = problems.pulse_table(n, S, S * 1e-3, seed=seed)
-    with StructuredEngine(n, n, device=dev.index or 0, dtype="c64") as e:
-        e.use_torch_stream()
-        e.set_terms(ising_x_terms(n, seed))
-        e.propagate(us[:2], 1e-3, st)
-        e.set_option("profile", -1); e.set_option("profile", 1)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        e.propagate(us, 1e-3, st)
-        torch.cuda.synchronize(); el_f = time.perf_counter() - t0
-        ms, by = e.info("prof_ms"), e.info("prof_bytes")
-        e.set_option("profile", 0)
-        e.energy_grad(us[:2], 1e-3, st, want_final=False)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        e.energy_grad(us, 1e-3, st, want_final=False)
-        torch.cuda.synchronize(); el_g = time.perf_counter() - t0
-        out["config5_pergpu_n18_B64_c64_structured"] = {
-            "fwd_steps_per_s": S / el_f, "fwd_adjoint_steps_per_s": S / el_g, "taylor_degree": int(e.info("degree")),
-            "roofline": {"bound": "hbm", "achieved": by / ms * 1e-6 if ms > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (by / ms * 1e-6 / 8000.0) if ms > 0 else 0.0,
-                         "note": "forward H.psi passes: algorithmic bytes (state-units x 2^n x B x 8 B) / HIP-event time"}}
+    out["config2_qaoa_n8_S1000_B1024_fwd"] = measure_config2(dev, seed, 1000, 1024, reps=1)
+    c5 = measure_config5(dev, seed, 20, 64, None)
+    out["config5_pergpu_n18_B64_c64_structured"] = {
+        "fwd_steps_per_s": c5["fwd_steps_per_s"], "fwd_adjoint_steps_per_s": c5["steps_per_s"], "taylor_degree": c5["degree"],
+        "roofline": c5["roofline"]}
     # the headline problem itself, given as Pauli strings to the matrix-free engine (complex128): what the same chain
     # costs when the Hamiltonian is never densified (HBM-bound state passes instead of d x d MFMA products)
     if headline is not None:
@@ -143,78 +440,173 @@ def other_configs(dev, seed, headline=None):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--qubits", type=int, default=12)
-    ap.add_argument("--batch", type=int, default=4096, help="states per GPU")
-    ap.add_argument("--dt", type=float, default=1e-3)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--skip-cpu-baseline", action="store_true")
-    ap.add_argument("--skip-other-configs", action="store_true")
-    ap.add_argument("--skip-general-path", action="store_true",
-                    help="do not run the general-complex-path extra (profiling: only the headline path's kernels)")
-    ap.add_argument("--chain", type=int, default=2000,
-                    help="length of the full configuration's chain: the timed slice uses ITS checkpoint stride")
-    ap.add_argument("--real-path", type=int, default=-1,
-                    help="-1 auto (real H -> cos/sin form on real MFMA products), 0 = general complex path only")
-    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated"), default="auto",
-                    help="N > 1: 'sliced' = chain split over time across the ranks (operator form; three collectives), "
-                         "'replicated' = every rank runs the whole chain on its batch shard (one all-reduce); "
-                         "auto = sliced if its warm-up gradient equals the replicated one on every rank")
-    a = ap.parse_args()
-
+def measure_config2(dev, seed, S, B, reps=3, first=0):
+    """BASELINE configs[1]: 8-qubit ring QAOA (K = 16), S Trotter steps, B states, fp64, forward only."""
     import torch
-    import torch.distributed as dist
+    from diffquantum_amd import problems
+    from diffquantum_amd.engine import Engine
+    p = problems.qaoa_ring(8)
+    u = torch.from_numpy(problems.pulse_table(16, S, 1.0, seed=seed)).to(dev)
+    psi = torch.from_numpy(problems.random_states(256, B, seed, first=first)).to(dev)
+    with Engine(256, 16, device=dev.index or 0) as e:
+        e.use_torch_stream()
+        e.set_hamiltonians(p["H0"].astype(np.complex128), p["Hs"].astype(np.complex128))
+        e.propagate(u, 1.0 / S, psi)
+        best, fin = None, None
+        for _ in range(max(1, reps)):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            fin = e.propagate(u, 1.0 / S, psi)
+            torch.cuda.synchronize(); el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        e.profile_enable(True); e.profile_reset()
+        e.propagate(u, 1.0 / S, psi)
+        prof = e.profile()
+        e.profile_enable(False)
+        info = {k: e.info(k) for k in INFO_KEYS}
+        return {"steps_per_s": S / best, "wall_s": best, "operator_form": bool(e.info("composed")),
+                "max_norm_drift": float((torch.linalg.norm(fin, dim=0) - 1).abs().max().item()),
+                "path": describe_expm(info), "kernel_ms": {k: v["ms"] for k, v in prof.items() if v["launches"]},
+                "kernel_launches": {k: v["launches"] for k, v in prof.items() if v["launches"]}, "_prof": prof, "_info": info}
+
+
+def measure_config5(dev, seed, S, B, dist, n=18, first=0):
+    """BASELINE configs[4] per GPU: n-qubit Ising + X controls as Pauli strings (never densified), complex64, B states,
+    S steps forward and fwd+adjoint on the matrix-free engine; roofline = HBM from the engine's per-pass HIP events."""
+    import torch
+    from diffquantum_amd import problems
+    from diffquantum_amd.structured import StructuredEngine, ising_x_terms
+    rng = np.random.default_rng([seed, first])
+    st = rng.standard_normal((1 << n, B)) + 1j * rng.standard_normal((1 << n, B))
+    st = torch.from_numpy((st / np.linalg.norm(st, axis=0)).astype(np.complex64)).to(dev)
+    us = problems.pulse_table(n, S, S * 1e-3, seed=seed)
+    with StructuredEngine(n, n, device=dev.index or 0, dtype="c64") as e:
+        e.use_torch_stream()
+        e.set_terms(ising_x_terms(n, seed))
+        e.propagate(us[:2], 1e-3, st)
+        e.set_option("profile", -1); e.set_option("profile", 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.propagate(us, 1e-3, st)
+        torch.cuda.synchronize(); el_f = time.perf_counter() - t0
+        ms_f, by_f = e.info("prof_ms"), e.info("prof_bytes")
+        e.set_option("profile", 0)
+        e.energy_grad(us[:2], 1e-3, st, want_final=False)
+        e.set_option("profile", -1); e.set_option("profile", 1)
+        if dist is not None:
+            dist.fence()
+        t0 = time.perf_counter()
+        loss, grad, _, _ = e.energy_grad(us, 1e-3, st, want_final=False)
+        if dist is not None and dist.on:
+            from diffquantum_amd.distributed import allreduce_loss_grad
+            loss, grad = allreduce_loss_grad(loss, grad, device=dev)
+        if dist is not None:
+            dist.fence()
+        else:
+            torch.cuda.synchronize()
+        el_g = time.perf_counter() - t0
+        ms_g, by_g, nl = e.info("prof_ms"), e.info("prof_bytes"), e.info("prof_launches")
+        e.set_option("profile", 0)
+        gb = by_g / ms_g * 1e-6 if ms_g > 0 else 0.0
+        gbf = by_f / ms_f * 1e-6 if ms_f > 0 else 0.0
+        return {"steps_per_s": S / el_g, "seconds": el_g, "fwd_steps_per_s": S / el_f, "degree": int(e.info("degree")),
+                "loss": loss, "grad_norm": float(np.linalg.norm(grad)),
+                "roofline": {"bound": "hbm", "kernel": "sapply_kernel / soverlap_kernel (matrix-free H.psi passes: sub-cube of 2^9 rows x 16 columns in LDS)",
+                             "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gb / PEAK_HBM_GBPS, "traffic": None,
+                             "launches": int(nl), "ms_in_timed_region": ms_g,
+                             "forward_only": {"achieved": gbf, "frac": gbf / PEAK_HBM_GBPS},
+                             "note": "fwd+adjoint passes of the timed region: algorithmic bytes (state-units x 2^n x B x 8 B per pass) / "
+                                     "HIP-event time; 6.29 TB/s is the measured copy rate of the part (guide), 8 TB/s the spec used as peak"}}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# config 2 / config 5 as the measured workload
+# ----------------------------------------------------------------------------------------------------------------
+
+def run_config2(a, D):
+    import torch
+    S = a.steps if a.steps is not None else 1000
+    B = a.batch if a.batch is not None else 1024
+    measure_config2(D.dev, a.seed, min(S, max(a.warmup, 1) * 10), B, reps=1, first=D.rank * B)   # warm-up
+    D.fence()
+    t0 = time.perf_counter()
+    m = measure_config2(D.dev, a.seed, S, B, reps=1, first=D.rank * B)
+    D.fence()
+    _ = time.perf_counter() - t0
+    el = D.max_over_ranks(m["wall_s"])
+    if D.rank == 0:
+        blocks = roofline_blocks(m["_prof"], m["_info"], 256)
+        rk = ranked(blocks)
+        W_alg = 8.0 * 256 * 256 * B
+        out = {"metric": "Trotter steps/sec (forward), n=8 qubits batch={}".format(B), "value": D.world * S / el,
+               "unit": "Trotter steps/s (each step = forward over one GPU's {}-state batch; aggregate over GPUs)".format(B),
+               "n_gpus": D.world, "steps": S, "warmup": a.warmup, "ms_per_step": el / S * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "backend": D.name(),
+               "config": {"workload": "BASELINE configs[1]: 8-qubit ring analog QAOA (d=256, 16 controls = 8 edge ZZ + 8 vertex X), {} Trotter "
+                                      "steps, batch {} per GPU, fp64 complex, forward only; the timed region is ONE dq_propagate over the whole "
+                                      "chain".format(S, B),
+                          "n_qubits": 8, "dim": 256, "n_controls": 16, "batch_per_gpu": B, "global_batch": B * D.world, "chain_steps": S,
+                          "operator_form": m["operator_form"], "path": m["path"],
+                          "parallelism": "dp{} (independent batch shards, forward only: no collective)".format(D.world)},
+               "roofline": rk[0] if rk else None, "roofline_other": rk[1] if len(rk) > 1 else None,
+               "end_to_end": {"algorithmic_flops_per_step": W_alg, "algorithmic_tflops": W_alg * S / el / 1e12,
+                              "note": "d = 256: the chain is composed by a log-depth tree of batched d x d products (operator form), "
+                                      "8 d^3 per step instead of 8 d^2 B; launch-latency, not a roofline, governs at this size",
+                              "kernel_ms": m["kernel_ms"], "kernel_launches": m["kernel_launches"]},
+               "max_norm_drift": m["max_norm_drift"]}
+        print(json.dumps(out))
+
+
+def run_config5(a, D):
+    S = a.steps if a.steps is not None else 20
+    total = a.batch if a.batch is not None else 512
+    if total % D.world:
+        raise SystemExit("--batch {} (the WHOLE batch of config 5) must divide over {} ranks".format(total, D.world))
+    B = total // D.world
+    n = a.qubits if a.qubits != 12 else 18
+    m = measure_config5(D.dev, a.seed, S, B, D, n=n, first=D.rank * B)
+    el = D.max_over_ranks(m["seconds"])
+    if D.rank == 0:
+        out = {"metric": "Trotter steps/sec (fwd+adjoint), n={} qubits batch={} (complex64, matrix-free)".format(n, total),
+               "value": S / el, "unit": "Trotter steps/s (each step = fwd+adjoint over the WHOLE {}-state batch, sharded over the GPUs)".format(total),
+               "n_gpus": D.world, "steps": S, "warmup": a.warmup, "ms_per_step": el / S * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": D.name(),
+               "config": {"workload": "BASELINE configs[4]: {}-qubit Ising drift + X_k controls as Pauli strings (d={}, never densified), "
+                                      "batch {} = {} per GPU, complex64, fwd + adjoint gradient, dt=1e-3; timed chain = {} of the 4000 Trotter "
+                                      "steps".format(n, 1 << n, total, B, S),
+                          "n_qubits": n, "dim": 1 << n, "n_controls": n, "batch_per_gpu": B, "global_batch": total, "chain_steps": S,
+                          "taylor_degree": m["degree"], "loss": m["loss"], "grad_norm": m["grad_norm"],
+                          "forward_only_steps_per_s_rank0": m["fwd_steps_per_s"],
+                          "parallelism": "dp{} (batch shards, one all-reduce of loss + dL/du)".format(D.world)},
+               "roofline": m["roofline"]}
+        print(json.dumps(out))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# config 3: the headline
+# ----------------------------------------------------------------------------------------------------------------
+
+def run_config3(a, D):
+    import torch
     from diffquantum_amd import problems
     from diffquantum_amd.distributed import allreduce_loss_grad, time_sliced_energy_grad
     from diffquantum_amd.engine import Engine
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and rank == 0:
-        print("warning: --gpus {} but WORLD_SIZE {}".format(a.gpus, world), file=sys.stderr)
-    # one process per GPU. (Rehearsal on a box with fewer GPUs than ranks: DQ_DIST_BACKEND=gloo shares the devices
-    # round-robin and stages the collectives through the host -- RCCL refuses two ranks on one device.)
-    backend = os.environ.get("DQ_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "MASTER_PORT" in os.environ
-    if use_dist:  # launched by torch.distributed.run (also exercised at world size 1)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("RANK", str(rank))
-        os.environ.setdefault("WORLD_SIZE", str(world))
-        import datetime
-        tmo = datetime.timedelta(minutes=5)  # a mismatched collective fails the run instead of hanging it
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
-        else:
-            dist.init_process_group(backend, timeout=tmo)
-
-    def all_reduce_(t, op):  # in place on a device tensor, whatever the backend
-        if backend == "nccl":
-            dist.all_reduce(t, op=op)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-
-    n, B, K, W = a.qubits, a.batch, a.steps, a.warmup
+    dist = D.dist
+    rank, world, dev = D.rank, D.world, D.dev
+    n, K, W = a.qubits, a.steps if a.steps is not None else 20, a.warmup
+    B = a.batch if a.batch is not None else 4096
+    a.steps = K
     d = 1 << n
     # ---- inputs, resident in HBM before the clock starts --------------------------------------
-    H0, Hs, M = problems.random_ising_torch(n, a.seed, dev)
+    if a.workload == "ising":
+        H0, Hs, M = problems.random_ising_torch(n, a.seed, dev)
+    else:
+        H0, Hs, M = problems.random_dense_torch(n, n, a.seed, dev, complex_h=(a.workload == "dense-complex"))
     u_all = problems.pulse_table(n, max(K, W, 1), a.dt * max(K, W, 1), seed=a.seed)
     psi0 = torch.from_numpy(problems.random_states(d, B, a.seed, first=rank * B)).to(dev)
-    eng = Engine(d, n, device=local)
+    eng = Engine(d, n, device=D.local)
     eng.use_torch_stream()
     eng.set_hamiltonians(H0, Hs)
     eng.set_observable(M)
+    del H0, Hs, M
     eng.set_option("real_path", a.real_path)
     eng.set_option("plan_steps", max(a.chain, K))  # checkpoint/rebuild ratio of the full 2000-step chain
     u_t = torch.from_numpy(u_all[:K].copy()).to(dev)
@@ -222,15 +614,16 @@ def main():
 
     # Propagator cache of the sliced form: a rank's slice of the planned chain is short enough to be cached WHOLE
     # ((q + 3) d^2 fp64 words per step, 2q + 2 with the sparse-generator scheme: 0.8-1.07 GB per step at q = 3), so the budget is
-    # what the slice needs, capped at 72 % of the HBM (the engine's auto mode stops at 96 GiB: bigger first-use allocations cost
-    # seconds, which a 2000-step single-GPU chain does not win back but a fully cached slice does, evaluation after evaluation)
+    # what the slice needs, capped at 72 % of the HBM (the arena itself only grows to what the steps of THIS call need)
     slice_steps = (max(a.chain, K) + world - 1) // world
-    sliced_cache_bytes = min(8.0 * d * d * 8 * slice_steps + (1 << 20), 0.72 * torch.cuda.get_device_properties(local).total_memory)
+    sliced_cache_bytes = min(8.0 * d * d * 8 * slice_steps + (1 << 20), 0.72 * torch.cuda.get_device_properties(D.local).total_memory)
 
     def run_replicated(u_dev, grad_dev):
         eng.set_option("plan_steps", max(a.chain, K))
         eng.set_option("cache_bytes", 0)
         loss, g, _, _ = eng.energy_grad(u_dev, a.dt, psi0, want_final=False, want_energies=False, grad_out=grad_dev)
+        if not D.on:
+            return loss, g
         return allreduce_loss_grad(loss, g, device=dev)
 
     def run_sliced(u_dev, grad_dev):
@@ -240,252 +633,189 @@ def main():
         eng.set_option("plan_steps", (max(a.chain, K) + world - 1) // world)
         eng.set_option("cache_bytes", sliced_cache_bytes)
         loss, g, _, _ = time_sliced_energy_grad(eng, u_dev, a.dt, psi0, device=dev)
-        g = torch.from_numpy(g).to(dev)
-        grad_dev.copy_(g)
+        grad_dev.copy_(torch.from_numpy(g).to(dev))
         return loss, grad_dev
 
-    mode = "replicated"
+    # Which multi-GPU form runs.  No exception handling around anything that contains a collective: every rank issues the
+    # same collectives in the same order with the same sizes, and a rank-local failure (OOM, DiffqcError) aborts the job
+    # non-zero instead of leaving the peers in a mismatched collective.
+    force = bool(os.environ.get("DQ_FORCE_COLLECTIVES")) and D.on
+    both = (world > 1 or force) and a.multi_gpu == "auto"
+    mode = "sliced" if (a.multi_gpu == "sliced" and D.on) or both else "replicated"
+    forms = {}
     sliced_check = None
-    if (world > 1 and a.multi_gpu != "replicated") or (use_dist and a.multi_gpu == "sliced"):
-        mode = "sliced"  # (asked for explicitly it also runs at world size 1: rehearsal of the collectives)
     if W > 0:
         uw = torch.from_numpy(u_all[:W].copy()).to(dev)
         lr, gr = run_replicated(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
         if mode == "sliced":
-            # the warm-up doubles as the check: same loss and gradient from both forms on every rank, or fall back
-            ok = 1.0
-            try:
-                ls, gs = run_sliced(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
-                err = float((gs - gr).abs().max().item()) if W > 0 else 0.0
-                sliced_check = {"max_abs_grad_diff_vs_replicated": err, "abs_loss_diff_vs_replicated": abs(ls - lr)}
-                if not (err <= 1e-9 * (1.0 + float(gr.abs().max().item())) and abs(ls - lr) <= 1e-9 * (1.0 + abs(lr))):
-                    ok = 0.0
-            except Exception as e:  # noqa: BLE001 -- any failure of the sliced form means: use the replicated one
-                sliced_check = {"error": repr(e)}
-                ok = 0.0
-            flag = torch.tensor([ok], dtype=torch.float64, device=dev)
-            all_reduce_(flag, dist.ReduceOp.MIN)
-            if float(flag.item()) < 1.0 and a.multi_gpu == "auto":
-                mode = "replicated"
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+            # the warm-up doubles as the check: same loss and gradient from both forms on every rank
+            ls, gs = run_sliced(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+            err = float((gs - gr).abs().max().item())
+            ok = err <= 1e-9 * (1.0 + float(gr.abs().max().item())) and abs(ls - lr) <= 1e-9 * (1.0 + abs(lr))
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+            D.all_reduce_(flag, dist.ReduceOp.MIN)
+            sliced_check = {"max_abs_grad_diff_vs_replicated": err, "abs_loss_diff_vs_replicated": abs(ls - lr),
+                            "agreed_on_every_rank": bool(flag.item() >= 1.0)}
+            if flag.item() < 1.0:
+                if a.multi_gpu == "sliced":
+                    raise SystemExit("sliced form disagrees with the replicated form: {}".format(sliced_check))
+                mode, both = "replicated", False
 
     # auto: which form is faster on THIS node is measured, not assumed -- both once on the K-step chain, outside the
     # timed region, max over ranks; the timed region then runs the faster one and the other is reported beside it
-    trial = {}
-    if mode == "sliced" and a.multi_gpu == "auto" and world > 1:
+    if both:
         for name, fn in (("sliced", run_sliced), ("replicated", run_replicated)):
-            try:
-                g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
-                fence()
-                t1 = time.perf_counter()
-                l2, g2 = fn(u_t, g2)
-                fence()
-                tm = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-                all_reduce_(tm, dist.ReduceOp.MAX)
-                trial[name] = (float(tm.item()), l2, g2.clone())
-            except Exception as e:  # noqa: BLE001
-                trial[name] = (float("inf"), repr(e), None)
-        if trial["replicated"][0] < trial["sliced"][0]:
-            mode = "replicated"
+            g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
+            D.fence()
+            t1 = time.perf_counter()
+            l2, g2 = fn(u_t, g2)
+            D.fence()
+            forms[name] = {"seconds": D.max_over_ranks(time.perf_counter() - t1), "loss": l2, "grad": g2.clone()}
+        mode = "replicated" if forms["replicated"]["seconds"] < forms["sliced"]["seconds"] else "sliced"
     run = run_sliced if mode == "sliced" else run_replicated
     eng.profile_enable(True)
     eng.profile_reset()
 
-    fence()
+    D.fence()
     t0 = time.perf_counter()
     loss, grad = run(u_t, grad_t)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        all_reduce_(tmax, dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    D.fence()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
     prof = eng.profile()
     eng.profile_enable(False)
-    other_mode = None
-    if trial:
-        oname = "replicated" if mode == "sliced" else "sliced"
-        t_o, l_o, g_o = trial[oname]
-        if g_o is None:
-            other_mode = {"form": oname, "error": l_o}
-        else:
-            other_mode = {"form": oname, "value": world * K / t_o, "ms_per_step": t_o / max(K, 1) * 1e3,
-                          "max_abs_grad_diff_vs_headline_form": float((g_o - grad).abs().max().item()),
-                          "abs_loss_diff_vs_headline_form": abs(l_o - loss),
-                          "trial_of_the_headline_form_ms_per_step": trial[mode][0] / max(K, 1) * 1e3}
-    info = {k: eng.info(k) for k in ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk",
-                                     "zgemm_alg", "real_path", "real_hamiltonians", "sparse_controls", "sparse_generator",
-                                     "control_nonzeros")}
-    general = None
-    if rank == 0 and world == 1 and info["real_path"] > 0 and not a.skip_general_path:
-        # the same chain on the general complex path (any Hermitian H), outside the timed region, short chain
-        Kg = min(K, 4)
-        eng.profile_enable(False)
-        eng.set_option("real_path", 0)
-        ug = torch.from_numpy(u_all[:Kg].copy()).to(dev)
-        gg = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
-        eng.energy_grad(ug[:1], a.dt, psi0, want_final=False, want_energies=False)
-        torch.cuda.synchronize(); tg = time.perf_counter()
-        lg, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gg)
-        torch.cuda.synchronize(); tg = time.perf_counter() - tg
-        eng.set_option("real_path", a.real_path)
-        gr = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
-        lr, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gr)
-        schemes = {}
-        for name, opts in (("sparse_controls_dense_drift", {"sparse_generator": 0}),
-                           ("dense_real_path", {"sparse_generator": 0, "sparse_controls": 0})):
-            # the same chain with the structure of the inputs ignored step by step: what a DENSE drift (then dense controls)
-            # of this size costs on the real path
-            for k_, v_ in opts.items():
-                eng.set_option(k_, v_)
-            gs_ = torch.zeros((Kg, n), dtype=torch.float64, device=dev)
-            eng.energy_grad(ug[:1], a.dt, psi0, want_final=False, want_energies=False)
-            torch.cuda.synchronize(); ts_ = time.perf_counter()
-            ls_, _, _, _ = eng.energy_grad(ug, a.dt, psi0, want_final=False, want_energies=False, grad_out=gs_)
-            torch.cuda.synchronize(); ts_ = time.perf_counter() - ts_
-            schemes[name] = {"steps_per_s": Kg / ts_, "max_abs_grad_diff_vs_headline_scheme": float((gs_ - gr).abs().max().item()),
-                             "abs_loss_diff_vs_headline_scheme": abs(ls_ - lr)}
-        eng.set_option("sparse_generator", -1)
-        eng.set_option("sparse_controls", 1)
-        general = {"steps_per_s": Kg / tg, "chain_steps": Kg, "products_per_step": "11 ZGEMMs (3M) of 8 d^3 + 3 (anti-)Hermitian-output ZGEMMs (half the tiles)",
-                   "other_real_schemes": schemes,
-                   "max_abs_grad_diff_vs_real_path": float((gg - gr).abs().max().item()),
-                   "abs_loss_diff_vs_real_path": abs(lg - lr),
-                   "note": "same inputs with real_path = 0: what a complex Hermitian H of this size costs; the two paths' "
-                           "gradients on the same {}-step chain differ by the amount shown".format(Kg)}
+    info = {k: eng.info(k) for k in INFO_KEYS}
+    opback = bool(eng.info("operator_backward"))
+    forms_out = None
+    if forms:
+        forms_out = {name: {"value": world * K / f["seconds"], "ms_per_step": f["seconds"] / max(K, 1) * 1e3, "loss": f["loss"]}
+                     for name, f in forms.items()}
+        forms_out["max_abs_grad_diff_sliced_vs_replicated"] = float((forms["sliced"]["grad"] - forms["replicated"]["grad"]).abs().max().item())
+        forms_out["abs_loss_diff_sliced_vs_replicated"] = abs(forms["sliced"]["loss"] - forms["replicated"]["loss"])
+        forms_out["note"] = "one untimed trial of each form on the same K-step chain (max over ranks); the timed region ran '{}'".format(mode)
 
-    if rank == 0:
-        z = prof["zgemm"]
-        rg, rs = prof["rgemm"], prof["rsym"]
-
-        def rate(p):
-            return p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
-        per_launch_flops = z["flops"] / max(1, z["launches"])
-        per_launch_ms = z["ms"] / max(1, z["launches"])
-        achieved = z["flops"] / (z["ms"] * 1e-3) / 1e12 if z["ms"] > 0 else 0.0
-        steps_per_s = world * K / elapsed
-        W_alg = 8.0 * d * d * B  # one complex (d x d).(d x B) product
-        out = {
-            "metric": "Trotter steps/sec (fwd+adjoint), n={} qubits batch={}".format(n, B),
-            "value": steps_per_s,
-            "unit": "Trotter steps/s (each step = fwd+adjoint over one GPU's {}-state batch; aggregate over GPUs)".format(B),
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": elapsed / max(K, 1) * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": "BASELINE configs[2]: {}-qubit random Ising H stored dense (d={}), {} controls X_k, "
-                            "B={} states per GPU, fwd + adjoint gradient, fp64 complex, dt={}; timed chain = {} of the "
-                            "{} Trotter steps (batch >= dim: the backward sweep runs in operator form without state checkpoints, "
-                            "so the per-step cost is chain-length independent; otherwise the slice uses the checkpoint "
-                            "stride of the full chain)".format(n, d, n, B, a.dt, K, max(a.chain, K)),
-                "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
-                "chain_steps": K, "dt": a.dt,
-                "parallelism": ("dp{} (batch shards, one all-reduce of loss+dL/du)".format(world) if mode == "replicated" else
-                                "dp{0} over the batch x {0} time slices: operator form, each rank builds and sweeps 1/{0} of "
-                                "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
-                                "(d x d) and of dL/du".format(world)),
-                "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "other_multi_gpu_form": other_mode,
-                "expm": ("cos X + i sin X, Taylor degree {0}: drift and controls sparse, so X_t is sparse -- the powers X^2 .. X^{0} by "
-                         "{1} sparse x dense passes, cos/sin as linear combinations of them (no MFMA product in the step "
-                         "exponential), theta<={2:.3g}".format(int(info["degree"]), int(info["products"]), info["theta"])
-                         if info["sparse_generator"] > 0 else
-                         "cos X + i sin X, Taylor degree {} ({} real symmetric-output products{}), theta<={:.3g}".format(
-                    int(info["degree"]), int(info["products"]),
-                    "; sparse controls: scatter assembly, last reverse-mode level as row dot products" if info["sparse_controls"] > 0 else "",
-                    info["theta"]) if info["real_path"] > 0 else
-                    "Taylor degree {} ({} complex products, {} squarings), theta<={:.3g}".format(
-                        int(info["degree"]), int(info["products"]), int(info["squarings"]), info["theta"])),
-                "path": "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path",
-                "checkpoint_stride": int(info["checkpoint_stride"]), "operator_backward": bool(eng.info("operator_backward")),
-                "trajectory_steps_per_s": steps_per_s * B,
-                "loss": loss, "grad_norm": float(torch.linalg.norm(grad).item()) if hasattr(grad, "norm") else float(np.linalg.norm(grad)),
-            },
-            "roofline": None,  # filled below: the kernel class with the largest share of the timed region
-            "roofline_other": None,
-            "general_complex_path": general,
-            "end_to_end": {
-                "algorithmic_flops_per_step": 3 * W_alg,
-                "algorithmic_tflops": 3 * W_alg * K / elapsed / 1e12,
-                "frac_of_peak": 3 * W_alg * K / elapsed / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                "zgemm_flops_per_step": z["flops"] / max(K, 1),
-                "rgemm_flops_per_step": (rg["flops"] + rs["flops"]) / max(K, 1),
-                "kernel_ms": {k: v["ms"] for k, v in prof.items()},
-                "kernel_launches": {k: v["launches"] for k, v in prof.items()},
-                "hbm_GBps": {k: (v["bytes"] / v["ms"] * 1e-6 if v["ms"] > 0 else 0.0) for k, v in prof.items()
-                             if k not in ("zgemm", "rgemm", "rsym")},
-            },
-        }
-        zg = {
-            "bound": "mfma",
-            "kernel": "zgemm_kernel<128,128,8,2,4,*,*,{}> (batched complex GEMM, v_mfma_f64_16x16x4_f64, {})".format(
-                int(info["zgemm_alg"]), "3M: 3 real MFMAs per complex tile step" if info["zgemm_alg"] else "4M"),
-            "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-            "traffic": TRAFFIC_BYTES_PER_LAUNCH,
-            "launches": z["launches"], "flops_per_launch": per_launch_flops, "ms_per_launch": per_launch_ms,
-            "ms_in_timed_region": z["ms"],
-            "mfma_executed_tflops": achieved * (0.75 if info["zgemm_alg"] else 1.0),
-            "frac_executed": achieved * (0.75 if info["zgemm_alg"] else 1.0) / PEAK_F64_MFMA_TFLOPS,
-            "note": "achieved = sum over the timed region's full-output ZGEMM launches of the ALGORITHMIC 8*M*N*K flops / sum of "
-                    "their HIP-event durations (rank 0). With the 3M complex product the kernel executes 6*M*N*K MFMA "
-                    "flops for 8*M*N*K algorithmic ones, so `frac` can exceed 1; `frac_executed` is the matrix-pipe "
-                    "utilisation. traffic = PMC FETCH/WRITE per launch (profiles/, separate --pmc passes)",
-        }
-        rsy = {
-            "bound": "mfma",
-            "kernel": "rgemm_kernel<128,128,16,4,4,sym> (batched real GEMM, v_mfma_f64_16x16x4_f64, LDS-DMA staged, "
-                      "symmetric-output form: tiles on/above the diagonal + mirror; one- and two-product launches)",
-            "achieved": rate(rs), "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": rate(rs) / PEAK_F64_MFMA_TFLOPS,
-            "traffic": TRAFFIC_RGEMM["rsym"],
-            "launches": rs["launches"], "flops_per_launch": rs["flops"] / max(1, rs["launches"]),
-            "ms_per_launch": rs["ms"] / max(1, rs["launches"]), "ms_in_timed_region": rs["ms"],
-            "note": "achieved = ALGORITHMIC flops of the symmetric-output products (2*K*128*128 per tile on/above the "
-                    "diagonal: the product of two commuting symmetric matrices is symmetric, the mirror half is not "
-                    "computed) / sum of their HIP-event durations (rank 0); equal to the executed MFMA flops. traffic = PMC "
-                    "FETCH/WRITE per launch incl. the fix-up pass (profiles/, separate --pmc passes)",
-            "full_output_form": {"achieved": rate(rg), "frac": rate(rg) / PEAK_F64_MFMA_TFLOPS, "launches": rg["launches"],
-                                 "ms_per_launch": rg["ms"] / max(1, rg["launches"]), "traffic": TRAFFIC_RGEMM["rgemm"]},
-        }
-        sp = prof["spmm"]
-        spm = {
-            "bound": "hbm",
-            "kernel": "rsp_mm_kernel (sparse generator x dense matrix: out[i,:] = sum over nnz(X[i,:]) of w X_m[j,:]; one wave per row)",
-            "achieved": sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
-            "frac": (sp["bytes"] / sp["ms"] * 1e-6 / 8000.0) if sp["ms"] > 0 else 0.0,
-            "traffic": TRAFFIC_SPMM, "launches": sp["launches"], "ms_per_launch": sp["ms"] / max(1, sp["launches"]),
-            "ms_in_timed_region": sp["ms"],
-            "note": "achieved = ALGORITHMIC bytes (operand read once, product written once: 2-3 x 8 d^2) / HIP-event time; the "
-                    "kernel re-reads a partner row per nonzero of X (13 per row at n = 12), mostly from L2 / Infinity Cache: "
-                    "`traffic` is the fabric-side PMC figure per launch",
-        }
-        ranked = sorted([(z["ms"], zg), (rs["ms"], rsy), (sp["ms"], spm)], key=lambda t: -t[0])
-        out["roofline"], out["roofline_other"] = ranked[0][1], ranked[1][1]
-        if world == 1 and not a.skip_other_configs:
-            try:
-                out["other_configs"] = other_configs(dev, a.seed, (n, a.dt, u_all[:K].copy(), psi0, loss))
-            except Exception as e:
-                out["other_configs"] = {"error": str(e)}
-        if world == 1 and not a.skip_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(n, B, a.seed, a.dt, u_all[0])
-            except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
-                out["cpu_baseline"] = {"value": None, "unit": "Trotter steps/s (fwd+adjoint)", "cores": os.cpu_count(),
-                                       "kind": "port", "sample": "failed: {}".format(e)}
-        print(json.dumps(out))
+    if rank != 0:
+        eng.close()
+        return
+    structure = None
+    if world == 1 and not D.on and a.workload == "ising" and info["real_path"] > 0 and not a.skip_general_path:
+        structure = by_input_structure(eng, a, dev, u_all, psi0, grad, loss)
+    blocks = roofline_blocks(prof, info, d)
+    rk = ranked(blocks)
+    steps_per_s = world * K / elapsed
+    W_alg = 8.0 * d * d * B  # one complex (d x d).(d x B) product
+    ex_tf = executed_tflops(blocks, elapsed)
+    structure_note = {
+        "ising": "diagonal Ising drift + X_k controls: real AND sparse -- the engine runs the step exponential as sparse x dense passes "
+                 "(input-structure-specific path; see by_input_structure for dense inputs of the same size)",
+        "dense-real": "dense random real symmetric H0 / H_k: cos X + i sin X on real symmetric-output MFMA products",
+        "dense-complex": "dense random complex Hermitian H0 / H_k: the general complex tape"}[a.workload]
+    out = {
+        "metric": "Trotter steps/sec (fwd+adjoint), n={} qubits batch={}".format(n, B),
+        "value": steps_per_s,
+        "unit": "Trotter steps/s (each step = fwd+adjoint over one GPU's {}-state batch; aggregate over GPUs)".format(B),
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / max(K, 1) * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "backend": D.name(),
+        "config": {
+            "workload": "BASELINE configs[{}]: {}-qubit {} stored dense (d={}), {} controls, B={} states per GPU, fwd + adjoint gradient, "
+                        "fp64 complex, dt={}; timed chain = {} of the {} Trotter steps (batch >= dim: operator-form backward sweep, no state "
+                        "checkpoints, per-step cost independent of the chain length; otherwise the slice uses the checkpoint stride of the "
+                        "full chain)".format(2 if world == 1 else 3, n,
+                                             {"ising": "random Ising H + X_k", "dense-real": "dense random real symmetric H",
+                                              "dense-complex": "dense random complex Hermitian H"}[a.workload], d, n, B, a.dt, K, max(a.chain, K)),
+            "input_structure": structure_note,
+            "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
+            "chain_steps": K, "dt": a.dt,
+            "parallelism": ("dp{} (batch shards, one all-reduce of loss+dL/du)".format(world) if mode == "replicated" else
+                            "dp{0} over the batch x {0} time slices: operator form, each rank builds and sweeps 1/{0} of "
+                            "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
+                            "(d x d) and of dL/du".format(world)),
+            "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "multi_gpu_forms": forms_out,
+            "collectives_forced_at_world_1": force and world == 1,
+            "expm": describe_expm(info),
+            "path": "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path",
+            "checkpoint_stride": int(info["checkpoint_stride"]), "operator_backward": opback,
+            "trajectory_steps_per_s": steps_per_s * B,
+            "loss": loss, "grad_norm": float(torch.linalg.norm(grad).item()) if hasattr(grad, "norm") else float(np.linalg.norm(grad)),
+        },
+        "roofline": rk[0] if rk else None,
+        "roofline_other": rk[1] if len(rk) > 1 else None,
+        "roofline_all_classes": {k: {kk: b[kk] for kk in ("frac", "achieved", "unit", "launches", "ms_per_launch", "share_of_kernel_time")}
+                                 for k, b in blocks.items() if b["launches"] > 0},
+        "by_input_structure": structure,
+        "end_to_end": {
+            "algorithmic_flops_per_step": 3 * W_alg,
+            "algorithmic_tflops": 3 * W_alg * world * K / elapsed / 1e12 / world,
+            "algorithmic_frac_of_peak": 3 * W_alg * K / elapsed / 1e12 / PEAK_F64_MFMA_TFLOPS,
+            "executed_mfma_tflops": ex_tf, "executed_mfma_frac_of_peak": ex_tf / PEAK_F64_MFMA_TFLOPS,
+            "note": "algorithmic = SURVEY 8-D4's 3 x 8 d^2 B flops per fwd+adjoint step (state apply, costate apply, outer product) x steps/s per "
+                    "GPU -- a work-normalised rate, NOT a fraction of what the chip executed: the sparse-generator scheme runs the exponential "
+                    "on HBM-bound passes and the 3M product executes 6 of every 8 flops.  executed_mfma_tflops = the flops the matrix "
+                    "pipe actually executed in the timed region (rank 0, from the per-launch events) / wall time",
+            "kernel_ms": {k: v["ms"] for k, v in prof.items()},
+            "kernel_launches": {k: v["launches"] for k, v in prof.items()},
+            "hbm_GBps": {k: (v["bytes"] / v["ms"] * 1e-6 if v["ms"] > 0 else 0.0) for k, v in prof.items()
+                         if k not in ("zgemm", "rgemm", "rsym", "zherm")},
+        },
+    }
+    if world == 1 and not D.on and not a.skip_other_configs:
+        oc = other_configs(dev, a.seed, (n, a.dt, u_all[:K].copy(), psi0, loss) if a.workload == "ising" else None)
+        for v in oc.values():
+            if isinstance(v, dict):
+                v.pop("_prof", None); v.pop("_info", None)
+        if not a.skip_full_chain and n == 12:
+            oc["full_chain_S{}".format(a.chain)] = full_chain(eng, a, dev, psi0)
+        out["other_configs"] = oc
+    if world == 1 and not D.on and not a.skip_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(n, B, a.seed, a.dt, u_all[0])
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
+            out["cpu_baseline"] = {"value": None, "unit": "Trotter steps/s (fwd+adjoint)", "cores": os.cpu_count(),
+                                   "kind": "port", "sample": "failed: {}".format(e)}
+    print(json.dumps(out))
     eng.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed Trotter steps (default 20; config 2: 1000)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5),
+                    help="3 = headline (BASELINE configs[2]/[3]); 2 = configs[1] (n=8 QAOA forward); 5 = configs[4] (n=18, c64, matrix-free)")
+    ap.add_argument("--workload", choices=("ising", "dense-real", "dense-complex"), default="ising",
+                    help="config 3 inputs: BASELINE's random Ising + X_k (default) or dense random matrices of the same size and norm")
+    ap.add_argument("--qubits", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=None, help="states per GPU (config 5: the WHOLE batch, default 512)")
+    ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-other-configs", action="store_true")
+    ap.add_argument("--skip-full-chain", action="store_true", help="do not run the full S = 2000 chain extra (about a minute)")
+    ap.add_argument("--skip-general-path", action="store_true",
+                    help="do not run the by_input_structure extras (profiling: only the headline path's kernels)")
+    ap.add_argument("--chain", type=int, default=2000,
+                    help="length of the full configuration's chain: the timed slice uses ITS checkpoint stride")
+    ap.add_argument("--real-path", type=int, default=-1,
+                    help="-1 auto (real H -> cos/sin form on real MFMA products), 0 = general complex path only")
+    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated"), default="auto",
+                    help="N > 1: 'sliced' = chain split over time across the ranks (operator form; three collectives), "
+                         "'replicated' = every rank runs the whole chain on its batch shard (one all-reduce); "
+                         "auto = both checked and tried, the faster one timed")
+    ap.add_argument("--launch", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
+    a = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.launch):
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+    D = Dist(a)
+    {2: run_config2, 3: run_config3, 5: run_config5}[a.config](a, D)
+    D.close()  # (only on success: a failing rank must not enter a barrier its peers will never reach -- it exits non-zero)
 
 
 if __name__ == "__main__":

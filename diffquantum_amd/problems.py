@@ -67,6 +67,31 @@ def random_ising_torch(n: int, seed: int, device):
     return H0, Hs, H0.clone()
 
 
+def random_dense_torch(n: int, K: int, seed: int, device, complex_h: bool = False, drift_norm1: float = 12.0,
+                       control_norm1: float = 1.0):
+    """(H0, Hs[K], M) DENSE random matrices built in device memory: real symmetric (stored complex128, imaginary parts
+    exactly zero) or complex Hermitian -- what `set_H` (diffqc.cc:43-67) accepts in general.  Every matrix is scaled to
+    a given 1-norm (drift 12, controls 1: the scale of the Ising + X_k workload, so the step exponential needs the same
+    polynomial degree) -- the structure of the data differs, not the size of the step."""
+    import torch
+    d = 1 << n
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed) + 777)
+
+    def one(norm1):
+        a = torch.randn((d, d), dtype=torch.float64, device=device, generator=gen)
+        if complex_h:
+            a = torch.complex(a, torch.randn((d, d), dtype=torch.float64, device=device, generator=gen))
+            a = a + a.conj().T
+        else:
+            a = torch.complex(a + a.T, torch.zeros((d, d), dtype=torch.float64, device=device))
+        return a * (norm1 / float(a.abs().sum(dim=0).max()))
+
+    H0 = one(drift_norm1)
+    Hs = torch.stack([one(control_norm1) for _ in range(K)]) if K else torch.zeros((0, d, d), dtype=torch.complex128, device=device)
+    return H0, Hs, one(drift_norm1)
+
+
 def random_hermitian_problem(n: int, K: int, seed: int = 0):
     """Dense random complex Hermitian H0, H_k, M (unit-ish norm) for parity tests at small n."""
     rng = np.random.default_rng(seed)
