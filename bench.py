@@ -245,11 +245,15 @@ def roofline_blocks(prof, info, d):
     z, zh, rg, rs, sp = prof["zgemm"], prof["zherm"], prof["rgemm"], prof["rsym"], prof["spmm"]
     alg = "3M: 3 real MFMAs per complex tile step" if three_m else "4M"
     blocks = {
-        "zgemm": mfma("zgemm", z, "zgemm_kernel<128,128,8,2,4,*,*,{}> (batched complex GEMM, v_mfma_f64_16x16x4_f64, {})".format(int(three_m), alg),
+        "zgemm": mfma("zgemm", z, ("zgemm_lin_kernel (complex GEMM, linear form: 128x128 tile, 16 waves x 32x32, LDS-DMA staging, 4 waves/SIMD; "
+                                   "operands without a k-major form stay on zgemm_kernel<128,128,8,2,4>), v_mfma_f64_16x16x4_f64, {}"
+                                   if int(info["zgemm_alg"]) == 2 and d >= 1024 else
+                                   "zgemm_kernel<128,128,8,2,4,*,*,{}> (batched complex GEMM, v_mfma_f64_16x16x4_f64, {})".format(int(three_m), "{}")).format(alg),
                       f3, per(z, "bytes"),
                       "achieved = EXECUTED MFMA flops (6*M*N*K per launch in the 3M form, 8*M*N*K in 4M) / sum of the launches' HIP-event "
                       "durations (rank 0); achieved_algorithmic = 8*M*N*K / the same time (can exceed the peak in the 3M form)"),
-        "zherm": mfma("zherm", zh, "zgemm_kernel<...,HERM> ((anti-)Hermitian-output complex GEMM: tiles on/above the diagonal + mirror, K-split tail, {})".format(alg),
+        "zherm": mfma("zherm", zh, "{} ((anti-)Hermitian-output complex GEMM: tiles on/above the diagonal + mirror, K-split tail, {})".format(
+                          "zgemm_lin_kernel<.,HERM>" if int(info["zgemm_alg"]) == 2 and d >= 1024 else "zgemm_kernel<...,HERM>", alg),
                       f3 * tri, per(zh, "bytes"),
                       "executed = the {}/{} tiles on and above the diagonal x (6 or 8)*K*128*128; algorithmic = 8*M*N*K of the delivered product".format(
                           nt * (nt + 1) // 2, nt * nt)),

@@ -42,6 +42,10 @@ struct ZgemmArgs {
   int batch;
   double alpha, beta;
   int opA, opB;         // 0 = as stored, 1 = conjugate transpose
+  // hintA (with opA == 0): what the caller knows about the stored A -- 0 nothing, 1 complex symmetric (A^T = A),
+  // 2 Hermitian, 3 anti-Hermitian.  A hint lets the launcher read A k-major (A = A^T, A^H, -A^H) and take the
+  // linear-form kernel (zgemm_lin.hip); results do not depend on it for operands that have the stated property.
+  int hintA = 0;
   // herm: 0 = general output; +1 / -1 = the caller asserts that the product is Hermitian / anti-Hermitian (e.g. X^H W X
   // for (anti-)Hermitian W): only the tiles on and above the diagonal are computed, the mirror image is +-conj (M == N)
   int herm;
@@ -51,8 +55,12 @@ struct ZgemmArgs {
 };
 
 // n_cu: compute units of the device (tail splitting of the herm form)
+// alg: 0 = 4M, 1 = 3M, 2 = 3M with the linear-form kernel (zgemm_lin.hip) wherever operand forms and shapes allow (fp64)
 template <class T>
 hipError_t zgemm_launch(const ZgemmArgs<T>& g, hipStream_t st, int force_tile, int alg, int n_cu = 256);
+// linear-form complex GEMM (zgemm_lin.hip): op(A) = A^T / A^H read k-major, B as stored; whole 128-tiles only
+bool zgemm_lin_eligible(const ZgemmArgs<double>& g);
+hipError_t zgemm_lin_launch(ZgemmArgs<double> g, int conj_a, hipStream_t st, int n_cu);
 int zgemm_pick_tile(int M, int N, int batch);
 
 // ---- elementwise / reduction kernels (elementwise.hip) ------------------------------

@@ -96,6 +96,7 @@ struct TapeOp {
   int kind;  // 0 = LIN, 1 = MUL
   int herm;  // MUL: +1 / -1 if the product is Hermitian / anti-Hermitian whenever A is anti-Hermitian (even / odd
              // polynomial in A with real coefficients), 0 otherwise -> (anti-)Hermitian output form of the ZGEMM
+  int apar;  // MUL: the same parity of the LEFT operand (it can then be read k-major: linear-form ZGEMM)
   int dst, a, b;
   int nlin;
   int lsrc[6];
@@ -219,6 +220,7 @@ ExpmPlan make_plan(int m, int q, int s) {
       if (lp != 2 && lp != pp) pp = 0;
       par[o.dst] = pp;
       o.herm = pp;
+      o.apar = par[o.a];
     }
     p.nprod += o.kind;
   }
@@ -303,7 +305,7 @@ struct Ctx : dq_ctx {
   std::vector<double> nHk;
   // options
   double checkpoint_bytes = 0.0, chunk_bytes = 0.0, expm_tol = 0.0, herm_tol = 0.0;
-  int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 1, compose_mode = -1, skew_trick = 1;
+  int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 2, compose_mode = -1, skew_trick = 1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0, last_tpar = 0;
   // workspace
@@ -381,6 +383,8 @@ struct Ctx : dq_ctx {
   }
 
   // herm: 0 general output; +1 / -1 the product is known to be Hermitian / anti-Hermitian (upper tiles + mirror)
+  // opA: 0 = as stored, 1 = conjugate transpose; 2 / 3 / 4 = as stored AND known to be complex symmetric / Hermitian /
+  // anti-Hermitian (a hint: the kernel may then read A k-major -- ZgemmArgs::hintA)
   void zgemm(int opA, int opB, int M, int N, int Kd, double alpha, const T2* A, long lda, long sA,
              const T2* B, long ldb, long sB, double beta, T2* C, long ldc, long sC, int batch, int herm = 0) {
     dq::ZgemmArgs<T> g;
@@ -390,7 +394,8 @@ struct Ctx : dq_ctx {
     g.sA = sA; g.sB = sB; g.sC = sC;
     g.batch = batch;
     g.alpha = alpha; g.beta = beta;
-    g.opA = opA; g.opB = opB;
+    g.opA = opA == 1 ? 1 : 0; g.opB = opB;
+    g.hintA = opA >= 2 ? opA - 1 : 0;
     g.herm = herm;
     g.ws = nullptr;
     g.ws_elems = 0;
@@ -486,7 +491,10 @@ typename dq::Cx<T>::type* expm_forward(Ctx<T>* c, const ExpmPlan& p, int n, bool
       c->lincomb(dst, o.nlin, x, o.lc, o.cI, n, false);
     }
     // a_antiherm (the chain: A = -i dt H with Hermitian H): even / odd powers of A are Hermitian / anti-Hermitian
-    if (o.kind == 1) c->mm(0, 0, c->mat(o.a, n), c->mat(o.b, n), dst, has_lin ? 1.0 : 0.0, n, a_antiherm ? o.herm : 0);
+    // (and the left operand's parity says whether it is Hermitian (opA hint 3) or anti-Hermitian (4) as stored)
+    if (o.kind == 1)
+      c->mm(a_antiherm && o.apar ? (o.apar > 0 ? 3 : 4) : 0, 0, c->mat(o.a, n), c->mat(o.b, n), dst, has_lin ? 1.0 : 0.0, n,
+            a_antiherm ? o.herm : 0);
   }
   c->last_degree = p.m;
   c->last_squarings = p.s;
@@ -541,7 +549,7 @@ typename dq::Cx<T>::type* expm_backward(Ctx<T>* c, const ExpmPlan& p, int n, boo
       c->timed(DQ_PROF_LINCOMB, 4.0 * c->nn() * n, 3.0 * by, [&] {
         return dq::tcombine_launch<T>(S, db, c->d, 0.5, 0.5, 0, (long)c->nn(), n, c->st);
       });
-      c->mm(0, 0, S, c->mat(0, n), X, 0.0, n);
+      c->mm(3, 0, S, c->mat(0, n), X, 0.0, n);  // S = herm(vbar): Hermitian as stored
       flush(0);  // pending linear contributions first, so that `accumulate` below is well defined
       c->timed(DQ_PROF_LINCOMB, 4.0 * c->nn() * n, (init[0] ? 4.0 : 3.0) * by, [&] {
         return dq::tcombine_launch<T>(adj(0), X, c->d, -1.0, 1.0, init[0] ? 1 : 0, (long)c->nn(), n, c->st);
@@ -1082,7 +1090,8 @@ TT* compose_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
       const int pairs = m / 2;
       T2* Y = c->mat(SLOT_TREE + (lvl & 1), (size_t)(pairs + (m & 1)));
       const long s2 = 2 * (long)c->nn();
-      c->zgemm(0, 0, d, d, d, 1.0, X + c->nn(), d, s2, X, d, s2, 0.0, Y, d, (long)c->nn(), pairs);
+      // (level 0 multiplies the propagators themselves: complex symmetric on the real path, U = cos X + i sin X)
+      c->zgemm(lvl == 0 && p.rq > 0 ? 2 : 0, 0, d, d, d, 1.0, X + c->nn(), d, s2, X, d, s2, 0.0, Y, d, (long)c->nn(), pairs);
       if (m & 1)
         HIPCK(hipMemcpyAsync(Y + (size_t)pairs * c->nn(), X + (size_t)(m - 1) * c->nn(), c->mat_bytes(),
                              hipMemcpyDeviceToDevice, c->st));
@@ -1095,7 +1104,7 @@ TT* compose_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
       HIPCK(hipMemcpyAsync(running, X, c->mat_bytes(), hipMemcpyDeviceToDevice, c->st));
     } else {
       T2* nxt = c->mat(running == c->mat(SLOT_TREE + 2, 1) ? SLOT_TREE + 3 : SLOT_TREE + 2, 1);
-      c->zgemm(0, 0, d, d, d, 1.0, X, d, 0, running, d, 0, 0.0, nxt, d, 0, 1);
+      c->zgemm(n == 1 && p.rq > 0 ? 2 : 0, 0, d, d, d, 1.0, X, d, 0, running, d, 0, 0.0, nxt, d, 0, 1);
       running = nxt;
     }
   }
@@ -1124,7 +1133,7 @@ int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
     const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
     T2* U = build_propagators(c, p, c0, n, dt);
     for (int t = 0; t < n; ++t) {
-      c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
+      c->zgemm(p.rq > 0 ? 2 : 0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
                (T2*)c->psi[cur ^ 1].p, B, 0, 1);
       cur ^= 1;
     }
@@ -1160,7 +1169,7 @@ template <class T>
 void do_energy(Ctx<T>* c, const TT* psi_dev, int B, TT* lam_out /*2 M psi*/, double* energies, double* total) {
   typedef TT T2;
   const int d = c->d;
-  c->zgemm(0, 0, d, B, d, 2.0, (const T2*)c->M.p, d, 0, psi_dev, B, 0, 0.0, lam_out, B, 0, 1);
+  c->zgemm(3, 0, d, B, d, 2.0, (const T2*)c->M.p, d, 0, psi_dev, B, 0, 0.0, lam_out, B, 0, 1);  // M Hermitian (checked at set)
   c->e_dev.ensure(sizeof(double) * ((size_t)B + 1));
   c->part.ensure(sizeof(double) * (size_t)dq::coldot_chunks(d) * B);
   c->timed(DQ_PROF_OTHER, 4.0 * d * B, 4.0 * sizeof(T) * d * B,
@@ -1358,7 +1367,7 @@ TT* opback_chunk(Ctx<T>* c, const TT* U, TT* G, TT* W, int n, bool skew_w) {
   for (int t = n - 1; t >= 0; --t) {
     const T2* Ut = U + (size_t)t * c->nn();
     T2* Gt = G + (size_t)t * c->nn();
-    c->zgemm(0, 0, d, d, d, 1.0, W, d, 0, Ut, d, 0, 0.0, Gt, d, 0, 1);  // G_t = W_{t+1} U_t
+    c->zgemm(skew_w ? 4 : 0, 0, d, d, d, 1.0, W, d, 0, Ut, d, 0, 0.0, Gt, d, 0, 1);  // G_t = W_{t+1} U_t (W anti-Hermitian as stored)
     T2* Wn = c->mat(W == c->mat(SLOT_TREE, 1) ? SLOT_TREE + 1 : SLOT_TREE, 1);
     c->zgemm(1, 0, d, d, d, 1.0, Ut, d, 0, Gt, d, 0, 0.0, Wn, d, 0, 1, skew_w ? -1 : 0);  // W_t = U_t^H G_t
     W = Wn;
@@ -1500,7 +1509,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
           c->timed(DQ_PROF_OTHER, 0.0, 2.0 * bytes,
                    [&] { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->st); });
         }
-        c->zgemm(0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
+        c->zgemm(p.rq > 0 ? 2 : 0, 0, d, B, d, 1.0, U + (size_t)t * c->nn(), d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0,
                  (T2*)c->psi[cur ^ 1].p, B, 0, 1);
         cur ^= 1;
       }
@@ -1849,10 +1858,13 @@ void do_zgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, co
   if (M < 0 || N < 0 || K < 0 || batch < 0) fail(DQ_ERR_INVALID, "negative dimension");
   if (herm < -1 || herm > 1) fail(DQ_ERR_INVALID, "herm must be 0, +1 (Hermitian product) or -1 (anti-Hermitian)");
   if (herm && M != N) fail(DQ_ERR_INVALID, "the (anti-)Hermitian output form needs M == N");
-  if ((opA | opB) & ~1) fail(DQ_ERR_INVALID, "op must be 0 (N) or 1 (conjugate transpose)");
+  if (opA < 0 || opA > 4 || (opB & ~1))
+    fail(DQ_ERR_INVALID, "opA must be 0 (N), 1 (conjugate transpose) or 2 / 3 / 4 (N, known complex symmetric / Hermitian / "
+                         "anti-Hermitian); opB 0 or 1");
+  if (opA >= 2 && M != K) fail(DQ_ERR_INVALID, "a symmetry hint needs a square A");
   if (M == 0 || N == 0 || batch == 0) return;
   if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
-  const long ar = opA ? K : M, ac = opA ? M : K;  // stored shape of A
+  const long ar = opA == 1 ? K : M, ac = opA == 1 ? M : K;  // stored shape of A
   const long br = opB ? N : K, bc = opB ? K : N;
   if (lda < ac || ldb < bc || ldc < N) fail(DQ_ERR_INVALID, "leading dimension smaller than the row length");
   auto span = [&](long rows, long ld, long cols, long stride) -> size_t {
@@ -1887,7 +1899,7 @@ void do_rgemm(Ctx<T>* c, int opA, int opB, int M, int N, int K, double alpha, co
   if (M == 0 || N == 0 || batch == 0) return;
   if (!A || !B || !C) fail(DQ_ERR_INVALID, "null matrix pointer");
   if (sym) { opA = 1; opB = 0; }
-  const long ar = opA ? K : M, ac = opA ? M : K;  // stored shape of A
+  const long ar = opA == 1 ? K : M, ac = opA == 1 ? M : K;  // stored shape of A
   const long br = opB ? N : K, bc = opB ? K : N;
   if (lda < ac || ldb < bc || ldc < N) fail(DQ_ERR_INVALID, "leading dimension smaller than the row length");
   auto span = [&](long rows, long ld, long cols, long stride) -> size_t {
@@ -2012,7 +2024,7 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->skew_trick = v != 0 ? 1 : 0;
   } else if (s == "zgemm_alg") {
     const int a = (int)v;
-    if (a != 0 && a != 1) fail(DQ_ERR_INVALID, "zgemm_alg must be 0 (4M) or 1 (3M)");
+    if (a < 0 || a > 2) fail(DQ_ERR_INVALID, "zgemm_alg must be 0 (4M), 1 (3M) or 2 (3M + linear-form kernel)");
     c->zgemm_alg = a;
   } else fail(DQ_ERR_INVALID, "unknown option '" + s + "'");
 }

@@ -377,6 +377,11 @@ __global__ void __launch_bounds__(256) zgemm_fixup_kernel(ZgemmArgs<T> g) {
   }
 }
 
+// fix-up pass for the 128-tile herm form of zgemm_lin.hip (same workspace layout)
+void zgemm_fixup_launch_128(const ZgemmArgs<double>& g, int rem, hipStream_t st) {
+  hipLaunchKernelGGL((zgemm_fixup_kernel<double, 128, 128>), dim3(128 * 128 / 256, (unsigned)rem), dim3(256), 0, st, g);
+}
+
 template <class T, int BM, int BN, int BK, int WGM, int WGN, int ALG3M>
 static void launch_cfg(ZgemmArgs<T> g, hipStream_t st, int n_cu) {
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
@@ -447,8 +452,16 @@ hipError_t zgemm_launch<double>(const ZgemmArgs<double>& g, hipStream_t st, int 
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
   if (g.herm && g.M != g.N) return hipErrorInvalidValue;
   const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
+  if (tile == 128 && alg == 2 && g.opB == 0 && (g.opA == 1 || g.hintA != 0) && zgemm_lin_eligible(g)) {
+    // left operand readable k-major: A^H as asked, or A = A^T / A^H / -A^H by the caller's hint
+    if (g.opA == 1 || g.hintA == 2) return zgemm_lin_launch(g, 1, st, n_cu);
+    if (g.hintA == 1) return zgemm_lin_launch(g, 0, st, n_cu);
+    ZgemmArgs<double> h = g;
+    h.alpha = -g.alpha;
+    return zgemm_lin_launch(h, 1, st, n_cu);
+  }
   if (tile == 128) {
-    if (alg == 1) launch_cfg<double, 128, 128, 8, 2, 4, 1>(g, st, n_cu);
+    if (alg >= 1) launch_cfg<double, 128, 128, 8, 2, 4, 1>(g, st, n_cu);
     else launch_cfg<double, 128, 128, 8, 2, 4, 0>(g, st, n_cu);
   } else if (tile == 64) launch_cfg<double, 64, 64, 8, 2, 2, 0>(g, st, n_cu);
   else launch_cfg<double, 32, 32, 8, 1, 1, 0>(g, st, n_cu);

@@ -353,7 +353,7 @@ class Engine:
         nb = A.shape[0]
         if B.shape[0] != nb:
             raise ValueError("batch mismatch")
-        M, K = (A.shape[2], A.shape[1]) if opA else (A.shape[1], A.shape[2])
+        M, K = (A.shape[2], A.shape[1]) if opA == 1 else (A.shape[1], A.shape[2])  # opA 2/3/4: as stored + symmetry hint
         K2, N = (B.shape[2], B.shape[1]) if opB else (B.shape[1], B.shape[2])
         if K != K2:
             raise ValueError("inner dimensions differ: {} vs {}".format(K, K2))

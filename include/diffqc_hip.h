@@ -119,7 +119,10 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   plan_steps         size the checkpoint stride for a chain of this many steps even if the call is shorter
  *   chunk_bytes        workspace for the steps whose propagators are built in one batched pass; 0 = 8 GiB, or 10 % of
  *                      the free HBM if that is more and dim <= 1024
- *   zgemm_alg          0 = four real MFMAs per complex tile step, 1 = the three-multiplication "3M" form (128x128 tile)
+ *   zgemm_alg          0 = four real MFMAs per complex tile step, 1 = the three-multiplication "3M" form (128x128 tile),
+ *                      2 (default) = 3M and, for whole 128-tiles at dim >= 1024 whose left operand can be read k-major
+ *                      (A^H, or an A the engine knows to be complex symmetric / (anti-)Hermitian), the 16-wave
+ *                      linear-form kernel (csrc/zgemm_lin.hip)
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
@@ -179,7 +182,10 @@ int dq_slice_backward(dq_ctx* ctx, const double* u, int n_steps, double dt, cons
                       void* W_start);
 
 /* Building blocks, exported for parity tests and reuse. */
-/* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements. */
+/* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements.
+ * opA may also be 2 / 3 / 4: A as stored (like 0), square, and KNOWN by the caller to be complex symmetric (A^T = A) /
+ * Hermitian / anti-Hermitian -- a hint that lets the kernel read A k-major (linear-form kernel); the result is the same
+ * as with opA = 0 for operands that have the stated property. */
 int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch);
 /* The same with herm = +1 / -1: the caller asserts that the product is Hermitian / anti-Hermitian (e.g. X^H W X for an

@@ -187,3 +187,54 @@ def test_expm_vjp_matches_frechet(d, norm, oracle):
         lhs = np.real(np.vdot(G[z], scipy.linalg.expm_frechet(A[z], E, compute_expm=False)))
         rhs = np.real(np.vdot(Ab[z], E))
         assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))
+
+
+# ---- linear-form complex GEMM (csrc/zgemm_lin.hip): 16 waves, LDS-DMA staging, op(A) read k-major -----------------
+
+def _structured(rng, n, kind):
+    a = _rand(rng, n, n)
+    return {1: a + a.T, 2: a + a.conj().T, 3: a - a.conj().T}[kind]
+
+
+@pytest.mark.parametrize("case", ["AH_B", "symmetric", "hermitian", "antihermitian", "AH_B_wide", "AH_B_deep_k"])
+def test_zgemm_linear_form_matches_numpy(eng16, case):
+    """Whole 128-tiles at >= 64 tiles take the linear-form kernel when op(A) = A^H or A carries a symmetry hint
+    (opA 2 / 3 / 4 = as stored and complex symmetric / Hermitian / anti-Hermitian); same product as numpy, and the same
+    BITS as the general 3M kernel (zgemm_alg = 1), whose arithmetic order it keeps."""
+    rng = np.random.default_rng(len(case))
+    M, N, K = {"AH_B_wide": (1024, 2048, 1024), "AH_B_deep_k": (1024, 1024, 1040)}.get(case, (1024, 1024, 1024))
+    if case.startswith("AH_B"):
+        A, opA, op = _rand(rng, K, M), 1, lambda a: a.conj().T
+    else:
+        hint = {"symmetric": 1, "hermitian": 2, "antihermitian": 3}[case]
+        A, opA, op = _structured(rng, 1024, hint), hint + 1, lambda a: a
+    B = _rand(rng, K, N)
+    C0 = _rand(rng, M, N)
+    got = eng16.zgemm(A, B, opA=opA, alpha=0.75, beta=-0.5, C_in=C0)
+    ref = 0.75 * (op(A) @ B) - 0.5 * C0
+    bound = np.finfo(np.float64).eps * K * np.max(np.abs(A)) * np.max(np.abs(B)) * 8
+    assert np.max(np.abs(got - ref)) < bound
+    eng16.set_option("zgemm_alg", 1)
+    try:
+        old = eng16.zgemm(A, B, opA=1 if opA == 1 else 0, alpha=0.75, beta=-0.5, C_in=C0)
+    finally:
+        eng16.set_option("zgemm_alg", 2)
+    if case in ("AH_B", "AH_B_wide", "AH_B_deep_k", "hermitian"):
+        assert np.max(np.abs(got - old)) < bound
+    assert np.max(np.abs(old - ref)) < bound
+
+
+@pytest.mark.parametrize("herm", [1, -1])
+def test_zgemm_linear_form_hermitian_output(eng16, herm):
+    """X^H W X for (anti-)Hermitian W at d = 1024 / 2048: triangle tiles + mirror on the linear-form kernel; 2048 has 136
+    triangle tiles (no K-split tail on 256 slots), the engine's d = 4096 chain products exercise the tail + fix-up pass
+    (tests/test_gpu_baseline_configs.py)."""
+    for d in (1024, 2048):
+        rng = np.random.default_rng(d + herm)
+        X = _rand(rng, d, d) / np.sqrt(d)
+        W = _structured(rng, d, 2 if herm > 0 else 3)
+        Z = W @ X
+        got = eng16.zgemm(X, Z, opA=1, herm=herm)
+        ref = X.conj().T @ Z
+        assert np.max(np.abs(got - ref)) < 1e-11 * np.max(np.abs(ref))
+        assert np.array_equal(got, herm * got.conj().T)          # exactly (anti-)Hermitian as stored
