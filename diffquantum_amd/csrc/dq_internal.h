@@ -205,10 +205,11 @@ hipError_t rsp_contract_launch(const T* Sb, const T* P, const T* Yb, const T* X,
 
 // ---- sparse generator (drift and controls sparse; realpath.hip) ----
 // out[z][i][:] = ca * Add[z][i][:] + sum_{e in row i} w_e V[z][col_e][:],  w_e = -dt (kid_e < 0 ? 1 : u[z*K + kid_e]) val_e
-// (Add may be null)
+// (Add may be null). slab: allow the XCD-slab form (16-B column blocks in 8 slabs) when d and the alignments permit
 template <class T>
 hipError_t rsp_mm_launch(T* out, const T* V, const T* Add, double ca, long stride, int d, const long* rowptr, const int* col,
-                         const int* kid, const double* val, const double* u, int K, int batch, double dt, hipStream_t st);
+                         const int* kid, const double* val, const double* u, int K, int batch, double dt, int slab,
+                         hipStream_t st);
 // nzval[z][e] = val_e (direct_e + sum_l <G[l][z][i,:], Xp[l][z][j,:]>) for the control entries (0 for drift entries);
 // direct_e = dc D[z][i][j] + sum_{e' in row i} w_e' G2[z][col_e'][j] if D is given
 template <class T>
@@ -216,11 +217,11 @@ hipError_t rsp_levels_launch(const T* const* G, const T* const* Xp, int nl, cons
                              int d, const long* rowptr, const int* col, const int* kid, const double* val, const double* u,
                              int K, int batch, double dt, long nnz, double* nzval, hipStream_t st);
 // rsp_mm_launch with the gradient level fused in: nzacc[z][e] (+)= <V[z][col_e,:], Xm[z][i,:]> for every entry e of row i
-// (out may be null: dot products only)
+// (out may be null: dot products only). part: batch * 8 * nnz doubles of scratch for the XCD-slab form, or null
 template <class T>
 hipError_t rsp_mm_dot_launch(T* out, const T* V, const T* Add, double ca, const T* Xm, long stride, int d, const long* rowptr,
                              const int* col, const int* kid, const double* val, const double* u, int K, int batch, double dt,
-                             long nnz, double* nzacc, int accumulate, hipStream_t st);
+                             long nnz, double* nzacc, int accumulate, double* part, hipStream_t st);
 // nzval[z][e] = val_e (nzacc[z][e] + dc D[z][j][i] + sum_{p in row j} w_p G2[z][col_p][i]) for control entries (i, j), else 0
 template <class T>
 hipError_t rsp_finish_launch(const double* nzacc, const T* D, const T* G2, double dc, long stride, int d, const long* rowptr,

@@ -290,7 +290,7 @@ struct Ctx : dq_ctx {
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
   // sparse control Hamiltonians (real path; realpath.hip): the nonzeros of all H_k in one CSR by row, and the same
   // entries grouped by control; sparse_mode: -1 auto (total nonzeros <= sparse_fill * dim), 0 off
-  DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval, sp_nzacc;
+  DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval, sp_nzacc, sp_part;
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
   bool sparse_h = false;   // a CSR exists (controls, and the drift too if sparse_x)
@@ -305,6 +305,7 @@ struct Ctx : dq_ctx {
   std::vector<double> nHk;
   // options
   double checkpoint_bytes = 0.0, chunk_bytes = 0.0, expm_tol = 0.0, herm_tol = 0.0;
+  int slab_spmm = 1;
   int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 2, compose_mode = -1, skew_trick = 1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0, last_tpar = 0;
@@ -666,7 +667,7 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
       c->timed(DQ_PROF_SPMM, 2.0 * c->sp_nnz * c->d * n, bym, [&] {
         return dq::rsp_mm_launch<T>(Xn, Xp[m], (const T*)nullptr, 0.0, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
                                     (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
-                                    c->u_dev.d() + (size_t)c0 * c->K, c->K, n, dts, c->st);
+                                    c->u_dev.d() + (size_t)c0 * c->K, c->K, n, dts, c->slab_spmm, c->st);
       });
       Xp[m + 1] = Xn;
     }
@@ -822,6 +823,8 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
   if (c->fuse_levels) {
     c->sp_nzacc.ensure(sizeof(double) * nz * n);
     double* nzacc = (double*)c->sp_nzacc.p;
+    c->sp_part.ensure(sizeof(double) * nz * n * 8);  // per-slab dot products of the XCD-slab form
+    double* part = c->slab_spmm ? (double*)c->sp_part.p : nullptr;
     bool started = false;
     for (int m = np - 1; m >= 1; --m) {
       T* dst = m >= 2 ? c->rmat(SLOT_ADJ + spx_slot(m), n) : nullptr;  // level 1: dot products only
@@ -833,7 +836,7 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
       c->timed(DQ_PROF_SPMM, 4.0 * c->sp_nnz * c->d * n, m >= 2 ? bym : 0.5 * bym, [&] {
         return dq::rsp_mm_dot_launch<T>(dst, src, add, ca, xm, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
                                         (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
-                                        c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->sp_nnz, nzacc, accf, c->st);
+                                        c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->sp_nnz, nzacc, accf, part, c->st);
       });
       started = true;
       if (m >= 2) Xb[m] = dst;
@@ -852,7 +855,7 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
       c->timed(DQ_PROF_SPMM, 2.0 * c->sp_nnz * c->d * n, 0.75 * bym, [&] {
         return dq::rsp_mm_launch<T>(dst, src, add, ca, (long)c->nn(), c->d, (const long*)c->sp_rowptr.p,
                                     (const int*)c->sp_col.p, (const int*)c->sp_kid.p, (const double*)c->sp_val.p,
-                                    c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->st);
+                                    c->u_dev.d() + (size_t)c0 * K, K, n, dts, c->slab_spmm, c->st);
       });
       Xb[m] = dst;
     }
@@ -2020,6 +2023,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->fuse_levels = v != 0 ? 1 : 0;
   } else if (s == "sparse_generator") {  // drift and controls sparse: -1 auto (dim >= 64 nonzeros-per-row), 0 off, 1 whenever possible
     c->sparse_gen_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "slab_spmm") {  // sparse x dense passes in XCD-slab form (1, default) or one wave per whole row (0)
+    c->slab_spmm = v != 0 ? 1 : 0;
   } else if (s == "skew_trick") {
     c->skew_trick = v != 0 ? 1 : 0;
   } else if (s == "zgemm_alg") {

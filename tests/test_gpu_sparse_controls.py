@@ -375,3 +375,61 @@ def test_sparse_generator_fused_levels_equal_separate_contraction(q):
         e.set_option("fuse_levels", 0)
         l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
     assert l1 == l0 and np.array_equal(f1, f0) and np.max(np.abs(g1 - g0)) < 1e-13 * max(1.0, np.abs(g0).max())
+
+
+# ---- XCD-slab form of the sparse x dense passes (dimension a multiple of 1024 in fp64, 2048 in fp32) ----------------
+
+def _slab_problem(d, seed):
+    """Sparse drift (diagonal + off-diagonal pairs) and two sparse controls at a slab-eligible dimension: one row/column with
+    ~100 nonzeros (more than the 64-entry lane staging of the product pass and than the 16-entry rounds of the fused dot
+    pass), an empty row, rows with 1-3 entries."""
+    rng = np.random.default_rng(seed)
+    H0 = np.diag(rng.standard_normal(d))
+    Hs = np.zeros((2, d, d))
+    for _ in range(d):
+        i, j = rng.integers(0, d, 2)
+        v = rng.standard_normal()
+        H0[i, j] += v
+        if i != j:
+            H0[j, i] += v
+    v = rng.standard_normal(d) * (rng.random(d) < 0.1)
+    Hs[0, 5, :] += v
+    Hs[0, :, 5] += v
+    for i in range(0, d - 1, 2):
+        Hs[1, i, i + 1] = Hs[1, i + 1, i] = rng.standard_normal()
+    for X in (H0, Hs[0], Hs[1]):
+        X[d // 2, :] = 0
+        X[:, d // 2] = 0
+    M = np.diag(rng.standard_normal(d))
+    return H0.astype(complex), Hs.astype(complex), M.astype(complex)
+
+
+def test_sparse_generator_slab_form_matches_row_form_and_oracle(oracle):
+    d, B, S, dt = 1024, 6, 2, 0.002
+    H0, Hs, M = _slab_problem(d, 3)
+    assert np.count_nonzero(Hs[0, 5]) + np.count_nonzero(H0[5]) > 64
+    u = np.random.default_rng(1).uniform(-1, 1, (S, 2))
+    psi0 = _states(d, B, seed=4)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    res = {}
+    for compose in (1, 0):
+        for slab in (1, 0):
+            with _engine(H0, Hs, M, sparse_generator=1, slab_spmm=slab, compose=compose) as e:
+                l, g, f, _ = e.energy_grad(u, dt, psi0)
+                assert e.info("sparse_generator") == 1 and e.info("operator_backward") == compose
+            assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL and np.max(np.abs(f - rf)) < TOL, (compose, slab)
+            res[(compose, slab)] = (l, g, f)
+        (l1, g1, f1), (l0, g0, f0) = res[(compose, 1)], res[(compose, 0)]
+        assert abs(l1 - l0) < 1e-12 * B and np.max(np.abs(g1 - g0)) < 1e-13 and np.max(np.abs(f1 - f0)) < 1e-14
+
+
+def test_sparse_generator_slab_form_fp32(oracle):
+    d, B, S, dt = 2048, 4, 2, 0.002
+    H0, Hs, M = _slab_problem(d, 9)
+    u = np.random.default_rng(2).uniform(-1, 1, (S, 2))
+    psi0 = _states(d, B, seed=5)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, dtype="c64", sparse_generator=1) as e:
+        l, g, f, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("sparse_generator") == 1
+    assert abs(l - rl) < 1e-4 * B and np.max(np.abs(g - rg)) < 1e-4 and np.max(np.abs(f - rf)) < 1e-4

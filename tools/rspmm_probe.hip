@@ -51,8 +51,10 @@ int main(int argc, char** argv) {
     printf("%-40s %.4f ms/launch  (%.0f GB/s algorithmic: 3 x 8 d^2 B)%s\n", name, ms / reps, 3.0 * nn * 8 / (ms / reps * 1e-3) / 1e9,
            err == hipSuccess ? "" : hipGetErrorString(err));
   };
-  timeit("library rsp_mm_kernel", [&](double* o) {
-    (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 0); }, O0);
+  timeit("library rsp_mm_kernel (one wave per row)", [&](double* o) {
+    (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 0, 0); }, O0);
+  timeit("library rsp_mm_slab_kernel", [&](double* o) {
+    (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 1, 0); }, O1);
 #ifndef PROBE_ONLY_OLD
   std::vector<double> h0(nn), h1(nn);
   (void)hipMemcpy(h0.data(), O0, nn * 8, hipMemcpyDeviceToHost);
