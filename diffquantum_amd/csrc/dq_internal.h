@@ -119,9 +119,10 @@ hipError_t mc_shift_launch(const typename Cx<T>::type* phi, const typename Cx<T>
                            typename Cx<T>::type* out, hipStream_t st);
 // out[0] = sum_b e[b]  (single block, deterministic)
 hipError_t sum_launch(const double* e, int n, double* out, hipStream_t st);
-// colsum[j] = sum_i |X[i][j]|  (for the 1-norm), d x d
+// colsum[j] = sum_i |X[i][j]|  (for the 1-norm), d x d; part: colabs_scratch_doubles(d) doubles (two-stage, fixed order)
 template <class T>
-hipError_t colabs_launch(const typename Cx<T>::type* X, int d, double* colsum, hipStream_t st);
+hipError_t colabs_launch(const typename Cx<T>::type* X, int d, double* colsum, double* part, hipStream_t st);
+int colabs_scratch_doubles(int d);
 // max |X - X^H| over the matrix -> out[0] (Hermiticity check)
 template <class T>
 hipError_t herm_defect_launch(const typename Cx<T>::type* X, int d, double* out, hipStream_t st);

@@ -900,8 +900,8 @@ void out_copy(Ctx<T>* c, void* dst, const void* src_dev, size_t bytes) {
 
 template <class T>
 double norm1_dev(Ctx<T>* c, const TT* X) {
-  c->scratch.ensure(sizeof(double) * (size_t)c->d);
-  HIPCK(dq::colabs_launch<T>(X, c->d, c->scratch.d(), c->st));
+  c->scratch.ensure(sizeof(double) * ((size_t)c->d + (size_t)dq::colabs_scratch_doubles(c->d)));
+  HIPCK(dq::colabs_launch<T>(X, c->d, c->scratch.d(), c->scratch.d() + c->d, c->st));
   std::vector<double> h(c->d);
   HIPCK(hipMemcpyAsync(h.data(), c->scratch.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->st));
   HIPCK(hipStreamSynchronize(c->st));

@@ -20,7 +20,9 @@ def short(name):
 
 stats = glob.glob(root + "/trace/*/*_kernel_stats.csv")
 if stats:
-    out.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 4 --warmup 1 --skip-cpu-baseline --skip-other-configs --skip-general-path) ==")
+    import os
+    cmd = open(root + "/cmd.txt").read().strip() if os.path.exists(root + "/cmd.txt") else "python3 bench.py --steps 4 --warmup 1 --skip-cpu-baseline --skip-other-configs --skip-general-path"
+    out.append("== rocprofv3 --kernel-trace --stats ({}) ==".format(cmd))
     out.append("%-62s %6s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for r in csv.DictReader(open(stats[0])):
         if float(r["Percentage"]) < 0.05:
