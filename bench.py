@@ -53,11 +53,11 @@ PEAK_HBM_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 T
 # HBM-side bytes per launch at d = B = 4096, fp64: rocprofv3 PMC, separate --pmc FETCH_SIZE / WRITE_SIZE passes,
 # read = 2 * FETCH_SIZE (gfx950 correction of the guide's HBM section), write = WRITE_SIZE.  (bytes, profiles/ file)
 TRAFFIC = {
-    "zgemm": (3.51e9, "profiles/r1_bench_s3_final_summary.txt"),
-    "zherm": (3.82e9, "profiles/r1_bench_s3_final_summary.txt"),   # incl. the 64 MB fix-up pass
+    "zgemm": (3.51e9, "profiles/r2_bench_headline_summary.txt"),     # zgemm_lin_kernel<.,0>: 3230 MB read + 277 MB written
+    "zherm": (3.84e9, "profiles/r2_bench_headline_summary.txt"),     # zgemm_lin_kernel<1,1> 3778 MB + the 64 MB fix-up pass
     "rgemm": (1.81e9, "profiles/r1_bench_v5_realpath_summary.txt"),
-    "rsym": (2.51e9, "profiles/r1_bench_s3_sparse_summary.txt"),
-    "spmm": (8.96e8, "profiles/r1_bench_s3_spx_summary.txt"),
+    "rsym": (2.68e9, "profiles/r2_bench_dense_real_summary.txt"),    # symmetric-output rgemm 2614 MB + fix-up 64 MB
+    "spmm": (8.50e8, "profiles/r2_bench_headline_summary.txt"),      # (2 x 754 MB rsp_mm_slab + 1043 MB rsp_mm_dot_slab) / 3
 }
 
 
