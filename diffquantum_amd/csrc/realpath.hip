@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(RSPD_WAVES * 64) rsp_mm_dot_kernel(T* __restri
 // XCD-slab form of the fused pass (see rsp_mm_slab_kernel): the dot products of a row are formed per slab (lane partial
 // sums over the slab's column blocks, one wave reduction per entry) into part[z][slab][e]; rsp_dotsum_kernel then adds the 8
 // slabs in a fixed order into nzacc -- deterministic, 8 nnz doubles of extra traffic.
-template <class T>
+template <class T, int NQG>
 __global__ void __launch_bounds__(256) rsp_mm_dot_slab_kernel(T* __restrict__ out, const T* __restrict__ V,
                                                               const T* __restrict__ Add, double ca, const T* __restrict__ Xm,
                                                               long stride, int d, const long* __restrict__ rowptr,
@@ -693,6 +693,7 @@ __global__ void __launch_bounds__(256) rsp_mm_dot_slab_kernel(T* __restrict__ ou
                                                               int K, double mdt, long nnz, double* __restrict__ part, int ncbw) {
   constexpr int VEC = 16 / sizeof(T);
   typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  static_assert(RSPS_NQ % NQG == 0, "groups of NQG loads in flight per round of RSPS_NQ entries");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int xcd = blockIdx.x & 7, i = (blockIdx.x >> 3) * 4 + wave;
   if (i >= d) return;
@@ -725,25 +726,30 @@ __global__ void __launch_bounds__(256) rsp_mm_dot_slab_kernel(T* __restrict__ ou
       else if (!first) acc = *(const vec_t*)(out + rbase + c0);
       else if (Add) acc = (T)ca * *(const vec_t*)(Add + rbase + c0);
       else acc = 0;
-      vec_t v[RSPS_NQ];
-      T w[RSPS_NQ];
 #pragma unroll
-      for (int k = 0; k < RSPS_NQ; ++k) {
-        const int q = k < cnt ? k : 0;
-        const int jc = __builtin_amdgcn_readlane(mycol, q);
-        w[k] = (T)__longlong_as_double(((long long)__builtin_amdgcn_readlane(wh, q) << 32) |
-                                       (unsigned)__builtin_amdgcn_readlane(wl, q));
-        v[k] = *(const vec_t*)(Vz + (long)jc * d);
-      }
+      for (int g0 = 0; g0 < RSPS_NQ; g0 += NQG) {
+        if (g0 < cnt || g0 == 0) {  // wave-uniform
+          vec_t v[NQG];
+          T w[NQG];
 #pragma unroll
-      for (int k = 0; k < RSPS_NQ; ++k)
-        if (k < cnt) {
-          acc += w[k] * v[k];
-          T t = 0;
+          for (int k = 0; k < NQG; ++k) {
+            const int q = g0 + k < cnt ? g0 + k : 0;
+            const int jc = __builtin_amdgcn_readlane(mycol, q);
+            w[k] = (T)__longlong_as_double(((long long)__builtin_amdgcn_readlane(wh, q) << 32) |
+                                           (unsigned)__builtin_amdgcn_readlane(wl, q));
+            v[k] = *(const vec_t*)(Vz + (long)jc * d);
+          }
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) t += xm[j] * v[k][j];
-          dacc[k] += (double)t;
+          for (int k = 0; k < NQG; ++k)
+            if (g0 + k < cnt) {
+              acc += w[k] * v[k];
+              T t = 0;
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) t += xm[j] * v[k][j];
+              dacc[g0 + k] += (double)t;
+            }
         }
+      }
       if (out) *(vec_t*)(out + rbase + c0) = acc;
     }
 #pragma unroll
@@ -777,8 +783,11 @@ hipError_t rsp_mm_dot_launch(T* out, const T* V, const T* Add, double ca, const 
   if (d <= 0 || batch <= 0) return hipSuccess;
   if (part && nnz > 0 && rsp_slab_ok<T>(out, V, Add, Xm, stride, d)) {
     constexpr int VEC = 16 / sizeof(T);
-    hipLaunchKernelGGL(rsp_mm_dot_slab_kernel<T>, dim3((unsigned)(8 * ((d + 3) / 4)), 1, (unsigned)batch), dim3(256), 0, st, out, V,
-                       Add, ca, Xm, stride, d, rowptr, col, kid, val, u, K, -dt, nnz, part, d / (8 * 64 * VEC));
+#ifndef DQ_RSPD_NQG
+#define DQ_RSPD_NQG 8
+#endif
+    hipLaunchKernelGGL((rsp_mm_dot_slab_kernel<T, DQ_RSPD_NQG>), dim3((unsigned)(8 * ((d + 3) / 4)), 1, (unsigned)batch), dim3(256), 0,
+                       st, out, V, Add, ca, Xm, stride, d, rowptr, col, kid, val, u, K, -dt, nnz, part, d / (8 * 64 * VEC));
     hipLaunchKernelGGL(rsp_dotsum_kernel, dim3((unsigned)((nnz + 255) / 256), 1, (unsigned)batch), dim3(256), 0, st, part, nnz, nzacc,
                        accumulate);
     return hipGetLastError();

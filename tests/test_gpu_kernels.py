@@ -238,3 +238,9 @@ def test_zgemm_linear_form_hermitian_output(eng16, herm):
         ref = X.conj().T @ Z
         assert np.max(np.abs(got - ref)) < 1e-11 * np.max(np.abs(ref))
         assert np.array_equal(got, herm * got.conj().T)          # exactly (anti-)Hermitian as stored
+        if d == 1024:   # accumulate into an (anti-)Hermitian C (the Paterson-Stockmeyer tape's R_i = P_q R_{i+1} + B_i)
+            C0 = _structured(rng, d, 2 if herm > 0 else 3)
+            got = eng16.zgemm(X, Z, opA=1, herm=herm, alpha=-0.5, beta=2.0, C_in=C0)
+            ref2 = -0.5 * ref + 2.0 * C0
+            assert np.max(np.abs(got - ref2)) < 1e-11 * np.max(np.abs(ref2))
+            assert np.array_equal(got, herm * got.conj().T)

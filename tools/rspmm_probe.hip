@@ -55,6 +55,25 @@ int main(int argc, char** argv) {
     (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 0, 0); }, O0);
   timeit("library rsp_mm_slab_kernel", [&](double* o) {
     (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 1, 0); }, O1);
+  {  // the fused dot pass: one wave per row (part = null) against the XCD-slab form (DQ_RSPD_NQG loads in flight per group)
+    const long nnz = rowptr[d];
+    double *Xm, *nz0, *nz1, *part;
+    (void)hipMalloc(&Xm, nn * 8); (void)hipMalloc(&nz0, nnz * 8); (void)hipMalloc(&nz1, nnz * 8); (void)hipMalloc(&part, nnz * 8 * 8);
+    (void)hipMemcpy(Xm, ha.data(), nn * 8, hipMemcpyHostToDevice);
+    timeit("library rsp_mm_dot_kernel (one wave per row)", [&](double* o) {
+      (void)dq::rsp_mm_dot_launch<double>(o, V, Add, ca, Xm, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, nnz, nz0, 0, nullptr, 0); }, O0);
+    timeit("library rsp_mm_dot_slab_kernel", [&](double* o) {
+      (void)dq::rsp_mm_dot_launch<double>(o, V, Add, ca, Xm, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, nnz, nz1, 0, part, 0); }, O1);
+    std::vector<double> a(nnz), b(nnz);
+    (void)hipMemcpy(a.data(), nz0, nnz * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), nz1, nnz * 8, hipMemcpyDeviceToHost);
+    double m = 0, sc = 0;
+    for (long e = 0; e < nnz; ++e) { m = fmax(m, fabs(a[e] - b[e])); sc = fmax(sc, fabs(a[e])); }
+    printf("    dot sums: max|slab - row| = %.3e (max %.3e)\n", m, sc);
+    timeit("library rsp_mm_slab_kernel again (reference for the pair)", [&](double* o) {
+      (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 1, 0); }, O1);
+    timeit("library rsp_mm_kernel -> O0 again", [&](double* o) {
+      (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 0, 0); }, O0);
+  }
 #ifndef PROBE_ONLY_OLD
   std::vector<double> h0(nn), h1(nn);
   (void)hipMemcpy(h0.data(), O0, nn * 8, hipMemcpyDeviceToHost);
