@@ -376,6 +376,7 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
             e2.use_torch_stream()
             e2.set_hamiltonians(H0, Hs)
             e2.set_observable(M)
+            e2.set_option("plan_steps", max(a.chain, K))  # propagator-cache share / checkpoint stride of the full chain
             del H0, Hs, M
             ent, _ = scheme_entry(e2, torch, u_dev, a.dt, psi0, d, K, note)
         out[name] = ent

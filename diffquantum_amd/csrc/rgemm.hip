@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
   const int wm = wave / WGN, wn = wave % WGN;
 
   // ---- workgroup -> tile (and, for tail pieces of the symmetric form, a K range) ---------------
@@ -147,6 +147,23 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
   const T* ga = A + (long)((kt0 - kt_shift) * BK) * lda + m0 + lane * EPL;
   const T* gb = B + (long)((kt0 - kt_shift) * BK) * ldb + n0 + lane * EPL;
   // one wave instruction per k-row: row r of the slab -> LDS row r of buffer buf_ (base is wave-uniform, + lane*16 B)
+  // (DQ_RGLDS_ASM, default: the DMA is issued through inline asm and the wait for it sits in front of the slab's barrier. With
+  //  __builtin_amdgcn_global_load_lds hipcc puts an `s_waitcnt vmcnt(0)` in front of the next LDS read -- it cannot tell that the
+  //  DMA writes the OTHER slab buffer -- which exposes the load latency once per slab; see zgemm_lin.hip.)
+#ifndef DQ_RGLDS_ASM
+#define DQ_RGLDS_ASM 1
+#endif
+#if DQ_RGLDS_ASM
+#define DQ_RGLDS_ONE(gp_, lp_)                                                                                 \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp_),                   \
+               "s"((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)(lp_)) : "memory")
+#define DQ_RGLDS_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define DQ_RGLDS_ONE(gp_, lp_)                                                                                 \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp_),                       \
+                                   (__attribute__((address_space(3))) void*)(lp_), 16, 0, 0)
+#define DQ_RGLDS_LANDED()
+#endif
 #define DQ_RGLDS(kt_, buf_)                                                                                    \
   {                                                                                                            \
     if (SYM && (kt_) == nkt && kt_shift == 0) { /* switch to the pair (B, A) */                                \
@@ -157,10 +174,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
       gb = B + n0 + lane * EPL;                                                                                \
     }                                                                                                          \
     _Pragma("unroll") for (int r = wave; r < BK; r += NW) {                                                    \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (long)r * lda),    \
-                                       (__attribute__((address_space(3))) void*)(As + ((buf_) * BK + r) * PA), 16, 0, 0); \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long)r * ldb),    \
-                                       (__attribute__((address_space(3))) void*)(Bs + ((buf_) * BK + r) * PB), 16, 0, 0); \
+      DQ_RGLDS_ONE(ga + (long)r * lda, As + ((buf_) * BK + r) * PA);                                           \
+      DQ_RGLDS_ONE(gb + (long)r * ldb, Bs + ((buf_) * BK + r) * PB);                                           \
     }                                                                                                          \
     ga += (long)BK * lda;                                                                                      \
     gb += (long)BK * ldb;                                                                                      \
@@ -263,11 +278,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
   if (GLDS) {
     if (kt0 < kt1) {
       DQ_RGLDS(kt0, 0);
-      __syncthreads();  // (hipcc drains vmcnt before the barrier: the slab has landed)
+      DQ_RGLDS_LANDED();
+      __syncthreads();  // (builtin form: hipcc drains vmcnt before the barrier)
       for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         if (kt + 1 < kt1 && !(DQ_RGEMM_ABLATE & 2)) DQ_RGLDS(kt + 1, cur ^ 1);
         DQ_RCOMPUTE_SLAB(cur);
+        DQ_RGLDS_LANDED();
         if (!(DQ_RGEMM_ABLATE & 1)) __syncthreads();
       }
     }
@@ -289,6 +306,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64, MINW) rgemm_kernel(RgemmArgs<T>
     }
   }
 #undef DQ_RGLDS
+#undef DQ_RGLDS_ONE
+#undef DQ_RGLDS_LANDED
 #undef DQ_RLOAD_FAST
 #undef DQ_RLOAD_CHECKED
 #undef DQ_RLOAD
