@@ -87,6 +87,27 @@ def launch_ranks(a, argv):
     return subprocess.run(cmd, env=env, cwd=ROOT).returncode
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """Keep stdout for the ONE JSON line: everything else a rank (or a library it loads -- RCCL prints a version banner, gloo
+    its rank table -- on stdout) writes goes to stderr from here on."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 class Dist:
     """One process per GPU.  RCCL ("nccl") on device tensors; DQ_DIST_BACKEND=gloo stages the collectives through the host
     and shares the devices round-robin (rehearsal on a box with fewer GPUs than ranks: RCCL refuses two ranks per device)."""
@@ -557,7 +578,7 @@ def run_config2(a, D):
                                       "8 d^3 per step instead of 8 d^2 B; launch-latency, not a roofline, governs at this size",
                               "kernel_ms": m["kernel_ms"], "kernel_launches": m["kernel_launches"]},
                "max_norm_drift": m["max_norm_drift"]}
-        print(json.dumps(out))
+        emit(out)
 
 
 def run_config5(a, D):
@@ -582,7 +603,7 @@ def run_config5(a, D):
                           "forward_only_steps_per_s_rank0": m["fwd_steps_per_s"],
                           "parallelism": "dp{} (batch shards, one all-reduce of loss + dL/du)".format(D.world)},
                "roofline": m["roofline"]}
-        print(json.dumps(out))
+        emit(out)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -784,7 +805,7 @@ def run_config3(a, D):
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
             out["cpu_baseline"] = {"value": None, "unit": "Trotter steps/s (fwd+adjoint)", "cores": os.cpu_count(),
                                    "kind": "port", "sample": "failed: {}".format(e)}
-    print(json.dumps(out))
+    emit(out)
     eng.close()
 
 
@@ -818,6 +839,7 @@ def main():
     a = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.launch):
         sys.exit(launch_ranks(a, sys.argv[1:]))
+    claim_stdout()
     D = Dist(a)
     {2: run_config2, 3: run_config3, 5: run_config5}[a.config](a, D)
     D.close()  # (only on success: a failing rank must not enter a barrier its peers will never reach -- it exits non-zero)
