@@ -10,10 +10,17 @@ but the time loop (``dH`` assembly, ``dH.exp()``, ``exp * psi``) runs in libdiff
 The pulse envelope ``f_u`` (diffqc.cc:95-135) is evaluated on the host for the whole time grid
 (diffquantum_amd.pulse.f_u_table) and handed to the engine as the u[t][h] table.
 
+When the compiled pybind11 module ``diffquantum_amd._diffqc_native`` (csrc/diffqc_module.cpp: the reference's module
+re-built over the C-ABI, pulse model included) is present, ``set_H`` / ``trotter`` / ``trotter_batch`` and the three
+test functions go through it; ``DQ_DIFFQC_PURE_PYTHON=1`` keeps everything on this file's Python twin. Both call the
+same HIP engine; the extensions ``energy_grad`` / ``fidelity_grad`` always use the Python-side handle.
+
 Differences from the reference, all deliberate: shape errors raise ValueError instead of being
 undefined behaviour (diffqc.cc:101-103), and ``trotter_batch`` evolves many states at once.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
@@ -22,19 +29,44 @@ from .engine import Engine
 
 __version__ = "dev"
 
-_state = {"engine": None, "channels": None, "duration": None, "func_type": None, "dim": 0}
+native = None
+if not os.environ.get("DQ_DIFFQC_PURE_PYTHON"):
+    try:
+        from . import _diffqc_native as native  # the compiled module (make -C diffquantum_amd/csrc)
+    except ImportError:
+        native = None
+
+_state = {"engine": None, "channels": None, "duration": None, "func_type": None, "dim": 0, "H": None, "native_set": False}
 
 
 def print_test():
+    if native is not None:
+        return native.print_test()
     print("hello")
 
 
 def complex_test(psi0):
+    if native is not None:
+        return native.complex_test([complex(z) for z in psi0])
     return [complex(z) for z in psi0]
 
 
 def test_eigen(v):
+    if native is not None:
+        return native.test_eigen([[float(x) for x in row] for row in v])
     return [[float(x) for x in row] for row in v]
+
+
+def _engine():
+    """The Python-side engine handle (built on first use when set_H went through the compiled module)."""
+    if _state["engine"] is None:
+        if _state["H"] is None:
+            raise RuntimeError("set_H must be called first")
+        H0, Hs = _state["H"]
+        eng = Engine(H0.shape[0], Hs.shape[0])
+        eng.set_hamiltonians(H0, Hs)
+        _state["engine"] = eng
+    return _state["engine"]
 
 
 def set_H(H0, Hs, channels, duration, func_type):
@@ -52,13 +84,17 @@ def set_H(H0, Hs, channels, duration, func_type):
                 raise ValueError("each channel row needs at least 4 entries (unused, omega, w, idx)")
     if _state["engine"] is not None:
         _state["engine"].close()
-    eng = Engine(d, Hs.shape[0])
-    eng.set_hamiltonians(H0, Hs)
-    _state.update(engine=eng, channels=chans, duration=float(duration), func_type=int(func_type), dim=d)
+    _state.update(engine=None, channels=chans, duration=float(duration), func_type=int(func_type), dim=d, H=(H0, Hs),
+                  native_set=False)
+    if native is not None:
+        native.set_H(H0.tolist(), Hs.tolist(), chans, float(duration), int(func_type))
+        _state["native_set"] = True
+    else:
+        _engine()
 
 
 def _table(T0, T, per_step, vv):
-    if _state["engine"] is None:
+    if _state["H"] is None:
         raise RuntimeError("set_H must be called before trotter")
     n_steps = pulse.n_steps_diffqc(int(per_step), float(T0), float(T))
     ts, dt = pulse.time_grid(float(T0), float(T), n_steps)
@@ -70,8 +106,13 @@ def trotter(psi0, T0, T, per_step, vv):
     psi = np.asarray(psi0, dtype=np.complex128).reshape(-1)
     if psi.shape[0] != _state["dim"]:
         raise ValueError("psi0 has length {} but set_H was given dimension {}".format(psi.shape[0], _state["dim"]))
+    if _state["native_set"]:
+        v = np.asarray(vv, dtype=np.float64)
+        if v.ndim != 3 or v.shape[0] != 2:
+            raise ValueError("vv must have shape [2][n_param][n_basis]")
+        return native.trotter(psi.tolist(), float(T0), float(T), int(per_step), v.tolist())
     u, dt = _table(T0, T, per_step, vv)
-    out = _state["engine"].propagate(u, dt, psi.reshape(-1, 1))
+    out = _engine().propagate(u, dt, psi.reshape(-1, 1))
     return [complex(z) for z in out[:, 0]]
 
 
@@ -80,12 +121,12 @@ def energy_grad(psi0, T0, T, per_step, vv, M):
 
     Returns (loss, dL/dvv with the shape of vv, psi_final) for L = sum_b <psi_b(T)|M|psi_b(T)>; psi0 is [dim] or
     [dim][batch]. The time chain and its adjoint run on the GPU, the chain rule through f_u (diffqc.cc:95-135) on the host."""
-    if _state["engine"] is None:
+    if _state["H"] is None:
         raise RuntimeError("set_H must be called before energy_grad")
     n_steps = pulse.n_steps_diffqc(int(per_step), float(T0), float(T))
     ts, dt = pulse.time_grid(float(T0), float(T), n_steps)
     u = pulse.f_u_table(vv, _state["channels"], _state["duration"], _state["func_type"], ts)
-    eng = _state["engine"]
+    eng = _engine()
     eng.set_observable(np.asarray(M, dtype=np.complex128))
     psi = np.asarray(psi0, dtype=np.complex128)
     loss, grad_u, fin, _ = eng.energy_grad(u, dt, psi.reshape(_state["dim"], -1))
@@ -95,13 +136,13 @@ def energy_grad(psi0, T0, T, per_step, vv, M):
 
 def fidelity_grad(psi0, targets, T0, T, per_step, vv):
     """Extension: L = sum_b (1 - |<target_b|psi_b(T)>|^2) and dL/dvv for a batch of (initial, target) pairs."""
-    if _state["engine"] is None:
+    if _state["H"] is None:
         raise RuntimeError("set_H must be called before fidelity_grad")
     n_steps = pulse.n_steps_diffqc(int(per_step), float(T0), float(T))
     ts, dt = pulse.time_grid(float(T0), float(T), n_steps)
     u = pulse.f_u_table(vv, _state["channels"], _state["duration"], _state["func_type"], ts)
     d = _state["dim"]
-    loss, grad_u, fin, fid = _state["engine"].fidelity_grad(u, dt, np.asarray(psi0, dtype=np.complex128).reshape(d, -1),
+    loss, grad_u, fin, fid = _engine().fidelity_grad(u, dt, np.asarray(psi0, dtype=np.complex128).reshape(d, -1),
                                                             np.asarray(targets, dtype=np.complex128).reshape(d, -1))
     gvv = pulse.grad_vv_from_grad_u(grad_u, vv, _state["channels"], _state["duration"], _state["func_type"], ts)
     return loss, gvv, fin, fid
@@ -110,4 +151,4 @@ def fidelity_grad(psi0, targets, T0, T, per_step, vv):
 def trotter_batch(psi0, T0, T, per_step, vv):
     """Extension: psi0 is [dim][batch] (numpy or CUDA torch complex128); returns the same kind."""
     u, dt = _table(T0, T, per_step, vv)
-    return _state["engine"].propagate(u, dt, psi0)
+    return _engine().propagate(u, dt, psi0)

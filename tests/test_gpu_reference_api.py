@@ -166,6 +166,32 @@ def test_diffqc_module_surface(capsys):
     assert diffqc.test_eigen([[1, 2], [3, 4]]) == [[1.0, 2.0], [3.0, 4.0]]
 
 
+def test_diffqc_native_module_and_python_twin_agree(oracle, monkeypatch):
+    """The compiled pybind11 module (csrc/diffqc_module.cpp: set_H / trotter of diffqc.cc:210-228 over the C-ABI, pulse model
+    in C++) against its pure-Python twin and the oracle, on the same inputs."""
+    from diffquantum_amd import diffqc
+    assert diffqc.native is not None and diffqc.native.__version__ == "dev"
+    H0, Hs, _ = problems.random_hermitian_problem(3, 2, seed=21)
+    vv = np.random.default_rng(3).normal(0, 1.0, (2, 3, 6)).tolist()
+    channels = [[[0.0, 2.0, 1.5, 0.0], [0.0, 0.8, -2.5, 1.0]], [[0.0, 3.0, 0.0, 2.0]]]
+    psi0 = problems.random_states(8, 3, seed=4)
+    for func_type in (0, 1):
+        diffqc.native.set_H(H0.tolist(), Hs.tolist(), channels, 1.6, func_type)
+        a = np.array(diffqc.native.trotter(psi0[:, 0].tolist(), 0.2, 1.6, 9, vv))
+        ab = diffqc.native.trotter_batch(psi0, 0.2, 1.6, 9, vv)
+        ref, _, _ = oracle.trotter_diffqc(H0, list(Hs), channels, 1.6, func_type, psi0[:, 0], 0.2, 1.6, 9, vv)
+        assert np.max(np.abs(a - ref)) < TOL and np.max(np.abs(ab[:, 0] - a)) < 1e-14
+        monkeypatch.setattr(diffqc, "native", None)                  # the Python twin
+        diffqc.set_H(H0.tolist(), Hs.tolist(), channels, 1.6, func_type)
+        b = np.array(diffqc.trotter(psi0[:, 0].tolist(), 0.2, 1.6, 9, vv))
+        monkeypatch.undo()
+        assert np.max(np.abs(a - b)) < 1e-13
+    with pytest.raises(ValueError):
+        diffqc.native.trotter([1, 0, 0], 0.0, 1.0, 10, vv)          # wrong length
+    with pytest.raises(ValueError):
+        diffqc.native.set_H(H0.tolist(), Hs.tolist(), [[[0.0, 1.0, 0.0]]] * 2, 1.0, 1)   # channel row too short
+
+
 @pytest.mark.parametrize("func_type", [0, 1])
 def test_diffqc_trotter_matches_oracle(oracle, func_type):
     from diffquantum_amd import diffqc
