@@ -1,0 +1,53 @@
+"""bench.py's roofline arithmetic on a synthetic profile (no GPU): `frac` is a fraction of EXECUTED work -- 6 M N K per
+launch for the 3M complex product, the triangle's tiles only for the Hermitian-output form -- the algorithmic 8 M N K rate is
+kept beside it, classes are ranked by their share of the timed region, and the HBM class is bytes / time / 8 TB/s."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def _prof(**kw):
+    z = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
+    p = {k: dict(z) for k in ("zgemm", "assemble", "lincomb", "gradc", "other", "rgemm", "rsym", "zherm", "spmm")}
+    p.update(kw)
+    return p
+
+
+def test_fractions_at_the_headline_shape():
+    d = 4096
+    W = 8.0 * d ** 3
+    prof = _prof(zgemm={"launches": 42, "ms": 42 * 5.83, "flops": 42 * W, "bytes": 42 * 805306368.0},
+                 zherm={"launches": 20, "ms": 20 * 3.01, "flops": 20 * W, "bytes": 20 * 805306368.0},
+                 spmm={"launches": 360, "ms": 360 * 0.146, "flops": 0.0, "bytes": 360 * 343e6},
+                 lincomb={"launches": 160, "ms": 16.0, "flops": 0.0, "bytes": 1e9})
+    b = bench.roofline_blocks(prof, {"zgemm_alg": 2.0}, d)
+    z, h, s = b["zgemm"], b["zherm"], b["spmm"]
+    assert abs(z["achieved_algorithmic"] - W / 5.83e-3 / 1e12) < 1e-9
+    assert abs(z["achieved"] - 0.75 * z["achieved_algorithmic"]) < 1e-9          # 3M: 6 of every 8 algorithmic flops executed
+    assert abs(z["frac"] - z["achieved"] / 78.6) < 1e-12 and 0.88 < z["frac"] < 0.92
+    assert abs(h["executed_over_algorithmic_flops"] - 0.75 * 528 / 1024) < 1e-12   # triangle: 528 of 1024 tiles
+    assert 0.88 < h["frac"] < 0.92
+    assert s["bound"] == "hbm" and abs(s["frac"] - (343e6 / 0.146e-3 / 1e9) / 8000.0) < 1e-9
+    assert abs(z["traffic_over_algorithmic"] - bench.TRAFFIC["zgemm"][0] / 805306368.0) < 1e-9
+    assert z["traffic_source"].startswith("profiles/") and os.path.exists(os.path.join(ROOT, z["traffic_source"]))
+    rk = bench.ranked(b)
+    assert [r is x for r, x in zip(rk[:3], (z, h, s))] == [True, True, True]
+    total = sum(v["ms"] for v in prof.values())
+    assert abs(z["share_of_kernel_time"] - 42 * 5.83 / total) < 1e-12
+    ex = bench.executed_tflops(b, 0.381)
+    assert abs(ex - (z["achieved"] * 42 * 5.83e-3 + h["achieved"] * 20 * 3.01e-3) / 0.381) < 1e-9
+    for blk in b.values():
+        assert 0.0 <= blk["frac"] <= 1.0
+
+
+def test_small_dimension_uses_the_4m_count_and_no_traffic_constant():
+    d = 256
+    W = 8.0 * d ** 3
+    b = bench.roofline_blocks(_prof(zgemm={"launches": 10, "ms": 1.0, "flops": 10 * W, "bytes": 1.0}), {"zgemm_alg": 2.0}, d)
+    z = b["zgemm"]
+    assert z["executed_over_algorithmic_flops"] == 1.0 and z["traffic"] is None and z["traffic_source"] is None
+    assert bench.ranked(b) == [z]
