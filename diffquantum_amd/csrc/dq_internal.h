@@ -172,6 +172,8 @@ struct RLincombArgs {
   long stride;
   int batch;
   int accumulate;
+  int pack;  // 1: the two results are written as ONE interleaved complex matrix out[0] = (result 0) + i (result 1)
+             // (U = C + i S without storing C and S; n_out must be 2, accumulate 0, out[1] unused)
 };
 template <class T>
 hipError_t rlincomb_launch(const RLincombArgs<T>& a, hipStream_t st);

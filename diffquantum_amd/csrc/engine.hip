@@ -671,17 +671,39 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
       });
       Xp[m + 1] = Xn;
     }
-    T* Cm = c->rmat(RS_C, n);
-    T* S = c->rmat(RS_S, n);
-    const T* ev[RQ_MAX + 1];
-    const T* od[RQ_MAX + 1];
-    for (int j = 1; j <= q; ++j) ev[j - 1] = Xp[2 * j];
-    for (int j = 0; j <= q; ++j) od[j] = Xp[2 * j + 1];
-    rlincomb2<T>(c, Cm, nullptr, q, ev, p.cc + 1, nullptr, p.cc[0], 0.0, n, false);
-    rlincomb2<T>(c, S, nullptr, q + 1, od, p.sc, nullptr, 0.0, 0.0, n, false);
+    // U = cos X + i sin X = (cc_0 I + sum_j cc_j X_2j) + i (sum_j sc_j X_2j+1): ONE pass over the stored powers X_1 .. X_2q+1
+    // that writes the interleaved complex U directly (C and S are never stored: nothing else reads them on this scheme)
     T2* U = c->mat(RS_U, n);
-    const long ne = (long)c->nn() * n;
-    c->timed(DQ_PROF_LINCOMB, 0.0, 4.0 * sizeof(T) * ne, [&] { return dq::pack_u_launch<T>(U, Cm, S, ne, c->st); });
+    if (np > 8) {  // more powers than one linear-combination launch takes (q >= 4): C and S separately, then U = C + i S
+      T* Cm = c->rmat(RS_C, n);
+      T* S = c->rmat(RS_S, n);
+      const T* ev[RQ_MAX + 1];
+      const T* od[RQ_MAX + 1];
+      for (int j = 1; j <= q; ++j) ev[j - 1] = Xp[2 * j];
+      for (int j = 0; j <= q; ++j) od[j] = Xp[2 * j + 1];
+      rlincomb2<T>(c, Cm, nullptr, q, ev, p.cc + 1, nullptr, p.cc[0], 0.0, n, false);
+      rlincomb2<T>(c, S, nullptr, q + 1, od, p.sc, nullptr, 0.0, 0.0, n, false);
+      const long ne = (long)c->nn() * n;
+      c->timed(DQ_PROF_LINCOMB, 0.0, 4.0 * sizeof(T) * ne, [&] { return dq::pack_u_launch<T>(U, Cm, S, ne, c->st); });
+    } else {
+      dq::RLincombArgs<T> a;
+      memset(&a, 0, sizeof(a));
+      a.out[0] = (T*)U;
+      a.n_out = 2;
+      a.pack = 1;
+      a.n_in = np;
+      for (int m = 1; m <= np; ++m) {
+        a.x[m - 1] = Xp[m];
+        a.c[0][m - 1] = (m & 1) ? 0.0 : p.cc[m / 2];
+        a.c[1][m - 1] = (m & 1) ? p.sc[(m - 1) / 2] : 0.0;
+      }
+      a.cI[0] = p.cc[0];
+      a.d = c->d;
+      a.stride = (long)c->nn();
+      a.batch = n;
+      const double by = (double)sizeof(T) * c->nn() * (np + 2.0) * n;
+      c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * np * n, by, [&] { return dq::rlincomb_launch<T>(a, c->st); });
+    }
     c->last_degree = p.m;
     c->last_squarings = 0;
     c->last_products = 2 * q;

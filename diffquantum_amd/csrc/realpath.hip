@@ -104,8 +104,15 @@ __global__ void __launch_bounds__(256) rlincomb_kernel(RLincombArgs<T> a) {
       v0 += (T)a.cI[0];
       v1 += (T)a.cI[1];
     }
-    a.out[0][base + e] = v0;
-    if (a.n_out > 1) a.out[1][base + e] = v1;
+    if (a.pack) {
+      typename Cx<T>::type u;
+      u.x = v0;
+      u.y = v1;
+      ((typename Cx<T>::type*)a.out[0])[base + e] = u;  // base counts complex elements here (same stride in elements)
+    } else {
+      a.out[0][base + e] = v0;
+      if (a.n_out > 1) a.out[1][base + e] = v1;
+    }
   }
 }
 
