@@ -35,6 +35,14 @@ namespace dq {
 
 typedef double zl_double4_t __attribute__((ext_vector_type(4)));
 
+// Ablation switches for tools/zgemm_lin_probe.hip only (never set in the library build; results are then wrong): 1 = no barrier
+// in the K loop, 2 = no DMA after the prologue, 4 = no wait for the DMA in front of the barrier.
+#ifndef DQ_ZL_ABLATE
+#define DQ_ZL_ABLATE 0
+#endif
+#ifndef DQ_ZL_DMA_AFTER
+#define DQ_ZL_DMA_AFTER 0  // k-steps of a slab computed before the next slab's DMA is issued (0 = DMA first)
+#endif
 #define DQ_ZL_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
 
 template <int CONJA, int HERM>
@@ -127,11 +135,11 @@ __global__ void __launch_bounds__(1024, 4) zgemm_lin_kernel(ZgemmArgs<double> g)
   }
 #define DQ_ZL_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-#define DQ_ZL_COMPUTE(buf_)                                                                                              \
+#define DQ_ZL_COMPUTE(buf_, ks0_, ks1_)                                                                                  \
   {                                                                                                                      \
     const double2* as_ = As + (buf_) * BK * BM + (lane >> 4) * BM + wm * TM + (lane & 15);                               \
     const double2* bs_ = Bs + (buf_) * BK * BN + (lane >> 4) * BN + wn * TN + (lane & 15);                               \
-    _Pragma("unroll") for (int ks = 0; ks < BK / 4; ++ks) {                                                              \
+    _Pragma("unroll") for (int ks = (ks0_); ks < (ks1_); ++ks) {                                                         \
       double2 a[MI], b[NI];                                                                                              \
       _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = as_[ks * 4 * BM + i * 16];                                   \
       _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = bs_[ks * 4 * BN + j * 16];                                   \
@@ -153,10 +161,14 @@ __global__ void __launch_bounds__(1024, 4) zgemm_lin_kernel(ZgemmArgs<double> g)
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = (kt - kt0) & 1;
-      if (kt + 1 < kt1) DQ_ZL_DMA(cur ^ 1);  // in flight during this slab's 48 MFMAs per wave
-      DQ_ZL_COMPUTE(cur);
-      DQ_ZL_LANDED();
-      __syncthreads();
+      // the next slab's DMA is issued BEHIND the first k-step's fragment reads and MFMAs: right after the barrier every wave
+      // of the workgroup is at the same point, and four DMA issues per wave in front of the first MFMA left the matrix pipe
+      // idle for that long once per slab (SQ_VALU_MFMA_BUSY 91.6 % of the kernel's cycles before, tools/profile_sq.sh)
+      DQ_ZL_COMPUTE(cur, 0, DQ_ZL_DMA_AFTER);
+      if (kt + 1 < kt1 && !(DQ_ZL_ABLATE & 2)) DQ_ZL_DMA(cur ^ 1);  // in flight during the rest of this slab's 48 MFMAs per wave
+      DQ_ZL_COMPUTE(cur, DQ_ZL_DMA_AFTER, BK / 4);
+      if (!(DQ_ZL_ABLATE & 4)) DQ_ZL_LANDED();
+      if (!(DQ_ZL_ABLATE & 1)) __syncthreads();
     }
   }
 #undef DQ_ZL_DMA

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_clock
 mkdir -p $OUT
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc -- python3 bench.py --steps 4 --warmup 1 --skip-cpu-baseline > $OUT/log.txt 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc -- python3 bench.py --steps 4 --warmup 1 --skip-cpu-baseline --skip-other-configs --skip-general-path > $OUT/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/prof_clock/pmc/*/*_counter_collection.csv")[0]

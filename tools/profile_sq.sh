@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_sq
 mkdir -p $OUT
 rocprofv3 -L 2>/dev/null | grep -oE "SQ_[A-Z_0-9]+" | sort -u | tr '\n' ' ' > $OUT/sq_counters.txt
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc -- python3 bench.py --steps 3 --warmup 1 --skip-cpu-baseline > $OUT/log.txt 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc -- python3 bench.py --steps 3 --warmup 1 --skip-cpu-baseline --skip-other-configs --skip-general-path > $OUT/log.txt 2>&1
 tail -3 $OUT/log.txt | cut -c1-300
 python3 - <<'PY'
 import csv, glob
