@@ -75,6 +75,19 @@ int main(int argc, char** argv) {
       (void)dq::rsp_mm_launch<double>(o, V, Add, ca, (long)nn, d, drp, dcol, dkid, dval, du, K, 1, dt, 0, 0); }, O0);
   }
 #ifndef PROBE_ONLY_OLD
+  {  // pitch experiment: the same pass with a row pitch of d + PAD doubles (is the power-of-two pitch costing L2 sets?)
+    for (int pad : {0, 16, 64, 272}) {
+      const long ld = d + pad;
+      double *Vp, *Ap, *Op;
+      (void)hipMalloc(&Vp, (size_t)ld * d * 8); (void)hipMalloc(&Ap, (size_t)ld * d * 8); (void)hipMalloc(&Op, (size_t)ld * d * 8);
+      (void)hipMemcpy2D(Vp, ld * 8, V, (size_t)d * 8, (size_t)d * 8, d, hipMemcpyDeviceToDevice);
+      (void)hipMemcpy2D(Ap, ld * 8, Add, (size_t)d * 8, (size_t)d * 8, d, hipMemcpyDeviceToDevice);
+      char name[96];
+      snprintf(name, sizeof name, "row x XCD slab, row pitch d + %d", pad);
+      timeit(name, [&](double* o) { probe::rowrange_ld_launch<13>(o, Vp, Ap, ca, ld, d, drp, dcol, dkid, dval, du, K, dt); }, Op);
+      (void)hipFree(Vp); (void)hipFree(Ap); (void)hipFree(Op);
+    }
+  }
   std::vector<double> h0(nn), h1(nn);
   (void)hipMemcpy(h0.data(), O0, nn * 8, hipMemcpyDeviceToHost);
   int bad = 0;
