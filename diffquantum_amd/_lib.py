@@ -61,6 +61,8 @@ SIGNATURES = {
     "dq_slice_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp]),
     "dq_slice_terminal": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dq_slice_backward": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, _vp]),
+    "dq_build_propagators": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp]),
+    "dq_propagator_vjp": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp]),
     "dq_zgemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_long, C.c_long,
                            _vp, C.c_long, C.c_long, C.c_double, _vp, C.c_long, C.c_long, C.c_int]),
     "dq_zgemm_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_long, C.c_long,

@@ -1693,6 +1693,71 @@ void do_slice_backward(Ctx<T>* c, const double* u, int n, double dt, const void*
   c->slice_valid = false;  // one backward per forward
 }
 
+// ---- explicit propagators in and out (SURVEY.md section 8-F2 in its literal form: "each GPU builds S/G propagators and
+// all-gathers them"): the step propagators U_t = exp(-i dt (H0 + sum_k u[t][k] H_k)) of a set of pulse rows as plain
+// [n][dim][dim] matrices, and the pull-back of cotangents G_t of those propagators to the pulse rows,
+//     dL/du[t][k] = Re <G_t, dU_t/du_k>      (pairing Re tr(G^H dU); the exp's exact reverse mode + the control contractions).
+// With dq_zgemm these two calls let a host run the STATE-form chain on propagators that were built elsewhere (another rank):
+// psi_{t+1} = U_t psi_t, lambda_t = U_t^H lambda_{t+1}, G_t = lambda_{t+1} psi_t^H (diffquantum_amd/distributed.py:
+// propagator_sharded_energy_grad). The reference builds every U_t where it uses it (diffqc.cc:192-198, sim_plain.py:137-146).
+template <class T>
+void do_build_propagators(Ctx<T>* c, const double* u, int n, double dt, void* U_out) {
+  typedef TT T2;
+  check_ctx(c);
+  require_H(c);
+  if (n < 0) fail(DQ_ERR_INVALID, "n_steps must be >= 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (n > 0 && !U_out) fail(DQ_ERR_INVALID, "null output");
+  if (n > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
+  if (n == 0) return;
+  std::vector<double> uh = fetch_u(c, u, n);
+  const int tc = time_chunk(c, n);
+  c->last_chunk = tc;
+  PcOff<T> pc_off{c};
+  for (auto& e : c->pcache) e.valid = false;
+  c->slice_valid = false;
+  c->pc_mode = 0;
+  for (int c0 = 0; c0 < n; c0 += tc) {
+    const int m = std::min(tc, n - c0);
+    const ExpmPlan p = chunk_plan(c, uh, c0, m, dt);
+    const T2* U = build_propagators(c, p, c0, m, dt);
+    out_copy(c, (char*)U_out + (size_t)c0 * c->mat_bytes(), U, (size_t)m * c->mat_bytes());
+  }
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+void do_propagator_vjp(Ctx<T>* c, const double* u, int n, double dt, const void* G_in, double* grad_u) {
+  typedef TT T2;
+  check_ctx(c);
+  require_H(c);
+  if (!c->hermitian) fail(DQ_ERR_UNSUPPORTED, "the gradient path needs Hermitian H0/H_k");
+  if (n < 0) fail(DQ_ERR_INVALID, "n_steps must be >= 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (n > 0 && (!G_in || !grad_u)) fail(DQ_ERR_INVALID, "null argument");
+  if (n > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
+  const int K = c->K;
+  if (n == 0 || K == 0) return;
+  std::vector<double> uh = fetch_u(c, u, n);
+  const int tc = time_chunk(c, n);
+  c->last_chunk = tc;
+  PcOff<T> pc_off{c};
+  for (auto& e : c->pcache) e.valid = false;
+  c->slice_valid = false;
+  c->pc_mode = 0;
+  c->grad_dev.ensure((size_t)n * K * sizeof(double));
+  for (int c0 = 0; c0 < n; c0 += tc) {
+    const int m = std::min(tc, n - c0);
+    const ExpmPlan p = chunk_plan(c, uh, c0, m, dt);
+    build_propagators(c, p, c0, m, dt);  // the polynomial's variables, for the reverse mode
+    T2* G = ubar_slot(c, p, m);
+    HIPCK(hipMemcpyAsync(G, (const char*)G_in + (size_t)c0 * c->mat_bytes(), (size_t)m * c->mat_bytes(), hipMemcpyDefault, c->st));
+    chunk_vjp(c, p, c0, m, dt);
+  }
+  out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)n * K);
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
 // The reference's "parameter-shift in time" Monte-Carlo estimator as one device-resident operation
 // (compute_energy_grad_MC, sim_plain.py:156-231): evolve 0 -> s on the first time grid, apply the 2K gates
 // (I +- i r H_k)/sqrt(1 + r^2), evolve all 2K shifted states s -> T on the second grid as ONE batch, measure M, and
@@ -2257,6 +2322,14 @@ int dq_slice_terminal(dq_ctx* c, const void* Q, const void* psi0, int batch, con
 int dq_slice_backward(dq_ctx* c, const double* u, int n_steps, double dt, const void* W_end, double* grad_u,
                       void* W_start) {
   return with_ctx(c, [&](auto* t) { do_slice_backward(t, u, n_steps, dt, W_end, grad_u, W_start); });
+}
+
+int dq_build_propagators(dq_ctx* c, const double* u, int n_steps, double dt, void* U_out) {
+  return with_ctx(c, [&](auto* t) { do_build_propagators(t, u, n_steps, dt, U_out); });
+}
+
+int dq_propagator_vjp(dq_ctx* c, const double* u, int n_steps, double dt, const void* G, double* grad_u) {
+  return with_ctx(c, [&](auto* t) { do_propagator_vjp(t, u, n_steps, dt, G, grad_u); });
 }
 
 int dq_zgemm(dq_ctx* c, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,

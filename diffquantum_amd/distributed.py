@@ -95,6 +95,147 @@ def _sliced_phases(engine, u, dt, psi0_shard, rank, world, targets=None, want_fi
     return float(buf[-1]), np.array(buf[:-1]).reshape(S, K), fin, en
 
 
+# ---- SURVEY.md 8-F2 in its literal form: the propagators of a chain built 1/G per rank and all-gathered ---------------------
+
+def _window_owner(t0, n_win, per_rank, world):
+    """Steps [t0, t0 + n_win) of a window: rank r owns the per_rank consecutive steps starting at t0 + r * per_rank
+    (fewer, possibly none, in the last window). Returns [(first, count)] per rank."""
+    spans = []
+    for r in range(world):
+        first = min(t0 + r * per_rank, t0 + n_win)
+        spans.append((first, max(0, min(per_rank, t0 + n_win - first))))
+    return spans
+
+
+def _propagator_sharded_phases(engine, M, u, dt, psi0_shard, rank, world, per_rank=1, want_final=False, want_energies=False):
+    """State-form fwd + adjoint of THIS rank's columns on propagators that are built 1/world per rank (generator of
+    collective requests, as _sliced_phases). Per window of world * per_rank steps:
+      forward : every rank builds the propagators of its own steps (dq_build_propagators), all-gather, apply in order;
+      backward: the window's propagators are built and gathered again, the states of the window recomputed from the window's
+                checkpoint, then for t descending  G_t = lambda_{t+1} psi_t^H (this rank's columns), lambda_t = U_t^H lambda_{t+1};
+                the G_t are summed over the ranks and scattered to their owners (reduce-scatter), which pull them back to their
+                own pulse rows (dq_propagator_vjp).
+    One all-reduce of the zero-padded gradient rows + loss at the end. Every rank issues the same sequence."""
+    S, K, d = int(u.shape[0]), engine.n_controls, engine.dim
+    u = np.ascontiguousarray(u.cpu().numpy() if hasattr(u, "cpu") else u, dtype=np.float64)
+    win = world * per_rank
+    windows = [(t0, min(win, S - t0)) for t0 in range(0, S, win)]
+
+    def gather_window(t0, n_win):
+        spans = _window_owner(t0, n_win, per_rank, world)
+        first, count = spans[rank]
+        Umine = engine.build_propagators(u[first:first + count], dt, like=psi0_shard)      # [count][d][d]
+        pad = _like_zeros(Umine, (per_rank, d, d))
+        if count:
+            pad[:count] = Umine
+        return spans, pad
+
+    psi = psi0_shard
+    checkpoints = []
+    for t0, n_win in windows:                                  # ---- forward ----
+        spans, pad = gather_window(t0, n_win)
+        Ugath = yield ("all_gather", pad)                      # list over ranks of [per_rank][d][d]
+        checkpoints.append(psi)
+        for r in range(world):
+            for j in range(spans[r][1]):
+                psi = engine.gemm(Ugath[r][j], psi)
+    energies, loss = engine.energy(psi)
+    lam = engine.gemm(M, psi, alpha=2.0)                       # Lambda_S = 2 M Psi_S
+    fin = psi
+    grad = np.zeros((S, K), dtype=np.float64)
+    for (t0, n_win), ck in zip(reversed(windows), reversed(checkpoints)):   # ---- backward ----
+        spans, pad = gather_window(t0, n_win)
+        Ugath = yield ("all_gather", pad)
+        Us = [Ugath[r][j] for r in range(world) for j in range(spans[r][1])]            # the window's steps in order
+        states = [ck]
+        for U in Us[:-1]:
+            states.append(engine.gemm(U, states[-1]))
+        Gs = _like_zeros(pad, (world * per_rank, d, d))
+        for i in range(len(Us) - 1, -1, -1):
+            r, j = divmod(i, per_rank)
+            engine.gemm(lam, states[i], opB=1, out=Gs[r * per_rank + j])               # G_t = lambda_{t+1} psi_t^H
+            lam = engine.gemm(Us[i], lam, opA=1)                                       # lambda_t = U_t^H lambda_{t+1}
+        Gmine = yield ("reduce_scatter", Gs)                   # [per_rank][d][d]: the sums over all ranks' columns, own steps
+        first, count = spans[rank]
+        if count:
+            grad[first:first + count] = engine.propagator_vjp(u[first:first + count], dt, Gmine[:count])
+    buf = np.zeros(S * K + 1, dtype=np.float64)
+    buf[:-1] = grad.reshape(-1)
+    buf[-1] = loss
+    buf = yield ("all_reduce", buf)
+    return float(buf[-1]), np.array(buf[:-1]).reshape(S, K), (fin if want_final else None), (energies if want_energies else None)
+
+
+def _like_zeros(like, shape):
+    if isinstance(like, np.ndarray):
+        return np.zeros(shape, dtype=like.dtype)
+    import torch
+    return torch.zeros(shape, dtype=like.dtype, device=like.device)
+
+
+def propagator_sharded_energy_grad(engine, M, u, dt, psi0_shard, group=None, device=None, per_rank=1, want_final=False,
+                                   want_energies=False):
+    """SURVEY.md section 8-F2 as written: "each GPU builds S/G propagators and all-gathers them" -- for the STATE-form regime
+    (batch per rank < 3/4 dim), where every rank needs every U_t for its own columns and the replicated form would make every
+    rank compute every exponential. M: the observable given to engine.set_observable (an array of the kind of psi0_shard).
+    Returns (loss, grad_u[S][K], psi_final of this rank's columns or None, their energies or None); loss and gradient are the
+    sums over all ranks' columns. Communication per step: 16 d^2 bytes all-gathered twice (forward, backward) and reduce-scattered
+    once -- at d = 4096 that is 0.8 GB per step, which is why the time-sliced OPERATOR form (three collectives per gradient
+    evaluation) is the faster choice wherever it applies; this form exists for completeness and for
+    generators that are not Hermitian-checked operator-form candidates."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        rank, world = 0, 1
+    else:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    gen = _propagator_sharded_phases(engine, M, u, dt, psi0_shard, rank, world, per_rank, want_final, want_energies)
+    req = next(gen)
+    while True:
+        kind, x = req
+        if world == 1:
+            res = [x] if kind == "all_gather" else x
+        else:
+            res = _torch_collective(kind, x, group, device)
+        try:
+            req = gen.send(res)
+        except StopIteration as done:
+            return done.value
+
+
+def virtual_propagator_sharded_energy_grad(engines, M, u, dt, psi0_shards, per_rank=1):
+    """The same program for len(engines) VIRTUAL ranks inside one process (tests, single-GPU rehearsal)."""
+    world = len(engines)
+    gens = [_propagator_sharded_phases(engines[r], M, u, dt, psi0_shards[r], r, world, per_rank, True, True) for r in range(world)]
+    reqs = [next(g) for g in gens]
+    results = [None] * world
+    while any(r is not None for r in reqs):
+        kinds = {r[0] for r in reqs if r is not None}
+        if len(kinds) != 1 or any(r is None for r in reqs):
+            raise RuntimeError("virtual ranks diverged: {}".format([None if r is None else r[0] for r in reqs]))
+        kind = kinds.pop()
+        xs = [r[1] for r in reqs]
+        if kind == "all_gather":
+            res = [list(xs) for _ in range(world)]
+        else:
+            tot = xs[0].copy() if isinstance(xs[0], np.ndarray) else xs[0].clone()
+            for x in xs[1:]:
+                tot += x
+            if kind == "reduce_scatter":
+                n = tot.shape[0] // world
+                res = [tot[r * n:(r + 1) * n] for r in range(world)]
+            else:
+                res = [tot.copy() if isinstance(tot, np.ndarray) else tot.clone() for _ in range(world)]
+        nxt = []
+        for r, g in enumerate(gens):
+            try:
+                nxt.append(g.send(res[r]))
+            except StopIteration as done:
+                results[r] = done.value
+                nxt.append(None)
+        reqs = nxt
+    return results
+
+
 def _torch_collective(kind, x, group, device):
     """Run one collective request through torch.distributed (nccl: device tensors in place; gloo: staged on the host)."""
     import torch
@@ -128,6 +269,20 @@ def _torch_collective(kind, x, group, device):
         tr = tr.contiguous()
         dist.all_reduce(tr, op=dist.ReduceOp.SUM, group=group)
         res = torch.view_as_complex(tr) if t.is_complex() else tr
+        if is_np:
+            return res.cpu().numpy()
+        return res.to(x.device) if on_dev else res
+    if kind == "reduce_scatter":  # x: [world * n][...] -> the sum over ranks of this rank's block [n][...]
+        tr = tr.contiguous()
+        n = tr.shape[0] // world
+        if backend == "nccl":
+            out = torch.empty((n,) + tuple(tr.shape[1:]), dtype=tr.dtype, device=tr.device)
+            dist.reduce_scatter_tensor(out, tr, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.all_reduce(tr, op=dist.ReduceOp.SUM, group=group)
+            r = dist.get_rank(group)
+            out = tr[r * n:(r + 1) * n].contiguous()
+        res = torch.view_as_complex(out) if t.is_complex() else out
         if is_np:
             return res.cpu().numpy()
         return res.to(x.device) if on_dev else res

@@ -309,6 +309,54 @@ class Engine:
         _lib.check(self._lib.dq_slice_backward(self._ctx, pu, n, float(dt), pw, grad.ctypes.data, ps))
         return (grad, Ws) if want_w_start else grad
 
+    # -- explicit propagators in and out (SURVEY.md 8-F2 in its literal form; see distributed.propagator_sharded_energy_grad) --
+    def build_propagators(self, u, dt: float, like=None):
+        """U[t] = exp(-i dt (H0 + sum_k u[t][k] H_k)) for the rows of u: an [n][dim][dim] array of the kind of `like`
+        (CUDA torch tensor -> the propagators stay on the device; otherwise numpy)."""
+        pu, ku, n = self._u(u)
+        if _is_torch(like):
+            import torch
+            U = torch.empty((n, self.dim, self.dim), dtype=torch.complex128 if self.dtype == "c128" else torch.complex64,
+                            device=like.device)
+            pU = U.data_ptr()
+        else:
+            U = np.empty((n, self.dim, self.dim), dtype=self.cdtype)
+            pU = U.ctypes.data
+        _lib.check(self._lib.dq_build_propagators(self._ctx, pu, n, float(dt), pU))
+        return U
+
+    def propagator_vjp(self, u, dt: float, G):
+        """grad_u[t][k] = Re <G[t], dU_t/du_k> for cotangents G [n][dim][dim] of the propagators of the rows of u."""
+        pu, ku, n = self._u(u)
+        pG, kG = self._c(G, (n, self.dim, self.dim), "G")
+        grad = np.zeros((n, self.n_controls), dtype=np.float64)
+        _lib.check(self._lib.dq_propagator_vjp(self._ctx, pu, n, float(dt), pG, grad.ctypes.data))
+        return grad
+
+    def gemm(self, A, B, opA=0, opB=0, alpha=1.0, out=None):
+        """alpha op(A) @ op(B) for 2-D complex arrays of either kind (CUDA torch tensors stay on the device); op 1 =
+        conjugate transpose. Shapes are taken from the arrays."""
+        ar, ac = int(A.shape[0]), int(A.shape[1])
+        br, bc = int(B.shape[0]), int(B.shape[1])
+        M, K = (ac, ar) if opA == 1 else (ar, ac)
+        K2, N = (bc, br) if opB == 1 else (br, bc)
+        if K != K2:
+            raise ValueError("inner dimensions differ: {} vs {}".format(K, K2))
+        pa, ka = self._c(A, (ar, ac), "A")
+        pb, kb = self._c(B, (br, bc), "B")
+        if out is None:
+            if _is_torch(A):
+                import torch
+                out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+            else:
+                out = np.empty((M, N), dtype=self.cdtype)
+        po, ko = self._c(out, (M, N), "out")
+        if not _is_torch(out) and ko is not out:
+            raise ValueError("out must be a contiguous buffer of the engine dtype")
+        _lib.check(self._lib.dq_zgemm_ex(self._ctx, int(opA), int(opB), M, N, K, float(alpha), pa, ac, ar * ac, pb, bc, br * bc,
+                                         0.0, po, N, M * N, 1, 0))
+        return out
+
     def matmul(self, A, B, opA=0, opB=0, herm=0, out=None):
         """op(A) @ op(B) for [dim][dim] matrices of either kind (CUDA torch tensors stay on the device);
         op 1 = conjugate transpose; herm = +1/-1: (anti-)Hermitian output form."""

@@ -181,6 +181,17 @@ int dq_slice_terminal(dq_ctx* ctx, const void* Q, const void* psi0, int batch, c
 int dq_slice_backward(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* W_end, double* grad_u,
                       void* W_start);
 
+/* ---- Explicit propagators in and out: SURVEY.md section 8-F2 in its literal form ("each GPU builds S/G propagators and
+ * all-gathers them"), for the STATE-form regime (batch per GPU < 3/4 dim) where every rank needs every U_t for its own columns.
+ * dq_build_propagators: U_out[t] = exp(-i dt (H0 + sum_k u[t][k] H_k)) for the n pulse rows given ([n][dim][dim] complex, host or
+ *   device) -- the reference builds the same matrix inside its time loop (diffqc.cc:192-198 `dH.exp()`, sim_plain.py:137-145).
+ * dq_propagator_vjp: pulls cotangents G[t] of those propagators back to the pulse rows with the exp's exact reverse mode and the
+ *   control contractions: grad_u[t][k] = Re <G[t], dU_t/du_k> (pairing Re tr(G^H dU)); needs Hermitian H0/H_k.
+ * With dq_zgemm (psi_{t+1} = U_t psi_t, lambda_t = U_t^H lambda_{t+1}, G_t = lambda_{t+1} psi_t^H summed over the ranks' columns)
+ * a host distributes the exponentials of a chain over G ranks: diffquantum_amd/distributed.py:propagator_sharded_energy_grad. */
+int dq_build_propagators(dq_ctx* ctx, const double* u, int n_steps, double dt, void* U_out);
+int dq_propagator_vjp(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* G, double* grad_u);
+
 /* Building blocks, exported for parity tests and reuse. */
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements.
  * opA may also be 2 / 3 / 4: A as stored (like 0), square, and KNOWN by the caller to be complex symmetric (A^T = A) /

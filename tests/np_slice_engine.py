@@ -56,3 +56,31 @@ class NumpySliceEngine:
                 grad[t, k] = np.real(np.vdot(G, dU))  # Re tr(G^H dU)
             W = U.conj().T @ G
         return (grad, W) if want_w_start else grad
+
+    # ---- explicit propagators in and out (Engine.build_propagators / propagator_vjp / gemm / energy) ----
+    def build_propagators(self, u, dt, like=None):
+        u = np.asarray(u, dtype=np.float64).reshape(-1, self.n_controls)
+        out = np.empty((u.shape[0], self.dim, self.dim), dtype=np.complex128)
+        for t, row in enumerate(u):
+            out[t] = sla.expm(orc.step_generator(self.H0, self.Hs, row, dt))
+        return out
+
+    def propagator_vjp(self, u, dt, G):
+        u = np.asarray(u, dtype=np.float64).reshape(-1, self.n_controls)
+        grad = np.zeros_like(u)
+        for t, row in enumerate(u):
+            A = orc.step_generator(self.H0, self.Hs, row, dt)
+            for k, Hk in enumerate(self.Hs):
+                grad[t, k] = np.real(np.vdot(G[t], sla.expm_frechet(A, -1j * dt * Hk, compute_expm=False)))
+        return grad
+
+    def gemm(self, A, B, opA=0, opB=0, alpha=1.0, out=None):
+        res = alpha * ((A.conj().T if opA else A) @ (B.conj().T if opB else B))
+        if out is not None:
+            out[...] = res
+            return out
+        return res
+
+    def energy(self, psi):
+        en = np.real(np.sum(psi.conj() * (self.M @ psi), axis=0))
+        return en, float(en.sum())

@@ -149,3 +149,74 @@ def test_two_rank_gloo_time_sliced_equals_single_process():
         for l, g in out:
             assert abs(l - loss) < 1e-12 and np.max(np.abs(g - grad)) < 1e-12
         assert np.max(np.abs(f - fin[:, first:first + count])) < 1e-12
+
+
+def _propagator_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from diffquantum_amd import problems
+    from diffquantum_amd.distributed import propagator_sharded_energy_grad, shard_range
+    from tests.np_slice_engine import NumpySliceEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (7, 2))
+    B = 5
+    first, count = shard_range(B, rank, world)
+    psi = problems.random_states(4, count, seed=9, first=first)
+    out = []
+    for per_rank in (1, 2):  # 7 steps: windows of 2 / 4 steps, the last one ragged (a rank without a step)
+        loss, grad, fin, en = propagator_sharded_energy_grad(NumpySliceEngine(H0, Hs, M), M, u, 0.1, psi, per_rank=per_rank,
+                                                             want_final=True, want_energies=True)
+        out.append((loss, grad))
+    q.put((rank, out, fin, first, count))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_propagator_sharded_equals_single_process():
+    """SURVEY 8-F2 in its literal form (propagators built 1/G per rank, all-gathered; cotangents reduce-scattered to their
+    owners) through real gloo collectives, with the oracle's arithmetic as the per-rank engine."""
+    import torch.multiprocessing as mp
+    from diffquantum_amd import problems
+    from oracle import trotter_oracle as orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_propagator_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (7, 2))
+    full = problems.random_states(4, 5, seed=9)
+    loss, grad, fin = orc.energy_grad(H0, list(Hs), M, u, 0.1, full)
+    for rank, out, f, first, count in res:
+        for l, g in out:
+            assert abs(l - loss) < 1e-12 and np.max(np.abs(g - grad)) < 1e-12
+        assert np.max(np.abs(f - fin[:, first:first + count])) < 1e-12
+
+
+def test_virtual_ranks_propagator_sharded_numpy():
+    from diffquantum_amd import problems
+    from diffquantum_amd.distributed import shard_range, virtual_propagator_sharded_energy_grad
+    from oracle import trotter_oracle as orc
+    from tests.np_slice_engine import NumpySliceEngine
+    H0, Hs, M = problems.random_hermitian_problem(3, 2, seed=7)
+    u = np.random.default_rng(2).uniform(-1, 1, (5, 2))
+    full = problems.random_states(8, 7, seed=3)
+    loss, grad, fin = orc.energy_grad(H0, list(Hs), M, u, 0.07, full)
+    for world, per_rank in ((1, 1), (3, 1), (3, 2), (4, 3)):
+        shards = [full[:, f:f + c] for f, c in (shard_range(7, r, world) for r in range(world))]
+        res = virtual_propagator_sharded_energy_grad([NumpySliceEngine(H0, Hs, M) for _ in range(world)], M, u, 0.07, shards,
+                                                     per_rank=per_rank)
+        for r, (l, g, f, en) in enumerate(res):
+            f0, c0 = shard_range(7, r, world)
+            assert abs(l - loss) < 1e-12 and np.max(np.abs(g - grad)) < 1e-12
+            assert np.max(np.abs(f - fin[:, f0:f0 + c0])) < 1e-12
