@@ -611,7 +611,7 @@ def run_config5(a, D):
 def run_config3(a, D):
     import torch
     from diffquantum_amd import problems
-    from diffquantum_amd.distributed import allreduce_loss_grad, time_sliced_energy_grad
+    from diffquantum_amd.distributed import allreduce_loss_grad, propagator_sharded_energy_grad, time_sliced_energy_grad
     from diffquantum_amd.engine import Engine
     dist = D.dist
     rank, world, dev = D.rank, D.world, D.dev
@@ -630,6 +630,7 @@ def run_config3(a, D):
     eng.use_torch_stream()
     eng.set_hamiltonians(H0, Hs)
     eng.set_observable(M)
+    M_dev = M if a.multi_gpu == "propagators" else None
     del H0, Hs, M
     eng.set_option("real_path", a.real_path)
     eng.set_option("plan_steps", max(a.chain, K))  # checkpoint/rebuild ratio of the full 2000-step chain
@@ -660,12 +661,19 @@ def run_config3(a, D):
         grad_dev.copy_(torch.from_numpy(g).to(dev))
         return loss, grad_dev
 
+    def run_propagators(u_dev, grad_dev):
+        # SURVEY 8-F2 in its literal form: every rank builds 1/world of each window's propagators, all-gather, state-form chain on
+        # its own batch shard, reduce-scatter of the propagators' cotangents to their owners, one all-reduce of the gradient rows
+        loss, g, _, _ = propagator_sharded_energy_grad(eng, M_dev, u_dev, a.dt, psi0, device=dev)
+        grad_dev.copy_(torch.from_numpy(g).to(dev))
+        return loss, grad_dev
+
     # Which multi-GPU form runs.  No exception handling around anything that contains a collective: every rank issues the
     # same collectives in the same order with the same sizes, and a rank-local failure (OOM, DiffqcError) aborts the job
     # non-zero instead of leaving the peers in a mismatched collective.
     force = bool(os.environ.get("DQ_FORCE_COLLECTIVES")) and D.on
     both = (world > 1 or force) and a.multi_gpu == "auto"
-    mode = "sliced" if (a.multi_gpu == "sliced" and D.on) or both else "replicated"
+    mode = "sliced" if (a.multi_gpu == "sliced" and D.on) or both else ("propagators" if a.multi_gpu == "propagators" else "replicated")
     forms = {}
     sliced_check = None
     if W > 0:
@@ -696,7 +704,11 @@ def run_config3(a, D):
             D.fence()
             forms[name] = {"seconds": D.max_over_ranks(time.perf_counter() - t1), "loss": l2, "grad": g2.clone()}
         mode = "replicated" if forms["replicated"]["seconds"] < forms["sliced"]["seconds"] else "sliced"
-    run = run_sliced if mode == "sliced" else run_replicated
+    prop_check = None
+    if mode == "propagators" and W > 0:   # the warm-up chain doubles as the check against the replicated form
+        lp, gp = run_propagators(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+        prop_check = {"max_abs_grad_diff_vs_replicated": float((gp - gr).abs().max().item()), "abs_loss_diff_vs_replicated": abs(lp - lr)}
+    run = {"sliced": run_sliced, "propagators": run_propagators}.get(mode, run_replicated)
     eng.profile_enable(True)
     eng.profile_reset()
 
@@ -758,10 +770,14 @@ def run_config3(a, D):
             "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
             "chain_steps": K, "dt": a.dt,
             "parallelism": ("dp{} (batch shards, one all-reduce of loss+dL/du)".format(world) if mode == "replicated" else
+                            "dp{0} over the batch, the propagators of every window of {0} steps built one per rank and all-gathered; "
+                            "state-form chain, reduce-scatter of the propagators' cotangents (SURVEY 8-F2 as written)".format(world)
+                            if mode == "propagators" else
                             "dp{0} over the batch x {0} time slices: operator form, each rank builds and sweeps 1/{0} of "
                             "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
                             "(d x d) and of dL/du".format(world)),
-            "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "multi_gpu_forms": forms_out,
+            "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "propagators_warmup_check": prop_check,
+            "multi_gpu_forms": forms_out,
             "collectives_forced_at_world_1": force and world == 1,
             "expm": describe_expm(info),
             "path": "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path",
@@ -829,10 +845,11 @@ def main():
                     help="length of the full configuration's chain: the timed slice uses ITS checkpoint stride")
     ap.add_argument("--real-path", type=int, default=-1,
                     help="-1 auto (real H -> cos/sin form on real MFMA products), 0 = general complex path only")
-    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated"), default="auto",
+    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated", "propagators"), default="auto",
                     help="N > 1: 'sliced' = chain split over time across the ranks (operator form; three collectives), "
                          "'replicated' = every rank runs the whole chain on its batch shard (one all-reduce); "
-                         "auto = both checked and tried, the faster one timed")
+                         "auto = both checked and tried, the faster one timed; 'propagators' = SURVEY 8-F2 as written: state-form "
+                         "chain on propagators built 1/N per rank and all-gathered (never chosen by auto: 0.8 GB of collectives per step)")
     ap.add_argument("--launch", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
     a = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.launch):

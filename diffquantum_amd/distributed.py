@@ -188,11 +188,13 @@ def propagator_sharded_energy_grad(engine, M, u, dt, psi0_shard, group=None, dev
         rank, world = 0, 1
     else:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # DQ_FORCE_COLLECTIVES=1: issue the collectives even at world size 1 (rehearsal of the RCCL calls on a one-GPU box)
+    local_only = world == 1 and not (os.environ.get("DQ_FORCE_COLLECTIVES") and dist.is_available() and dist.is_initialized())
     gen = _propagator_sharded_phases(engine, M, u, dt, psi0_shard, rank, world, per_rank, want_final, want_energies)
     req = next(gen)
     while True:
         kind, x = req
-        if world == 1:
+        if local_only:
             res = [x] if kind == "all_gather" else x
         else:
             res = _torch_collective(kind, x, group, device)

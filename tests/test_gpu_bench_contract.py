@@ -108,6 +108,17 @@ def test_bench_launches_its_own_ranks_and_runs_the_collectives_through_rccl():
     assert abs(rep - ref) < 0.06 * ref, (rep, ref)          # same chain, same GPU, seconds apart (measured: see DESIGN.md)
 
 
+def test_bench_propagator_sharded_form_through_rccl():
+    """SURVEY 8-F2 as written (`--multi-gpu propagators`), ranks started by the launcher, N = 1 with forced collectives: the
+    all-gather of the propagators and the reduce-scatter of their cotangents run on device tensors through RCCL; the warm-up
+    chain's gradient equals the replicated form's."""
+    d = _run(["--gpus", "1", "--launch", "--multi-gpu", "propagators", "--qubits", "10", "--batch", "256", "--steps", "5",
+              "--warmup", "3", "--skip-other-configs", "--skip-cpu-baseline", "--skip-general-path"], env={"DQ_FORCE_COLLECTIVES": "1"})
+    assert d["backend"].startswith("nccl") and d["config"]["multi_gpu_form"] == "propagators" and d["value"] > 0
+    chk = d["config"]["propagators_warmup_check"]
+    assert chk["max_abs_grad_diff_vs_replicated"] < 1e-10 and chk["abs_loss_diff_vs_replicated"] < 1e-9
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "2"], cwd=ROOT,
                          capture_output=True, text=True, timeout=300)
