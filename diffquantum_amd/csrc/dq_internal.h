@@ -43,7 +43,7 @@ struct ZgemmArgs {
   double alpha, beta;
   int opA, opB;         // 0 = as stored, 1 = conjugate transpose
   // hintA (with opA == 0): what the caller knows about the stored A -- 0 nothing, 1 complex symmetric (A^T = A),
-  // 2 Hermitian, 3 anti-Hermitian.  A hint lets the launcher read A k-major (A = A^T, A^H, -A^H) and take the
+  // 2 Hermitian, 3 anti-Hermitian; 5 (engine-internal): the buffer already holds A^T ([K][M], lda = M).  A hint lets the launcher read A k-major (A = A^T, A^H, -A^H) and take the
   // linear-form kernel (zgemm_lin.hip); results do not depend on it for operands that have the stated property.
   int hintA = 0;
   // herm: 0 = general output; +1 / -1 = the caller asserts that the product is Hermitian / anti-Hermitian (e.g. X^H W X
@@ -90,6 +90,11 @@ hipError_t lincomb_launch(const LincombArgs<T>& a, hipStream_t st);
 template <class T>
 hipError_t tcombine_launch(typename Cx<T>::type* out, const typename Cx<T>::type* X, int d, double a, double b,
                            int accumulate, long stride, int batch, hipStream_t st);
+
+// out[z] (cols x rows, ldo) = in[z]^T (in: rows x cols, ldi), conjugated if conj != 0
+template <class T>
+hipError_t ztranspose_launch(typename Cx<T>::type* out, long ldo, long so, const typename Cx<T>::type* in, long ldi, long si,
+                             int rows, int cols, int conj, int batch, hipStream_t st);
 
 // part[z][blk][k] = sum over the block's elements of Im(conj(Abar[z][e]) * Hs[k][e]) (accumulated in fp64);
 // grad[z][k] = scale * sum_blk part   (deterministic two-stage reduction)

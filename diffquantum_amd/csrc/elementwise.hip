@@ -134,6 +134,46 @@ hipError_t tcombine_launch(typename Cx<T>::type* out, const typename Cx<T>::type
 template hipError_t tcombine_launch<double>(double2*, const double2*, int, double, double, int, long, int, hipStream_t);
 template hipError_t tcombine_launch<float>(float2*, const float2*, int, double, double, int, long, int, hipStream_t);
 
+// ---- out[z][j][i] = in[z][i][j] (conj: its complex conjugate), rows x cols -> cols x rows, explicit leading dimensions ----
+// The pre-pass that gives a complex GEMM operand a k-major form (zgemm_lin.hip) when it has none: LDS-tiled, both sides coalesced.
+template <class T>
+__global__ void __launch_bounds__(256) ztranspose_kernel(typename Cx<T>::type* __restrict__ out, long ldo, long so,
+                                                         const typename Cx<T>::type* __restrict__ in, long ldi, long si,
+                                                         int rows, int cols, int conj) {
+  typedef typename Cx<T>::type T2;
+  __shared__ T2 tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const T2* I = in + (long)blockIdx.z * si;
+  T2* O = out + (long)blockIdx.z * so;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = I[(long)r * ldi + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;  // output row c, output column r
+    if (r < rows && c < cols) {
+      T2 v = tile[tx][ty + 8 * k];
+      if (conj) v.y = -v.y;
+      O[(long)c * ldo + r] = v;
+    }
+  }
+}
+
+template <class T>
+hipError_t ztranspose_launch(typename Cx<T>::type* out, long ldo, long so, const typename Cx<T>::type* in, long ldi, long si,
+                             int rows, int cols, int conj, int batch, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return hipSuccess;
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+  hipLaunchKernelGGL(ztranspose_kernel<T>, grid, dim3(256), 0, st, out, ldo, so, in, ldi, si, rows, cols, conj);
+  return hipGetLastError();
+}
+template hipError_t ztranspose_launch<double>(double2*, long, long, const double2*, long, long, int, int, int, int, hipStream_t);
+template hipError_t ztranspose_launch<float>(float2*, long, long, const float2*, long, long, int, int, int, int, hipStream_t);
+
 // ---- dL/du_k[t] = Re<Abar_t, -i dt H_k>_F = dt * sum Im(conj(Abar) .* H_k) ---------------
 // Stage 1: per-block partial sums for up to KC controls at a time; stage 2: fixed-order sum over
 // blocks (no atomics -> bitwise reproducible gradients).

@@ -290,6 +290,7 @@ struct Ctx : dq_ctx {
   bool have_H = false, have_M = false, hermitian = false, real_h = false;
   // sparse control Hamiltonians (real path; realpath.hip): the nonzeros of all H_k in one CSR by row, and the same
   // entries grouped by control; sparse_mode: -1 auto (total nonzeros <= sparse_fill * dim), 0 off
+  DevBuf zta, ztb;  // transposed operand copies for the linear-form complex GEMM
   DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval, sp_nzacc, sp_part;
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
@@ -305,7 +306,7 @@ struct Ctx : dq_ctx {
   std::vector<double> nHk;
   // options
   double checkpoint_bytes = 0.0, chunk_bytes = 0.0, expm_tol = 0.0, herm_tol = 0.0;
-  int slab_spmm = 1;
+  int slab_spmm = 1, transpose_fallback = 1;
   int force_degree = 0, force_s = -1, force_tile = 0, zgemm_alg = 2, compose_mode = -1, skew_trick = 1;
   // info
   double last_degree = 0, last_squarings = 0, last_chunk = 0, last_cstride = 0, last_theta = 0, last_products = 0, last_composed = 0, last_opback = 0, last_tpar = 0;
@@ -405,6 +406,31 @@ struct Ctx : dq_ctx {
       zws.ensure(elems * sizeof(T2));
       g.ws = (T2*)zws.p;
       g.ws_elems = elems;
+    }
+    // Operands without a k-major form (A as stored with no symmetry hint; B^H) get one by a transposing pre-pass into scratch,
+    // so that the product runs on the linear-form kernel too (zgemm_lin.hip): 0.12 ms per 268 MB matrix against the ~0.5 ms the
+    // 16-wave kernel saves on a d = 4096 product. Only for big single products (fp64, whole 128-tiles, K >= 1024).
+    if (sizeof(T) == 8 && zgemm_alg == 2 && transpose_fallback && (force_tile == 0 || force_tile == 128) && batch == 1 &&
+        M % 128 == 0 && N % 128 == 0 && Kd % 16 == 0 && Kd >= 1024 && (long)(M / 128) * (N / 128) >= 64 &&
+        ((g.opA == 0 && g.hintA == 0) || g.opB == 1)) {
+      if (g.opB == 1) {  // B stored [N][K]: B^H -> [K][N]
+        ztb.ensure((size_t)Kd * N * sizeof(T2));
+        const T2* Bsrc = B;
+        const long ldb0 = ldb;
+        T2* Bt = (T2*)ztb.p;
+        timed(DQ_PROF_LINCOMB, 0.0, 2.0 * sizeof(T2) * (double)Kd * N,
+              [&] { return dq::ztranspose_launch<T>(Bt, N, 0, Bsrc, ldb0, 0, N, Kd, 1, 1, st); });
+        g.B = Bt; g.ldb = N; g.opB = 0;
+      }
+      if (g.opA == 0 && g.hintA == 0) {  // A stored [M][K]: A^T -> [K][M], read k-major without conjugation (hint 1: A^T of A^T)
+        zta.ensure((size_t)M * Kd * sizeof(T2));
+        const T2* Asrc = A;
+        const long lda0 = lda;
+        T2* At = (T2*)zta.p;
+        timed(DQ_PROF_LINCOMB, 0.0, 2.0 * sizeof(T2) * (double)M * Kd,
+              [&] { return dq::ztranspose_launch<T>(At, M, 0, Asrc, lda0, 0, M, Kd, 0, 1, st); });
+        g.A = At; g.lda = M; g.hintA = 5;  // 5: "this buffer holds A^T": the launcher reads it k-major as it stands
+      }
     }
     // algorithmic flops of the product that is delivered (the herm form executes about half of them)
     const double fl = 8.0 * M * N * (double)Kd * batch;
@@ -2110,6 +2136,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->fuse_levels = v != 0 ? 1 : 0;
   } else if (s == "sparse_generator") {  // drift and controls sparse: -1 auto (dim >= 64 nonzeros-per-row), 0 off, 1 whenever possible
     c->sparse_gen_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "transpose_fallback") {  // transposing pre-pass for big complex products whose operands have no k-major form
+    c->transpose_fallback = v != 0 ? 1 : 0;
   } else if (s == "slab_spmm") {  // sparse x dense passes in XCD-slab form (1, default) or one wave per whole row (0)
     c->slab_spmm = v != 0 ? 1 : 0;
   } else if (s == "skew_trick") {

@@ -455,7 +455,7 @@ hipError_t zgemm_launch<double>(const ZgemmArgs<double>& g, hipStream_t st, int 
   if (tile == 128 && alg == 2 && g.opB == 0 && (g.opA == 1 || g.hintA != 0) && zgemm_lin_eligible(g)) {
     // left operand readable k-major: A^H as asked, or A = A^T / A^H / -A^H by the caller's hint
     if (g.opA == 1 || g.hintA == 2) return zgemm_lin_launch(g, 1, st, n_cu);
-    if (g.hintA == 1) return zgemm_lin_launch(g, 0, st, n_cu);
+    if (g.hintA == 1 || g.hintA == 5) return zgemm_lin_launch(g, 0, st, n_cu);  // (5: the buffer already holds A^T, [K][M])
     ZgemmArgs<double> h = g;
     h.alpha = -g.alpha;
     return zgemm_lin_launch(h, 1, st, n_cu);

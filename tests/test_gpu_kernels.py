@@ -244,3 +244,24 @@ def test_zgemm_linear_form_hermitian_output(eng16, herm):
             ref2 = -0.5 * ref + 2.0 * C0
             assert np.max(np.abs(got - ref2)) < 1e-11 * np.max(np.abs(ref2))
             assert np.array_equal(got, herm * got.conj().T)
+
+
+@pytest.mark.parametrize("opA,opB", [(0, 0), (0, 1), (1, 1)])
+def test_zgemm_transposing_prepass_for_operands_without_a_k_major_form(eng16, opA, opB):
+    """Big single products whose operands have no k-major form (A as stored without a symmetry hint; B^H) reach the linear-form
+    kernel through a transposing pre-pass; same product as numpy and as the general kernel (transpose_fallback = 0)."""
+    rng = np.random.default_rng(opA * 2 + opB)
+    M, N, K = 1024, 1152, 1040
+    A = _rand(rng, *((K, M) if opA else (M, K)))
+    B = _rand(rng, *((N, K) if opB else (K, N)))
+    C0 = _rand(rng, M, N)
+    got = eng16.zgemm(A, B, opA=opA, opB=opB, alpha=-0.5, beta=0.25, C_in=C0)
+    eng16.set_option("transpose_fallback", 0)
+    try:
+        old = eng16.zgemm(A, B, opA=opA, opB=opB, alpha=-0.5, beta=0.25, C_in=C0)
+    finally:
+        eng16.set_option("transpose_fallback", 1)
+    ref = -0.5 * ((A.conj().T if opA else A) @ (B.conj().T if opB else B)) + 0.25 * C0
+    bound = np.finfo(np.float64).eps * K * np.max(np.abs(A)) * np.max(np.abs(B)) * 8
+    assert np.max(np.abs(got - ref)) < bound and np.max(np.abs(old - ref)) < bound
+    assert np.array_equal(got, old)          # same 3M arithmetic in the same order on both kernels
