@@ -203,3 +203,40 @@ def test_config5_n18_properties():
         fd, an = (L(u + eps * v) - L(u - eps * v)) / (2 * eps), float(np.sum(grad * v))
         assert abs(fd - an) < 2e-3 * max(1.0, abs(an)), (fd, an)
         assert e.info("degree") >= 4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a dimension that is NOT a power of two, large enough for the 16-wave linear-form GEMM (1536 = 12 x 128) but not for the
+# XCD-slab sparse passes (1024-multiples only): the kernel-selection boundaries against the oracle
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind", ["complex", "real_sparse"])
+def test_dimension_1536_matches_oracle(oracle, kind):
+    from diffquantum_amd.engine import Engine
+    d, K, B, S, dt = 1536, 2, 24, 2, 0.004
+    rng = np.random.default_rng(1536)
+    if kind == "complex":
+        def herm():
+            a = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+            return (a + a.conj().T) / (4.0 * np.sqrt(d))
+        H0, Hs = herm(), np.stack([herm() for _ in range(K)])
+    else:
+        H0 = np.diag(rng.standard_normal(d)).astype(complex)
+        Hs = np.zeros((K, d, d), dtype=complex)
+        for k in range(K):
+            for i in range(0, d - (k + 1), 2 * (k + 1)):
+                Hs[k, i, i + k + 1] = Hs[k, i + k + 1, i] = rng.standard_normal()
+    M = np.diag(rng.standard_normal(d)).astype(complex)
+    u = rng.uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=7)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    for compose in (1, 0):
+        with Engine(d, K) as e:
+            e.set_hamiltonians(H0, Hs)
+            e.set_observable(M)
+            e.set_option("compose", compose)
+            loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+            if kind == "real_sparse":
+                assert e.info("sparse_generator") == 1
+        assert np.max(np.abs(fin - rf)) < TOL and abs(loss - rl) < TOL * B
+        assert np.max(np.abs(grad - rg)) < TOL, (kind, compose, np.max(np.abs(grad - rg)))
