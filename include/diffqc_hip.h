@@ -123,6 +123,10 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      2 (default) = 3M and, for whole 128-tiles at dim >= 1024 whose left operand can be read k-major
  *                      (A^H, or an A the engine knows to be complex symmetric / (anti-)Hermitian), the 16-wave
  *                      linear-form kernel (csrc/zgemm_lin.hip)
+ *   transpose_fallback 1 (default): big single complex products whose operands have no k-major form (A as stored without a symmetry
+ *                      hint, B^H) get one by a transposing pre-pass into scratch, so that they run on the linear-form kernel too
+ *   slab_spmm          1 (default): the sparse x dense passes of the sparse-generator scheme in XCD-slab form (16-B lanes, one
+ *                      column slab per XCD; dim a multiple of 1024 in fp64 / 2048 in fp32), 0 = one wave per whole row
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
