@@ -238,4 +238,32 @@ hipError_t rsp_finish_launch(const double* nzacc, const T* D, const T* G2, doubl
 hipError_t rsp_reduce_launch(const double* nzval, long nnz, const long* kptr, const long* kent, int K, int batch, double scale,
                              double* grad, hipStream_t st);
 
+// ---- xorexp.hip: sparse generator with an XOR-regular pattern: besides offset-0 diagonals, row i holds exactly the entries
+// (i, i ^ xoff[j]), j < R, each XOR-diagonal from one control and of constant magnitude ----
+constexpr int XR_RMAX = 16;  // off-diagonal XOR-diagonals
+constexpr int XR_DMAX = 16;  // diagonals at offset 0 (one per source matrix that has diagonal entries; any per-row values)
+constexpr int XR_SLOTS = XR_RMAX + XR_DMAX;
+constexpr int XR_QMAX = 3;   // cos / sin polynomial: powers X_1 .. X_{2q+1}
+constexpr int XR_RPT = 8;    // rows per thread (workgroup = d / 8 threads)
+struct XrTab {
+  int R, nd;
+  int xoff[XR_RMAX];
+  int kid[XR_RMAX];      // the control the diagonal belongs to (-1: the drift)
+  double cmag[XR_RMAX];  // |value| along the diagonal
+  int dkid[XR_DMAX];     // source of an offset-0 diagonal: control index, or -1 for the drift
+  const unsigned* sgn;   // [d] bit j set: entry (i, i ^ xoff[j]) is -cmag[j]; null when no entry is negative
+  const double* dval;    // [nd][d] values of the offset-0 diagonals
+};
+struct XrPoly {
+  int q;
+  double cc[XR_QMAX + 1], sc[XR_QMAX + 1];  // cos X = sum cc_j X^2j, sin X = sum sc_j X^(2j+1)
+};
+bool xr_supported(int d, int q, int R, int nd, size_t elem);  // elem = sizeof(real type): complex128 engines only
+int xr_blocks(int d);  // workgroups per step (scratch of xr_reverse_launch: batch * xr_blocks(d) * XR_SLOTS doubles)
+hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                             const XrPoly& pol, int batch, hipStream_t st);
+hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* grad, int accumulate,
+                             hipStream_t st);
+
 }  // namespace dq

@@ -108,6 +108,7 @@ struct ExpmPlan {
   int m = 0, s = 0, nvars = 0, out = 0, nprod = 0;
   int rq = 0;  // > 0: real-symmetric plan (cos/sin polynomials in Y = X^2 up to Y^rq); `ops` is empty then
   int spx = 0; // real plan evaluated with the sparse generator: powers X_{m+1} = X X_m by sparse x dense products
+  int xr = 0;  // spx plan whose generator is XOR-regular: column form in LDS (xorexp.hip), no stored powers
   double cc[8] = {0}, sc[8] = {0};  // cos X = sum cc[j] Y^j,  sin X = X sum sc[j] Y^j
   std::vector<TapeOp> ops;
   int products() const { return nprod; }
@@ -292,6 +293,12 @@ struct Ctx : dq_ctx {
   // entries grouped by control; sparse_mode: -1 auto (total nonzeros <= sparse_fill * dim), 0 off
   DevBuf zta, ztb;  // transposed operand copies for the linear-form complex GEMM
   DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval, sp_nzacc, sp_part;
+  // XOR-regular generator (xorexp.hip): table found by build_sparse_controls; xor_mode: -1 auto, 0 off
+  DevBuf xr_sgn, xr_dval, xr_part;
+  dq::XrTab xr_tab;
+  bool xr_ok = false;
+  int xor_mode = -1;
+  double last_xr = 0;
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
   bool sparse_h = false;   // a CSR exists (controls, and the drift too if sparse_x)
@@ -339,6 +346,9 @@ struct Ctx : dq_ctx {
   bool sparse_gen_on() const {
     if (!(sparse_on() && sparse_x) || sparse_gen_mode == 0) return false;
     return sparse_gen_mode > 0 || (double)d * d >= 64.0 * (double)sp_nnz;
+  }
+  bool xr_on(int q) const {
+    return xr_ok && xor_mode != 0 && sparse_gen_on() && dq::xr_supported(d, q, xr_tab.R, xr_tab.nd, sizeof(T));
   }
   size_t nn() const { return (size_t)d * d; }
   size_t mat_bytes() const { return nn() * sizeof(T2); }
@@ -653,6 +663,32 @@ void rlincomb2(Ctx<T>* c, T* out0, T* out1, int n_in, const T* const* x, const d
   c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n_in * a.n_out * batch, by, [&] { return dq::rlincomb_launch<T>(a, c->st); });
 }
 
+inline dq::XrPoly xr_poly(const ExpmPlan& p) {
+  dq::XrPoly pol;
+  memset(&pol, 0, sizeof(pol));
+  pol.q = p.rq;
+  for (int j = 0; j <= p.rq && j <= dq::XR_QMAX; ++j) { pol.cc[j] = p.cc[j]; pol.sc[j] = p.sc[j]; }
+  return pol;
+}
+// (the column-form kernels exist for complex128 engines only: xr_supported() keeps the others off this path)
+inline hipError_t xr_forward_any(double2* U, long stride, int d, const dq::XrTab& tab, const double* u, int K, double dt,
+                                 const dq::XrPoly& pol, int batch, hipStream_t st) {
+  return dq::xr_forward_launch(U, stride, d, tab, u, K, dt, pol, batch, st);
+}
+inline hipError_t xr_forward_any(float2*, long, int, const dq::XrTab&, const double*, int, double, const dq::XrPoly&, int,
+                                 hipStream_t) {
+  return hipErrorInvalidValue;
+}
+inline hipError_t xr_reverse_any(const double2* G, long stride, int d, const dq::XrTab& tab, const double* u, int K, double dt,
+                                 const dq::XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* grad,
+                                 hipStream_t st) {
+  return dq::xr_reverse_launch(G, stride, d, tab, u, K, dt, pol, batch, part, zero_sgn, grad, 0, st);
+}
+inline hipError_t xr_reverse_any(const float2*, long, int, const dq::XrTab&, const double*, int, double, const dq::XrPoly&, int,
+                                 double*, const unsigned*, double*, hipStream_t) {
+  return hipErrorInvalidValue;
+}
+
 // assemble X and evaluate U = cos X + i sin X for `n` stacked steps; returns the complex propagators
 template <class T>
 typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
@@ -661,6 +697,23 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
   T* X = c->rmat(RS_X, n);
   const double by = (double)sizeof(T) * c->nn() * (c->K + 2.0) * n;
   const double dts = std::ldexp(dt, -p.s);  // X = -(dt / 2^s) H
+  c->last_xr = 0;
+  if (p.spx && p.xr) {
+    // XOR-regular sparse generator: U column by column in LDS (xorexp.hip) -- no dense X, no stored powers, no combination pass
+    T2* U = c->mat(RS_U, n);
+    const dq::XrPoly pol = xr_poly(p);
+    const double rows = (double)c->xr_tab.R + 1.0;
+    c->timed(DQ_PROF_SPMM, 2.0 * rows * c->nn() * 2.0 * q * n, (double)sizeof(T2) * c->nn() * n, [&] {
+      return xr_forward_any(U, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * c->K, c->K, dts, pol, n, c->st);
+    });
+    c->last_degree = p.m;
+    c->last_squarings = 0;
+    c->last_products = 2 * q;
+    c->last_real_q = q;
+    c->last_spx = 1;
+    c->last_xr = 1;
+    return U;
+  }
   if (c->sparse_on()) {
     // dense pass over H0 only (or zeros, if the drift's nonzeros are in the CSR too), then the nonzeros are scattered in
     if (c->sparse_x) {
@@ -845,6 +898,17 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
   typedef typename dq::Cx<T>::type T2;
   const int q = p.rq, np = 2 * q + 1, K = c->K;
   const T2* G = c->mat(SLOT_ADJ + RS_U, n);
+  if (p.xr) {
+    // column form: rows of G in, control gradients out (the powers of the column are rebuilt in registers)
+    const dq::XrPoly pol = xr_poly(p);
+    c->xr_part.ensure(sizeof(double) * (size_t)n * dq::xr_blocks(c->d) * dq::XR_SLOTS);
+    const double rows = (double)c->xr_tab.R + 1.0;
+    c->timed(DQ_PROF_SPMM, 2.0 * rows * c->nn() * (4.0 * q + 1.0) * n, (double)sizeof(T2) * c->nn() * n, [&] {
+      return xr_reverse_any(G, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * K, K, dt, pol, n,
+                            (double*)c->xr_part.p, (const unsigned*)c->xr_sgn.p, grad_out, c->st);
+    });
+    return;
+  }
   T* Cb = c->rmat(SLOT_ADJ + RS_C, n);
   T* Sb = c->rmat(SLOT_ADJ + RS_S, n);
   c->timed(DQ_PROF_LINCOMB, 2.0 * c->nn() * n, 6.0 * sizeof(T) * c->nn() * n,
@@ -1036,6 +1100,7 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
     if (c->real_mode > 0) {
       ExpmPlan p = make_real_plan(std::min(c->real_mode, (int)RQ_MAX));
       p.spx = c->sparse_gen_on() ? 1 : 0;
+      p.xr = p.spx && c->xr_on(p.rq) ? 1 : 0;
       return p;
     }
     if (c->sparse_gen_on() && c->force_degree <= 0 && c->force_s < 0 && c->d >= c->real_min_dim) {
@@ -1044,6 +1109,7 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
         if (taylor_remainder(th, 2 * q + 1) <= c->expm_tol) {
           ExpmPlan p = make_real_plan(q, 0);
           p.spx = 1;
+          p.xr = c->xr_on(q) ? 1 : 0;
           p.nprod = 2 * q;
           return p;
         }
@@ -1080,7 +1146,7 @@ TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
     const size_t idx = (size_t)(c0 / std::max(c->pc_tc, 1));
     const size_t mat = c->nn() * sizeof(T) * (size_t)n;  // one real variable of the chunk
     const int q = p.rq;
-    const int nreal = p.spx ? 2 * q : q + 1;
+    const int nreal = p.xr ? 0 : (p.spx ? 2 * q : q + 1);  // (column form: nothing but U is kept)
     auto real_slot = [&](int i) {
       if (p.spx) return spx_slot(i + 1);                      // X_1 .. X_2q
       return i == 0 ? (int)RS_X : (i < q ? i : (int)RS_P);    // X, Y_1 .. Y_{q-1}, P
@@ -1089,13 +1155,14 @@ TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
       for (int i = 0; i < nreal; ++i) c->redirect[real_slot(i)] = base + (size_t)i * mat;
       c->redirect[RS_U] = base + (size_t)nreal * mat;
     };
-    const int tag = p.spx ? -q : q;  // which scheme filled the entry
+    const int tag = p.xr ? -(100 + q) : (p.spx ? -q : q);  // which scheme filled the entry
     if (cacheable && c->pc_mode == 2 && idx < c->pcache.size()) {
       auto& e = c->pcache[idx];
       if (e.valid && e.c0 == c0 && e.n == n && e.rq == tag) {
         point_at((char*)c->pc_arena.p + e.off);
         c->last_degree = p.m; c->last_squarings = 0; c->last_products = p.nprod; c->last_real_q = q;
         c->last_spx = p.spx;
+        c->last_xr = p.xr;
         return c->mat(RS_U, n);
       }
     }
@@ -1316,7 +1383,7 @@ void setup_pcache(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
   const ExpmPlan p0 = chunk_plan(c, uh, 0, std::min(tc, S), dt);
   if (p0.rq == 0 || p0.s > 0) return;
   // per step: X, Y_1..Y_{q-1}, P (real) + U (complex); sparse-generator scheme: X_1..X_2q + U
-  const double per_step = ((p0.spx ? 2.0 * p0.rq : p0.rq + 1.0) + 2.0) * c->nn() * sizeof(T);
+  const double per_step = ((p0.xr ? 0.0 : (p0.spx ? 2.0 * p0.rq : p0.rq + 1.0)) + 2.0) * c->nn() * sizeof(T);
   const double S_plan = (double)std::max<long>(S, c->plan_steps);
   const double share = std::min(1.0, budget / (per_step * S_plan));
   // the sparse-generator scheme rebuilds with 2q cheap passes: holding tens of GB for a few percent of the steps is not
@@ -1836,6 +1903,73 @@ void do_mc_shift(Ctx<T>* c, const double* u_a, int n_a, double dt_a, const doubl
   HIPCK(hipStreamSynchronize(c->st));
 }
 
+// Is the sparse generator XOR-regular (xorexp.hip)?  Group the CSR's entries by (column ^ row, source): every group off the
+// diagonal must hold one entry per row, all of one magnitude (signs free); groups at offset 0 may hold anything.  Fills
+// c->xr_tab (sign words and diagonal values in device memory) and sets c->xr_ok.
+template <class T>
+void find_xor_regular(Ctx<T>* c, const std::vector<long>& rowptr, long nnz) {
+  c->xr_ok = false;
+  const int d = c->d;
+  if (nnz <= 0 || d < 2 || (d & (d - 1)) != 0) return;
+  std::vector<int> col((size_t)nnz), kid((size_t)nnz);
+  std::vector<double> val((size_t)nnz);
+  HIPCK(hipMemcpyAsync(col.data(), c->sp_col.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipMemcpyAsync(kid.data(), c->sp_kid.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipMemcpyAsync(val.data(), c->sp_val.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  dq::XrTab tab;
+  memset(&tab, 0, sizeof(tab));
+  struct Grp { int x, kid, j; long count; double mag; };
+  std::vector<Grp> groups;  // off-diagonal groups in order of first appearance (row 0 names them all, if regular)
+  std::vector<int> dsrc;    // sources with diagonal entries
+  std::vector<unsigned> sgn((size_t)d, 0u);
+  std::vector<double> dval;
+  bool neg = false;
+  for (int i = 0; i < d; ++i)
+    for (long e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+      const int x = col[e] ^ i;
+      if (x == 0) {
+        size_t jd = 0;
+        while (jd < dsrc.size() && dsrc[jd] != kid[e]) ++jd;
+        if (jd == dsrc.size()) {
+          if ((int)dsrc.size() == dq::XR_DMAX) return;
+          dsrc.push_back(kid[e]);
+          dval.resize(dsrc.size() * (size_t)d, 0.0);
+        }
+        dval[jd * (size_t)d + i] += val[e];
+        continue;
+      }
+      size_t g = 0;
+      while (g < groups.size() && !(groups[g].x == x && groups[g].kid == kid[e])) ++g;
+      if (g == groups.size()) {
+        if (i != 0 || (int)groups.size() == dq::XR_RMAX) return;  // a diagonal that row 0 lacks, or too many
+        groups.push_back({x, kid[e], (int)g, 0, std::fabs(val[e])});
+      }
+      if (std::fabs(val[e]) != groups[g].mag || groups[g].count != i) return;  // (count == i: exactly one entry per row so far)
+      groups[g].count++;
+      if (val[e] < 0.0) { sgn[i] |= 1u << g; neg = true; }
+    }
+  for (const Grp& g : groups)
+    if (g.count != d || g.mag == 0.0) return;
+  for (size_t a = 0; a < groups.size(); ++a)  // one diagonal per offset and source; symmetric signs (H_k symmetric: a sanity check)
+    for (int i = 0; i < d; ++i)
+      if (((sgn[i] >> a) & 1u) != ((sgn[i ^ groups[a].x] >> a) & 1u)) return;
+  tab.R = (int)groups.size();
+  tab.nd = (int)dsrc.size();
+  for (int j = 0; j < tab.R; ++j) { tab.xoff[j] = groups[j].x; tab.kid[j] = groups[j].kid; tab.cmag[j] = groups[j].mag; }
+  for (int j = 0; j < tab.nd; ++j) tab.dkid[j] = dsrc[j];
+  c->xr_sgn.ensure(sizeof(unsigned) * (size_t)d);
+  c->xr_dval.ensure(sizeof(double) * std::max<size_t>(dval.size(), 1));
+  HIPCK(hipMemcpyAsync(c->xr_sgn.p, sgn.data(), sizeof(unsigned) * (size_t)d, hipMemcpyHostToDevice, c->st));
+  if (!dval.empty())
+    HIPCK(hipMemcpyAsync(c->xr_dval.p, dval.data(), sizeof(double) * dval.size(), hipMemcpyHostToDevice, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  tab.sgn = neg ? (const unsigned*)c->xr_sgn.p : nullptr;
+  tab.dval = (const double*)c->xr_dval.p;
+  c->xr_tab = tab;
+  c->xr_ok = true;
+}
+
 // CSR of the Hamiltonians' nonzeros (real path), if they are sparse enough to pay: at most sparse_fill nonzeros per row
 // summed over the sources (X-type Paulis: one per control). Two tiers: controls AND drift sparse (sparse_x: the drift's
 // entries join the CSR with kid = -1, so X_t itself is sparse and the polynomial runs on sparse x dense products), or the
@@ -1845,6 +1979,7 @@ template <class T>
 void build_sparse_controls(Ctx<T>* c) {
   c->sparse_h = false;
   c->sparse_x = false;
+  c->xr_ok = false;
   c->sp_nnz = 0;
   const int d = c->d, K = c->K;
   if (!c->real_h || K <= 0) return;
@@ -1907,6 +2042,7 @@ void build_sparse_controls(Ctx<T>* c) {
   c->sp_nnz_c = nnz_c;
   c->sparse_h = true;
   c->sparse_x = with_drift;
+  if (with_drift) find_xor_regular(c, rowptr, nnz);
 }
 
 template <class T>
@@ -2138,6 +2274,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->sparse_gen_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "transpose_fallback") {  // transposing pre-pass for big complex products whose operands have no k-major form
     c->transpose_fallback = v != 0 ? 1 : 0;
+  } else if (s == "xor_regular") {  // column-form kernels for XOR-regular sparse generators: -1 auto (default), 0 off
+    c->xor_mode = v != 0 ? -1 : 0;
   } else if (s == "slab_spmm") {  // sparse x dense passes in XCD-slab form (1, default) or one wave per whole row (0)
     c->slab_spmm = v != 0 ? 1 : 0;
   } else if (s == "skew_trick") {
@@ -2167,6 +2305,8 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "sparse_controls") return c->sparse_on() ? 1.0 : 0.0;
   if (s == "control_nonzeros") return c->sparse_h ? (double)c->sp_nnz_c : -1.0;
   if (s == "sparse_generator") return c->last_spx;
+  if (s == "xor_regular") return c->last_xr;
+  if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : -1.0;
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;

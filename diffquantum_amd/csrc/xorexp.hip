@@ -1,0 +1,462 @@
+// Sparse generator with an XOR-regular pattern: the step exponential and its reverse mode column by column in LDS.
+//
+// The sparse-generator scheme (realpath.hip, engine.hip real_forward / real_backward_spx; the step itself is the reference's
+// expm(-1j * dt * H) of sim_plain.py:145-146 / diffqc.cc:192-198) evaluates U = cos X + i sin X with X = -dt H sparse from the
+// powers X_{m+1} = X X_m.  Every column of every power is an independent chain of sparse matrix-vector products,
+//     x_0 = e_c,  x_{m+1} = X x_m,     U[:, c] = sum_j cc_j x_{2j} + i sum_j sc_j x_{2j+1},
+// and when X's pattern is XOR-regular -- besides its diagonal, row i holds exactly the entries (i, i ^ x_j), j < R, the same
+// offsets x_j in every row, each of constant magnitude along its XOR-diagonal: sums of Pauli strings, e.g. an Ising drift with
+// X_k controls -- the column needs no index arrays at all: the vector lives in LDS (d * sizeof(T) bytes, two images), a thread
+// owns the XR_RPT rows r * NT + t, the partner of row i under offset x_j is a conflict-free LDS read at i ^ x_j, the weight
+// w_j = -dt u[kid_j] cmag_j is wave-uniform (a sign bit per row and diagonal where entries are negative), and all diagonals at
+// offset 0 (the drift's, Z-type controls') collapse into one per-row weight.  HBM traffic of a whole step exponential = U
+// written once (the dense powers, the dense X and the linear-combination pass no longer exist); the kernel is bound by LDS
+// reads (R per row and power).
+//
+// Reverse mode (xr_reverse_kernel), per column c with (cbar | sbar) = (Re | Im) of ROW c of G = Ubar (the cotangents enter
+// through the transposed matrices: X and the controls are symmetric, so <Xi^T, H_k> = <Xi, H_k>):
+//     xbar_{2q+1} = sc_q sbar,   xbar_m = coef_m (cbar | sbar) + X xbar_{m+1}   (m = 2q .. 1),
+//     dL/du_k    = -dt sum_{j: kid_j = k} sum_i val_ij sum_{m=0}^{2q} xbar_{m+1}[i ^ x_j] x_m[i]
+// -- the partner value fetched for the product is the one the dot product needs (as in rsp_mm_dot_kernel); x_1 .. x_2q of the
+// column are recomputed first and stay in the registers of the rows' owners, so nothing but G is read and a few sums per
+// workgroup are written.  Results differ from the row-wise kernels by rounding only (different summation order).
+#include "dq_internal.h"
+
+namespace dq {
+
+template <class T>
+__device__ inline T xr_uniform(T v);
+template <>
+__device__ inline double xr_uniform<double>(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ inline double xr_flip(double v, unsigned bit) {
+  return __longlong_as_double(__double_as_longlong(v) ^ ((long long)bit << 63));
+}
+
+// per-thread constants of a launch: the weights of the XOR-diagonals (wave-uniform), the rows' sign words and diagonal weights;
+// in LDS: jof[x] = the (last) diagonal whose offset is x (R for x = 0, R + 1 for none), nxt[j] = the next one with the same
+// offset (>= R: none), and the weights
+template <class T, int NT, bool SIGN>
+struct XrRows {
+  T dg[XR_RPT];  // sum over the offset-0 diagonals of -dt u val
+  unsigned sg[XR_RPT];
+  int R;
+  const unsigned char *jof, *nxt;
+  const T* Wl;
+  __device__ __forceinline__ void load(const XrTab& tab, const double* __restrict__ uz, double mdt, int t, unsigned char* s_jof,
+                                       T* s_w) {
+    unsigned char* s_nxt = (unsigned char*)(s_w + XR_RMAX + 2);
+    constexpr int D = NT * XR_RPT;
+    R = tab.R;
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) {
+      sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+      dg[r] = 0;
+    }
+    for (int j = 0; j < tab.nd; ++j) {
+      const int k = tab.dkid[j];
+      const double w = mdt * (k < 0 ? 1.0 : uz[k]);
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) dg[r] += (T)(w * tab.dval[(long)j * D + r * NT + t]);
+    }
+    for (int i = t; i < D; i += NT) s_jof[i] = (unsigned char)(tab.R + 1);
+    __syncthreads();
+    if (t < tab.R) {
+      const int k = tab.kid[t];
+      s_w[t] = (T)(mdt * (k < 0 ? 1.0 : uz[k]) * tab.cmag[t]);
+    }
+    if (t == 0) {  // diagonals that share an offset (X_a and X_a Z_b, say) are chained: jof -> the last one, nxt -> the others
+      for (int j = 0; j < tab.R; ++j) {
+        s_nxt[j] = s_jof[tab.xoff[j]];
+        s_jof[tab.xoff[j]] = (unsigned char)j;
+      }
+      s_jof[0] = (unsigned char)tab.R;
+      s_w[tab.R] = 0;
+      s_w[tab.R + 1] = 0;
+    }
+    __syncthreads();
+    jof = s_jof;
+    nxt = s_nxt;
+    Wl = s_w;
+  }
+  // x_1 = X e_c (column c of X) at the thread's rows: the diagonal weight at row c, +-w_j at the rows c ^ x_j
+  __device__ __forceinline__ void first(int t, int c, T* x1) const {
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) {
+      const int i = r * NT + t;
+      T w = 0;
+      for (unsigned j = jof[i ^ c]; j < (unsigned)R; j = nxt[j]) w += SIGN ? xr_flip(Wl[j], (sg[r] >> j) & 1u) : Wl[j];
+      x1[r] = i == c ? dg[r] : w;
+    }
+  }
+};
+
+// dacc[j] += s for a wave-uniform j (register arrays need static indices: a chain of scalar compares)
+template <int I>
+__device__ __forceinline__ void xr_acc(double* dacc, int j, double s) {
+  if constexpr (I < XR_RMAX) {
+    if (j == I) {
+      asm volatile("" : "+v"(dacc[I]));  // (keeps the chain from being turned into an indexed access to a scratch array)
+      dacc[I] += s;
+    }
+    xr_acc<I + 1>(dacc, j, s);
+  }
+}
+
+// one sweep  o += (X - diag) v  with v in LDS image `src`; optional dot products with xm[] (DOT).  The loop over the
+// diagonals is a runtime loop on purpose: unrolled, the compiler hoists sign masks and LDS addresses of all R diagonals out of
+// the column loop, prefetches across diagonals and spills hundreds of registers.
+template <class T, int NT, bool SIGN, bool DOT>
+__device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, SIGN>& rw, const T* __restrict__ src, int t, T* o,
+                                          const T* xm, double* dacc) {
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < tab.R; ++j) {
+    const int xo = tab.xoff[j];
+    const T w = rw.Wl[j];
+    const T* base = src + (t ^ (xo & (NT - 1)));
+    const int xh = xo / NT;
+    T vs[XR_RPT];
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) vs[r] = base[(r ^ xh) * NT];
+    if (SIGN) {
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) vs[r] = xr_flip(vs[r], (rw.sg[r] >> j) & 1u);
+    }
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) o[r] = __builtin_fma(w, vs[r], o[r]);
+    if (DOT) {
+      T s = 0;
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) s = __builtin_fma(vs[r], xm[r], s);
+      xr_acc<0>(dacc, j, (double)s);
+    }
+  }
+}
+
+// level 0 of the gradient, by lane 0 of the workgroup: xbar_1 (LDS image `src`) pairs with x_0 = e_c, i.e. the entries
+// (c, c ^ x_j) -- sign taken at row c ^ x_j (the diagonals are symmetric)
+template <class T, int J>
+__device__ __forceinline__ void xr_level0(const XrTab& tab, const T* __restrict__ src, int c, double* dacc) {
+  if constexpr (J < XR_RMAX) {
+    if (J < tab.R) {
+      const int row = c ^ tab.xoff[J];
+      const unsigned bit = tab.sgn ? (tab.sgn[row] >> J) & 1u : 0u;
+      dacc[J] += (double)xr_flip(src[row], bit);
+    }
+    xr_level0<T, J + 1>(tab, src, c, dacc);
+  }
+}
+
+// stored powers by (wave-uniform) index: register arrays need static indices, so a chain of scalar compares
+template <class T, int N, int I>
+__device__ __forceinline__ void xr_put(T (*xm)[XR_RPT], int idx, const T* v) {
+  if constexpr (I < N) {
+    if (idx == I) {
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) xm[I][r] = v[r];
+    }
+    xr_put<T, N, I + 1>(xm, idx, v);
+  }
+}
+template <class T, int N, int I>
+__device__ __forceinline__ void xr_get(const T (*xm)[XR_RPT], int idx, T* v) {
+  if constexpr (I < N) {
+    if (idx == I) {
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) v[r] = xm[I][r];
+    }
+    xr_get<T, N, I + 1>(xm, idx, v);
+  }
+}
+
+// LDS of both kernels: `images` vectors of D, then jof (D bytes), then XR_RMAX + 2 weights, then nxt (XR_RMAX bytes)
+template <class T, int NT>
+constexpr size_t xr_lds_bytes(int images) {
+  return (size_t)images * sizeof(T) * NT * XR_RPT + (size_t)NT * XR_RPT + sizeof(T) * (XR_RMAX + 2) + XR_RMAX;
+}
+
+// U[z][c][:] for the columns c = blockIdx.x, blockIdx.x + gridDim.x, ...   (U symmetric: row c = column c)
+template <class T, int NT, bool SIGN>
+__global__ void __launch_bounds__(NT, (NT * 2 + 255) / 256) xr_forward_kernel(typename Cx<T>::type* __restrict__ U, long stride, XrTab tab,
+                                                        const double* __restrict__ u, int K, double mdt, XrPoly pol) {
+  typedef typename Cx<T>::type T2;
+  constexpr int D = NT * XR_RPT;
+  extern __shared__ __align__(16) unsigned char xr_lds_raw[];
+  T* lds = (T*)xr_lds_raw;  // two images of D
+  const int t = threadIdx.x;
+  const long z = blockIdx.y;
+  const int np = 2 * pol.q + 1;
+  XrRows<T, NT, SIGN> rw;
+  rw.load(tab, u + z * K, mdt, t, xr_lds_raw + 2 * sizeof(T) * D, (T*)(xr_lds_raw + 2 * sizeof(T) * D + D));
+  int p = 1;  // image read last
+  for (int c = blockIdx.x; c < D; c += gridDim.x) {
+    T cur[XR_RPT], are[XR_RPT], aim[XR_RPT];
+    rw.first(t, c, cur);
+    p ^= 1;
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) {
+      lds[p * D + r * NT + t] = cur[r];
+      are[r] = (r * NT + t) == c ? (T)pol.cc[0] : (T)0;
+      aim[r] = (T)pol.sc[0] * cur[r];
+    }
+    __syncthreads();
+    for (int m = 2; m <= np; ++m) {
+      T o[XR_RPT];
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) o[r] = rw.dg[r] * cur[r];
+      xr_gather<T, NT, SIGN, false>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
+      const T cf = (T)((m & 1) ? pol.sc[(m - 1) / 2] : pol.cc[m / 2]);
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) {
+        cur[r] = o[r];
+        if (m & 1) aim[r] = __builtin_fma(cf, o[r], aim[r]);
+        else are[r] = __builtin_fma(cf, o[r], are[r]);
+      }
+      if (m < np) {
+        p ^= 1;
+#pragma unroll
+        for (int r = 0; r < XR_RPT; ++r) lds[p * D + r * NT + t] = o[r];
+        __syncthreads();
+      }
+    }
+    T2* urow = U + z * stride + (long)c * D;
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) {
+      T2 v;
+      v.x = are[r];
+      v.y = aim[r];
+      urow[r * NT + t] = v;
+    }
+  }
+}
+
+// part[(z * gridDim.x + blockIdx.x) * XR_SLOTS + s]: this workgroup's share, over its columns, of
+//   s < XR_RMAX:  sum_i sign_ij Xi[i ^ x_j, i]  (before the factors cmag_j and -dt);   s = XR_RMAX + j: the offset-0 diagonal j,
+//   sum_i dval_j[i] Xi[i, i]  (diagctl: some control has diagonal entries).   Q: the polynomial's q; x_2 .. x_2q of the column
+// stay in registers (x_1 is cheap to rebuild).  LDS: four images (the two of the sweeps, cbar, sbar); one workgroup per CU.
+// The sweeps are runtime loops (one copy of the gather code each way); the stored powers are reached through xr_put / xr_get.
+template <class T, int NT, int Q, bool SIGN, bool DIAGCTL>
+__global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::type* __restrict__ G, long stride, XrTab tab,
+                                                        const double* __restrict__ u, int K, double mdt, XrPoly pol,
+                                                        double* __restrict__ part) {
+  typedef typename Cx<T>::type T2;
+  constexpr int D = NT * XR_RPT, NPM1 = 2 * Q, NST = NPM1 - 1;
+  extern __shared__ __align__(16) unsigned char xr_lds_raw[];
+  T* lds = (T*)xr_lds_raw;
+  T* lcb = lds + 2 * D;
+  T* lsb = lds + 3 * D;
+  const int t = threadIdx.x;
+  const long z = blockIdx.y;
+  XrRows<T, NT, SIGN> rw;
+  rw.load(tab, u + z * K, mdt, t, xr_lds_raw + 4 * sizeof(T) * D, (T*)(xr_lds_raw + 4 * sizeof(T) * D + D));
+  double dacc[XR_RMAX], rowacc[XR_RPT];
+#pragma unroll
+  for (int j = 0; j < XR_RMAX; ++j) dacc[j] = 0.0;
+#pragma unroll
+  for (int r = 0; r < XR_RPT; ++r) rowacc[r] = 0.0;
+  int p = 1;
+  for (int c = blockIdx.x; c < D; c += gridDim.x) {
+    // cotangents of the column: row c of G, parked in LDS (own rows only: no barrier needed)
+    const T2* grow = G + z * stride + (long)c * D;
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) {
+      const T2 g = grow[r * NT + t];
+      lcb[r * NT + t] = g.x;
+      lsb[r * NT + t] = g.y;
+    }
+    T xm[NST][XR_RPT];  // x_2 .. x_2q at the thread's rows
+    T cur[XR_RPT];
+    rw.first(t, c, cur);
+    p ^= 1;
+#pragma unroll
+    for (int r = 0; r < XR_RPT; ++r) lds[p * D + r * NT + t] = cur[r];
+    __syncthreads();
+    for (int m = 2; m <= NPM1; ++m) {
+      T o[XR_RPT];
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) o[r] = rw.dg[r] * cur[r];
+      xr_gather<T, NT, SIGN, false>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
+      xr_put<T, NST, 0>(xm, m - 2, o);
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) cur[r] = o[r];
+      if (m < NPM1) {
+        p ^= 1;
+#pragma unroll
+        for (int r = 0; r < XR_RPT; ++r) lds[p * D + r * NT + t] = o[r];
+        __syncthreads();
+      }
+    }
+    p ^= 1;
+    {
+      const T cf = (T)pol.sc[Q];
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) {
+        cur[r] = cf * lsb[r * NT + t];
+        lds[p * D + r * NT + t] = cur[r];
+      }
+    }
+    __syncthreads();
+    for (int m = NPM1; m >= 1; --m) {
+      T o[XR_RPT], xmm[XR_RPT];
+      if (m == 1) rw.first(t, c, xmm);
+      else xr_get<T, NST, 0>(xm, m - 2, xmm);
+      const T cf = (T)((m & 1) ? pol.sc[(m - 1) / 2] : pol.cc[m / 2]);
+      const T* add = (m & 1) ? lsb : lcb;
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) {
+        o[r] = __builtin_fma(cf, add[r * NT + t], rw.dg[r] * cur[r]);
+        if (DIAGCTL) rowacc[r] = __builtin_fma((double)cur[r], (double)xmm[r], rowacc[r]);
+      }
+      xr_gather<T, NT, SIGN, true>(tab, rw, lds + p * D, t, o, xmm, dacc);
+      p ^= 1;
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) {
+        cur[r] = o[r];
+        lds[p * D + r * NT + t] = o[r];
+      }
+      __syncthreads();
+    }
+    // level 0 (x_0 = e_c): xbar_1 is in image p
+    if (t == 0) xr_level0<T, 0>(tab, lds + p * D, c, dacc);
+    if (DIAGCTL) {
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r)
+        if ((r * NT + t) == c) rowacc[r] += (double)cur[r];
+    }
+  }
+  // fixed-order reduction: lanes (butterfly), then the waves in order
+  __syncthreads();
+  double* red = (double*)xr_lds_raw;  // [NT / 64][XR_SLOTS]
+  const int lane = t & 63, wave = t >> 6;
+  auto put = [&](int slot, double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave * XR_SLOTS + slot] = v;
+  };
+#pragma unroll
+  for (int j = 0; j < XR_RMAX; ++j) put(j, dacc[j]);
+  for (int j = 0; j < XR_DMAX; ++j) {
+    double v = 0.0;
+    if (DIAGCTL && j < tab.nd && tab.dkid[j] >= 0) {
+#pragma unroll
+      for (int r = 0; r < XR_RPT; ++r) v = __builtin_fma(tab.dval[(long)j * D + r * NT + t], rowacc[r], v);
+    }
+    put(XR_RMAX + j, v);
+  }
+  __syncthreads();
+  if (t < XR_SLOTS) {
+    double s = 0.0;
+    for (int w = 0; w < NT / 64; ++w) s += red[w * XR_SLOTS + t];
+    part[(z * gridDim.x + blockIdx.x) * XR_SLOTS + t] = s;
+  }
+}
+
+// grad[z][k] (+)= scale * (sum_j [kid_j == k] cmag_j sum_b part[z][b][j] + sum_j [dkid_j == k] sum_b part[z][b][XR_RMAX + j])
+__global__ void __launch_bounds__(64) xr_finish_kernel(const double* __restrict__ part, int nblk, XrTab tab, int K, double scale,
+                                                       double* __restrict__ grad, int accumulate) {
+  const long z = blockIdx.x;
+  const int j = threadIdx.x;
+  __shared__ double s_j[XR_SLOTS];
+  if (j < XR_SLOTS) {
+    const bool live = j < XR_RMAX ? j < tab.R : (j - XR_RMAX < tab.nd && tab.dkid[j - XR_RMAX] >= 0);
+    double s = 0.0;
+    if (live)
+      for (int b = 0; b < nblk; ++b) s += part[(z * nblk + b) * XR_SLOTS + j];
+    s_j[j] = live ? s * (j < XR_RMAX ? tab.cmag[j] : 1.0) : 0.0;
+  }
+  __syncthreads();
+  for (int k = j; k < K; k += 64) {
+    double g = accumulate ? grad[z * K + k] : 0.0;
+    for (int q = 0; q < tab.R; ++q)
+      if (tab.kid[q] == k) g += scale * s_j[q];
+    for (int q = 0; q < tab.nd; ++q)
+      if (tab.dkid[q] == k) g += scale * s_j[XR_RMAX + q];
+    grad[z * K + k] = g;
+  }
+}
+
+bool xr_supported(int d, int q, int R, int nd, size_t elem) {
+  if (elem != sizeof(double)) return false;  // (complex64 engines keep the row-wise kernels)
+  if (R < 0 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || q < 1 || q > XR_QMAX) return false;
+  return d == 512 || d == 1024 || d == 2048 || d == 4096;
+}
+
+int xr_blocks(int d) { return d < 512 ? d : 512; }
+
+template <class T, int NT>
+static hipError_t xr_forward_go(typename Cx<T>::type* U, long stride, const XrTab& tab, const double* u, int K, double mdt,
+                                const XrPoly& pol, int batch, hipStream_t st) {
+  const size_t lds = xr_lds_bytes<T, NT>(2);
+  const dim3 grid((unsigned)xr_blocks(NT * XR_RPT), (unsigned)batch);
+  void (*kf)(typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly) =
+      tab.sgn ? xr_forward_kernel<T, NT, true> : xr_forward_kernel<T, NT, false>;
+  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, U, stride, tab, u, K, mdt, pol);
+  return hipGetLastError();
+}
+
+// U[z] = cos X_z + i sin X_z for `batch` stacked steps (X_z = -dt H(u[z])), U row-major d x d complex, stride elements apart
+hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                             const XrPoly& pol, int batch, hipStream_t st) {
+  if (batch <= 0) return hipSuccess;
+  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double))) return hipErrorInvalidValue;
+  switch (d) {
+    case 4096: return xr_forward_go<double, 512>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 2048: return xr_forward_go<double, 256>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 1024: return xr_forward_go<double, 128>(U, stride, tab, u, K, -dt, pol, batch, st);
+    default: return xr_forward_go<double, 64>(U, stride, tab, u, K, -dt, pol, batch, st);
+  }
+}
+
+template <class T, int NT>
+static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, const XrTab& tab, const double* u, int K, double mdt,
+                                const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, hipStream_t st) {
+  const size_t lds = xr_lds_bytes<T, NT>(4);
+  const dim3 grid((unsigned)xr_blocks(NT * XR_RPT), (unsigned)batch);
+  // two variants: plain (no negative entries, no control with diagonal entries) and full (sign words -- `zero_sgn`, d zeros,
+  // stands in when the table has none -- and the per-row sums of the offset-0 diagonals)
+  bool full = tab.sgn != nullptr;
+  for (int j = 0; j < tab.nd; ++j) full = full || tab.dkid[j] >= 0;
+  XrTab tb = tab;
+  if (full && !tb.sgn) tb.sgn = zero_sgn;
+  if (full && !tb.sgn) return hipErrorInvalidValue;
+#define XR_REV(Q)                                                                                               \
+  case Q: {                                                                                                     \
+    void (*kf)(const typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly, double*) =         \
+        full ? xr_reverse_kernel<T, NT, Q, true, true> : xr_reverse_kernel<T, NT, Q, false, false>;             \
+    (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tb, u, K, mdt, pol, part);                       \
+    break;                                                                                                      \
+  }
+  switch (pol.q) {
+    XR_REV(1)
+    XR_REV(2)
+    XR_REV(3)
+    default: return hipErrorInvalidValue;
+  }
+#undef XR_REV
+  return hipGetLastError();
+}
+
+// grad[z][k] (+)= dL/du_k of step z given G[z] = Ubar_z; part: batch * xr_blocks(d) * XR_SLOTS doubles of scratch;
+// zero_sgn: d zero words (used when a control has diagonal entries but the table has no sign words)
+hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* grad, int accumulate,
+                             hipStream_t st) {
+  if (batch <= 0) return hipSuccess;
+  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double))) return hipErrorInvalidValue;
+  hipError_t e;
+  switch (d) {
+    case 4096: e = xr_reverse_go<double, 512>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
+    case 2048: e = xr_reverse_go<double, 256>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
+    case 1024: e = xr_reverse_go<double, 128>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
+    default: e = xr_reverse_go<double, 64>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st);
+  }
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(64), 0, st, part, xr_blocks(d), tab, K, -dt, grad, accumulate);
+  return hipGetLastError();
+}
+
+}  // namespace dq

@@ -41,7 +41,8 @@ def ising12(oracle):
 
 SCHEMES = {
     # name: (options, expected info)
-    "sparse_generator": ({}, {"real_path": True, "sparse_generator": True}),
+    "sparse_generator": ({}, {"real_path": True, "sparse_generator": True, "xor_regular": True}),
+    "sparse_generator_row_kernels": ({"xor_regular": 0}, {"real_path": True, "sparse_generator": True, "xor_regular": False}),
     "sparse_controls_dense_drift": ({"sparse_generator": 0}, {"real_path": True, "sparse_generator": False, "sparse_controls": True}),
     "dense_real": ({"sparse_generator": 0, "sparse_controls": 0}, {"real_path": True, "sparse_generator": False, "sparse_controls": False}),
     "complex_tape": ({"real_path": 0}, {"real_path": False}),
@@ -70,6 +71,8 @@ def test_headline_dimension_matches_oracle(ising12, scheme, compose):
             assert (e.info("sparse_generator") >= 1) == want["sparse_generator"]
         if "sparse_controls" in want:
             assert (e.info("sparse_controls") >= 1) == want["sparse_controls"]
+        if "xor_regular" in want:
+            assert (e.info("xor_regular") >= 1) == want["xor_regular"]
         assert e.info("operator_backward") == (1 if compose else 0)
     assert np.max(np.abs(fwd - P["fin"])) < TOL
     assert np.max(np.abs(fin - P["fin"])) < TOL

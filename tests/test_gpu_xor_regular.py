@@ -1,0 +1,141 @@
+"""GPU parity of the column-form kernels for XOR-regular sparse generators (diffquantum_amd/csrc/xorexp.hip): the same step
+U = expm(-1j dt H(u)) (sim_plain.py:145-146, diffqc.cc:192-198) and its adjoint gradient as every other scheme of the engine,
+evaluated column by column in LDS when H is a sum of Pauli strings.  Checked against the oracle (d = 512) and against the
+row-wise sparse kernels of the same engine (option xor_regular = 0) up to the headline dimension.
+
+Tolerance (BASELINE.json north_star): 1e-10 on amplitudes and gradients in fp64.
+"""
+import numpy as np
+import pytest
+
+from diffquantum_amd import problems
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+PX = np.array([[0, 1], [1, 0]], dtype=float)
+PZ = np.array([[1, 0], [0, -1]], dtype=float)
+PIY = np.array([[0, 1], [-1, 0]], dtype=float)   # i Y (real): an even number of them makes a real symmetric string
+
+
+def _string(n, ops):
+    """Kronecker product of one-qubit operators; ops = {qubit: 'X' | 'Z' | 'Y'}; pairs of Y become -(iY)(iY)."""
+    m = np.ones((1, 1))
+    ny = sum(1 for v in ops.values() if v == "Y")
+    assert ny % 2 == 0
+    for q in range(n):
+        o = ops.get(q)
+        m = np.kron(m, np.eye(2) if o is None else PX if o == "X" else PZ if o == "Z" else PIY)
+    return m * ((-1.0) ** (ny // 2))
+
+
+def _pauli_problem(n, seed):
+    """Drift: ZZ couplings + Z fields (diagonal) + a transverse term h X_0 (drift entries off the diagonal).  Controls: X_k;
+    X_a X_b (two-bit offset); Y_a Y_b (negative entries); X_a Z_b (sign pattern); Z_a (a control that is diagonal);
+    X_a + 0.5 Z_b (one control with both an XOR-diagonal and diagonal entries)."""
+    rng = np.random.default_rng(seed)
+    d = 1 << n
+    H0 = np.zeros((d, d))
+    for a in range(n):
+        H0 += rng.standard_normal() * _string(n, {a: "Z"})
+        H0 += rng.standard_normal() * _string(n, {a: "Z", (a + 1) % n: "Z"})
+    H0 += 0.7 * _string(n, {0: "X"})
+    Hs = [_string(n, {k: "X"}) for k in range(1, 4)]
+    Hs.append(_string(n, {1: "X", 4: "X"}))
+    Hs.append(_string(n, {2: "Y", 5: "Y"}))
+    Hs.append(1.5 * _string(n, {3: "X", 6: "Z"}))
+    Hs.append(_string(n, {4: "Z"}))
+    Hs.append(_string(n, {7: "X"}) + 0.5 * _string(n, {2: "Z"}))
+    M = rng.standard_normal((d, d))
+    M = (M + M.T) / 2
+    return H0.astype(complex), np.array(Hs).astype(complex), M.astype(complex)
+
+
+def _engine(H0, Hs, M, **opts):
+    from diffquantum_amd.engine import Engine
+    e = Engine(len(H0), len(Hs))
+    e.set_hamiltonians(H0, Hs)
+    e.set_observable(M)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    return e
+
+
+@pytest.mark.parametrize("B", [6, 512])
+def test_ising_column_form_matches_oracle(oracle, B):
+    """d = 512 (the smallest dimension the kernels take), BASELINE's family; state form (B < d) and operator form (B = d)."""
+    n, S, dt = 9, 3, 1e-3
+    H0, Hs, M = problems.random_ising(n, seed=4)
+    u = np.random.default_rng(1).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, sparse_generator=1) as e:
+        assert e.info("xor_regular_found") == n
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("xor_regular") == 1
+        p1 = e.propagate(u, dt, psi0)
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("xor_regular") == 0
+    assert abs(l1 - rl) < TOL * max(1, B / 8) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+    assert np.max(np.abs(p1 - rf)) < TOL
+    assert abs(l1 - l0) < 1e-12 * B and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
+
+
+@pytest.mark.parametrize("q", [1, 2, 3])
+def test_pauli_strings_with_signs_and_diagonal_controls(oracle, q):
+    """Every entry class of the table: drift entries off the diagonal, two-bit offsets, negative entries, a diagonal control,
+    a control with both kinds of entries -- at each polynomial size the kernels are instantiated for."""
+    n, S, B = 9, 3, 5
+    dt = {1: 2e-5, 2: 4e-4, 3: 2e-3}[q]
+    H0, Hs, M = _pauli_problem(n, seed=q)
+    u = np.random.default_rng(q).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, sparse_generator=1, real_path=q) as e:
+        assert e.info("xor_regular_found") == 8          # X_0 (drift), X_1..X_3, XX, YY, XZ, X_7
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 1 and e.info("real_path") == q
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 0
+    assert abs(l1 - l0) < 1e-12 and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
+    assert abs(l1 - rl) < 1e-9 and np.max(np.abs(g1 - rg)) < 1e-9 and np.max(np.abs(f1 - rf)) < 1e-9
+
+
+def test_irregular_patterns_keep_the_row_kernels():
+    """A diagonal of varying magnitude, or a missing entry, is not XOR-regular: the row-wise kernels stay."""
+    n = 9
+    d = 1 << n
+    H0, Hs, M = problems.random_ising(n, seed=1)
+    Hs = Hs.copy()
+    Hs[0, 0, 1 << (n - 1)] = Hs[0, 1 << (n - 1), 0] = 2.0        # one pair of another magnitude
+    u = np.random.default_rng(0).uniform(-1, 1, (2, n))
+    psi0 = problems.random_states(d, 4, seed=1)
+    with _engine(H0, Hs, M, sparse_generator=1) as e:
+        assert e.info("xor_regular_found") == -1
+        e.energy_grad(u, 0.01, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("xor_regular") == 0
+    Hs[0, 0, 1 << (n - 1)] = Hs[0, 1 << (n - 1), 0] = 0.0        # ... and a hole
+    with _engine(H0, Hs, M, sparse_generator=1) as e:
+        assert e.info("xor_regular_found") == -1
+
+
+@pytest.mark.parametrize("n,B,S", [(10, 1024, 4), (11, 64, 3), (12, 4096, 2), (12, 32, 3)])
+def test_column_form_against_row_kernels_up_to_the_headline_dimension(n, B, S):
+    """d = 1024 .. 4096 (all workgroup shapes), automatic scheme choice; B >= d is the operator form of the headline."""
+    from diffquantum_amd.engine import Engine
+    dt = 5e-4
+    H0, Hs, M = problems.random_ising(n, seed=n)
+    u = problems.pulse_table(n, S, S * dt, seed=2)
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    with Engine(1 << n, n) as e:
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        assert e.info("xor_regular_found") == n
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("xor_regular") == 1
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 0
+    assert abs(l1 - l0) < 1e-11 * B and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
