@@ -21,10 +21,11 @@ N GPUs = N batch shards of 4096 (weak scaling): value = N*K / max-over-ranks wal
 
 THE HEADLINE NUMBER DEPENDS ON THE STRUCTURE OF THE INPUTS.  The engine inspects H0 / H_k at `dq_set_hamiltonians`: real
 matrices take the cos X + i sin X form on real products, sparse controls their nonzeros only, a sparse drift too turns the
-whole step exponential into sparse x dense passes.  BASELINE's workload (diagonal Ising drift, X_k controls) is of the last
-kind.  `by_input_structure` in the JSON line gives, in the same run and with their own `roofline` blocks, the rates for
-dense real symmetric and dense complex Hermitian inputs of the same size (random data, 20-step chains), and for the Ising
-inputs with the structure ignored step by step (gradients equal to rounding).
+whole step exponential into sparse x dense passes, and a generator that is a sum of Pauli strings (XOR-regular pattern)
+builds every column of U in LDS with no dense intermediate at all.  BASELINE's workload (diagonal Ising drift, X_k controls)
+is of the last kind.  `by_input_structure` in the JSON line gives, in the same run and with their own `roofline` blocks, the
+rates for dense real symmetric and dense complex Hermitian inputs of the same size (random data, 20-step chains), and for
+the Ising inputs with the structure ignored step by step (gradients equal to rounding).
 
 JSON extras: `roofline` = the kernel class with the largest share of the timed region, decided live from the per-launch
 HIP events the library records on the launch stream.  For MFMA classes `achieved` is the EXECUTED matrix-pipe rate (the
@@ -50,6 +51,7 @@ sys.path.insert(0, ROOT)
 PEAK_F64_MFMA_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 64 cycles/instr/SIMD measured (tools/mfma_f64_probe.hip)
                              # = 32 flop/clk/SIMD * 1024 SIMDs * 2.4 GHz; equals the datasheet FP64-matrix figure
 PEAK_HBM_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+PEAK_LDS_GBPS = 256 * 256 * 2.4  # same guide, LDS table: ds_read_b64 = 2 LDS cycles per wave = 256 B/clk/CU x 256 CUs x 2.4 GHz
 # HBM-side bytes per launch at d = B = 4096, fp64: rocprofv3 PMC, separate --pmc FETCH_SIZE / WRITE_SIZE passes,
 # read = 2 * FETCH_SIZE (gfx950 correction of the guide's HBM section), write = WRITE_SIZE.  (bytes, profiles/ file)
 TRAFFIC = {
@@ -58,6 +60,7 @@ TRAFFIC = {
     "rgemm": (1.81e9, "profiles/r1_bench_v5_realpath_summary.txt"),
     "rsym": (2.68e9, "profiles/r2_bench_dense_real_summary.txt"),    # symmetric-output rgemm 2614 MB + fix-up 64 MB
     "spmm": (8.50e8, "profiles/r2_bench_headline_summary.txt"),      # (2 x 754 MB rsp_mm_slab + 1043 MB rsp_mm_dot_slab) / 3
+    "xr": (None, None),                                              # column-form kernels: filled from the PMC pass of the round
 }
 
 
@@ -284,17 +287,37 @@ def roofline_blocks(prof, info, d):
         "rgemm": mfma("rgemm", rg, "rgemm_kernel<128,128,16,4,4> (batched real GEMM, full output, LDS-DMA staged)", 1.0, per(rg, "bytes"),
                       "executed = algorithmic = 2*M*N*K"),
     }
-    tr, src = TRAFFIC["spmm"]
-    use_tr = d == 4096 and sp["launches"] > 0
-    gbps = sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0
-    blocks["spmm"] = {
-        "bound": "hbm", "kernel": "rsp_mm_kernel / rsp_mm_dot_kernel (sparse generator x dense matrix: out[i,:] = sum over nnz(X[i,:]) of w X_m[j,:])",
-        "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-        "traffic": tr if use_tr else None, "traffic_source": src if use_tr else None,
-        "traffic_over_algorithmic": (tr / per(sp, "bytes")) if (use_tr and sp["bytes"]) else None,
-        "launches": sp["launches"], "ms_per_launch": per(sp, "ms"), "ms_in_timed_region": sp["ms"],
-        "note": "achieved = ALGORITHMIC bytes (operand read once, product written once: 2-3 x 8 d^2) / HIP-event time; the partner "
-                "rows of a row's nonzeros are re-read from L2 / Infinity Cache: `traffic` is the fabric-side PMC figure per launch"}
+    if info.get("xor_regular", 0) > 0:
+        # column form: the class holds xr_forward_kernel / xr_reverse_kernel; booked flops = 2 per (row, diagonal, power, column)
+        # with the diagonal included, so LDS reads = flops / 2 * R / (R + 1) doubles
+        R = max(1.0, float(info["xor_regular_found"]))
+        lds_bytes = sp["flops"] / 2.0 * R / (R + 1.0) * 8.0
+        gbps = lds_bytes / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0
+        tr, src = TRAFFIC["xr"]
+        use_tr = d == 4096 and sp["launches"] > 0 and tr is not None
+        blocks["spmm"] = {
+            "bound": "lds", "kernel": "xr_forward_kernel / xr_reverse_kernel (XOR-regular sparse generator: a column of U = cos X + i sin X, or of its "
+                                      "reverse mode, as a chain of sparse matrix-vector products on a vector held in LDS; partner rows = ds_read_b64 at i ^ x_j)",
+            "achieved": gbps, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": gbps / PEAK_LDS_GBPS,
+            "hbm_gbps_algorithmic": sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0,
+            "traffic": tr if use_tr else None, "traffic_source": src if use_tr else None,
+            "traffic_over_algorithmic": (tr / per(sp, "bytes")) if (use_tr and sp["bytes"]) else None,
+            "launches": sp["launches"], "ms_per_launch": per(sp, "ms"), "ms_in_timed_region": sp["ms"],
+            "note": "achieved = LDS bytes gathered (8 B per row, off-diagonal XOR-diagonal, power and column) / HIP-event time, against the "
+                    "LDS array's 256 B/clk/CU; algorithmic HBM bytes are one complex d x d matrix per launch (U written, or Ubar read): "
+                    "hbm_gbps_algorithmic.  The kernels are latency-bound (8-16 waves per CU, one barrier per power), not at either roof"}
+    else:
+        tr, src = TRAFFIC["spmm"]
+        use_tr = d == 4096 and sp["launches"] > 0
+        gbps = sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0
+        blocks["spmm"] = {
+            "bound": "hbm", "kernel": "rsp_mm_kernel / rsp_mm_dot_kernel (sparse generator x dense matrix: out[i,:] = sum over nnz(X[i,:]) of w X_m[j,:])",
+            "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+            "traffic": tr if use_tr else None, "traffic_source": src if use_tr else None,
+            "traffic_over_algorithmic": (tr / per(sp, "bytes")) if (use_tr and sp["bytes"]) else None,
+            "launches": sp["launches"], "ms_per_launch": per(sp, "ms"), "ms_in_timed_region": sp["ms"],
+            "note": "achieved = ALGORITHMIC bytes (operand read once, product written once: 2-3 x 8 d^2) / HIP-event time; the partner "
+                    "rows of a row's nonzeros are re-read from L2 / Infinity Cache: `traffic` is the fabric-side PMC figure per launch"}
     total = sum(v["ms"] for v in prof.values())
     for b in blocks.values():
         b["share_of_kernel_time"] = b["ms_in_timed_region"] / total if total > 0 else 0.0
@@ -311,10 +334,15 @@ def executed_tflops(blocks, seconds):
 
 
 INFO_KEYS = ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk", "zgemm_alg", "real_path",
-             "real_hamiltonians", "sparse_controls", "sparse_generator", "control_nonzeros")
+             "real_hamiltonians", "sparse_controls", "sparse_generator", "control_nonzeros", "xor_regular", "xor_regular_found")
 
 
 def describe_expm(info):
+    if info["sparse_generator"] > 0 and info.get("xor_regular", 0) > 0:
+        return ("cos X + i sin X, Taylor degree {0}: drift and controls are sums of Pauli strings ({1} XOR-diagonals + the diagonal), so every "
+                "column of U is a chain of {2} sparse matrix-vector products held in LDS (xorexp.hip: no dense power, no MFMA product and "
+                "no HBM traffic but U itself in the step exponential; reverse mode from the rows of Ubar the same way), theta<={3:.3g}".format(
+                    int(info["degree"]), int(info["xor_regular_found"]), int(info["products"]), info["theta"]))
     if info["sparse_generator"] > 0:
         return ("cos X + i sin X, Taylor degree {0}: drift and controls sparse, so X_t is sparse -- the powers X^2 .. X^{0} by {1} sparse x dense "
                 "passes, cos/sin as linear combinations of them (no MFMA product in the step exponential), theta<={2:.3g}".format(
@@ -371,6 +399,9 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
     out = {}
     # (1) the headline's own inputs with their structure ignored step by step: gradients must agree to rounding
     for name, opts, note in (
+            ("ising_inputs_sparse_row_kernels", {"xor_regular": 0},
+             "same inputs, the XOR-regular (Pauli-string) structure of the generator ignored: the step exponential as 2q sparse x dense "
+             "passes over stored dense powers (what any sparse drift + sparse controls get)"),
             ("ising_inputs_sparse_controls_dense_drift", {"sparse_generator": 0},
              "same inputs, the drift treated as dense: real symmetric MFMA products for the step exponential, controls by their nonzeros"),
             ("ising_inputs_dense_real_path", {"sparse_generator": 0, "sparse_controls": 0},
@@ -383,6 +414,7 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
         ent["max_abs_grad_diff_vs_headline"] = float((g - grad_ref).abs().max().item())
         ent["abs_loss_diff_vs_headline"] = abs(ent["loss"] - loss_ref)
         out[name] = ent
+        eng.set_option("xor_regular", -1)
         eng.set_option("sparse_generator", -1)
         eng.set_option("sparse_controls", 1)
         eng.set_option("real_path", a.real_path)
@@ -741,8 +773,11 @@ def run_config3(a, D):
     W_alg = 8.0 * d * d * B  # one complex (d x d).(d x B) product
     ex_tf = executed_tflops(blocks, elapsed)
     structure_note = {
-        "ising": "diagonal Ising drift + X_k controls: real AND sparse -- the engine runs the step exponential as sparse x dense passes "
-                 "(input-structure-specific path; see by_input_structure for dense inputs of the same size)",
+        "ising": ("diagonal Ising drift + X_k controls: real, sparse and a sum of Pauli strings -- the engine builds the step exponential column "
+                  "by column in LDS (input-structure-specific path; see by_input_structure for the same inputs on the general sparse kernels "
+                  "and for dense inputs of the same size)") if info.get("xor_regular", 0) > 0 else
+                 ("diagonal Ising drift + X_k controls: real AND sparse -- the engine runs the step exponential as sparse x dense passes "
+                  "(input-structure-specific path; see by_input_structure for dense inputs of the same size)"),
         "dense-real": "dense random real symmetric H0 / H_k: cos X + i sin X on real symmetric-output MFMA products",
         "dense-complex": "dense random complex Hermitian H0 / H_k: the general complex tape"}[a.workload]
     out = {

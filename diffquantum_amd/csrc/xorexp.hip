@@ -7,7 +7,7 @@
 // and when X's pattern is XOR-regular -- besides its diagonal, row i holds exactly the entries (i, i ^ x_j), j < R, the same
 // offsets x_j in every row, each of constant magnitude along its XOR-diagonal: sums of Pauli strings, e.g. an Ising drift with
 // X_k controls -- the column needs no index arrays at all: the vector lives in LDS (d * sizeof(T) bytes, two images), a thread
-// owns the XR_RPT rows r * NT + t, the partner of row i under offset x_j is a conflict-free LDS read at i ^ x_j, the weight
+// owns the RPT rows r * NT + t, the partner of row i under offset x_j is a conflict-free LDS read at i ^ x_j, the weight
 // w_j = -dt u[kid_j] cmag_j is wave-uniform (a sign bit per row and diagonal where entries are negative), and all diagonals at
 // offset 0 (the drift's, Z-type controls') collapse into one per-row weight.  HBM traffic of a whole step exponential = U
 // written once (the dense powers, the dense X and the linear-combination pass no longer exist); the kernel is bound by LDS
@@ -39,20 +39,20 @@ __device__ inline double xr_flip(double v, unsigned bit) {
 // per-thread constants of a launch: the weights of the XOR-diagonals (wave-uniform), the rows' sign words and diagonal weights;
 // in LDS: jof[x] = the (last) diagonal whose offset is x (R for x = 0, R + 1 for none), nxt[j] = the next one with the same
 // offset (>= R: none), and the weights
-template <class T, int NT, bool SIGN>
+template <class T, int NT, int RPT, bool SIGN>
 struct XrRows {
-  T dg[XR_RPT];  // sum over the offset-0 diagonals of -dt u val
-  unsigned sg[XR_RPT];
+  T dg[RPT];  // sum over the offset-0 diagonals of -dt u val
+  unsigned sg[RPT];
   int R;
   const unsigned char *jof, *nxt;
   const T* Wl;
   __device__ __forceinline__ void load(const XrTab& tab, const double* __restrict__ uz, double mdt, int t, unsigned char* s_jof,
                                        T* s_w) {
     unsigned char* s_nxt = (unsigned char*)(s_w + XR_RMAX + 2);
-    constexpr int D = NT * XR_RPT;
+    constexpr int D = NT * RPT;
     R = tab.R;
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
       dg[r] = 0;
     }
@@ -60,7 +60,7 @@ struct XrRows {
       const int k = tab.dkid[j];
       const double w = mdt * (k < 0 ? 1.0 : uz[k]);
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) dg[r] += (T)(w * tab.dval[(long)j * D + r * NT + t]);
+      for (int r = 0; r < RPT; ++r) dg[r] += (T)(w * tab.dval[(long)j * D + r * NT + t]);
     }
     for (int i = t; i < D; i += NT) s_jof[i] = (unsigned char)(tab.R + 1);
     __syncthreads();
@@ -85,7 +85,7 @@ struct XrRows {
   // x_1 = X e_c (column c of X) at the thread's rows: the diagonal weight at row c, +-w_j at the rows c ^ x_j
   __device__ __forceinline__ void first(int t, int c, T* x1) const {
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       const int i = r * NT + t;
       T w = 0;
       for (unsigned j = jof[i ^ c]; j < (unsigned)R; j = nxt[j]) w += SIGN ? xr_flip(Wl[j], (sg[r] >> j) & 1u) : Wl[j];
@@ -109,30 +109,46 @@ __device__ __forceinline__ void xr_acc(double* dacc, int j, double s) {
 // one sweep  o += (X - diag) v  with v in LDS image `src`; optional dot products with xm[] (DOT).  The loop over the
 // diagonals is a runtime loop on purpose: unrolled, the compiler hoists sign masks and LDS addresses of all R diagonals out of
 // the column loop, prefetches across diagonals and spills hundreds of registers.
-template <class T, int NT, bool SIGN, bool DOT>
-__device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, SIGN>& rw, const T* __restrict__ src, int t, T* o,
+template <class T, int NT, int RPT, bool SIGN, bool DOT, bool PAIR>
+__device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, RPT, SIGN>& rw, const T* __restrict__ src, int t, T* o,
                                           const T* xm, double* dacc) {
-#pragma clang loop unroll(disable)
-  for (int j = 0; j < tab.R; ++j) {
+  // PAIR: two diagonals per trip (16 LDS reads in flight per lane) -- not where that spills (reverse kernel with sign words)
+  auto fetch = [&](int j, T* vs) {
     const int xo = tab.xoff[j];
-    const T w = rw.Wl[j];
     const T* base = src + (t ^ (xo & (NT - 1)));
     const int xh = xo / NT;
-    T vs[XR_RPT];
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) vs[r] = base[(r ^ xh) * NT];
+    for (int r = 0; r < RPT; ++r) vs[r] = base[(r ^ xh) * NT];
+  };
+  auto use = [&](int j, T* vs) {
     if (SIGN) {
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) vs[r] = xr_flip(vs[r], (rw.sg[r] >> j) & 1u);
+      for (int r = 0; r < RPT; ++r) vs[r] = xr_flip(vs[r], (rw.sg[r] >> j) & 1u);
     }
+    const T w = rw.Wl[j];
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) o[r] = __builtin_fma(w, vs[r], o[r]);
+    for (int r = 0; r < RPT; ++r) o[r] = __builtin_fma(w, vs[r], o[r]);
     if (DOT) {
       T s = 0;
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) s = __builtin_fma(vs[r], xm[r], s);
+      for (int r = 0; r < RPT; ++r) s = __builtin_fma(vs[r], xm[r], s);
       xr_acc<0>(dacc, j, (double)s);
     }
+  };
+  int j = 0;
+#pragma clang loop unroll(disable)
+  for (; PAIR && j + 1 < tab.R; j += 2) {
+    T va[RPT], vb[RPT];
+    fetch(j, va);
+    fetch(j + 1, vb);
+    use(j, va);
+    use(j + 1, vb);
+  }
+#pragma clang loop unroll(disable)
+  for (; j < tab.R; ++j) {
+    T va[RPT];
+    fetch(j, va);
+    use(j, va);
   }
 }
 
@@ -151,66 +167,66 @@ __device__ __forceinline__ void xr_level0(const XrTab& tab, const T* __restrict_
 }
 
 // stored powers by (wave-uniform) index: register arrays need static indices, so a chain of scalar compares
-template <class T, int N, int I>
-__device__ __forceinline__ void xr_put(T (*xm)[XR_RPT], int idx, const T* v) {
+template <class T, int RPT, int N, int I>
+__device__ __forceinline__ void xr_put(T (*xm)[RPT], int idx, const T* v) {
   if constexpr (I < N) {
     if (idx == I) {
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) xm[I][r] = v[r];
+      for (int r = 0; r < RPT; ++r) xm[I][r] = v[r];
     }
-    xr_put<T, N, I + 1>(xm, idx, v);
+    xr_put<T, RPT, N, I + 1>(xm, idx, v);
   }
 }
-template <class T, int N, int I>
-__device__ __forceinline__ void xr_get(const T (*xm)[XR_RPT], int idx, T* v) {
+template <class T, int RPT, int N, int I>
+__device__ __forceinline__ void xr_get(const T (*xm)[RPT], int idx, T* v) {
   if constexpr (I < N) {
     if (idx == I) {
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) v[r] = xm[I][r];
+      for (int r = 0; r < RPT; ++r) v[r] = xm[I][r];
     }
-    xr_get<T, N, I + 1>(xm, idx, v);
+    xr_get<T, RPT, N, I + 1>(xm, idx, v);
   }
 }
 
 // LDS of both kernels: `images` vectors of D, then jof (D bytes), then XR_RMAX + 2 weights, then nxt (XR_RMAX bytes)
-template <class T, int NT>
+template <class T, int D>
 constexpr size_t xr_lds_bytes(int images) {
-  return (size_t)images * sizeof(T) * NT * XR_RPT + (size_t)NT * XR_RPT + sizeof(T) * (XR_RMAX + 2) + XR_RMAX;
+  return (size_t)images * sizeof(T) * D + (size_t)D + sizeof(T) * (XR_RMAX + 2) + XR_RMAX;
 }
 
 // U[z][c][:] for the columns c = blockIdx.x, blockIdx.x + gridDim.x, ...   (U symmetric: row c = column c)
-template <class T, int NT, bool SIGN>
+template <class T, int NT, int RPT, bool SIGN>
 __global__ void __launch_bounds__(NT, (NT * 2 + 255) / 256) xr_forward_kernel(typename Cx<T>::type* __restrict__ U, long stride, XrTab tab,
                                                         const double* __restrict__ u, int K, double mdt, XrPoly pol) {
   typedef typename Cx<T>::type T2;
-  constexpr int D = NT * XR_RPT;
+  constexpr int D = NT * RPT;
   extern __shared__ __align__(16) unsigned char xr_lds_raw[];
   T* lds = (T*)xr_lds_raw;  // two images of D
   const int t = threadIdx.x;
   const long z = blockIdx.y;
   const int np = 2 * pol.q + 1;
-  XrRows<T, NT, SIGN> rw;
+  XrRows<T, NT, RPT, SIGN> rw;
   rw.load(tab, u + z * K, mdt, t, xr_lds_raw + 2 * sizeof(T) * D, (T*)(xr_lds_raw + 2 * sizeof(T) * D + D));
   int p = 1;  // image read last
   for (int c = blockIdx.x; c < D; c += gridDim.x) {
-    T cur[XR_RPT], are[XR_RPT], aim[XR_RPT];
+    T cur[RPT], are[RPT], aim[RPT];
     rw.first(t, c, cur);
     p ^= 1;
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       lds[p * D + r * NT + t] = cur[r];
       are[r] = (r * NT + t) == c ? (T)pol.cc[0] : (T)0;
       aim[r] = (T)pol.sc[0] * cur[r];
     }
     __syncthreads();
     for (int m = 2; m <= np; ++m) {
-      T o[XR_RPT];
+      T o[RPT];
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) o[r] = rw.dg[r] * cur[r];
-      xr_gather<T, NT, SIGN, false>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
+      for (int r = 0; r < RPT; ++r) o[r] = rw.dg[r] * cur[r];
+      xr_gather<T, NT, RPT, SIGN, false, true>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
       const T cf = (T)((m & 1) ? pol.sc[(m - 1) / 2] : pol.cc[m / 2]);
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) {
+      for (int r = 0; r < RPT; ++r) {
         cur[r] = o[r];
         if (m & 1) aim[r] = __builtin_fma(cf, o[r], aim[r]);
         else are[r] = __builtin_fma(cf, o[r], are[r]);
@@ -218,13 +234,13 @@ __global__ void __launch_bounds__(NT, (NT * 2 + 255) / 256) xr_forward_kernel(ty
       if (m < np) {
         p ^= 1;
 #pragma unroll
-        for (int r = 0; r < XR_RPT; ++r) lds[p * D + r * NT + t] = o[r];
+        for (int r = 0; r < RPT; ++r) lds[p * D + r * NT + t] = o[r];
         __syncthreads();
       }
     }
     T2* urow = U + z * stride + (long)c * D;
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       T2 v;
       v.x = are[r];
       v.y = aim[r];
@@ -238,54 +254,54 @@ __global__ void __launch_bounds__(NT, (NT * 2 + 255) / 256) xr_forward_kernel(ty
 //   sum_i dval_j[i] Xi[i, i]  (diagctl: some control has diagonal entries).   Q: the polynomial's q; x_2 .. x_2q of the column
 // stay in registers (x_1 is cheap to rebuild).  LDS: four images (the two of the sweeps, cbar, sbar); one workgroup per CU.
 // The sweeps are runtime loops (one copy of the gather code each way); the stored powers are reached through xr_put / xr_get.
-template <class T, int NT, int Q, bool SIGN, bool DIAGCTL>
+template <class T, int NT, int RPT, int Q, bool SIGN, bool DIAGCTL>
 __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::type* __restrict__ G, long stride, XrTab tab,
                                                         const double* __restrict__ u, int K, double mdt, XrPoly pol,
                                                         double* __restrict__ part) {
   typedef typename Cx<T>::type T2;
-  constexpr int D = NT * XR_RPT, NPM1 = 2 * Q, NST = NPM1 - 1;
+  constexpr int D = NT * RPT, NPM1 = 2 * Q, NST = NPM1 - 1;
   extern __shared__ __align__(16) unsigned char xr_lds_raw[];
   T* lds = (T*)xr_lds_raw;
   T* lcb = lds + 2 * D;
   T* lsb = lds + 3 * D;
   const int t = threadIdx.x;
   const long z = blockIdx.y;
-  XrRows<T, NT, SIGN> rw;
+  XrRows<T, NT, RPT, SIGN> rw;
   rw.load(tab, u + z * K, mdt, t, xr_lds_raw + 4 * sizeof(T) * D, (T*)(xr_lds_raw + 4 * sizeof(T) * D + D));
-  double dacc[XR_RMAX], rowacc[XR_RPT];
+  double dacc[XR_RMAX], rowacc[RPT];
 #pragma unroll
   for (int j = 0; j < XR_RMAX; ++j) dacc[j] = 0.0;
 #pragma unroll
-  for (int r = 0; r < XR_RPT; ++r) rowacc[r] = 0.0;
+  for (int r = 0; r < RPT; ++r) rowacc[r] = 0.0;
   int p = 1;
   for (int c = blockIdx.x; c < D; c += gridDim.x) {
     // cotangents of the column: row c of G, parked in LDS (own rows only: no barrier needed)
     const T2* grow = G + z * stride + (long)c * D;
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       const T2 g = grow[r * NT + t];
       lcb[r * NT + t] = g.x;
       lsb[r * NT + t] = g.y;
     }
-    T xm[NST][XR_RPT];  // x_2 .. x_2q at the thread's rows
-    T cur[XR_RPT];
+    T xm[NST][RPT];  // x_2 .. x_2q at the thread's rows
+    T cur[RPT];
     rw.first(t, c, cur);
     p ^= 1;
 #pragma unroll
-    for (int r = 0; r < XR_RPT; ++r) lds[p * D + r * NT + t] = cur[r];
+    for (int r = 0; r < RPT; ++r) lds[p * D + r * NT + t] = cur[r];
     __syncthreads();
     for (int m = 2; m <= NPM1; ++m) {
-      T o[XR_RPT];
+      T o[RPT];
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) o[r] = rw.dg[r] * cur[r];
-      xr_gather<T, NT, SIGN, false>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
-      xr_put<T, NST, 0>(xm, m - 2, o);
+      for (int r = 0; r < RPT; ++r) o[r] = rw.dg[r] * cur[r];
+      xr_gather<T, NT, RPT, SIGN, false, !DIAGCTL>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
+      xr_put<T, RPT, NST, 0>(xm, m - 2, o);
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) cur[r] = o[r];
+      for (int r = 0; r < RPT; ++r) cur[r] = o[r];
       if (m < NPM1) {
         p ^= 1;
 #pragma unroll
-        for (int r = 0; r < XR_RPT; ++r) lds[p * D + r * NT + t] = o[r];
+        for (int r = 0; r < RPT; ++r) lds[p * D + r * NT + t] = o[r];
         __syncthreads();
       }
     }
@@ -293,27 +309,27 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
     {
       const T cf = (T)pol.sc[Q];
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) {
+      for (int r = 0; r < RPT; ++r) {
         cur[r] = cf * lsb[r * NT + t];
         lds[p * D + r * NT + t] = cur[r];
       }
     }
     __syncthreads();
     for (int m = NPM1; m >= 1; --m) {
-      T o[XR_RPT], xmm[XR_RPT];
+      T o[RPT], xmm[RPT];
       if (m == 1) rw.first(t, c, xmm);
-      else xr_get<T, NST, 0>(xm, m - 2, xmm);
+      else xr_get<T, RPT, NST, 0>(xm, m - 2, xmm);
       const T cf = (T)((m & 1) ? pol.sc[(m - 1) / 2] : pol.cc[m / 2]);
       const T* add = (m & 1) ? lsb : lcb;
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) {
+      for (int r = 0; r < RPT; ++r) {
         o[r] = __builtin_fma(cf, add[r * NT + t], rw.dg[r] * cur[r]);
         if (DIAGCTL) rowacc[r] = __builtin_fma((double)cur[r], (double)xmm[r], rowacc[r]);
       }
-      xr_gather<T, NT, SIGN, true>(tab, rw, lds + p * D, t, o, xmm, dacc);
+      xr_gather<T, NT, RPT, SIGN, true, !DIAGCTL>(tab, rw, lds + p * D, t, o, xmm, dacc);
       p ^= 1;
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) {
+      for (int r = 0; r < RPT; ++r) {
         cur[r] = o[r];
         lds[p * D + r * NT + t] = o[r];
       }
@@ -323,7 +339,7 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
     if (t == 0) xr_level0<T, 0>(tab, lds + p * D, c, dacc);
     if (DIAGCTL) {
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r)
+      for (int r = 0; r < RPT; ++r)
         if ((r * NT + t) == c) rowacc[r] += (double)cur[r];
     }
   }
@@ -341,7 +357,7 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
     double v = 0.0;
     if (DIAGCTL && j < tab.nd && tab.dkid[j] >= 0) {
 #pragma unroll
-      for (int r = 0; r < XR_RPT; ++r) v = __builtin_fma(tab.dval[(long)j * D + r * NT + t], rowacc[r], v);
+      for (int r = 0; r < RPT; ++r) v = __builtin_fma(tab.dval[(long)j * D + r * NT + t], rowacc[r], v);
     }
     put(XR_RMAX + j, v);
   }
@@ -385,13 +401,13 @@ bool xr_supported(int d, int q, int R, int nd, size_t elem) {
 
 int xr_blocks(int d) { return d < 512 ? d : 512; }
 
-template <class T, int NT>
+template <class T, int NT, int RPT>
 static hipError_t xr_forward_go(typename Cx<T>::type* U, long stride, const XrTab& tab, const double* u, int K, double mdt,
                                 const XrPoly& pol, int batch, hipStream_t st) {
-  const size_t lds = xr_lds_bytes<T, NT>(2);
-  const dim3 grid((unsigned)xr_blocks(NT * XR_RPT), (unsigned)batch);
+  const size_t lds = xr_lds_bytes<T, NT * RPT>(2);
+  const dim3 grid((unsigned)xr_blocks(NT * RPT), (unsigned)batch);
   void (*kf)(typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly) =
-      tab.sgn ? xr_forward_kernel<T, NT, true> : xr_forward_kernel<T, NT, false>;
+      tab.sgn ? xr_forward_kernel<T, NT, RPT, true> : xr_forward_kernel<T, NT, RPT, false>;
   (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, U, stride, tab, u, K, mdt, pol);
   return hipGetLastError();
@@ -403,18 +419,21 @@ hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, c
   if (batch <= 0) return hipSuccess;
   if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double))) return hipErrorInvalidValue;
   switch (d) {
-    case 4096: return xr_forward_go<double, 512>(U, stride, tab, u, K, -dt, pol, batch, st);
-    case 2048: return xr_forward_go<double, 256>(U, stride, tab, u, K, -dt, pol, batch, st);
-    case 1024: return xr_forward_go<double, 128>(U, stride, tab, u, K, -dt, pol, batch, st);
-    default: return xr_forward_go<double, 64>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 4096: return xr_forward_go<double, 512, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 2048: return xr_forward_go<double, 256, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 1024: return xr_forward_go<double, 128, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    default: return xr_forward_go<double, 64, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
   }
 }
 
-template <class T, int NT>
+#ifndef XR_RPT_REV
+#define XR_RPT_REV 8
+#endif
+template <class T, int NT, int RPT>
 static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, const XrTab& tab, const double* u, int K, double mdt,
                                 const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, hipStream_t st) {
-  const size_t lds = xr_lds_bytes<T, NT>(4);
-  const dim3 grid((unsigned)xr_blocks(NT * XR_RPT), (unsigned)batch);
+  const size_t lds = xr_lds_bytes<T, NT * RPT>(4);
+  const dim3 grid((unsigned)xr_blocks(NT * RPT), (unsigned)batch);
   // two variants: plain (no negative entries, no control with diagonal entries) and full (sign words -- `zero_sgn`, d zeros,
   // stands in when the table has none -- and the per-row sums of the offset-0 diagonals)
   bool full = tab.sgn != nullptr;
@@ -425,7 +444,7 @@ static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, cons
 #define XR_REV(Q)                                                                                               \
   case Q: {                                                                                                     \
     void (*kf)(const typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly, double*) =         \
-        full ? xr_reverse_kernel<T, NT, Q, true, true> : xr_reverse_kernel<T, NT, Q, false, false>;             \
+        full ? xr_reverse_kernel<T, NT, RPT, Q, true, true> : xr_reverse_kernel<T, NT, RPT, Q, false, false>;             \
     (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
     hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tb, u, K, mdt, pol, part);                       \
     break;                                                                                                      \
@@ -449,10 +468,10 @@ hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& 
   if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double))) return hipErrorInvalidValue;
   hipError_t e;
   switch (d) {
-    case 4096: e = xr_reverse_go<double, 512>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
-    case 2048: e = xr_reverse_go<double, 256>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
-    case 1024: e = xr_reverse_go<double, 128>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
-    default: e = xr_reverse_go<double, 64>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st);
+    case 4096: e = xr_reverse_go<double, 4096 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
+    case 2048: e = xr_reverse_go<double, 2048 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
+    case 1024: e = xr_reverse_go<double, 1024 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
+    default: e = xr_reverse_go<double, 512 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st);
   }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(64), 0, st, part, xr_blocks(d), tab, K, -dt, grad, accumulate);

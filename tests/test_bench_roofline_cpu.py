@@ -51,3 +51,20 @@ def test_small_dimension_uses_the_4m_count_and_no_traffic_constant():
     z = b["zgemm"]
     assert z["executed_over_algorithmic_flops"] == 1.0 and z["traffic"] is None and z["traffic_source"] is None
     assert bench.ranked(b) == [z]
+
+
+def test_column_form_class_is_priced_against_the_lds_array():
+    """XOR-regular generator: the class holds the column-form kernels; achieved = LDS bytes gathered / time against 256 B/clk/CU."""
+    d, R, q = 4096, 12, 3
+    nn = float(d) * d
+    fwd = 2.0 * (R + 1) * nn * 2 * q            # flops booked by the engine per forward launch (diagonal included)
+    rev = 2.0 * (R + 1) * nn * (4 * q + 1)
+    prof = _prof(spmm={"launches": 60, "ms": 40 * 0.2 + 20 * 0.83, "flops": 40 * fwd + 20 * rev, "bytes": 60 * 16 * nn})
+    b = bench.roofline_blocks(prof, {"zgemm_alg": 2.0, "xor_regular": 1.0, "xor_regular_found": float(R)}, d)
+    s = b["spmm"]
+    lds = (40 * fwd + 20 * rev) / 2.0 * R / (R + 1.0) * 8.0
+    assert s["bound"] == "lds" and s["peak"] == 256 * 256 * 2.4
+    assert abs(s["achieved"] - lds / ((40 * 0.2 + 20 * 0.83) * 1e-3) / 1e9) < 1e-6
+    assert 0.0 < s["frac"] < 1.0 and s["kernel"].startswith("xr_forward_kernel")
+    assert abs(s["hbm_gbps_algorithmic"] - 60 * 16 * nn / ((40 * 0.2 + 20 * 0.83) * 1e-3) / 1e9) < 1e-6
+    assert bench.executed_tflops(b, 1.0) == 0.0          # (no MFMA class in this synthetic profile)

@@ -61,8 +61,10 @@ def test_bench_json_contract():
     for name in ("ising_inputs_dense_real_path", "ising_inputs_complex_tape", "dense_real_symmetric_H", "dense_complex_hermitian_H"):
         assert st[name]["value"] > 0 and st[name]["chain_steps"] == 6, name
         _check_roofline(st[name]["roofline"])
-    for name in ("ising_inputs_sparse_controls_dense_drift", "ising_inputs_dense_real_path", "ising_inputs_complex_tape"):
+    for name in ("ising_inputs_sparse_row_kernels", "ising_inputs_sparse_controls_dense_drift", "ising_inputs_dense_real_path",
+                 "ising_inputs_complex_tape"):
         assert st[name]["max_abs_grad_diff_vs_headline"] < 1e-10, name
+    assert st["ising_inputs_sparse_row_kernels"]["value"] > 0    # (d = 256 here: below the column-form kernels' sizes)
 
 
 def test_bench_general_path_only():
