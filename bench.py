@@ -59,8 +59,8 @@ TRAFFIC = {
     "zherm": (3.84e9, "profiles/r2_bench_headline_summary.txt"),     # zgemm_lin_kernel<1,1> 3778 MB + the 64 MB fix-up pass
     "rgemm": (1.81e9, "profiles/r1_bench_v5_realpath_summary.txt"),
     "rsym": (2.68e9, "profiles/r2_bench_dense_real_summary.txt"),    # symmetric-output rgemm 2614 MB + fix-up 64 MB
-    "spmm": (8.50e8, "profiles/r2_bench_headline_summary.txt"),      # (2 x 754 MB rsp_mm_slab + 1043 MB rsp_mm_dot_slab) / 3
-    "xr": (None, None),                                              # column-form kernels: filled from the PMC pass of the round
+    "spmm": (8.50e8, "profiles/r2_bench_headline_row_kernels_summary.txt"),     # (2 x 754 MB rsp_mm_slab + 1043 MB rsp_mm_dot_slab) / 3
+    "xr": (2.84e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 315 MB xr_reverse [Ubar read]) / 3
 }
 
 

@@ -94,15 +94,16 @@ struct XrRows {
   }
 };
 
-// dacc[j] += s for a wave-uniform j (register arrays need static indices: a chain of scalar compares)
-template <int I>
+// dacc[j] += s for a wave-uniform j (register arrays need static indices: a binary tree of scalar compares)
+template <int LO, int HI>
 __device__ __forceinline__ void xr_acc(double* dacc, int j, double s) {
-  if constexpr (I < XR_RMAX) {
-    if (j == I) {
-      asm volatile("" : "+v"(dacc[I]));  // (keeps the chain from being turned into an indexed access to a scratch array)
-      dacc[I] += s;
-    }
-    xr_acc<I + 1>(dacc, j, s);
+  if constexpr (HI - LO == 1) {
+    asm volatile("" : "+v"(dacc[LO]));  // (keeps the tree from being turned into an indexed access to a scratch array)
+    dacc[LO] += s;
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (j < MID) xr_acc<LO, MID>(dacc, j, s);
+    else xr_acc<MID, HI>(dacc, j, s);
   }
 }
 
@@ -116,9 +117,14 @@ __device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, 
   auto fetch = [&](int j, T* vs) {
     const int xo = tab.xoff[j];
     const T* base = src + (t ^ (xo & (NT - 1)));
-    const int xh = xo / NT;
+    if (xo < NT) {  // (wave-uniform) the partner rows keep their place in the thread's row list: immediate offsets
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) vs[r] = base[(r ^ xh) * NT];
+      for (int r = 0; r < RPT; ++r) vs[r] = base[r * NT];
+    } else {
+      const int xh = xo / NT;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) vs[r] = base[(r ^ xh) * NT];
+    }
   };
   auto use = [&](int j, T* vs) {
     if (SIGN) {
@@ -132,7 +138,7 @@ __device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, 
       T s = 0;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) s = __builtin_fma(vs[r], xm[r], s);
-      xr_acc<0>(dacc, j, (double)s);
+      xr_acc<0, XR_RMAX>(dacc, j, (double)s);
     }
   };
   int j = 0;
@@ -370,20 +376,20 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
 }
 
 // grad[z][k] (+)= scale * (sum_j [kid_j == k] cmag_j sum_b part[z][b][j] + sum_j [dkid_j == k] sum_b part[z][b][XR_RMAX + j])
-__global__ void __launch_bounds__(64) xr_finish_kernel(const double* __restrict__ part, int nblk, XrTab tab, int K, double scale,
-                                                       double* __restrict__ grad, int accumulate) {
+// One workgroup per step: 32 lanes per slot, lane l adds the workgroups l, l + 32, ... in order, then a fixed butterfly.
+__global__ void __launch_bounds__(XR_SLOTS * 32) xr_finish_kernel(const double* __restrict__ part, int nblk, XrTab tab, int K,
+                                                                  double scale, double* __restrict__ grad, int accumulate) {
   const long z = blockIdx.x;
-  const int j = threadIdx.x;
+  const int slot = threadIdx.x >> 5, l = threadIdx.x & 31;
   __shared__ double s_j[XR_SLOTS];
-  if (j < XR_SLOTS) {
-    const bool live = j < XR_RMAX ? j < tab.R : (j - XR_RMAX < tab.nd && tab.dkid[j - XR_RMAX] >= 0);
-    double s = 0.0;
-    if (live)
-      for (int b = 0; b < nblk; ++b) s += part[(z * nblk + b) * XR_SLOTS + j];
-    s_j[j] = live ? s * (j < XR_RMAX ? tab.cmag[j] : 1.0) : 0.0;
-  }
+  const bool live = slot < XR_RMAX ? slot < tab.R : (slot - XR_RMAX < tab.nd && tab.dkid[slot - XR_RMAX] >= 0);
+  double s = 0.0;
+  if (live)
+    for (int b = l; b < nblk; b += 32) s += part[(z * nblk + b) * XR_SLOTS + slot];
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+  if (l == 0) s_j[slot] = live ? s * (slot < XR_RMAX ? tab.cmag[slot] : 1.0) : 0.0;
   __syncthreads();
-  for (int k = j; k < K; k += 64) {
+  for (int k = threadIdx.x; k < K; k += XR_SLOTS * 32) {
     double g = accumulate ? grad[z * K + k] : 0.0;
     for (int q = 0; q < tab.R; ++q)
       if (tab.kid[q] == k) g += scale * s_j[q];
@@ -474,7 +480,7 @@ hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& 
     default: e = xr_reverse_go<double, 512 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st);
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(64), 0, st, part, xr_blocks(d), tab, K, -dt, grad, accumulate);
+  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d), tab, K, -dt, grad, accumulate);
   return hipGetLastError();
 }
 
