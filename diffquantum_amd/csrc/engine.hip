@@ -1842,7 +1842,8 @@ void do_propagator_vjp(Ctx<T>* c, const double* u, int n, double dt, const void*
   for (int c0 = 0; c0 < n; c0 += tc) {
     const int m = std::min(tc, n - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, m, dt);
-    build_propagators(c, p, c0, m, dt);  // the polynomial's variables, for the reverse mode
+    if (!p.xr) build_propagators(c, p, c0, m, dt);  // the polynomial's variables, for the reverse mode (column form: none)
+    else for (auto& r : c->redirect) r = nullptr;
     T2* G = ubar_slot(c, p, m);
     HIPCK(hipMemcpyAsync(G, (const char*)G_in + (size_t)c0 * c->mat_bytes(), (size_t)m * c->mat_bytes(), hipMemcpyDefault, c->st));
     chunk_vjp(c, p, c0, m, dt);

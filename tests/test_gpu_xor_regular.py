@@ -139,3 +139,24 @@ def test_column_form_against_row_kernels_up_to_the_headline_dimension(n, B, S):
         l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
         assert e.info("xor_regular") == 0
     assert abs(l1 - l0) < 1e-11 * B and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
+
+
+def test_explicit_propagators_and_their_vjp_in_column_form():
+    """dq_build_propagators / dq_propagator_vjp (the propagator-sharded multi-GPU form's two calls): U_t and the pull-back of
+    arbitrary cotangents G_t, column form against the row-wise kernels."""
+    n, S, dt = 9, 3, 1e-3
+    d = 1 << n
+    H0, Hs, M = problems.random_ising(n, seed=7)
+    u = np.random.default_rng(3).uniform(-1, 1, (S, n))
+    rng = np.random.default_rng(4)
+    G = rng.standard_normal((S, d, d)) + 1j * rng.standard_normal((S, d, d))
+    with _engine(H0, Hs, M, sparse_generator=1) as e:
+        U1 = e.build_propagators(u, dt)
+        assert e.info("xor_regular") == 1
+        g1 = e.propagator_vjp(u, dt, G)
+        e.set_option("xor_regular", 0)
+        U0 = e.build_propagators(u, dt)
+        assert e.info("xor_regular") == 0
+        g0 = e.propagator_vjp(u, dt, G)
+    assert np.max(np.abs(U1 - U0)) < 1e-14 and np.max(np.abs(g1 - g0)) < 1e-11 * np.max(np.abs(g0))
+    assert np.max(np.abs(U1 - np.transpose(U1, (0, 2, 1)))) < 1e-15       # complex symmetric (rows written as columns)
