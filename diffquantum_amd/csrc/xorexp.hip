@@ -114,9 +114,12 @@ template <class T, int NT, int RPT, bool SIGN, bool DOT, bool PAIR>
 __device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, RPT, SIGN>& rw, const T* __restrict__ src, int t, T* o,
                                           const T* xm, double* dacc) {
   // PAIR: two diagonals per trip (16 LDS reads in flight per lane) -- not where that spills (reverse kernel with sign words)
+  // (volatile reads: hipcc otherwise merges neighbours into ds_read2st64_b64, which the LDS array serves at half the rate of
+  // ds_read_b64 -- 128 against 256 B/clk/CU -- and this loop lives on that rate)
   auto fetch = [&](int j, T* vs) {
     const int xo = tab.xoff[j];
-    const T* base = src + (t ^ (xo & (NT - 1)));
+    typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
+    lds_ptr base = (lds_ptr)(src + (t ^ (xo & (NT - 1))));
     if (xo < NT) {  // (wave-uniform) the partner rows keep their place in the thread's row list: immediate offsets
 #pragma unroll
       for (int r = 0; r < RPT; ++r) vs[r] = base[r * NT];

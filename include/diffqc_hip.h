@@ -127,10 +127,18 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      hint, B^H) get one by a transposing pre-pass into scratch, so that they run on the linear-form kernel too
  *   slab_spmm          1 (default): the sparse x dense passes of the sparse-generator scheme in XCD-slab form (16-B lanes, one
  *                      column slab per XCD; dim a multiple of 1024 in fp64 / 2048 in fp32), 0 = one wave per whole row
+ *   xor_regular        -1 / 1 (default): a sparse generator whose pattern is XOR-regular (besides its diagonal, row i holds exactly
+ *                      the entries (i, i ^ x_j) for the same offsets x_j in every row, each XOR-diagonal from one source matrix and
+ *                      of one magnitude: sums of real Pauli strings, e.g. an Ising drift with X_k controls) takes the column-form
+ *                      kernels of csrc/xorexp.hip (complex128, dim 512 .. 4096, polynomial q <= 3): U and the control gradients
+ *                      column by column in LDS, no dense intermediate; 0 = the row-wise sparse x dense passes.
+ *                      dq_get_info("xor_regular_found") = number of XOR-diagonals found (-1: not of that class),
+ *                      ("xor_regular") = 1 if the last call ran the column form
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
- * "time_parallel", "cached_steps", "slice_skew", "sparse_controls", "control_nonzeros" (-1 = dense), "sparse_generator", "sparse_drift", "zgemm_alg", "norm_H0", "dim", "n_controls", "dtype". */
+ * "time_parallel", "cached_steps", "slice_skew", "sparse_controls", "control_nonzeros" (-1 = dense), "sparse_generator", "sparse_drift", "xor_regular", "xor_regular_found", "zgemm_alg", "norm_H0", "dim",
+ * "n_controls", "dtype". */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
 
