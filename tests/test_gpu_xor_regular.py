@@ -160,3 +160,33 @@ def test_explicit_propagators_and_their_vjp_in_column_form():
         g0 = e.propagator_vjp(u, dt, G)
     assert np.max(np.abs(U1 - U0)) < 1e-14 and np.max(np.abs(g1 - g0)) < 1e-11 * np.max(np.abs(g0))
     assert np.max(np.abs(U1 - np.transpose(U1, (0, 2, 1)))) < 1e-15       # complex symmetric (rows written as columns)
+
+
+def test_column_form_with_the_propagator_cache_and_time_slices():
+    """A cached column-form chunk keeps U alone (no powers): the backward sweep reuses it and the reverse kernel needs nothing else.
+    Same numbers with and without the cache, and through the time-sliced form on three virtual ranks."""
+    from diffquantum_amd.distributed import shard_range, virtual_time_sliced_energy_grad
+    n, B, S, dt = 9, 512, 12, 1e-3
+    H0, Hs, M = problems.random_ising(n, seed=2)
+    u = np.random.default_rng(0).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    with _engine(H0, Hs, M, sparse_generator=1, cache_bytes=2e9) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 1 and e.info("cached_steps") == S
+        e.set_option("cache_bytes", -1)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 1 and e.info("cached_steps") == 0
+        e.set_option("xor_regular", 0)
+        l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
+    assert l1 == l0 and np.array_equal(g1, g0) and np.array_equal(f1, f0)      # same kernels on the same data
+    assert abs(l1 - l2) < 1e-12 * B and np.max(np.abs(g1 - g2)) < 1e-12
+    engines = [_engine(H0, Hs, M, sparse_generator=1) for _ in range(3)]
+    try:
+        shards = [np.ascontiguousarray(psi0[:, f:f + c]) for f, c in (shard_range(B, r, 3) for r in range(3))]
+        res = virtual_time_sliced_energy_grad(engines, u, dt, shards)
+        assert all(e.info("xor_regular") == 1 for e in engines)
+    finally:
+        for e in engines:
+            e.close()
+    for l, g, f, en in res:
+        assert abs(l - l2) < 1e-10 * B and np.max(np.abs(g - g2)) < TOL
