@@ -243,8 +243,7 @@ hipError_t rsp_reduce_launch(const double* nzval, long nnz, const long* kptr, co
 constexpr int XR_RMAX = 16;  // off-diagonal XOR-diagonals
 constexpr int XR_DMAX = 16;  // diagonals at offset 0 (one per source matrix that has diagonal entries; any per-row values)
 constexpr int XR_SLOTS = XR_RMAX + XR_DMAX;
-constexpr int XR_QMAX = 3;   // cos / sin polynomial: powers X_1 .. X_{2q+1}
-constexpr int XR_RPT = 8;    // rows per thread (workgroup = d / 8 threads)
+constexpr int XR_QMAX = 6;   // cos / sin polynomial: powers X_1 .. X_{2q+1}
 struct XrTab {
   int R, nd;
   int xoff[XR_RMAX];
@@ -263,7 +262,8 @@ int xr_blocks(int d);  // workgroups per step (scratch of xr_reverse_launch: bat
 hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
                              const XrPoly& pol, int batch, hipStream_t st);
 hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
-                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* grad, int accumulate,
-                             hipStream_t st);
+                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* xpow, double* grad,
+                             int accumulate, hipStream_t st);
+size_t xr_pow_elems(int d, int q);  // per step: scratch of the reverse kernel (xpow), in doubles
 
 }  // namespace dq

@@ -294,7 +294,7 @@ struct Ctx : dq_ctx {
   DevBuf zta, ztb;  // transposed operand copies for the linear-form complex GEMM
   DevBuf sp_rowptr, sp_col, sp_kid, sp_val, sp_kptr, sp_kent, sp_nzval, sp_nzacc, sp_part;
   // XOR-regular generator (xorexp.hip): table found by build_sparse_controls; xor_mode: -1 auto, 0 off
-  DevBuf xr_sgn, xr_dval, xr_part;
+  DevBuf xr_sgn, xr_dval, xr_part, xr_pow;
   dq::XrTab xr_tab;
   bool xr_ok = false;
   int xor_mode = -1;
@@ -680,12 +680,12 @@ inline hipError_t xr_forward_any(float2*, long, int, const dq::XrTab&, const dou
   return hipErrorInvalidValue;
 }
 inline hipError_t xr_reverse_any(const double2* G, long stride, int d, const dq::XrTab& tab, const double* u, int K, double dt,
-                                 const dq::XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* grad,
-                                 hipStream_t st) {
-  return dq::xr_reverse_launch(G, stride, d, tab, u, K, dt, pol, batch, part, zero_sgn, grad, 0, st);
+                                 const dq::XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* xpow,
+                                 double* grad, hipStream_t st) {
+  return dq::xr_reverse_launch(G, stride, d, tab, u, K, dt, pol, batch, part, zero_sgn, xpow, grad, 0, st);
 }
 inline hipError_t xr_reverse_any(const float2*, long, int, const dq::XrTab&, const double*, int, double, const dq::XrPoly&, int,
-                                 double*, const unsigned*, double*, hipStream_t) {
+                                 double*, const unsigned*, double*, double*, hipStream_t) {
   return hipErrorInvalidValue;
 }
 
@@ -902,10 +902,11 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
     // column form: rows of G in, control gradients out (the powers of the column are rebuilt in registers)
     const dq::XrPoly pol = xr_poly(p);
     c->xr_part.ensure(sizeof(double) * (size_t)n * dq::xr_blocks(c->d) * dq::XR_SLOTS);
+    c->xr_pow.ensure(sizeof(double) * (size_t)n * dq::xr_pow_elems(c->d, q));
     const double rows = (double)c->xr_tab.R + 1.0;
     c->timed(DQ_PROF_SPMM, 2.0 * rows * c->nn() * (4.0 * q + 1.0) * n, (double)sizeof(T2) * c->nn() * n, [&] {
       return xr_reverse_any(G, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * K, K, dt, pol, n,
-                            (double*)c->xr_part.p, (const unsigned*)c->xr_sgn.p, grad_out, c->st);
+                            (double*)c->xr_part.p, (const unsigned*)c->xr_sgn.p, (double*)c->xr_pow.p, grad_out, c->st);
     });
     return;
   }

@@ -17,9 +17,9 @@
 // through the transposed matrices: X and the controls are symmetric, so <Xi^T, H_k> = <Xi, H_k>):
 //     xbar_{2q+1} = sc_q sbar,   xbar_m = coef_m (cbar | sbar) + X xbar_{m+1}   (m = 2q .. 1),
 //     dL/du_k    = -dt sum_{j: kid_j = k} sum_i val_ij sum_{m=0}^{2q} xbar_{m+1}[i ^ x_j] x_m[i]
-// -- the partner value fetched for the product is the one the dot product needs (as in rsp_mm_dot_kernel); x_1 .. x_2q of the
-// column are recomputed first and stay in the registers of the rows' owners, so nothing but G is read and a few sums per
-// workgroup are written.  Results differ from the row-wise kernels by rounding only (different summation order).
+// -- the partner value fetched for the product is the one the dot product needs (as in rsp_mm_dot_kernel); x_2 .. x_2q of the
+// column are recomputed first and parked in a per-workgroup scratch that stays in L2, so from HBM nothing but G is read and a
+// few sums per workgroup are written.  Results differ from the row-wise kernels by rounding only (different summation order).
 #include "dq_internal.h"
 
 namespace dq {
@@ -175,28 +175,6 @@ __device__ __forceinline__ void xr_level0(const XrTab& tab, const T* __restrict_
   }
 }
 
-// stored powers by (wave-uniform) index: register arrays need static indices, so a chain of scalar compares
-template <class T, int RPT, int N, int I>
-__device__ __forceinline__ void xr_put(T (*xm)[RPT], int idx, const T* v) {
-  if constexpr (I < N) {
-    if (idx == I) {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) xm[I][r] = v[r];
-    }
-    xr_put<T, RPT, N, I + 1>(xm, idx, v);
-  }
-}
-template <class T, int RPT, int N, int I>
-__device__ __forceinline__ void xr_get(const T (*xm)[RPT], int idx, T* v) {
-  if constexpr (I < N) {
-    if (idx == I) {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) v[r] = xm[I][r];
-    }
-    xr_get<T, RPT, N, I + 1>(xm, idx, v);
-  }
-}
-
 // LDS of both kernels: `images` vectors of D, then jof (D bytes), then XR_RMAX + 2 weights, then nxt (XR_RMAX bytes)
 template <class T, int D>
 constexpr size_t xr_lds_bytes(int images) {
@@ -260,23 +238,28 @@ __global__ void __launch_bounds__(NT, (NT * 2 + 255) / 256) xr_forward_kernel(ty
 
 // part[(z * gridDim.x + blockIdx.x) * XR_SLOTS + s]: this workgroup's share, over its columns, of
 //   s < XR_RMAX:  sum_i sign_ij Xi[i ^ x_j, i]  (before the factors cmag_j and -dt);   s = XR_RMAX + j: the offset-0 diagonal j,
-//   sum_i dval_j[i] Xi[i, i]  (diagctl: some control has diagonal entries).   Q: the polynomial's q; x_2 .. x_2q of the column
-// stay in registers (x_1 is cheap to rebuild).  LDS: four images (the two of the sweeps, cbar, sbar); one workgroup per CU.
-// The sweeps are runtime loops (one copy of the gather code each way); the stored powers are reached through xr_put / xr_get.
-template <class T, int NT, int RPT, int Q, bool SIGN, bool DIAGCTL>
+//   sum_i dval_j[i] Xi[i, i]  (DIAGCTL: some control has diagonal entries).
+// The column's powers x_2 .. x_2q are recomputed first and parked in a scratch buffer in device memory (xpow: per workgroup
+// 2q - 1 vectors of D, each element written by the thread that reads it back: no synchronisation; they live in L2 / Infinity
+// Cache) -- in registers they cost 2 (2q - 1) RPT VGPRs, pin the kernel to 8 waves per CU and q to a template parameter
+// (measured: the same speed).  x_1 is rebuilt from the lookup table.  LDS: four images (the two of the sweeps, cbar, sbar);
+// NT = D / 4 threads (16 waves per CU at D = 4096), one workgroup per CU.
+template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL>
 __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::type* __restrict__ G, long stride, XrTab tab,
-                                                        const double* __restrict__ u, int K, double mdt, XrPoly pol,
-                                                        double* __restrict__ part) {
+                                                               const double* __restrict__ u, int K, double mdt, XrPoly pol,
+                                                               double* __restrict__ part, T* __restrict__ xpow) {
   typedef typename Cx<T>::type T2;
-  constexpr int D = NT * RPT, NPM1 = 2 * Q, NST = NPM1 - 1;
+  constexpr int D = NT * RPT;
   extern __shared__ __align__(16) unsigned char xr_lds_raw[];
   T* lds = (T*)xr_lds_raw;
   T* lcb = lds + 2 * D;
   T* lsb = lds + 3 * D;
   const int t = threadIdx.x;
   const long z = blockIdx.y;
+  const int npm1 = 2 * pol.q;
   XrRows<T, NT, RPT, SIGN> rw;
   rw.load(tab, u + z * K, mdt, t, xr_lds_raw + 4 * sizeof(T) * D, (T*)(xr_lds_raw + 4 * sizeof(T) * D + D));
+  T* xp = xpow + (z * gridDim.x + blockIdx.x) * (long)(npm1 - 1) * D + t;  // [m - 2][r * NT + t]
   double dacc[XR_RMAX], rowacc[RPT];
 #pragma unroll
   for (int j = 0; j < XR_RMAX; ++j) dacc[j] = 0.0;
@@ -284,7 +267,6 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
   for (int r = 0; r < RPT; ++r) rowacc[r] = 0.0;
   int p = 1;
   for (int c = blockIdx.x; c < D; c += gridDim.x) {
-    // cotangents of the column: row c of G, parked in LDS (own rows only: no barrier needed)
     const T2* grow = G + z * stride + (long)c * D;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -292,22 +274,23 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
       lcb[r * NT + t] = g.x;
       lsb[r * NT + t] = g.y;
     }
-    T xm[NST][RPT];  // x_2 .. x_2q at the thread's rows
     T cur[RPT];
     rw.first(t, c, cur);
     p ^= 1;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) lds[p * D + r * NT + t] = cur[r];
     __syncthreads();
-    for (int m = 2; m <= NPM1; ++m) {
+    for (int m = 2; m <= npm1; ++m) {
       T o[RPT];
 #pragma unroll
       for (int r = 0; r < RPT; ++r) o[r] = rw.dg[r] * cur[r];
-      xr_gather<T, NT, RPT, SIGN, false, !DIAGCTL>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
-      xr_put<T, RPT, NST, 0>(xm, m - 2, o);
+      xr_gather<T, NT, RPT, SIGN, false, true>(tab, rw, lds + p * D, t, o, nullptr, nullptr);
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) cur[r] = o[r];
-      if (m < NPM1) {
+      for (int r = 0; r < RPT; ++r) {
+        cur[r] = o[r];
+        xp[(long)(m - 2) * D + r * NT] = o[r];
+      }
+      if (m < npm1) {
         p ^= 1;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) lds[p * D + r * NT + t] = o[r];
@@ -316,7 +299,7 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
     }
     p ^= 1;
     {
-      const T cf = (T)pol.sc[Q];
+      const T cf = (T)pol.sc[pol.q];
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         cur[r] = cf * lsb[r * NT + t];
@@ -324,10 +307,14 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
       }
     }
     __syncthreads();
-    for (int m = NPM1; m >= 1; --m) {
+    for (int m = npm1; m >= 1; --m) {
       T o[RPT], xmm[RPT];
-      if (m == 1) rw.first(t, c, xmm);
-      else xr_get<T, RPT, NST, 0>(xm, m - 2, xmm);
+      if (m == 1) {
+        rw.first(t, c, xmm);
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) xmm[r] = xp[(long)(m - 2) * D + r * NT];
+      }
       const T cf = (T)((m & 1) ? pol.sc[(m - 1) / 2] : pol.cc[m / 2]);
       const T* add = (m & 1) ? lsb : lcb;
 #pragma unroll
@@ -344,7 +331,6 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
       }
       __syncthreads();
     }
-    // level 0 (x_0 = e_c): xbar_1 is in image p
     if (t == 0) xr_level0<T, 0>(tab, lds + p * D, c, dacc);
     if (DIAGCTL) {
 #pragma unroll
@@ -352,7 +338,6 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
         if ((r * NT + t) == c) rowacc[r] += (double)cur[r];
     }
   }
-  // fixed-order reduction: lanes (butterfly), then the waves in order
   __syncthreads();
   double* red = (double*)xr_lds_raw;  // [NT / 64][XR_SLOTS]
   const int lane = t & 63, wave = t >> 6;
@@ -435,52 +420,41 @@ hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, c
   }
 }
 
-#ifndef XR_RPT_REV
-#define XR_RPT_REV 8
-#endif
 template <class T, int NT, int RPT>
-static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, const XrTab& tab, const double* u, int K, double mdt,
-                                const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, hipStream_t st) {
+static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, const XrTab& tab, const double* u, int K,
+                                       double mdt, const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, T* xpow,
+                                       hipStream_t st) {
   const size_t lds = xr_lds_bytes<T, NT * RPT>(4);
   const dim3 grid((unsigned)xr_blocks(NT * RPT), (unsigned)batch);
-  // two variants: plain (no negative entries, no control with diagonal entries) and full (sign words -- `zero_sgn`, d zeros,
-  // stands in when the table has none -- and the per-row sums of the offset-0 diagonals)
   bool full = tab.sgn != nullptr;
   for (int j = 0; j < tab.nd; ++j) full = full || tab.dkid[j] >= 0;
   XrTab tb = tab;
   if (full && !tb.sgn) tb.sgn = zero_sgn;
   if (full && !tb.sgn) return hipErrorInvalidValue;
-#define XR_REV(Q)                                                                                               \
-  case Q: {                                                                                                     \
-    void (*kf)(const typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly, double*) =         \
-        full ? xr_reverse_kernel<T, NT, RPT, Q, true, true> : xr_reverse_kernel<T, NT, RPT, Q, false, false>;             \
-    (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-    hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tb, u, K, mdt, pol, part);                       \
-    break;                                                                                                      \
-  }
-  switch (pol.q) {
-    XR_REV(1)
-    XR_REV(2)
-    XR_REV(3)
-    default: return hipErrorInvalidValue;
-  }
-#undef XR_REV
+  void (*kf)(const typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly, double*, T*) =
+      full ? xr_reverse_kernel<T, NT, RPT, true, true> : xr_reverse_kernel<T, NT, RPT, false, false>;
+  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tb, u, K, mdt, pol, part, xpow);
   return hipGetLastError();
 }
 
-// grad[z][k] (+)= dL/du_k of step z given G[z] = Ubar_z; part: batch * xr_blocks(d) * XR_SLOTS doubles of scratch;
-// zero_sgn: d zero words (used when a control has diagonal entries but the table has no sign words)
+// scratch of the reverse kernel: the powers x_2 .. x_2q of one column per workgroup and step
+size_t xr_pow_elems(int d, int q) { return (size_t)xr_blocks(d) * (size_t)(2 * q - 1) * (size_t)d; }
+
+// grad[z][k] (+)= dL/du_k of step z given G[z] = Ubar_z; part: batch * xr_blocks(d) * XR_SLOTS doubles of scratch, xpow: batch *
+// xr_pow_elems(d, q) doubles of scratch; zero_sgn: d zero words (used when a control has diagonal entries but the table has no
+// sign words)
 hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
-                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* grad, int accumulate,
-                             hipStream_t st) {
+                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* xpow, double* grad,
+                             int accumulate, hipStream_t st) {
   if (batch <= 0) return hipSuccess;
-  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double))) return hipErrorInvalidValue;
+  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double)) || !xpow) return hipErrorInvalidValue;
   hipError_t e;
   switch (d) {
-    case 4096: e = xr_reverse_go<double, 4096 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
-    case 2048: e = xr_reverse_go<double, 2048 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
-    case 1024: e = xr_reverse_go<double, 1024 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st); break;
-    default: e = xr_reverse_go<double, 512 / XR_RPT_REV, XR_RPT_REV>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, st);
+    case 4096: e = xr_reverse_go<double, 1024, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    case 2048: e = xr_reverse_go<double, 512, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    case 1024: e = xr_reverse_go<double, 256, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    default: e = xr_reverse_go<double, 128, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
   }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d), tab, K, -dt, grad, accumulate);

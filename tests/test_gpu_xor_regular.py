@@ -82,12 +82,12 @@ def test_ising_column_form_matches_oracle(oracle, B):
     assert abs(l1 - l0) < 1e-12 * B and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
 
 
-@pytest.mark.parametrize("q", [1, 2, 3])
+@pytest.mark.parametrize("q", [1, 2, 3, 4, 6])
 def test_pauli_strings_with_signs_and_diagonal_controls(oracle, q):
     """Every entry class of the table: drift entries off the diagonal, two-bit offsets, negative entries, a diagonal control,
-    a control with both kinds of entries -- at each polynomial size the kernels are instantiated for."""
+    a control with both kinds of entries -- at several polynomial sizes (q is a runtime parameter of the kernels)."""
     n, S, B = 9, 3, 5
-    dt = {1: 2e-5, 2: 4e-4, 3: 2e-3}[q]
+    dt = {1: 2e-5, 2: 4e-4, 3: 2e-3, 4: 5e-3, 6: 1.5e-2}[q]
     H0, Hs, M = _pauli_problem(n, seed=q)
     u = np.random.default_rng(q).uniform(-1, 1, (S, len(Hs)))
     psi0 = problems.random_states(1 << n, B, seed=3)

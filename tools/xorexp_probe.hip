@@ -71,8 +71,9 @@ int main(int argc, char** argv) {
     hipError_t err = hipGetLastError();
     printf("%-44s %.4f ms/launch %s\n", name, ms / reps, err == hipSuccess ? "" : hipGetErrorString(err));
   };
+  double* xpow; (void)hipMalloc(&xpow, dq::xr_pow_elems(d, q) * 8);
   timeit("xr_forward (U = cos X + i sin X)", [&] { (void)dq::xr_forward_launch(U, (long)nn, d, tab, du, K, dt, pol, 1, 0); });
-  timeit("xr_reverse (control gradients from G)", [&] { (void)dq::xr_reverse_launch(G, (long)nn, d, tab, du, K, dt, pol, 1, part, dsgn, grad, 0, 0); });
+  timeit("xr_reverse (control gradients from G)", [&] { (void)dq::xr_reverse_launch(G, (long)nn, d, tab, du, K, dt, pol, 1, part, dsgn, xpow, grad, 0, 0); });
 
   // host evaluation
   auto val = [&](int i, int j) { return (sgn[i] >> j) & 1 ? -tab.cmag[j] : tab.cmag[j]; };
