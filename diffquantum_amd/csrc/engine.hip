@@ -345,7 +345,9 @@ struct Ctx : dq_ctx {
   // break-even near d = 80 nnz/row (at d = 256 the MFMA product wins 6x)
   bool sparse_gen_on() const {
     if (!(sparse_on() && sparse_x) || sparse_gen_mode == 0) return false;
-    return sparse_gen_mode > 0 || (double)d * d >= 64.0 * (double)sp_nnz;
+    if (sparse_gen_mode > 0 || (double)d * d >= 64.0 * (double)sp_nnz) return true;
+    // (XOR-regular generators: the column form, xorexp.hip, beats the MFMA products wherever its kernels exist)
+    return xr_ok && xor_mode != 0 && dq::xr_supported(d, 1, xr_tab.R, xr_tab.nd, sizeof(T));
   }
   bool xr_on(int q) const {
     return xr_ok && xor_mode != 0 && sparse_gen_on() && dq::xr_supported(d, q, xr_tab.R, xr_tab.nd, sizeof(T));
@@ -901,8 +903,8 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
   if (p.xr) {
     // column form: rows of G in, control gradients out (the powers of the column are rebuilt in registers)
     const dq::XrPoly pol = xr_poly(p);
-    c->xr_part.ensure(sizeof(double) * (size_t)n * dq::xr_blocks(c->d) * dq::XR_SLOTS);
-    c->xr_pow.ensure(sizeof(double) * (size_t)n * dq::xr_pow_elems(c->d, q));
+    c->xr_part.ensure(sizeof(double) * (size_t)n * dq::xr_blocks(c->d, n) * dq::XR_SLOTS);
+    c->xr_pow.ensure(sizeof(double) * (size_t)n * dq::xr_pow_elems(c->d, q, n));
     const double rows = (double)c->xr_tab.R + 1.0;
     c->timed(DQ_PROF_SPMM, 2.0 * rows * c->nn() * (4.0 * q + 1.0) * n, (double)sizeof(T2) * c->nn() * n, [&] {
       return xr_reverse_any(G, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * K, K, dt, pol, n,

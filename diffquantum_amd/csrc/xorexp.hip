@@ -390,16 +390,22 @@ __global__ void __launch_bounds__(XR_SLOTS * 32) xr_finish_kernel(const double* 
 bool xr_supported(int d, int q, int R, int nd, size_t elem) {
   if (elem != sizeof(double)) return false;  // (complex64 engines keep the row-wise kernels)
   if (R < 0 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || q < 1 || q > XR_QMAX) return false;
-  return d == 512 || d == 1024 || d == 2048 || d == 4096;
+  return d == 256 || d == 512 || d == 1024 || d == 2048 || d == 4096;
 }
 
-int xr_blocks(int d) { return d < 512 ? d : 512; }
+// workgroups per step: 512 for a single step (two per CU), fewer when many steps are stacked in one launch (about 4096
+// workgroups in all), so that a workgroup's set-up (diagonal weights, lookup table) is spread over many columns
+int xr_blocks(int d, int batch) {
+  int nb = 512;
+  while (nb > 1 && (long)nb * batch > 4096) nb >>= 1;
+  return nb < d ? nb : d;
+}
 
 template <class T, int NT, int RPT>
 static hipError_t xr_forward_go(typename Cx<T>::type* U, long stride, const XrTab& tab, const double* u, int K, double mdt,
                                 const XrPoly& pol, int batch, hipStream_t st) {
   const size_t lds = xr_lds_bytes<T, NT * RPT>(2);
-  const dim3 grid((unsigned)xr_blocks(NT * RPT), (unsigned)batch);
+  const dim3 grid((unsigned)xr_blocks(NT * RPT, batch), (unsigned)batch);
   void (*kf)(typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly) =
       tab.sgn ? xr_forward_kernel<T, NT, RPT, true> : xr_forward_kernel<T, NT, RPT, false>;
   (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -416,7 +422,8 @@ hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, c
     case 4096: return xr_forward_go<double, 512, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
     case 2048: return xr_forward_go<double, 256, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
     case 1024: return xr_forward_go<double, 128, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
-    default: return xr_forward_go<double, 64, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 512: return xr_forward_go<double, 64, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    default: return xr_forward_go<double, 64, 4>(U, stride, tab, u, K, -dt, pol, batch, st);
   }
 }
 
@@ -425,7 +432,7 @@ static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, cons
                                        double mdt, const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, T* xpow,
                                        hipStream_t st) {
   const size_t lds = xr_lds_bytes<T, NT * RPT>(4);
-  const dim3 grid((unsigned)xr_blocks(NT * RPT), (unsigned)batch);
+  const dim3 grid((unsigned)xr_blocks(NT * RPT, batch), (unsigned)batch);
   bool full = tab.sgn != nullptr;
   for (int j = 0; j < tab.nd; ++j) full = full || tab.dkid[j] >= 0;
   XrTab tb = tab;
@@ -439,10 +446,10 @@ static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, cons
 }
 
 // scratch of the reverse kernel: the powers x_2 .. x_2q of one column per workgroup and step
-size_t xr_pow_elems(int d, int q) { return (size_t)xr_blocks(d) * (size_t)(2 * q - 1) * (size_t)d; }
+size_t xr_pow_elems(int d, int q, int batch) { return (size_t)xr_blocks(d, batch) * (size_t)(2 * q - 1) * (size_t)d; }
 
-// grad[z][k] (+)= dL/du_k of step z given G[z] = Ubar_z; part: batch * xr_blocks(d) * XR_SLOTS doubles of scratch, xpow: batch *
-// xr_pow_elems(d, q) doubles of scratch; zero_sgn: d zero words (used when a control has diagonal entries but the table has no
+// grad[z][k] (+)= dL/du_k of step z given G[z] = Ubar_z; part: batch * xr_blocks(d, batch) * XR_SLOTS doubles of scratch, xpow: batch *
+// xr_pow_elems(d, q, batch) doubles of scratch; zero_sgn: d zero words (used when a control has diagonal entries but the table has no
 // sign words)
 hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
                              const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* xpow, double* grad,
@@ -454,10 +461,11 @@ hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& 
     case 4096: e = xr_reverse_go<double, 1024, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
     case 2048: e = xr_reverse_go<double, 512, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
     case 1024: e = xr_reverse_go<double, 256, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    default: e = xr_reverse_go<double, 128, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
+    case 512: e = xr_reverse_go<double, 128, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    default: e = xr_reverse_go<double, 64, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d), tab, K, -dt, grad, accumulate);
+  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d, batch), tab, K, -dt, grad, accumulate);
   return hipGetLastError();
 }
 

@@ -326,10 +326,13 @@ def test_sparse_generator_auto_rule():
     H0, Hs = p["H0"].astype(complex), p["Hs"].astype(complex)
     u = np.random.default_rng(0).uniform(-1, 1, (3, len(Hs)))
     psi0 = problems.random_states(1 << n, 4, seed=3)
-    with _engine(H0, Hs, H0, real_min_dim=128) as e:
+    with _engine(H0, Hs, H0, real_min_dim=128, xor_regular=0) as e:
         assert e.info("sparse_drift") == 1
         e.energy_grad(u, 2e-3, psi0)
         assert e.info("sparse_generator") == 0 and e.info("sparse_controls") == 1 and e.info("real_path") >= 1
+        e.set_option("xor_regular", 1)        # ... unless the generator is a sum of Pauli strings: the column form needs no pass at all
+        e.energy_grad(u, 2e-3, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("xor_regular") == 1
     H0, Hs, M = problems.random_ising(10, seed=1)   # d = 1024, 11 nonzeros per row: the sparse passes win
     u = np.random.default_rng(0).uniform(-1, 1, (2, 10))
     psi0 = problems.random_states(1024, 4, seed=3)

@@ -190,3 +190,26 @@ def test_column_form_with_the_propagator_cache_and_time_slices():
             e.close()
     for l, g, f, en in res:
         assert abs(l - l2) < 1e-10 * B and np.max(np.abs(g - g2)) < TOL
+
+
+@pytest.mark.parametrize("B,S", [(7, 5), (256, 20)])
+def test_qaoa_ring_d256_column_form_matches_oracle(oracle, B, S):
+    """BASELINE configs[1]'s problem (8-qubit ring QAOA: X_k and Z_k Z_k+1 controls, d = 256 -- the smallest dimension of the
+    kernels, one wave per workgroup, many steps stacked per launch): taken automatically, against the oracle and the MFMA scheme."""
+    n, dt = 8, 2e-3
+    p = problems.qaoa_ring(n)
+    H0, Hs, M = p["H0"].astype(complex), p["Hs"].astype(complex), p["H_cost"].astype(complex)
+    u = np.random.default_rng(S).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=5)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("xor_regular_found") >= n
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("sparse_generator") == 1 and e.info("xor_regular") == 1
+        p1 = e.propagate(u, dt, psi0)
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 0 and e.info("sparse_generator") == 0
+    assert abs(l1 - rl) < TOL * max(1, B / 8) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+    assert np.max(np.abs(p1 - rf)) < TOL
+    assert abs(l1 - l0) < 1e-12 * max(1, B) and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13

@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
   unsigned* dsgn;
   (void)hipMalloc(&U, nn * 16); (void)hipMalloc(&G, nn * 16);
   (void)hipMalloc(&du, K * 8); (void)hipMalloc(&dgen, 2 * d * 8); (void)hipMalloc(&dsgn, d * 4);
-  (void)hipMalloc(&part, (size_t)dq::xr_blocks(d) * dq::XR_SLOTS * 8); (void)hipMalloc(&grad, K * 8);
+  (void)hipMalloc(&part, (size_t)dq::xr_blocks(d, 1) * dq::XR_SLOTS * 8); (void)hipMalloc(&grad, K * 8);
   (void)hipMemcpy(du, u.data(), K * 8, hipMemcpyHostToDevice);
   (void)hipMemcpy(dgen, diag.data(), 2 * d * 8, hipMemcpyHostToDevice);
   (void)hipMemcpy(dsgn, sgn.data(), d * 4, hipMemcpyHostToDevice);
@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     hipError_t err = hipGetLastError();
     printf("%-44s %.4f ms/launch %s\n", name, ms / reps, err == hipSuccess ? "" : hipGetErrorString(err));
   };
-  double* xpow; (void)hipMalloc(&xpow, dq::xr_pow_elems(d, q) * 8);
+  double* xpow; (void)hipMalloc(&xpow, dq::xr_pow_elems(d, q, 1) * 8);
   timeit("xr_forward (U = cos X + i sin X)", [&] { (void)dq::xr_forward_launch(U, (long)nn, d, tab, du, K, dt, pol, 1, 0); });
   timeit("xr_reverse (control gradients from G)", [&] { (void)dq::xr_reverse_launch(G, (long)nn, d, tab, du, K, dt, pol, 1, part, dsgn, xpow, grad, 0, 0); });
 
