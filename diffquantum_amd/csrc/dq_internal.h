@@ -257,12 +257,17 @@ struct XrPoly {
   int q;
   double cc[XR_QMAX + 1], sc[XR_QMAX + 1];  // cos X = sum cc_j X^2j, sin X = sum sc_j X^(2j+1)
 };
-bool xr_supported(int d, int q, int R, int nd, size_t elem);  // elem = sizeof(real type): complex128 engines only
+bool xr_supported(int d, int q, int R, int nd, size_t elem);  // elem = sizeof(real type)
 int xr_blocks(int d, int batch);  // workgroups per step (scratch of xr_reverse_launch: batch * xr_blocks(d, batch) * XR_SLOTS doubles)
 hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
                              const XrPoly& pol, int batch, hipStream_t st);
+hipError_t xr_forward_launch(float2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt, const XrPoly& pol,
+                             int batch, hipStream_t st);
 hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
                              const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* xpow, double* grad,
+                             int accumulate, hipStream_t st);
+hipError_t xr_reverse_launch(const float2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, float* xpow, double* grad,
                              int accumulate, hipStream_t st);
 size_t xr_pow_elems(int d, int q, int batch);  // per step: scratch of the reverse kernel (xpow), in doubles
 

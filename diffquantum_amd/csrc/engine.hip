@@ -672,25 +672,6 @@ inline dq::XrPoly xr_poly(const ExpmPlan& p) {
   for (int j = 0; j <= p.rq && j <= dq::XR_QMAX; ++j) { pol.cc[j] = p.cc[j]; pol.sc[j] = p.sc[j]; }
   return pol;
 }
-// (the column-form kernels exist for complex128 engines only: xr_supported() keeps the others off this path)
-inline hipError_t xr_forward_any(double2* U, long stride, int d, const dq::XrTab& tab, const double* u, int K, double dt,
-                                 const dq::XrPoly& pol, int batch, hipStream_t st) {
-  return dq::xr_forward_launch(U, stride, d, tab, u, K, dt, pol, batch, st);
-}
-inline hipError_t xr_forward_any(float2*, long, int, const dq::XrTab&, const double*, int, double, const dq::XrPoly&, int,
-                                 hipStream_t) {
-  return hipErrorInvalidValue;
-}
-inline hipError_t xr_reverse_any(const double2* G, long stride, int d, const dq::XrTab& tab, const double* u, int K, double dt,
-                                 const dq::XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* xpow,
-                                 double* grad, hipStream_t st) {
-  return dq::xr_reverse_launch(G, stride, d, tab, u, K, dt, pol, batch, part, zero_sgn, xpow, grad, 0, st);
-}
-inline hipError_t xr_reverse_any(const float2*, long, int, const dq::XrTab&, const double*, int, double, const dq::XrPoly&, int,
-                                 double*, const unsigned*, double*, double*, hipStream_t) {
-  return hipErrorInvalidValue;
-}
-
 // assemble X and evaluate U = cos X + i sin X for `n` stacked steps; returns the complex propagators
 template <class T>
 typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
@@ -706,7 +687,7 @@ typename dq::Cx<T>::type* real_forward(Ctx<T>* c, const ExpmPlan& p, int c0, int
     const dq::XrPoly pol = xr_poly(p);
     const double rows = (double)c->xr_tab.R + 1.0;
     c->timed(DQ_PROF_SPMM, 2.0 * rows * c->nn() * 2.0 * q * n, (double)sizeof(T2) * c->nn() * n, [&] {
-      return xr_forward_any(U, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * c->K, c->K, dts, pol, n, c->st);
+      return dq::xr_forward_launch(U, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * c->K, c->K, dts, pol, n, c->st);
     });
     c->last_degree = p.m;
     c->last_squarings = 0;
@@ -904,11 +885,11 @@ void real_backward_spx(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt, d
     // column form: rows of G in, control gradients out (the powers of the column are rebuilt in registers)
     const dq::XrPoly pol = xr_poly(p);
     c->xr_part.ensure(sizeof(double) * (size_t)n * dq::xr_blocks(c->d, n) * dq::XR_SLOTS);
-    c->xr_pow.ensure(sizeof(double) * (size_t)n * dq::xr_pow_elems(c->d, q, n));
+    c->xr_pow.ensure(sizeof(T) * (size_t)n * dq::xr_pow_elems(c->d, q, n));
     const double rows = (double)c->xr_tab.R + 1.0;
     c->timed(DQ_PROF_SPMM, 2.0 * rows * c->nn() * (4.0 * q + 1.0) * n, (double)sizeof(T2) * c->nn() * n, [&] {
-      return xr_reverse_any(G, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * K, K, dt, pol, n,
-                            (double*)c->xr_part.p, (const unsigned*)c->xr_sgn.p, (double*)c->xr_pow.p, grad_out, c->st);
+      return dq::xr_reverse_launch(G, (long)c->nn(), c->d, c->xr_tab, c->u_dev.d() + (size_t)c0 * K, K, dt, pol, n,
+                                   (double*)c->xr_part.p, (const unsigned*)c->xr_sgn.p, (T*)c->xr_pow.p, grad_out, 0, c->st);
     });
     return;
   }

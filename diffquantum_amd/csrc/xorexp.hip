@@ -24,17 +24,12 @@
 
 namespace dq {
 
-template <class T>
-__device__ inline T xr_uniform(T v);
-template <>
-__device__ inline double xr_uniform<double>(double v) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
 __device__ inline double xr_flip(double v, unsigned bit) {
   return __longlong_as_double(__double_as_longlong(v) ^ ((long long)bit << 63));
 }
+__device__ inline float xr_flip(float v, unsigned bit) { return __int_as_float(__float_as_int(v) ^ (int)(bit << 31)); }
+__device__ inline double xr_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float xr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // per-thread constants of a launch: the weights of the XOR-diagonals (wave-uniform), the rows' sign words and diagonal weights;
 // in LDS: jof[x] = the (last) diagonal whose offset is x (R for x = 0, R + 1 for none), nxt[j] = the next one with the same
@@ -136,11 +131,11 @@ __device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, 
     }
     const T w = rw.Wl[j];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) o[r] = __builtin_fma(w, vs[r], o[r]);
+    for (int r = 0; r < RPT; ++r) o[r] = xr_fma(w, vs[r], o[r]);
     if (DOT) {
       T s = 0;
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) s = __builtin_fma(vs[r], xm[r], s);
+      for (int r = 0; r < RPT; ++r) s = xr_fma(vs[r], xm[r], s);
       xr_acc<0, XR_RMAX>(dacc, j, (double)s);
     }
   };
@@ -215,8 +210,8 @@ __global__ void __launch_bounds__(NT, (NT * 2 + 255) / 256) xr_forward_kernel(ty
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         cur[r] = o[r];
-        if (m & 1) aim[r] = __builtin_fma(cf, o[r], aim[r]);
-        else are[r] = __builtin_fma(cf, o[r], are[r]);
+        if (m & 1) aim[r] = xr_fma(cf, o[r], aim[r]);
+        else are[r] = xr_fma(cf, o[r], are[r]);
       }
       if (m < np) {
         p ^= 1;
@@ -319,7 +314,7 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
       const T* add = (m & 1) ? lsb : lcb;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        o[r] = __builtin_fma(cf, add[r * NT + t], rw.dg[r] * cur[r]);
+        o[r] = xr_fma(cf, add[r * NT + t], rw.dg[r] * cur[r]);
         if (DIAGCTL) rowacc[r] = __builtin_fma((double)cur[r], (double)xmm[r], rowacc[r]);
       }
       xr_gather<T, NT, RPT, SIGN, true, !DIAGCTL>(tab, rw, lds + p * D, t, o, xmm, dacc);
@@ -351,7 +346,7 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
     double v = 0.0;
     if (DIAGCTL && j < tab.nd && tab.dkid[j] >= 0) {
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) v = __builtin_fma(tab.dval[(long)j * D + r * NT + t], rowacc[r], v);
+      for (int r = 0; r < RPT; ++r) v = __builtin_fma((double)tab.dval[(long)j * D + r * NT + t], rowacc[r], v);
     }
     put(XR_RMAX + j, v);
   }
@@ -388,7 +383,7 @@ __global__ void __launch_bounds__(XR_SLOTS * 32) xr_finish_kernel(const double* 
 }
 
 bool xr_supported(int d, int q, int R, int nd, size_t elem) {
-  if (elem != sizeof(double)) return false;  // (complex64 engines keep the row-wise kernels)
+  if (elem != sizeof(double) && elem != sizeof(float)) return false;
   if (R < 0 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || q < 1 || q > XR_QMAX) return false;
   return d == 256 || d == 512 || d == 1024 || d == 2048 || d == 4096;
 }
@@ -414,17 +409,26 @@ static hipError_t xr_forward_go(typename Cx<T>::type* U, long stride, const XrTa
 }
 
 // U[z] = cos X_z + i sin X_z for `batch` stacked steps (X_z = -dt H(u[z])), U row-major d x d complex, stride elements apart
+template <class T>
+static hipError_t xr_forward_t(typename Cx<T>::type* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                               const XrPoly& pol, int batch, hipStream_t st) {
+  if (batch <= 0) return hipSuccess;
+  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(T))) return hipErrorInvalidValue;
+  switch (d) {
+    case 4096: return xr_forward_go<T, 512, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 2048: return xr_forward_go<T, 256, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 1024: return xr_forward_go<T, 128, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    case 512: return xr_forward_go<T, 64, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
+    default: return xr_forward_go<T, 64, 4>(U, stride, tab, u, K, -dt, pol, batch, st);
+  }
+}
 hipError_t xr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
                              const XrPoly& pol, int batch, hipStream_t st) {
-  if (batch <= 0) return hipSuccess;
-  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double))) return hipErrorInvalidValue;
-  switch (d) {
-    case 4096: return xr_forward_go<double, 512, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
-    case 2048: return xr_forward_go<double, 256, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
-    case 1024: return xr_forward_go<double, 128, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
-    case 512: return xr_forward_go<double, 64, 8>(U, stride, tab, u, K, -dt, pol, batch, st);
-    default: return xr_forward_go<double, 64, 4>(U, stride, tab, u, K, -dt, pol, batch, st);
-  }
+  return xr_forward_t<double>(U, stride, d, tab, u, K, dt, pol, batch, st);
+}
+hipError_t xr_forward_launch(float2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt, const XrPoly& pol,
+                             int batch, hipStream_t st) {
+  return xr_forward_t<float>(U, stride, d, tab, u, K, dt, pol, batch, st);
 }
 
 template <class T, int NT, int RPT>
@@ -451,22 +455,34 @@ size_t xr_pow_elems(int d, int q, int batch) { return (size_t)xr_blocks(d, batch
 // grad[z][k] (+)= dL/du_k of step z given G[z] = Ubar_z; part: batch * xr_blocks(d, batch) * XR_SLOTS doubles of scratch, xpow: batch *
 // xr_pow_elems(d, q, batch) doubles of scratch; zero_sgn: d zero words (used when a control has diagonal entries but the table has no
 // sign words)
+template <class T>
+static hipError_t xr_reverse_t(const typename Cx<T>::type* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                               const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, T* xpow, double* grad,
+                               int accumulate, hipStream_t st) {
+  if (batch <= 0) return hipSuccess;
+  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(T)) || !xpow) return hipErrorInvalidValue;
+  hipError_t e;
+  switch (d) {
+    case 4096: e = xr_reverse_go<T, 1024, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    case 2048: e = xr_reverse_go<T, 512, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    case 1024: e = xr_reverse_go<T, 256, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    case 512: e = xr_reverse_go<T, 128, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+    default: e = xr_reverse_go<T, 64, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
+  }
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d, batch), tab, K, -dt, grad,
+                     accumulate);
+  return hipGetLastError();
+}
 hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
                              const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, double* xpow, double* grad,
                              int accumulate, hipStream_t st) {
-  if (batch <= 0) return hipSuccess;
-  if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(double)) || !xpow) return hipErrorInvalidValue;
-  hipError_t e;
-  switch (d) {
-    case 4096: e = xr_reverse_go<double, 1024, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    case 2048: e = xr_reverse_go<double, 512, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    case 1024: e = xr_reverse_go<double, 256, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    case 512: e = xr_reverse_go<double, 128, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    default: e = xr_reverse_go<double, 64, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
-  }
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d, batch), tab, K, -dt, grad, accumulate);
-  return hipGetLastError();
+  return xr_reverse_t<double>(G, stride, d, tab, u, K, dt, pol, batch, part, zero_sgn, xpow, grad, accumulate, st);
+}
+hipError_t xr_reverse_launch(const float2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
+                             const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, float* xpow, double* grad,
+                             int accumulate, hipStream_t st) {
+  return xr_reverse_t<float>(G, stride, d, tab, u, K, dt, pol, batch, part, zero_sgn, xpow, grad, accumulate, st);
 }
 
 }  // namespace dq

@@ -130,7 +130,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   xor_regular        -1 / 1 (default): a sparse generator whose pattern is XOR-regular (besides its diagonal, row i holds exactly
  *                      the entries (i, i ^ x_j) for the same offsets x_j in every row, each XOR-diagonal from one source matrix and
  *                      of one magnitude: sums of real Pauli strings, e.g. an Ising drift with X_k controls) takes the column-form
- *                      kernels of csrc/xorexp.hip (complex128, dim 256 .. 4096, polynomial q <= 6): U and the control gradients
+ *                      kernels of csrc/xorexp.hip (dim 256 .. 4096, polynomial q <= 6): U and the control gradients
  *                      column by column in LDS, no dense intermediate; 0 = the row-wise sparse x dense passes.
  *                      dq_get_info("xor_regular_found") = number of XOR-diagonals found (-1: not of that class),
  *                      ("xor_regular") = 1 if the last call ran the column form

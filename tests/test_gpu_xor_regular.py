@@ -51,9 +51,9 @@ def _pauli_problem(n, seed):
     return H0.astype(complex), np.array(Hs).astype(complex), M.astype(complex)
 
 
-def _engine(H0, Hs, M, **opts):
+def _engine(H0, Hs, M, dtype="c128", **opts):
     from diffquantum_amd.engine import Engine
-    e = Engine(len(H0), len(Hs))
+    e = Engine(len(H0), len(Hs), dtype=dtype)
     e.set_hamiltonians(H0, Hs)
     e.set_observable(M)
     for k, v in opts.items():
@@ -213,3 +213,24 @@ def test_qaoa_ring_d256_column_form_matches_oracle(oracle, B, S):
     assert abs(l1 - rl) < TOL * max(1, B / 8) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
     assert np.max(np.abs(p1 - rf)) < TOL
     assert abs(l1 - l0) < 1e-12 * max(1, B) and np.max(np.abs(g1 - g0)) < 1e-12 and np.max(np.abs(f1 - f0)) < 1e-13
+
+
+@pytest.mark.parametrize("signed", [False, True])
+def test_column_form_fp32(oracle, signed):
+    """complex64 engines take the same kernels in float (1e-4, BASELINE's fp32 tolerance); gradients accumulate in double."""
+    n, S, B, dt = 9, 4, 6, 1e-3
+    if signed:
+        H0, Hs, M = _pauli_problem(n, seed=11)
+    else:
+        H0, Hs, M = problems.random_ising(n, seed=6)
+    u = np.random.default_rng(8).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=9)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, dtype="c64", sparse_generator=1) as e:
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("xor_regular") == 1
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("xor_regular") == 0
+    assert abs(l1 - rl) < 1e-4 * B and np.max(np.abs(g1 - rg)) < 1e-4 and np.max(np.abs(f1 - rf)) < 1e-4
+    assert abs(l1 - l0) < 1e-4 * B and np.max(np.abs(g1 - g0)) < 1e-4 and np.max(np.abs(f1 - f0)) < 1e-5
