@@ -112,6 +112,12 @@ struct SApply {
   unsigned lmask;
   int B;
   T sr, si;         // complex scale of the bracket
+  // fused overlaps (OVL kernels): part[blk][m] = sum over the tile of conj(y[i ^ x_m]) * (-1)^popc(i & z_m) * zo[i],
+  // i.e. <y, P'_m zo> with the roles of soverlap_kernel swapped (y is the tile here, zo is read at the thread's own rows)
+  const T2* zo;
+  const DTerm* oterms;
+  int n_ovl;
+  double* part;     // [nblocks * waves][n_ovl][2]
 };
 
 template <class T2, int V>
@@ -123,7 +129,37 @@ struct alignas(sizeof(T2) * V) CVec {
 // Which optional operands exist is a compile-time property (FLAGS bit 0 prev, 1 add, 2 acc, 3 diag): a runtime
 // "load or zero" per element makes hipcc branch around every load and drain vmcnt each time (measured 3.9 -> 2.7 TB/s).
 // V = batch columns per lane (2 when the batch is even: 16-byte accesses for complex64, half the address math).
-template <class T, int FLAGS, int V>
+constexpr int SOVL_TCH = 12;  // control strings per register chunk of the overlap sums (soverlap_kernel, fused sapply_kernel)
+
+// Wave-wide sum without the LDS pipe (ds_bpermute shuffles of 2 x 12 sums per tile cost more than the tile's HBM time share):
+// DPP adds inside each row of 16 lanes (xor 1, xor 2, half mirror, mirror), then the four row sums through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float s_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double s_dpp(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double s_lane(float x, int l) { return (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ double s_lane(double x, int l) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <class T>
+__device__ __forceinline__ double s_wave_sum(T x) {
+  x += s_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += s_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += s_dpp<0x141>(x);  // row_half_mirror
+  x += s_dpp<0x140>(x);  // row_mirror
+  return (s_lane(x, 0) + s_lane(x, 16)) + (s_lane(x, 32) + s_lane(x, 48));
+}
+
+template <class T, int FLAGS, int V, bool OVL = false>
 __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
   constexpr bool HAS_PREV = FLAGS & 1, HAS_ADD = FLAGS & 2, HAS_ACC = FLAGS & 4, HAS_DIAG = FLAGS & 8;
   typedef typename dq::Cx<T>::type T2;
@@ -136,12 +172,15 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
   __shared__ unsigned rowidx[1 << PMAX];
   __shared__ DTerm tt[SMAXT];
   __shared__ T2 tc[SMAXT];
+  __shared__ DTerm to[OVL ? SOVL_TCH : 1];
   const int R = 1 << a.p;
   const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
   const unsigned base = deposit_bits(blockIdx.x, full & ~a.lmask);
   const int c0 = blockIdx.y * SBC;
   for (int r = threadIdx.x; r < R; r += STHREADS) rowidx[r] = base | deposit_bits((unsigned)r, a.lmask);
   for (int m = threadIdx.x; m < a.nterms; m += STHREADS) { tt[m] = a.terms[m]; tc[m] = a.coef[a.terms[m].slot]; }
+  if (OVL)
+    for (int m = threadIdx.x; m < a.n_ovl; m += STHREADS) to[m] = a.oterms[m];
   __syncthreads();
   const int c = (threadIdx.x % CPL) * V;
   const int rbase = threadIdx.x / CPL;
@@ -155,10 +194,16 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
     *(VT*)(tile + r * SBC + c) = v;
   }
   __syncthreads();
-  if (!col_ok) return;
+  if (!OVL && !col_ok) return;
   // every global operand of this thread's rows is requested before the LDS work starts
-  VT pv[RPT], ad[RPT], ac[RPT];
+  VT pv[RPT], ad[RPT], ac[RPT], zo[OVL ? RPT : 1];
   T dg[RPT];
+  T px[OVL ? SOVL_TCH : 1], py[OVL ? SOVL_TCH : 1];
+  if (OVL) {
+#pragma unroll
+    for (int mm = 0; mm < SOVL_TCH; ++mm) { px[mm] = 0; py[mm] = 0; }
+  }
+  if (col_ok) {
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const int r = min(rbase + q * RSTEP, R - 1);  // clamped: loads stay unconditional
@@ -167,6 +212,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
     if (HAS_ADD) ad[q] = *(const VT*)(a.add + off);
     if (HAS_ACC) ac[q] = *(const VT*)(a.acc + off);
     if (HAS_DIAG) dg[q] = a.diag[rowidx[r]];
+    if (OVL) zo[q] = *(const VT*)(a.zo + off);
   }
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -210,6 +256,36 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
       for (int w = 0; w < V; ++w) { w2.v[w].x = ac[q].v[w].x + o.v[w].x; w2.v[w].y = ac[q].v[w].y + o.v[w].y; }
       *(VT*)(a.acc + off) = w2;
     }
+    if (OVL) {
+#pragma unroll
+      for (int mm = 0; mm < SOVL_TCH; ++mm)
+        if (mm < a.n_ovl) {  // uniform
+          const DTerm t = to[mm];
+          const VT v = *(const VT*)(tile + (r ^ t.xloc) * SBC + c);
+          T qx = 0, qy = 0;
+#pragma unroll
+          for (int w = 0; w < V; ++w) {
+            qx += v.v[w].x * zo[q].v[w].x + v.v[w].y * zo[q].v[w].y;   // conj(y[i ^ x]) * zo[i]
+            qy += v.v[w].x * zo[q].v[w].y - v.v[w].y * zo[q].v[w].x;
+          }
+          if (t.zmask != 0 && (__popc(i & t.zmask) & 1)) { qx = -qx; qy = -qy; }
+          px[mm] += qx; py[mm] += qy;
+        }
+    }
+  }
+  }
+  if (OVL) {  // one sum per wave and string (no workgroup barrier); soverlap_finish_kernel adds waves and workgroups in order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t blk = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (STHREADS / 64) + wave;
+#pragma unroll
+    for (int mm = 0; mm < SOVL_TCH; ++mm)
+      if (mm < a.n_ovl) {
+        const double tx = s_wave_sum<T>(px[mm]), ty = s_wave_sum<T>(py[mm]);
+        if (lane == 0) {
+          a.part[(blk * a.n_ovl + mm) * 2 + 0] = tx;
+          a.part[(blk * a.n_ovl + mm) * 2 + 1] = ty;
+        }
+      }
   }
 }
 
@@ -218,9 +294,27 @@ void sapply_launch_f(const SApply<T>& a, dim3 grid, hipStream_t st) {
   if ((a.B & 1) == 0) hipLaunchKernelGGL((sapply_kernel<T, F, 2>), grid, dim3(STHREADS), 0, st, a);
   else hipLaunchKernelGGL((sapply_kernel<T, F, 1>), grid, dim3(STHREADS), 0, st, a);
 }
+template <class T, int F>
+void sapply_launch_ovl(const SApply<T>& a, dim3 grid, hipStream_t st) {
+  if ((a.B & 1) == 0) hipLaunchKernelGGL((sapply_kernel<T, F, 2, true>), grid, dim3(STHREADS), 0, st, a);
+  else hipLaunchKernelGGL((sapply_kernel<T, F, 1, true>), grid, dim3(STHREADS), 0, st, a);
+}
+// operand sets of the reverse-mode apply (no addend): first / middle / last group, with or without the diagonal
+inline bool sapply_ovl_flags_ok(int f) { return f == 0 || f == 1 || f == 4 || f == 5 || f == 8 || f == 12; }
 template <class T>
 void sapply_launch(const SApply<T>& a, dim3 grid, hipStream_t st) {
   const int f = (a.prev ? 1 : 0) | (a.add ? 2 : 0) | (a.acc ? 4 : 0) | (a.diag ? 8 : 0);
+  if (a.n_ovl > 0) {
+    switch (f) {
+      case 0: sapply_launch_ovl<T, 0>(a, grid, st); return;
+      case 1: sapply_launch_ovl<T, 1>(a, grid, st); return;
+      case 4: sapply_launch_ovl<T, 4>(a, grid, st); return;
+      case 5: sapply_launch_ovl<T, 5>(a, grid, st); return;
+      case 8: sapply_launch_ovl<T, 8>(a, grid, st); return;
+      case 12: sapply_launch_ovl<T, 12>(a, grid, st); return;
+      default: sfail(DQ_ERR_HIP, "fused overlap pass asked for an operand set it is not built for");
+    }
+  }
   switch (f) {
     case 0: sapply_launch_f<T, 0>(a, grid, st); break;
     case 1: sapply_launch_f<T, 1>(a, grid, st); break;
@@ -446,7 +540,8 @@ struct SCtx : dq_sctx {
   int force_degree = 0;
   double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
-  std::vector<SBuf> zs, ck;
+  std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
+  int fuse_overlaps = 0;  // measured slower: kept as an option and under test
   // profile of the streaming passes
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> recs;
@@ -663,10 +758,13 @@ void set_terms(SCtx<T>* c, int nt, const int* owner, const unsigned* x, const un
 }
 
 // one application  out = add + scale * (H_like y)   over the groups of `groups`
+// zo != null: every pass also forms its group's control overlaps <y, P'_m zo> (part[g]: per-workgroup partial sums; the
+// caller runs soverlap_finish_kernel on them) -- the partner rows of y are in the tile anyway, zo costs one more read
 template <class T>
 void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>::T2* coef, const T* diag,
                   const typename SCtx<T>::T2* y, const typename SCtx<T>::T2* add, typename SCtx<T>::T2* out,
-                  typename SCtx<T>::T2* acc, double sr, double si, int B) {
+                  typename SCtx<T>::T2* acc, double sr, double si, int B, const typename SCtx<T>::T2* zo = nullptr,
+                  std::vector<SBuf>* parts = nullptr) {
   typedef typename SCtx<T>::T2 T2;
   const size_t sb = c->state_bytes(B);
   const int ng = (int)groups.size();
@@ -674,6 +772,7 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
   for (int g = 0; g < ng; ++g) {
     const bool last = (g == ng - 1);
     SApply<T> a;
+    a.zo = nullptr; a.oterms = nullptr; a.n_ovl = 0; a.part = nullptr;
     a.y = y; a.prev = prev;
     a.add = last ? add : nullptr;
     a.acc = last ? acc : nullptr;
@@ -687,7 +786,14 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
     T2* dst = last ? out : (T2*)c->tmp[g & 1].p;
     a.out = dst;
     dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
-    const double units = 2.0 + (prev ? 1 : 0) + (a.add ? 1 : 0) + (a.acc ? 2 : 0);
+    if (zo && !groups[g].ovl.empty()) {
+      a.zo = zo;
+      a.oterms = (const DTerm*)groups[g].d_ovl.p;
+      a.n_ovl = (int)groups[g].ovl.size();
+      (*parts)[g].ensure((size_t)grid.x * grid.y * (STHREADS / 64) * a.n_ovl * 16);
+      a.part = (double*)(*parts)[g].p;
+    }
+    const double units = 2.0 + (prev ? 1 : 0) + (a.add ? 1 : 0) + (a.acc ? 2 : 0) + (a.zo ? 1 : 0);
     c->timed(units * sb, [&] { sapply_launch<T>(a, grid, c->st); });
     c->last_passes += 1;
     c->last_bytes += units * sb;
@@ -887,9 +993,19 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     T2* lam_new = (T2*)c->lam[lcur ^ 1].p;
     SHIP(hipMemcpyAsync(lam_new, c->lam[lcur].p, sb, hipMemcpyDeviceToDevice, c->st));
     const T2* zb_prev = (const T2*)c->lam[lcur].p;
+    // option fuse_overlaps = 1: the reverse apply of a group also forms that group's overlaps (zbar_{j-1} is its tile, z_j read
+    // at the own rows) -- one state-unit less per group and Horner stage, but the fused kernel's accumulators cost the second
+    // workgroup per CU (64-VGPR limit): 256 -> 231-242 steps/s at n = 18, B = 64.  Default: separate overlap passes.
+    bool fuse = c->fuse_overlaps != 0;
+    for (size_t g = 0; g < c->hgroups.size(); ++g) {
+      if ((int)c->hgroups[g].ovl.size() > SOVL_TCH) fuse = false;
+      const int f = (g > 0 ? 1 : 0) | (g + 1 == c->hgroups.size() ? 4 : 0) | (g == 0 && step_diag(c) ? 8 : 0);
+      if (!c->hgroups[g].ovl.empty() && !sapply_ovl_flags_ok(f)) fuse = false;
+    }
+    if (c->oparts.size() < c->hgroups.size()) c->oparts.resize(c->hgroups.size());
     for (int j = 1; j <= m; ++j) {
       for (auto& g : c->hgroups) {
-        if (g.ovl.empty()) continue;
+        if (fuse || g.ovl.empty()) continue;
         SOverlap<T> o;
         o.za = zb_prev; o.zb = z[j];
         o.terms = (const DTerm*)g.d_ovl.p; o.nterms = (int)g.ovl.size();
@@ -915,7 +1031,18 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       c->zbar[j & 1].ensure(sb);
       T2* zb_new = (T2*)c->zbar[j & 1].p;
       apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zb_prev, (const T2*)nullptr, zb_new, lam_new, 0.0,
-                   dt / j, B);
+                   dt / j, B, fuse ? z[j] : (const T2*)nullptr, &c->oparts);
+      if (fuse)
+        for (size_t gi = 0; gi < c->hgroups.size(); ++gi) {
+          auto& g = c->hgroups[gi];
+          if (g.ovl.empty()) continue;
+          const int nblk = (int)((c->d >> g.p) * ((B + SBC - 1) / SBC)) * (STHREADS / 64);
+          hipLaunchKernelGGL(soverlap_finish_kernel, dim3((unsigned)g.ovl.size()), dim3(256), 0, c->st,
+                             (const double*)c->oparts[gi].p, nblk, (int)g.ovl.size(), (const int*)g.d_ovl_slots.p,
+                             (const int*)c->d_owner.p, (const double*)c->d_wre.p, (const double*)c->d_wim.p, dt / j,
+                             (double*)c->grad_dev.p + (size_t)t * K);
+          SHIP(hipGetLastError());
+        }
       zb_prev = zb_new;
     }
     lcur ^= 1;
@@ -989,6 +1116,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     if (s == "tol") { if (!(v > 0)) sfail(DQ_ERR_INVALID, "tol must be > 0"); t->tol = v; }
     else if (s == "force_degree") t->force_degree = (int)v;
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
+    else if (s == "fuse_overlaps") t->fuse_overlaps = v != 0 ? 1 : 0;
     else if (s == "profile") { t->collect(); t->prof_on = v != 0; if (v < 0) { t->prof_ms = 0; t->prof_bytes = 0; t->prof_launches = 0; } }
     else sfail(DQ_ERR_INVALID, "unknown option '" + s + "'");
   });

@@ -99,6 +99,31 @@ def test_two_groups_and_checkpoint_stride(oracle):
     assert np.max(np.abs(f0 - rf)) < 1e-10 and np.max(np.abs(g0 - rg)) < 1e-10 * B and abs(l0 - rl) < 1e-10 * B
 
 
+@pytest.mark.parametrize("dtype,tol", [("c128", 1e-11), ("c64", 2e-5)])
+@pytest.mark.parametrize("kind,B", [("ising", 6), ("ising", 5), ("random", 8)])
+def test_fused_overlap_passes_equal_separate_ones(kind, B, dtype, tol):
+    """Option `fuse_overlaps = 1`: the reverse-mode apply pass of a group also forms that group's control overlaps; the default
+    (0) runs the separate overlap passes.  Same gradients: two groups (n = 10 / 11), odd and even batches, X / Y / Z strings of weight <= 3
+    and diagonal control strings (their overlaps ride in group 0)."""
+    n, K, S, dt = (10, 10, 5, 0.02) if kind == "ising" else (11, 4, 4, 0.02)
+    terms = ising_x_terms(n, seed=4) if kind == "ising" else random_terms(n, K, seed=9) + [(0, "Z" + "I" * (n - 1), 0.7), (1, "IZZ" + "I" * (n - 3), -0.4)]
+    u = problems.pulse_table(K, S, S * dt, seed=1)
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    if dtype == "c64":
+        psi0 = psi0.astype(np.complex64)
+    with StructuredEngine(n, K, dtype=dtype) as e:
+        e.set_terms(terms)
+        assert e.info("groups") >= (2 if kind == "ising" else 1)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        p0 = e.info("passes")
+        e.set_option("fuse_overlaps", 1)
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        p1 = e.info("passes")
+    assert p1 < p0                                   # fewer streaming passes
+    assert abs(l1 - l0) <= tol * B and np.max(np.abs(g1 - g0)) < tol * B and np.array_equal(f1, f0)
+    assert np.max(np.abs(g0)) > 1e-3
+
+
 def test_properties_at_n16():
     """n = 16 (d = 65536, dense H would be 64 GB): norm conservation, linearity, reversibility, directional derivative."""
     n, B, S, dt = 16, 8, 6, 0.01
