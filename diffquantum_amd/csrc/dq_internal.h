@@ -249,6 +249,7 @@ struct XrTab {
   int xoff[XR_RMAX];
   int kid[XR_RMAX];      // the control the diagonal belongs to (-1: the drift)
   double cmag[XR_RMAX];  // |value| along the diagonal
+  int phase[XR_RMAX];    // complex tables (zxr_* kernels): 0 = entries +-cmag, 1 = entries +-i cmag; real tables: 0
   int dkid[XR_DMAX];     // source of an offset-0 diagonal: control index, or -1 for the drift
   const unsigned* sgn;   // [d] bit j set: entry (i, i ^ xoff[j]) is -cmag[j]; null when no entry is negative
   const double* dval;    // [nd][d] values of the offset-0 diagonals
@@ -269,6 +270,16 @@ hipError_t xr_reverse_launch(const double2* G, long stride, int d, const XrTab& 
 hipError_t xr_reverse_launch(const float2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt,
                              const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, float* xpow, double* grad,
                              int accumulate, hipStream_t st);
-size_t xr_pow_elems(int d, int q, int batch);  // per step: scratch of the reverse kernel (xpow), in doubles
+size_t xr_pow_elems(int d, int q, int batch);
+// Complex Hermitian XOR-regular generators (phases +-1 / +-i along the XOR-diagonals, real diagonal from the drift only):
+// U = sum_{m <= L} A^m / m!, A = -i dt H, row by row in LDS; reverse mode from the rows of Ubar.  complex128, d = 256 .. 4096.
+bool zxr_supported(int d, int L, int R, int nd);
+hipError_t zxr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt, int L, int batch,
+                              hipStream_t st);
+// xpow: batch * zxr_pow_elems(d, L, batch) double2 of scratch; part as for xr_reverse_launch
+size_t zxr_pow_elems(int d, int L, int batch);
+hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt, int L,
+                              int batch, double* part, const unsigned* zero_sgn, double2* xpow, double* grad, int accumulate,
+                              hipStream_t st);  // per step: scratch of the reverse kernel (xpow), in doubles
 
 }  // namespace dq

@@ -485,4 +485,375 @@ hipError_t xr_reverse_launch(const float2* G, long stride, int d, const XrTab& t
   return xr_reverse_t<float>(G, stride, d, tab, u, K, dt, pol, batch, part, zero_sgn, xpow, grad, accumulate, st);
 }
 
+// =====================================================================================================================
+// Complex Hermitian XOR-regular generators (X and Y drives: H = sum of Pauli strings with an odd number of Y's among them).
+// No cos / sin split exists for them; the step is U = exp(A) = sum_{m <= L} A^m / m!, A = -i dt H anti-Hermitian, and the same
+// column idea applies with complex vectors (two LDS images of 16 D bytes).  The kernels work in the TRANSPOSED world,
+// A~ = A^T (entries A~[i, i ^ x_j] = -i dt conj(H[i, i ^ x_j])):  x_m = A~ x_{m-1} / m from x_0 = e_c gives ROW c of U, which is
+// what the chain's products read; and, with g = row c of G = Ubar and H~_k = conj(H_k),
+//     dL/du_k = dt Im sum_c sum_{a < L} < y_a , H~_k x_a >,     y_{L-1} = g / L,   y_a = (g - A~ y_{a+1}) / (a + 1)
+// (from dL = Re tr(G^H dU), dU = sum_l 1/l! sum_{a+b=l-1} A^a dA A^b, dA = -i dt H_k du_k, transposed under the trace; A~^H = -A~).
+// The partner value y_{a+1}[i ^ x_j] fetched for the product is the factor of the level-(a+1) dot product (Hermitian symmetry
+// of H~_k moves the conjugate onto it); an XOR-diagonal with entries +-c contributes sigma (v_r x_i - v_i x_r), one with entries
+// +-i c contributes sigma (v_r x_r + v_i x_i) -- one real accumulator per diagonal, as in the real kernels.
+// Table: XrTab with phase[j]; sign words as in the real case; offset-0 diagonals real and from the drift only.
+
+template <int NT, int RPT, bool SIGN>
+struct ZxrRows {
+  double dg[RPT];  // dt * sum over the offset-0 diagonals of u val (real)
+  unsigned sg[RPT];
+  int R;
+  const unsigned char *jof, *nxt;
+  const double* Wl;  // dt u_j c_j
+  const int* ph;
+  __device__ __forceinline__ void load(const XrTab& tab, const double* __restrict__ uz, double dt, int t, unsigned char* s_jof,
+                                       double* s_w) {
+    constexpr int D = NT * RPT;
+    unsigned char* s_nxt = (unsigned char*)(s_w + XR_RMAX + 2);
+    int* s_ph = (int*)(s_nxt + XR_RMAX);
+    R = tab.R;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+      dg[r] = 0;
+    }
+    for (int j = 0; j < tab.nd; ++j) {
+      const int k = tab.dkid[j];
+      const double w = dt * (k < 0 ? 1.0 : uz[k]);
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) dg[r] += w * tab.dval[(long)j * D + r * NT + t];
+    }
+    for (int i = t; i < D; i += NT) s_jof[i] = (unsigned char)(tab.R + 1);
+    __syncthreads();
+    if (t < XR_RMAX) s_ph[t] = t < tab.R ? tab.phase[t] : 0;
+    if (t < tab.R) {
+      const int k = tab.kid[t];
+      s_w[t] = dt * (k < 0 ? 1.0 : uz[k]) * tab.cmag[t];
+    }
+    if (t == 0) {
+      for (int j = 0; j < tab.R; ++j) {
+        s_nxt[j] = s_jof[tab.xoff[j]];
+        s_jof[tab.xoff[j]] = (unsigned char)j;
+      }
+      s_jof[0] = (unsigned char)tab.R;
+      s_w[tab.R] = 0;
+      s_w[tab.R + 1] = 0;
+    }
+    __syncthreads();
+    jof = s_jof;
+    nxt = s_nxt;
+    Wl = s_w;
+    ph = s_ph;
+  }
+  // x_1 = A~ e_c at the thread's rows: A~[i, c] = -i w sigma (phase 0) or -w sigma (phase 1) where i ^ x_j = c; -i dg at i = c
+  __device__ __forceinline__ void first(int t, int c, double2* x1) const {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int i = r * NT + t;
+      double2 v;
+      v.x = 0;
+      v.y = 0;
+      for (unsigned j = jof[i ^ c]; j < (unsigned)R; j = nxt[j]) {
+        const double w = SIGN ? xr_flip(Wl[j], (sg[r] >> j) & 1u) : Wl[j];
+        if (ph[j]) v.x -= w;
+        else v.y -= w;
+      }
+      if (i == c) v.y -= dg[r];
+      x1[r] = v;
+    }
+  }
+};
+
+// o += s * (A~ - diag) v  with v in the LDS image `src` (interleaved re, im); DOT: dacc[j] += sigma (v_r x_i - v_i x_r) or
+// sigma (v_r x_r + v_i x_i) with x = xm (the thread's own rows)
+template <int NT, int RPT, bool SIGN, bool DOT>
+__device__ __forceinline__ void zxr_gather(const XrTab& tab, const ZxrRows<NT, RPT, SIGN>& rw, const double2* __restrict__ src, int t,
+                                           double s, double2* o, const double2* xm, double* dacc) {
+  typedef const volatile __attribute__((address_space(3))) double* lds_ptr;
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < rw.R; ++j) {
+    const int xo = tab.xoff[j];
+    const double w = s * rw.Wl[j];
+    const int phj = rw.ph[j];
+    lds_ptr base = (lds_ptr)(src + (t ^ (xo & (NT - 1))));
+    const int xh = xo / NT;
+    double vr[RPT], vi[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      vr[r] = base[2 * ((r ^ xh) * NT)];
+      vi[r] = base[2 * ((r ^ xh) * NT) + 1];
+    }
+    if (SIGN) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const unsigned b = (rw.sg[r] >> j) & 1u;
+        vr[r] = xr_flip(vr[r], b);
+        vi[r] = xr_flip(vi[r], b);
+      }
+    }
+    if (phj) {  // entries -w sigma
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        o[r].x = __builtin_fma(-w, vr[r], o[r].x);
+        o[r].y = __builtin_fma(-w, vi[r], o[r].y);
+      }
+    } else {  // entries -i w sigma
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        o[r].x = __builtin_fma(w, vi[r], o[r].x);
+        o[r].y = __builtin_fma(-w, vr[r], o[r].y);
+      }
+    }
+    if (DOT) {
+      double d = 0;
+      if (phj) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) d = __builtin_fma(vr[r], xm[r].x, __builtin_fma(vi[r], xm[r].y, d));
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) d = __builtin_fma(vr[r], xm[r].y, __builtin_fma(-vi[r], xm[r].x, d));
+      }
+      xr_acc<0, XR_RMAX>(dacc, j, d);
+    }
+  }
+}
+
+constexpr size_t zxr_lds_bytes(int D) {
+  return (size_t)2 * 16 * D + (size_t)D + 8 * (XR_RMAX + 2) + XR_RMAX + 4 * XR_RMAX;
+}
+
+// U[z][c][:] = row c of exp(A_z), rows c = blockIdx.x, blockIdx.x + gridDim.x, ...
+template <int NT, int RPT, bool SIGN>
+__global__ void __launch_bounds__(NT) zxr_forward_kernel(double2* __restrict__ U, long stride, XrTab tab, const double* __restrict__ u,
+                                                         int K, double dt, int L) {
+  constexpr int D = NT * RPT;
+  extern __shared__ __align__(16) unsigned char xr_lds_raw[];
+  double2* lds = (double2*)xr_lds_raw;  // two images of D
+  const int t = threadIdx.x;
+  const long z = blockIdx.y;
+  ZxrRows<NT, RPT, SIGN> rw;
+  rw.load(tab, u + z * K, dt, t, xr_lds_raw + 32 * D, (double*)(xr_lds_raw + 32 * D + D));
+  int p = 1;
+  for (int c = blockIdx.x; c < D; c += gridDim.x) {
+    double2 cur[RPT], acc[RPT];
+    rw.first(t, c, cur);
+    p ^= 1;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      lds[p * D + r * NT + t] = cur[r];
+      acc[r].x = cur[r].x + ((r * NT + t) == c ? 1.0 : 0.0);
+      acc[r].y = cur[r].y;
+    }
+    __syncthreads();
+    for (int m = 2; m <= L; ++m) {
+      double2 o[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {  // the diagonal: -i dg v
+        o[r].x = rw.dg[r] * cur[r].y;
+        o[r].y = -rw.dg[r] * cur[r].x;
+      }
+      zxr_gather<NT, RPT, SIGN, false>(tab, rw, lds + p * D, t, 1.0, o, nullptr, nullptr);
+      const double inv = 1.0 / m;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        o[r].x *= inv;
+        o[r].y *= inv;
+        cur[r] = o[r];
+        acc[r].x += o[r].x;
+        acc[r].y += o[r].y;
+      }
+      if (m < L) {
+        p ^= 1;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) lds[p * D + r * NT + t] = o[r];
+        __syncthreads();
+      }
+    }
+    double2* urow = U + z * stride + (long)c * D;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) urow[r * NT + t] = acc[r];
+  }
+}
+
+// part[(z * gridDim.x + blockIdx.x) * XR_SLOTS + j] = this workgroup's share of sum_c sum_a of the level dot products of
+// XOR-diagonal j (before the factors cmag_j and dt); xpow: per workgroup the powers x_1 .. x_{L-1} of the current row
+template <int NT, int RPT, bool SIGN>
+__global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restrict__ G, long stride, XrTab tab,
+                                                         const double* __restrict__ u, int K, double dt, int L,
+                                                         double* __restrict__ part, double2* __restrict__ xpow) {
+  constexpr int D = NT * RPT;
+  extern __shared__ __align__(16) unsigned char xr_lds_raw[];
+  double2* lds = (double2*)xr_lds_raw;
+  const int t = threadIdx.x;
+  const long z = blockIdx.y;
+  ZxrRows<NT, RPT, SIGN> rw;
+  rw.load(tab, u + z * K, dt, t, xr_lds_raw + 32 * D, (double*)(xr_lds_raw + 32 * D + D));
+  double2* xp = xpow + (z * gridDim.x + blockIdx.x) * (long)(L - 1) * D + t;  // [a - 1][r * NT + t], a = 1 .. L - 1
+  double dacc[XR_RMAX];
+#pragma unroll
+  for (int j = 0; j < XR_RMAX; ++j) dacc[j] = 0.0;
+  int p = 1;
+  for (int c = blockIdx.x; c < D; c += gridDim.x) {
+    const double2* grow = G + z * stride + (long)c * D + t;
+    // x_1 .. x_{L-1}
+    double2 cur[RPT];
+    rw.first(t, c, cur);
+    p ^= 1;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      lds[p * D + r * NT + t] = cur[r];
+      if (L > 1) xp[r * NT] = cur[r];
+    }
+    __syncthreads();
+    for (int m = 2; m < L; ++m) {
+      double2 o[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        o[r].x = rw.dg[r] * cur[r].y;
+        o[r].y = -rw.dg[r] * cur[r].x;
+      }
+      zxr_gather<NT, RPT, SIGN, false>(tab, rw, lds + p * D, t, 1.0, o, nullptr, nullptr);
+      const double inv = 1.0 / m;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        o[r].x *= inv;
+        o[r].y *= inv;
+        cur[r] = o[r];
+        xp[(long)(m - 1) * D + r * NT] = o[r];
+      }
+      if (m < L - 1) {
+        p ^= 1;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) lds[p * D + r * NT + t] = o[r];
+        __syncthreads();
+      }
+    }
+    // y_{L-1} = g / L
+    p ^= 1;
+    {
+      const double inv = 1.0 / L;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const double2 g = grow[r * NT];
+        cur[r].x = g.x * inv;
+        cur[r].y = g.y * inv;
+        lds[p * D + r * NT + t] = cur[r];
+      }
+    }
+    __syncthreads();
+    // the sweep that forms y_{a-1} from y_a pairs y_a with x_a (a = L-1 .. 1); y_0 is left in image p
+    for (int a = L - 1; a >= 1; --a) {
+      double2 o[RPT], xm[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        xm[r] = xp[(long)(a - 1) * D + r * NT];
+        const double2 g = grow[r * NT];
+        o[r].x = g.x - rw.dg[r] * cur[r].y;   // g - (-i dg y)
+        o[r].y = g.y + rw.dg[r] * cur[r].x;
+      }
+      zxr_gather<NT, RPT, SIGN, true>(tab, rw, lds + p * D, t, -1.0, o, xm, dacc);
+      const double inv = 1.0 / a;
+      p ^= 1;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        cur[r].x = o[r].x * inv;
+        cur[r].y = o[r].y * inv;
+        lds[p * D + r * NT + t] = cur[r];
+      }
+      __syncthreads();
+    }
+    // level 0: x_0 = e_c pairs with y_0 at the rows c ^ x_j (sign and phase of entry (c, c ^ x_j))
+    if (t == 0) {
+      for (int j = 0; j < tab.R; ++j) {
+        const double2 v = lds[p * D + (c ^ tab.xoff[j])];
+        const unsigned b = tab.sgn ? (tab.sgn[c] >> j) & 1u : 0u;
+        const double d = tab.phase[j] ? v.x : -v.y;
+        xr_acc<0, XR_RMAX>(dacc, j, b ? -d : d);
+      }
+    }
+  }
+  __syncthreads();
+  double* red = (double*)xr_lds_raw;  // [NT / 64][XR_SLOTS]
+  const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int j = 0; j < XR_SLOTS; ++j) {
+    double v = j < XR_RMAX ? dacc[j < XR_RMAX ? j : 0] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave * XR_SLOTS + j] = v;
+  }
+  __syncthreads();
+  if (t < XR_SLOTS) {
+    double sum = 0.0;
+    for (int w = 0; w < NT / 64; ++w) sum += red[w * XR_SLOTS + t];
+    part[(z * gridDim.x + blockIdx.x) * XR_SLOTS + t] = sum;
+  }
+}
+
+bool zxr_supported(int d, int L, int R, int nd) {
+  if (R < 1 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || L < 1 || L > 16) return false;
+  return d == 256 || d == 512 || d == 1024 || d == 2048 || d == 4096;
+}
+
+size_t zxr_pow_elems(int d, int L, int batch) { return (size_t)xr_blocks(d, batch) * (size_t)(L > 1 ? L - 1 : 1) * (size_t)d; }
+
+template <int NT, int RPT>
+static hipError_t zxr_forward_go(double2* U, long stride, const XrTab& tab, const double* u, int K, double dt, int L, int batch,
+                                 hipStream_t st) {
+  const size_t lds = zxr_lds_bytes(NT * RPT);
+  const dim3 grid((unsigned)xr_blocks(NT * RPT, batch), (unsigned)batch);
+  void (*kf)(double2*, long, XrTab, const double*, int, double, int) =
+      tab.sgn ? zxr_forward_kernel<NT, RPT, true> : zxr_forward_kernel<NT, RPT, false>;
+  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, U, stride, tab, u, K, dt, L);
+  return hipGetLastError();
+}
+
+hipError_t zxr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt, int L, int batch,
+                              hipStream_t st) {
+  if (batch <= 0) return hipSuccess;
+  if (!zxr_supported(d, L, tab.R, tab.nd)) return hipErrorInvalidValue;
+  switch (d) {
+    case 4096: return zxr_forward_go<512, 8>(U, stride, tab, u, K, dt, L, batch, st);
+    case 2048: return zxr_forward_go<256, 8>(U, stride, tab, u, K, dt, L, batch, st);
+    case 1024: return zxr_forward_go<128, 8>(U, stride, tab, u, K, dt, L, batch, st);
+    case 512: return zxr_forward_go<64, 8>(U, stride, tab, u, K, dt, L, batch, st);
+    default: return zxr_forward_go<64, 4>(U, stride, tab, u, K, dt, L, batch, st);
+  }
+}
+
+template <int NT, int RPT>
+static hipError_t zxr_reverse_go(const double2* G, long stride, const XrTab& tab, const double* u, int K, double dt, int L, int batch,
+                                 double* part, double2* xpow, hipStream_t st) {
+  const size_t lds = zxr_lds_bytes(NT * RPT);
+  const dim3 grid((unsigned)xr_blocks(NT * RPT, batch), (unsigned)batch);
+  void (*kf)(const double2*, long, XrTab, const double*, int, double, int, double*, double2*) =
+      tab.sgn ? zxr_reverse_kernel<NT, RPT, true> : zxr_reverse_kernel<NT, RPT, false>;
+  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tab, u, K, dt, L, part, xpow);
+  return hipGetLastError();
+}
+
+hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab& tab, const double* u, int K, double dt, int L,
+                              int batch, double* part, const unsigned* zero_sgn, double2* xpow, double* grad, int accumulate,
+                              hipStream_t st) {
+  (void)zero_sgn;
+  if (batch <= 0) return hipSuccess;
+  if (!zxr_supported(d, L, tab.R, tab.nd) || !xpow) return hipErrorInvalidValue;
+  for (int j = 0; j < tab.nd; ++j)
+    if (tab.dkid[j] >= 0) return hipErrorInvalidValue;  // (controls with diagonal entries: not built for the complex table)
+  hipError_t e;
+  switch (d) {
+    case 4096: e = zxr_reverse_go<1024, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+    case 2048: e = zxr_reverse_go<512, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+    case 1024: e = zxr_reverse_go<256, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+    case 512: e = zxr_reverse_go<128, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+    default: e = zxr_reverse_go<64, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st);
+  }
+  if (e != hipSuccess) return e;
+  // dL/du_k = +dt * sum_j [kid_j == k] cmag_j * (sum of the workgroups' parts)
+  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d, batch), tab, K, dt, grad,
+                     accumulate);
+  return hipGetLastError();
+}
+
 }  // namespace dq
