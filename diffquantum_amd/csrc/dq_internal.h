@@ -274,6 +274,8 @@ size_t xr_pow_elems(int d, int q, int batch);
 // Complex Hermitian XOR-regular generators (phases +-1 / +-i along the XOR-diagonals, real diagonal from the drift only):
 // U = sum_{m <= L} A^m / m!, A = -i dt H, row by row in LDS; reverse mode from the rows of Ubar.  complex128, d = 256 .. 4096.
 bool zxr_supported(int d, int L, int R, int nd);
+hipError_t zsp_count_launch(const double2* H, int d, int K, int* cnt, hipStream_t st);  // cnt[k * d + i] = nonzeros of row i of H[k]
+hipError_t zsp_fill_launch(const double2* H, int d, int K, const long* base, int* col, double* re, double* im, hipStream_t st);
 hipError_t zxr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt, int L, int batch,
                               hipStream_t st);
 // xpow: batch * zxr_pow_elems(d, L, batch) double2 of scratch; part as for xr_reverse_launch

@@ -109,6 +109,7 @@ struct ExpmPlan {
   int rq = 0;  // > 0: real-symmetric plan (cos/sin polynomials in Y = X^2 up to Y^rq); `ops` is empty then
   int spx = 0; // real plan evaluated with the sparse generator: powers X_{m+1} = X X_m by sparse x dense products
   int xr = 0;  // spx plan whose generator is XOR-regular: column form in LDS (xorexp.hip), no stored powers
+  int zxr = 0; // complex Hermitian XOR-regular generator: U = sum_{l <= m} A^l / l! row by row in LDS (zxr_* kernels); no tape
   double cc[8] = {0}, sc[8] = {0};  // cos X = sum cc[j] Y^j,  sin X = X sum sc[j] Y^j
   std::vector<TapeOp> ops;
   int products() const { return nprod; }
@@ -297,6 +298,8 @@ struct Ctx : dq_ctx {
   DevBuf xr_sgn, xr_dval, xr_part, xr_pow;
   dq::XrTab xr_tab;
   bool xr_ok = false;
+  dq::XrTab zxr_tab;    // complex Hermitian generators (phases +-1 / +-i): table of the zxr_* kernels
+  bool zxr_ok = false;
   int xor_mode = -1;
   double last_xr = 0;
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
@@ -349,6 +352,7 @@ struct Ctx : dq_ctx {
     // (XOR-regular generators: the column form, xorexp.hip, beats the MFMA products wherever its kernels exist)
     return xr_ok && xor_mode != 0 && dq::xr_supported(d, 1, xr_tab.R, xr_tab.nd, sizeof(T));
   }
+  bool zxr_on() const { return zxr_ok && xor_mode != 0 && real_mode != 0 && force_degree <= 0 && force_s < 0; }
   bool xr_on(int q) const {
     return xr_ok && xor_mode != 0 && sparse_gen_on() && dq::xr_supported(d, q, xr_tab.R, xr_tab.nd, sizeof(T));
   }
@@ -1113,7 +1117,35 @@ ExpmPlan chunk_plan(Ctx<T>* c, const std::vector<double>& uh, int c0, int n, dou
       if (bq > 0) return make_real_plan(bq, bs);
     }
   }
+  if (!c->real_h && c->zxr_on()) {
+    for (int L = 1; L <= 16; ++L)
+      if (taylor_remainder(th, L) <= c->expm_tol && dq::zxr_supported(c->d, L, c->zxr_tab.R, c->zxr_tab.nd)) {
+        ExpmPlan p;
+        p.zxr = 1;
+        p.m = L;
+        p.out = RS_U;
+        p.nvars = RS_U + 1;
+        return p;
+      }
+  }
   return choose_plan(th, c->expm_tol, c->force_degree, c->force_s);
+}
+
+// (the complex column form exists for complex128 engines; the table is never set for others)
+inline hipError_t zxr_forward_any(double2* U, long stride, int d, const dq::XrTab& tab, const double* u, int K, double dt, int L, int n,
+                                  hipStream_t st) {
+  return dq::zxr_forward_launch(U, stride, d, tab, u, K, dt, L, n, st);
+}
+inline hipError_t zxr_forward_any(float2*, long, int, const dq::XrTab&, const double*, int, double, int, int, hipStream_t) {
+  return hipErrorInvalidValue;
+}
+inline hipError_t zxr_reverse_any(const double2* G, long stride, int d, const dq::XrTab& tab, const double* u, int K, double dt, int L,
+                                  int n, double* part, void* xpow, double* grad, hipStream_t st) {
+  return dq::zxr_reverse_launch(G, stride, d, tab, u, K, dt, L, n, part, nullptr, (double2*)xpow, grad, 0, st);
+}
+inline hipError_t zxr_reverse_any(const float2*, long, int, const dq::XrTab&, const double*, int, double, int, int, double*, void*,
+                                  double*, hipStream_t) {
+  return hipErrorInvalidValue;
 }
 
 // assemble + exp for steps [c0, c0+n): returns pointer to n stacked propagators
@@ -1160,6 +1192,22 @@ TT* build_propagators(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
       c->last_cached += n;
     }
     return real_forward(c, p, c0, n, dt);
+  }
+  c->last_xr = 0;
+  if (p.zxr) {
+    // complex Hermitian Pauli-string generator: the rows of U = exp(-i dt H) built in LDS (no assembly, no tape, no product)
+    T2* U = c->mat(RS_U, n);
+    const double rows = (double)c->zxr_tab.R + 1.0;
+    c->timed(DQ_PROF_SPMM, 8.0 * rows * c->nn() * (p.m - 1.0) * n, (double)sizeof(T2) * c->nn() * n, [&] {
+      return zxr_forward_any(U, (long)c->nn(), c->d, c->zxr_tab, c->u_dev.d() + (size_t)c0 * c->K, c->K, dt, p.m, n, c->st);
+    });
+    c->last_degree = p.m;
+    c->last_squarings = 0;
+    c->last_products = 0;
+    c->last_real_q = 0;
+    c->last_spx = 0;
+    c->last_xr = 2;
+    return U;
   }
   T2* A = c->mat(0, n);
   const double by = 2.0 * sizeof(T) * c->nn() * (c->K + 2.0) * n;
@@ -1485,6 +1533,17 @@ void chunk_vjp(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
   const int K = c->K;
   const int nblk = dq::grad_contract_blocks((long)c->nn());
   c->part.ensure(sizeof(double) * (size_t)n * nblk * std::max(K, 1));
+  if (p.zxr) {
+    const T2* G = ubar_slot(c, p, n);
+    c->xr_part.ensure(sizeof(double) * (size_t)n * dq::xr_blocks(c->d, n) * dq::XR_SLOTS);
+    c->xr_pow.ensure(2 * sizeof(double) * (size_t)n * dq::zxr_pow_elems(c->d, p.m, n));
+    const double rows = (double)c->zxr_tab.R + 1.0;
+    c->timed(DQ_PROF_SPMM, 8.0 * rows * c->nn() * (2.0 * p.m - 1.0) * n, (double)sizeof(T2) * c->nn() * n, [&] {
+      return zxr_reverse_any(G, (long)c->nn(), c->d, c->zxr_tab, c->u_dev.d() + (size_t)c0 * K, K, dt, p.m, n, (double*)c->xr_part.p,
+                             c->xr_pow.p, c->grad_dev.d() + (size_t)c0 * K, c->st);
+    });
+    return;
+  }
   if (p.rq > 0 && p.spx) {
     real_backward_spx(c, p, c0, n, dt, c->grad_dev.d() + (size_t)c0 * K);
     return;
@@ -1826,7 +1885,7 @@ void do_propagator_vjp(Ctx<T>* c, const double* u, int n, double dt, const void*
   for (int c0 = 0; c0 < n; c0 += tc) {
     const int m = std::min(tc, n - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, m, dt);
-    if (!p.xr) build_propagators(c, p, c0, m, dt);  // the polynomial's variables, for the reverse mode (column form: none)
+    if (!p.xr && !p.zxr) build_propagators(c, p, c0, m, dt);  // the polynomial's variables, for the reverse mode (column form: none)
     else for (auto& r : c->redirect) r = nullptr;
     T2* G = ubar_slot(c, p, m);
     HIPCK(hipMemcpyAsync(G, (const char*)G_in + (size_t)c0 * c->mat_bytes(), (size_t)m * c->mat_bytes(), hipMemcpyDefault, c->st));
@@ -1955,6 +2014,99 @@ void find_xor_regular(Ctx<T>* c, const std::vector<long>& rowptr, long nnz) {
   c->xr_ok = true;
 }
 
+// Complex Hermitian H0 / H_k that are sums of Pauli strings with X and Y factors (XOR-regular pattern, every XOR-diagonal of one
+// magnitude and either real, +-c, or imaginary, +-i c; a real diagonal from the drift alone): table for the zxr_* kernels.
+// The nonzeros are collected on the device (count, fill) and analysed on the host like find_xor_regular does for real ones.
+template <class T>
+void find_zxor_regular(Ctx<T>* c) {
+  c->zxr_ok = false;
+  if (sizeof(T) != 8 || !c->hermitian || c->real_h || c->K <= 0) return;
+  const int d = c->d, K = c->K, NS = K + 1;
+  if (!dq::zxr_supported(d, 1, 1, 0)) return;
+  DevBuf cnt_dev, base_dev, col_dev, re_dev, im_dev;
+  cnt_dev.ensure(sizeof(int) * (size_t)NS * d);
+  HIPCK(dq::zsp_count_launch((const double2*)c->H0.p, d, 1, (int*)cnt_dev.p, c->st));
+  HIPCK(dq::zsp_count_launch((const double2*)c->Hs.p, d, K, (int*)cnt_dev.p + d, c->st));
+  std::vector<int> cnt((size_t)NS * d);
+  HIPCK(hipMemcpyAsync(cnt.data(), cnt_dev.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  std::vector<long> base((size_t)NS * d);
+  long nnz = 0;
+  for (size_t q = 0; q < cnt.size(); ++q) { base[q] = nnz; nnz += cnt[q]; }
+  if (nnz == 0 || nnz > (long)(dq::XR_RMAX + 1) * d) return;
+  base_dev.ensure(sizeof(long) * base.size());
+  col_dev.ensure(sizeof(int) * (size_t)nnz);
+  re_dev.ensure(sizeof(double) * (size_t)nnz);
+  im_dev.ensure(sizeof(double) * (size_t)nnz);
+  HIPCK(hipMemcpyAsync(base_dev.p, base.data(), sizeof(long) * base.size(), hipMemcpyHostToDevice, c->st));
+  HIPCK(dq::zsp_fill_launch((const double2*)c->H0.p, d, 1, (const long*)base_dev.p, (int*)col_dev.p, (double*)re_dev.p,
+                            (double*)im_dev.p, c->st));
+  HIPCK(dq::zsp_fill_launch((const double2*)c->Hs.p, d, K, (const long*)base_dev.p + d, (int*)col_dev.p, (double*)re_dev.p,
+                            (double*)im_dev.p, c->st));
+  std::vector<int> col((size_t)nnz);
+  std::vector<double> re((size_t)nnz), im((size_t)nnz);
+  HIPCK(hipMemcpyAsync(col.data(), col_dev.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipMemcpyAsync(re.data(), re_dev.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipMemcpyAsync(im.data(), im_dev.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  struct Grp { int x, kid, phase; long count; double mag; };
+  std::vector<Grp> groups;
+  std::vector<unsigned> sgn((size_t)d, 0u);
+  std::vector<double> dval((size_t)d, 0.0);
+  bool have_diag = false, have_imag = false;
+  for (int sidx = 0; sidx < NS; ++sidx)      // source 0 = drift (kid -1), source k + 1 = control k
+    for (int i = 0; i < d; ++i) {
+      const long e0 = base[(size_t)sidx * d + i];
+      for (long e = e0; e < e0 + cnt[(size_t)sidx * d + i]; ++e) {
+        const int x = col[e] ^ i, kid = sidx - 1;
+        if (x == 0) {
+          if (kid >= 0 || im[e] != 0.0) return;  // (controls with diagonal entries: not built for the complex table)
+          dval[i] += re[e];
+          have_diag = true;
+          continue;
+        }
+        if (re[e] != 0.0 && im[e] != 0.0) return;  // phases +-1 / +-i only
+        const int ph = im[e] != 0.0 ? 1 : 0;
+        const double v = ph ? im[e] : re[e];
+        size_t g = 0;
+        while (g < groups.size() && !(groups[g].x == x && groups[g].kid == kid)) ++g;
+        if (g == groups.size()) {
+          if (i != 0 || (int)groups.size() == dq::XR_RMAX) return;
+          groups.push_back({x, kid, ph, 0, std::fabs(v)});
+        }
+        if (ph != groups[g].phase || std::fabs(v) != groups[g].mag || groups[g].count != i) return;
+        groups[g].count++;
+        if (v < 0.0) sgn[i] |= 1u << g;
+        have_imag = have_imag || ph;
+      }
+    }
+  if (groups.empty() || !have_imag) return;
+  for (size_t a = 0; a < groups.size(); ++a) {
+    if (groups[a].count != d) return;
+    for (int i = 0; i < d; ++i) {  // Hermitian: real diagonals have symmetric signs, imaginary ones antisymmetric
+      const unsigned s0 = (sgn[i] >> a) & 1u, s1 = (sgn[i ^ groups[a].x] >> a) & 1u;
+      if (groups[a].phase ? s0 == s1 : s0 != s1) return;
+    }
+  }
+  dq::XrTab tab;
+  memset(&tab, 0, sizeof(tab));
+  tab.R = (int)groups.size();
+  tab.nd = have_diag ? 1 : 0;
+  tab.dkid[0] = -1;
+  for (int j = 0; j < tab.R; ++j) {
+    tab.xoff[j] = groups[j].x; tab.kid[j] = groups[j].kid; tab.cmag[j] = groups[j].mag; tab.phase[j] = groups[j].phase;
+  }
+  c->xr_sgn.ensure(sizeof(unsigned) * (size_t)d);
+  c->xr_dval.ensure(sizeof(double) * (size_t)d);
+  HIPCK(hipMemcpyAsync(c->xr_sgn.p, sgn.data(), sizeof(unsigned) * (size_t)d, hipMemcpyHostToDevice, c->st));
+  HIPCK(hipMemcpyAsync(c->xr_dval.p, dval.data(), sizeof(double) * (size_t)d, hipMemcpyHostToDevice, c->st));
+  HIPCK(hipStreamSynchronize(c->st));
+  tab.sgn = (const unsigned*)c->xr_sgn.p;
+  tab.dval = (const double*)c->xr_dval.p;
+  c->zxr_tab = tab;
+  c->zxr_ok = true;
+}
+
 // CSR of the Hamiltonians' nonzeros (real path), if they are sparse enough to pay: at most sparse_fill nonzeros per row
 // summed over the sources (X-type Paulis: one per control). Two tiers: controls AND drift sparse (sparse_x: the drift's
 // entries join the CSR with kid = -1, so X_t itself is sparse and the polynomial runs on sparse x dense products), or the
@@ -2069,6 +2221,7 @@ void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
     if (!c->real_h) { c->H0r.release(); c->Hsr.release(); }
   }
   build_sparse_controls(c);
+  find_zxor_regular(c);
   c->have_H = true;
 }
 
@@ -2291,7 +2444,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "control_nonzeros") return c->sparse_h ? (double)c->sp_nnz_c : -1.0;
   if (s == "sparse_generator") return c->last_spx;
   if (s == "xor_regular") return c->last_xr;
-  if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : -1.0;
+  if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;
   if (s == "real_path") return c->last_real_q;

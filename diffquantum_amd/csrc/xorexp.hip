@@ -856,4 +856,51 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
   return hipGetLastError();
 }
 
+// ---- nonzeros of complex matrices (the complex table is found from them): counts, then (column, re, im) per (source, row) ----
+template <class T2>
+__global__ void __launch_bounds__(64) zsp_count_kernel(const T2* __restrict__ H, int d, int* __restrict__ cnt) {
+  const int i = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
+  const T2* row = H + ((long)k * d + i) * d;
+  int n = 0;
+  for (int j0 = 0; j0 < d; j0 += 64) {
+    const int j = j0 + lane;
+    const bool nz = j < d && (row[j].x != 0 || row[j].y != 0);
+    n += __popcll(__ballot(nz));
+  }
+  if (lane == 0) cnt[(long)k * d + i] = n;
+}
+template <class T2>
+__global__ void __launch_bounds__(64) zsp_fill_kernel(const T2* __restrict__ H, int d, const long* __restrict__ base,
+                                                      int* __restrict__ col, double* __restrict__ re, double* __restrict__ im) {
+  const int i = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
+  const T2* row = H + ((long)k * d + i) * d;
+  long at = base[(long)k * d + i];
+  for (int j0 = 0; j0 < d; j0 += 64) {
+    const int j = j0 + lane;
+    T2 v;
+    v.x = 0;
+    v.y = 0;
+    if (j < d) v = row[j];
+    const bool nz = v.x != 0 || v.y != 0;
+    const unsigned long long m = __ballot(nz);
+    if (nz) {
+      const long e = at + __popcll(m & ((1ull << lane) - 1ull));
+      col[e] = j;
+      re[e] = (double)v.x;
+      im[e] = (double)v.y;
+    }
+    at += __popcll(m);
+  }
+}
+hipError_t zsp_count_launch(const double2* H, int d, int K, int* cnt, hipStream_t st) {
+  if (d <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(zsp_count_kernel<double2>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, H, d, cnt);
+  return hipGetLastError();
+}
+hipError_t zsp_fill_launch(const double2* H, int d, int K, const long* base, int* col, double* re, double* im, hipStream_t st) {
+  if (d <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(zsp_fill_kernel<double2>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, H, d, base, col, re, im);
+  return hipGetLastError();
+}
+
 }  // namespace dq

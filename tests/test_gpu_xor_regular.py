@@ -234,3 +234,93 @@ def test_column_form_fp32(oracle, signed):
         assert e.info("xor_regular") == 0
     assert abs(l1 - rl) < 1e-4 * B and np.max(np.abs(g1 - rg)) < 1e-4 and np.max(np.abs(f1 - rf)) < 1e-4
     assert abs(l1 - l0) < 1e-4 * B and np.max(np.abs(g1 - g0)) < 1e-4 and np.max(np.abs(f1 - f0)) < 1e-5
+
+
+# ---- complex Hermitian generators: X and Y drives (zxr_* kernels) ---------------------------------------------------------
+
+PY = np.array([[0, -1j], [1j, 0]])
+
+
+def _cstring(n, ops):
+    m = np.ones((1, 1), dtype=complex)
+    for q in range(n):
+        o = ops.get(q)
+        m = np.kron(m, np.eye(2) if o is None else PX if o == "X" else PZ if o == "Z" else PY)
+    return m
+
+
+def _xy_problem(n, seed, extra=True):
+    """Ising drift (ZZ + Z, diagonal) with a transverse X_0 and a Y_1 term in the drift; controls X_k and Y_k on several qubits
+    (X_a and Y_a share an XOR offset), and with `extra` a X_a Y_b string (imaginary entries, two-bit offset) and a Y_a Z_b string."""
+    rng = np.random.default_rng(seed)
+    d = 1 << n
+    H0 = np.zeros((d, d), dtype=complex)
+    for a in range(n):
+        H0 += rng.standard_normal() * _cstring(n, {a: "Z"}) + rng.standard_normal() * _cstring(n, {a: "Z", (a + 1) % n: "Z"})
+    H0 += 0.6 * _cstring(n, {0: "X"}) - 0.4 * _cstring(n, {1: "Y"})
+    Hs = [_cstring(n, {k: "X"}) for k in range(2, 5)] + [0.5 * _cstring(n, {k: "Y"}) for k in range(3, 7)]
+    if extra:
+        Hs.append(_cstring(n, {2: "X", 7: "Y"}))
+        Hs.append(1.25 * _cstring(n, {5: "Y", 8 % n: "Z"}))
+    M = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    M = (M + M.conj().T) / 2
+    return H0, np.array(Hs), M
+
+
+@pytest.mark.parametrize("B", [5, 512])
+def test_complex_pauli_generator_matches_oracle_and_the_tape(oracle, B):
+    """X and Y drives: H complex Hermitian, sparse, XOR-regular with phases +-1 / +-i.  The complex column form (rows of
+    U = exp(-i dt H) built in LDS, gradients from the rows of Ubar) against the oracle and against the complex tape."""
+    n, S, dt = 9, 3, 2e-3
+    H0, Hs, M = _xy_problem(n, seed=3)
+    u = np.random.default_rng(2).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=4)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("real_hamiltonians") == 0 and e.info("xor_regular_found") == 11   # X_0, Y_1 (drift), 3 X, 4 Y, XY, YZ
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 2 and e.info("real_path") == 0
+        p1 = e.propagate(u, dt, psi0)
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 0
+    assert abs(l1 - rl) < TOL * max(1, B / 8) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+    assert np.max(np.abs(p1 - rf)) < TOL
+    assert abs(l1 - l0) < 1e-11 * max(1, B) and np.max(np.abs(g1 - g0)) < 1e-11 and np.max(np.abs(f1 - f0)) < 1e-12
+
+
+@pytest.mark.parametrize("n,B,S", [(8, 256, 6), (10, 64, 3), (12, 32, 2), (12, 4096, 2)])
+def test_complex_column_form_against_the_tape_up_to_the_headline_dimension(n, B, S):
+    """d = 256 .. 4096 (every workgroup shape), state form and operator form; the tape is the reference here."""
+    from diffquantum_amd.engine import Engine
+    dt = 5e-4
+    H0, Hs, M = _xy_problem(n, seed=n, extra=n >= 9)
+    u = np.random.default_rng(1).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=3)
+    with Engine(1 << n, len(Hs)) as e:
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(M)
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 2
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 0
+    assert abs(l1 - l0) < 1e-11 * B and np.max(np.abs(g1 - g0)) < 1e-11 and np.max(np.abs(f1 - f0)) < 1e-12
+    assert np.max(np.abs(g0)) > 1e-6
+
+
+def test_complex_generators_outside_the_class_keep_the_tape():
+    """A control with diagonal entries (Z_a), or an entry with both real and imaginary part: not in the complex table."""
+    n = 8
+    H0, Hs, M = _xy_problem(n, seed=1, extra=False)
+    u = np.random.default_rng(0).uniform(-1, 1, (2, len(Hs) + 1))
+    psi0 = problems.random_states(1 << n, 3, seed=1)
+    Hz = np.concatenate([Hs, _cstring(n, {2: "Z"})[None]])
+    with _engine(H0, Hz, M) as e:
+        assert e.info("xor_regular_found") == -1
+        e.energy_grad(u, 1e-3, psi0)
+        assert e.info("xor_regular") == 0
+    Hm = Hs.copy()
+    Hm[0] = Hm[0] + 0.5 * _cstring(n, {2: "Y"})            # X_2 + 0.5 Y_2: entries 1 -+ 0.5 i
+    with _engine(H0, Hm, M) as e:
+        assert e.info("xor_regular_found") == -1
