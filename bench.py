@@ -291,7 +291,8 @@ def roofline_blocks(prof, info, d):
         # column form: the class holds xr_forward_kernel / xr_reverse_kernel; booked flops = 2 per (row, diagonal, power, column)
         # with the diagonal included, so LDS reads = flops / 2 * R / (R + 1) doubles
         R = max(1.0, float(info["xor_regular_found"]))
-        lds_bytes = sp["flops"] / 2.0 * R / (R + 1.0) * 8.0
+        # (complex column form, xor_regular = 2: 8 booked flops and 16 B per gathered value)
+        lds_bytes = sp["flops"] * (2.0 if info["xor_regular"] > 1 else 4.0) * R / (R + 1.0)
         gbps = lds_bytes / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0
         tr, src = TRAFFIC["xr"]
         use_tr = d == 4096 and sp["launches"] > 0 and tr is not None
@@ -338,6 +339,11 @@ INFO_KEYS = ("degree", "squarings", "products", "theta", "checkpoint_stride", "t
 
 
 def describe_expm(info):
+    if info.get("xor_regular", 0) > 1:
+        return ("Taylor degree {0}: H complex Hermitian and a sum of Pauli strings ({1} XOR-diagonals with entries +-c or +-i c, a real "
+                "diagonal): every row of U = exp(-i dt H) is a chain of {0} complex sparse matrix-vector products held in LDS (xorexp.hip, "
+                "zxr_* kernels; no assembly, no tape, no MFMA product in the step exponential), theta<={2:.3g}".format(
+                    int(info["degree"]), int(info["xor_regular_found"]), info["theta"]))
     if info["sparse_generator"] > 0 and info.get("xor_regular", 0) > 0:
         return ("cos X + i sin X, Taylor degree {0}: drift and controls are sums of Pauli strings ({1} XOR-diagonals + the diagonal), so every "
                 "column of U is a chain of {2} sparse matrix-vector products held in LDS (xorexp.hip: no dense power, no MFMA product and "
@@ -434,6 +440,26 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
             ent, _ = scheme_entry(e2, torch, u_dev, a.dt, psi0, d, K, note)
         out[name] = ent
         torch.cuda.empty_cache()
+    # (3) X and Y drives: a complex Hermitian, sparse (Pauli-string) generator -- column form in complex arithmetic, and the same
+    # inputs on the general complex tape
+    H0, Hs, M = problems.xy_drives_torch(n, a.seed, dev, n_x=n // 2, n_y=n - n // 2)
+    with Engine(d, n, device=dev.index or 0) as e3:
+        e3.use_torch_stream()
+        e3.set_hamiltonians(H0, Hs)
+        e3.set_observable(M)
+        e3.set_option("plan_steps", max(a.chain, K))
+        del H0, Hs, M
+        ent, g3 = scheme_entry(e3, torch, u_dev, a.dt, psi0, d, K,
+                               "random Ising drift, X_k controls on half of the qubits and Y_k controls on the other half (I/Q drives): complex "
+                               "Hermitian and a sum of Pauli strings -- the rows of U = exp(-i dt H) built in LDS (complex column form, xorexp.hip)")
+        ent["xor_regular"] = e3.info("xor_regular")
+        out["xy_drives_complex_pauli_H"] = ent
+        e3.set_option("xor_regular", 0)
+        ent, g4 = scheme_entry(e3, torch, u_dev, a.dt, psi0, d, K,
+                               "the same X / Y-drive inputs on the general complex tape (structure ignored)")
+        ent["max_abs_grad_diff_vs_column_form"] = float((g4 - g3).abs().max().item())
+        out["xy_drives_complex_tape"] = ent
+    torch.cuda.empty_cache()
     return out
 
 

@@ -67,6 +67,25 @@ def random_ising_torch(n: int, seed: int, device):
     return H0, Hs, H0.clone()
 
 
+def xy_drives_torch(n: int, seed: int, device, n_x: int = 6, n_y: int = 6):
+    """Random Ising drift (as random_ising) with X_k controls on the first n_x qubits and Y_k controls on the last n_y ones: a
+    COMPLEX Hermitian, sparse generator (I/Q drives) built in device memory.  K = n_x + n_y controls; M = H0."""
+    import torch
+    d = 1 << n
+    diag = torch.from_numpy(ising_diagonal(n, seed)).to(device)
+    H0 = torch.zeros((d, d), dtype=torch.complex128, device=device)
+    H0.diagonal().copy_(diag.to(torch.complex128))
+    Hs = torch.zeros((n_x + n_y, d, d), dtype=torch.complex128, device=device)
+    idx = torch.arange(d, device=device)
+    for q in range(n_x):
+        Hs[q, idx, idx ^ (1 << (n - 1 - q))] = 1.0
+    for j in range(n_y):
+        e = 1 << (n - 1 - (n - n_y + j))
+        bit = ((idx & e) != 0).to(torch.float64)
+        Hs[n_x + j, idx, idx ^ e] = torch.complex(torch.zeros_like(bit), 2.0 * bit - 1.0)   # Y[0,1] = -i, Y[1,0] = +i
+    return H0, Hs, H0.clone()
+
+
 def random_dense_torch(n: int, K: int, seed: int, device, complex_h: bool = False, drift_norm1: float = 12.0,
                        control_norm1: float = 1.0):
     """(H0, Hs[K], M) DENSE random matrices built in device memory: real symmetric (stored complex128, imaginary parts

@@ -62,7 +62,7 @@ def test_column_form_class_is_priced_against_the_lds_array():
     prof = _prof(spmm={"launches": 60, "ms": 40 * 0.2 + 20 * 0.83, "flops": 40 * fwd + 20 * rev, "bytes": 60 * 16 * nn})
     b = bench.roofline_blocks(prof, {"zgemm_alg": 2.0, "xor_regular": 1.0, "xor_regular_found": float(R)}, d)
     s = b["spmm"]
-    lds = (40 * fwd + 20 * rev) / 2.0 * R / (R + 1.0) * 8.0
+    lds = (40 * fwd + 20 * rev) * 4.0 * R / (R + 1.0)
     assert s["bound"] == "lds" and s["peak"] == 256 * 256 * 2.4
     assert abs(s["achieved"] - lds / ((40 * 0.2 + 20 * 0.83) * 1e-3) / 1e9) < 1e-6
     assert 0.0 < s["frac"] < 1.0 and s["kernel"].startswith("xr_forward_kernel")

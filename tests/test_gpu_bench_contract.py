@@ -64,7 +64,9 @@ def test_bench_json_contract():
     for name in ("ising_inputs_sparse_row_kernels", "ising_inputs_sparse_controls_dense_drift", "ising_inputs_dense_real_path",
                  "ising_inputs_complex_tape"):
         assert st[name]["max_abs_grad_diff_vs_headline"] < 1e-10, name
-    assert st["ising_inputs_sparse_row_kernels"]["value"] > 0    # (d = 256 here: below the column-form kernels' sizes)
+    assert st["ising_inputs_sparse_row_kernels"]["value"] > 0
+    xy, xt = st["xy_drives_complex_pauli_H"], st["xy_drives_complex_tape"]   # complex Hermitian Pauli generator: column form vs tape
+    assert xy["xor_regular"] == 2 and xy["value"] > 0 and xt["value"] > 0 and xt["max_abs_grad_diff_vs_column_form"] < 1e-10
 
 
 def test_bench_general_path_only():
