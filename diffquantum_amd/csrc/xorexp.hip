@@ -566,23 +566,34 @@ struct ZxrRows {
 
 // o += s * (A~ - diag) v  with v in the LDS image `src` (interleaved re, im); DOT: dacc[j] += sigma (v_r x_i - v_i x_r) or
 // sigma (v_r x_r + v_i x_i) with x = xm (the thread's own rows)
-template <int NT, int RPT, bool SIGN, bool DOT>
+template <int NT, int RPT, bool SIGN, bool DOT, bool PAIR = false>
 __device__ __forceinline__ void zxr_gather(const XrTab& tab, const ZxrRows<NT, RPT, SIGN>& rw, const double2* __restrict__ src, int t,
                                            double s, double2* o, const double2* xm, double* dacc) {
-  typedef const volatile __attribute__((address_space(3))) double* lds_ptr;
-#pragma clang loop unroll(disable)
-  for (int j = 0; j < rw.R; ++j) {
+  typedef double zxr_v2 __attribute__((ext_vector_type(2)));
+  typedef const volatile __attribute__((address_space(3))) zxr_v2* lds_ptr;  // one ds_read_b128 per partner value
+  auto fetch = [&](int j, double* vr, double* vi) {
     const int xo = tab.xoff[j];
+    lds_ptr base = (lds_ptr)(src + (t ^ (xo & (NT - 1))));
+    if (xo < NT) {  // (wave-uniform) immediate offsets
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const zxr_v2 v = base[r * NT];
+        vr[r] = v.x;
+        vi[r] = v.y;
+      }
+    } else {
+      const int xh = xo / NT;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const zxr_v2 v = base[(r ^ xh) * NT];
+        vr[r] = v.x;
+        vi[r] = v.y;
+      }
+    }
+  };
+  auto use = [&](int j, double* vr, double* vi) {
     const double w = s * rw.Wl[j];
     const int phj = rw.ph[j];
-    lds_ptr base = (lds_ptr)(src + (t ^ (xo & (NT - 1))));
-    const int xh = xo / NT;
-    double vr[RPT], vi[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      vr[r] = base[2 * ((r ^ xh) * NT)];
-      vi[r] = base[2 * ((r ^ xh) * NT) + 1];
-    }
     if (SIGN) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
@@ -615,6 +626,21 @@ __device__ __forceinline__ void zxr_gather(const XrTab& tab, const ZxrRows<NT, R
       }
       xr_acc<0, XR_RMAX>(dacc, j, d);
     }
+  };
+  int j = 0;
+#pragma clang loop unroll(disable)
+  for (; PAIR && j + 1 < rw.R; j += 2) {
+    double ar[RPT], ai[RPT], br[RPT], bi[RPT];
+    fetch(j, ar, ai);
+    fetch(j + 1, br, bi);
+    use(j, ar, ai);
+    use(j + 1, br, bi);
+  }
+#pragma clang loop unroll(disable)
+  for (; j < rw.R; ++j) {
+    double ar[RPT], ai[RPT];
+    fetch(j, ar, ai);
+    use(j, ar, ai);
   }
 }
 
@@ -652,7 +678,7 @@ __global__ void __launch_bounds__(NT) zxr_forward_kernel(double2* __restrict__ U
         o[r].x = rw.dg[r] * cur[r].y;
         o[r].y = -rw.dg[r] * cur[r].x;
       }
-      zxr_gather<NT, RPT, SIGN, false>(tab, rw, lds + p * D, t, 1.0, o, nullptr, nullptr);
+      zxr_gather<NT, RPT, SIGN, false, true>(tab, rw, lds + p * D, t, 1.0, o, nullptr, nullptr);
       const double inv = 1.0 / m;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
@@ -712,7 +738,7 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
         o[r].x = rw.dg[r] * cur[r].y;
         o[r].y = -rw.dg[r] * cur[r].x;
       }
-      zxr_gather<NT, RPT, SIGN, false>(tab, rw, lds + p * D, t, 1.0, o, nullptr, nullptr);
+      zxr_gather<NT, RPT, SIGN, false, true>(tab, rw, lds + p * D, t, 1.0, o, nullptr, nullptr);
       const double inv = 1.0 / m;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
