@@ -2052,17 +2052,24 @@ void find_zxor_regular(Ctx<T>* c) {
   struct Grp { int x, kid, phase; long count; double mag; };
   std::vector<Grp> groups;
   std::vector<unsigned> sgn((size_t)d, 0u);
-  std::vector<double> dval((size_t)d, 0.0);
-  bool have_diag = false, have_imag = false;
+  std::vector<int> dsrc;      // sources with (real) diagonal entries: the drift, Z-type controls
+  std::vector<double> dval;
+  bool have_imag = false;
   for (int sidx = 0; sidx < NS; ++sidx)      // source 0 = drift (kid -1), source k + 1 = control k
     for (int i = 0; i < d; ++i) {
       const long e0 = base[(size_t)sidx * d + i];
       for (long e = e0; e < e0 + cnt[(size_t)sidx * d + i]; ++e) {
         const int x = col[e] ^ i, kid = sidx - 1;
         if (x == 0) {
-          if (kid >= 0 || im[e] != 0.0) return;  // (controls with diagonal entries: not built for the complex table)
-          dval[i] += re[e];
-          have_diag = true;
+          if (im[e] != 0.0) return;  // (Hermitian: cannot happen beyond rounding; be strict)
+          size_t jd = 0;
+          while (jd < dsrc.size() && dsrc[jd] != kid) ++jd;
+          if (jd == dsrc.size()) {
+            if ((int)dsrc.size() == dq::XR_DMAX) return;
+            dsrc.push_back(kid);
+            dval.resize(dsrc.size() * (size_t)d, 0.0);
+          }
+          dval[jd * (size_t)d + i] += re[e];
           continue;
         }
         if (re[e] != 0.0 && im[e] != 0.0) return;  // phases +-1 / +-i only
@@ -2091,15 +2098,16 @@ void find_zxor_regular(Ctx<T>* c) {
   dq::XrTab tab;
   memset(&tab, 0, sizeof(tab));
   tab.R = (int)groups.size();
-  tab.nd = have_diag ? 1 : 0;
-  tab.dkid[0] = -1;
+  tab.nd = (int)dsrc.size();
+  for (int j = 0; j < tab.nd; ++j) tab.dkid[j] = dsrc[j];
   for (int j = 0; j < tab.R; ++j) {
     tab.xoff[j] = groups[j].x; tab.kid[j] = groups[j].kid; tab.cmag[j] = groups[j].mag; tab.phase[j] = groups[j].phase;
   }
   c->xr_sgn.ensure(sizeof(unsigned) * (size_t)d);
-  c->xr_dval.ensure(sizeof(double) * (size_t)d);
+  c->xr_dval.ensure(sizeof(double) * std::max<size_t>(dval.size(), 1));
   HIPCK(hipMemcpyAsync(c->xr_sgn.p, sgn.data(), sizeof(unsigned) * (size_t)d, hipMemcpyHostToDevice, c->st));
-  HIPCK(hipMemcpyAsync(c->xr_dval.p, dval.data(), sizeof(double) * (size_t)d, hipMemcpyHostToDevice, c->st));
+  if (!dval.empty())
+    HIPCK(hipMemcpyAsync(c->xr_dval.p, dval.data(), sizeof(double) * dval.size(), hipMemcpyHostToDevice, c->st));
   HIPCK(hipStreamSynchronize(c->st));
   tab.sgn = (const unsigned*)c->xr_sgn.p;
   tab.dval = (const double*)c->xr_dval.p;

@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(NT) zxr_forward_kernel(double2* __restrict__ U
 
 // part[(z * gridDim.x + blockIdx.x) * XR_SLOTS + j] = this workgroup's share of sum_c sum_a of the level dot products of
 // XOR-diagonal j (before the factors cmag_j and dt); xpow: per workgroup the powers x_1 .. x_{L-1} of the current row
-template <int NT, int RPT, bool SIGN>
+template <int NT, int RPT, bool SIGN, bool DIAGCTL>
 __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restrict__ G, long stride, XrTab tab,
                                                          const double* __restrict__ u, int K, double dt, int L,
                                                          double* __restrict__ part, double2* __restrict__ xpow) {
@@ -715,9 +715,11 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
   ZxrRows<NT, RPT, SIGN> rw;
   rw.load(tab, u + z * K, dt, t, xr_lds_raw + 32 * D, (double*)(xr_lds_raw + 32 * D + D));
   double2* xp = xpow + (z * gridDim.x + blockIdx.x) * (long)(L - 1) * D + t;  // [a - 1][r * NT + t], a = 1 .. L - 1
-  double dacc[XR_RMAX];
+  double dacc[XR_RMAX], rowacc[DIAGCTL ? RPT : 1];  // rowacc: sum over levels and rows c of Im(conj(y_a[i]) x_a[i]) (diagonal controls)
 #pragma unroll
   for (int j = 0; j < XR_RMAX; ++j) dacc[j] = 0.0;
+#pragma unroll
+  for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
   int p = 1;
   for (int c = blockIdx.x; c < D; c += gridDim.x) {
     const double2* grow = G + z * stride + (long)c * D + t;
@@ -776,6 +778,7 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
         const double2 g = grow[r * NT];
         o[r].x = g.x - rw.dg[r] * cur[r].y;   // g - (-i dg y)
         o[r].y = g.y + rw.dg[r] * cur[r].x;
+        if (DIAGCTL) rowacc[r] += cur[r].x * xm[r].y - cur[r].y * xm[r].x;
       }
       zxr_gather<NT, RPT, SIGN, true>(tab, rw, lds + p * D, t, -1.0, o, xm, dacc);
       const double inv = 1.0 / a;
@@ -797,15 +800,29 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
         xr_acc<0, XR_RMAX>(dacc, j, b ? -d : d);
       }
     }
+    if (DIAGCTL) {  // level 0 of the diagonal controls: x_0 = e_c, Im(conj(y_0[c])) = -Im y_0[c]
+#pragma unroll
+      for (int r = 0; r < RPT; ++r)
+        if ((r * NT + t) == c) rowacc[r] -= cur[r].y;
+    }
   }
   __syncthreads();
   double* red = (double*)xr_lds_raw;  // [NT / 64][XR_SLOTS]
   const int lane = t & 63, wave = t >> 6;
 #pragma unroll
-  for (int j = 0; j < XR_SLOTS; ++j) {
-    double v = j < XR_RMAX ? dacc[j < XR_RMAX ? j : 0] : 0.0;
+  for (int j = 0; j < XR_RMAX; ++j) {
+    double v = dacc[j];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0) red[wave * XR_SLOTS + j] = v;
+  }
+  for (int j = 0; j < XR_DMAX; ++j) {
+    double v = 0.0;
+    if (DIAGCTL && j < tab.nd && tab.dkid[j] >= 0) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) v = __builtin_fma(tab.dval[(long)j * D + r * NT + t], rowacc[r], v);
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave * XR_SLOTS + XR_RMAX + j] = v;
   }
   __syncthreads();
   if (t < XR_SLOTS) {
@@ -852,8 +869,12 @@ static hipError_t zxr_reverse_go(const double2* G, long stride, const XrTab& tab
                                  double* part, double2* xpow, hipStream_t st) {
   const size_t lds = zxr_lds_bytes(NT * RPT);
   const dim3 grid((unsigned)xr_blocks(NT * RPT, batch), (unsigned)batch);
+  bool dc = false;
+  for (int j = 0; j < tab.nd; ++j) dc = dc || tab.dkid[j] >= 0;
+  if (dc && !tab.sgn) return hipErrorInvalidValue;  // (the full variant reads the sign words; complex tables always carry them)
   void (*kf)(const double2*, long, XrTab, const double*, int, double, int, double*, double2*) =
-      tab.sgn ? zxr_reverse_kernel<NT, RPT, true> : zxr_reverse_kernel<NT, RPT, false>;
+      dc ? zxr_reverse_kernel<NT, RPT, true, true>
+         : (tab.sgn ? zxr_reverse_kernel<NT, RPT, true, false> : zxr_reverse_kernel<NT, RPT, false, false>);
   (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tab, u, K, dt, L, part, xpow);
   return hipGetLastError();
@@ -865,8 +886,6 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
   (void)zero_sgn;
   if (batch <= 0) return hipSuccess;
   if (!zxr_supported(d, L, tab.R, tab.nd) || !xpow) return hipErrorInvalidValue;
-  for (int j = 0; j < tab.nd; ++j)
-    if (tab.dkid[j] >= 0) return hipErrorInvalidValue;  // (controls with diagonal entries: not built for the complex table)
   hipError_t e;
   switch (d) {
     case 4096: e = zxr_reverse_go<1024, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;

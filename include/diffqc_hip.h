@@ -132,8 +132,8 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      of one magnitude: sums of real Pauli strings, e.g. an Ising drift with X_k controls) takes the column-form
  *                      kernels of csrc/xorexp.hip (dim 256 .. 4096, polynomial q <= 6): U and the control gradients
  *                      column by column in LDS, no dense intermediate; 0 = the row-wise sparse x dense passes.  Complex Hermitian
- *                      generators of the same kind (X and Y drives: XOR-diagonals with entries +-c or +-i c, real diagonal from the
- *                      drift; complex128) take the complex form of the same kernels instead of the tape (info "xor_regular" = 2).
+ *                      generators of the same kind (X and Y drives: XOR-diagonals with entries +-c or +-i c, real diagonals: X, Y and Z
+ *                      drives; complex128) take the complex form of the same kernels instead of the tape (info "xor_regular" = 2).
  *                      dq_get_info("xor_regular_found") = number of XOR-diagonals found (-1: not of that class),
  *                      ("xor_regular") = 1 if the last call ran the column form
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)

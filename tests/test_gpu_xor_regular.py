@@ -310,17 +310,35 @@ def test_complex_column_form_against_the_tape_up_to_the_headline_dimension(n, B,
 
 
 def test_complex_generators_outside_the_class_keep_the_tape():
-    """A control with diagonal entries (Z_a), or an entry with both real and imaginary part: not in the complex table."""
+    """An entry with both a real and an imaginary part (X_a + 0.5 Y_a in ONE control) is not in the complex table."""
     n = 8
     H0, Hs, M = _xy_problem(n, seed=1, extra=False)
-    u = np.random.default_rng(0).uniform(-1, 1, (2, len(Hs) + 1))
+    Hm = Hs.copy()
+    Hm[0] = Hm[0] + 0.5 * _cstring(n, {2: "Y"})            # X_2 + 0.5 Y_2: entries 1 -+ 0.5 i
+    u = np.random.default_rng(0).uniform(-1, 1, (2, len(Hs)))
     psi0 = problems.random_states(1 << n, 3, seed=1)
-    Hz = np.concatenate([Hs, _cstring(n, {2: "Z"})[None]])
-    with _engine(H0, Hz, M) as e:
+    with _engine(H0, Hm, M) as e:
         assert e.info("xor_regular_found") == -1
         e.energy_grad(u, 1e-3, psi0)
         assert e.info("xor_regular") == 0
-    Hm = Hs.copy()
-    Hm[0] = Hm[0] + 0.5 * _cstring(n, {2: "Y"})            # X_2 + 0.5 Y_2: entries 1 -+ 0.5 i
-    with _engine(H0, Hm, M) as e:
-        assert e.info("xor_regular_found") == -1
+
+
+@pytest.mark.parametrize("B", [4, 256])
+def test_complex_generator_with_z_controls(oracle, B):
+    """X, Y and Z drives together: controls with diagonal entries ride in the offset-0 part of the complex table (their gradients
+    come from a per-row accumulator), one control mixes an XOR-diagonal with diagonal entries (Y_a + 0.5 Z_b)."""
+    n, S, dt = 8, 4, 2e-3
+    H0, Hs, M = _xy_problem(n, seed=5, extra=False)
+    Hs = np.concatenate([Hs, _cstring(n, {2: "Z"})[None], (_cstring(n, {6: "Y"}) + 0.5 * _cstring(n, {1: "Z", 3: "Z"}))[None]])
+    u = np.random.default_rng(3).uniform(-1, 1, (S, len(Hs)))
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        assert e.info("xor_regular_found") >= 9
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("xor_regular") == 2
+        e.set_option("xor_regular", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+    assert abs(l1 - rl) < TOL * max(1, B / 8) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
+    assert abs(l1 - l0) < 1e-11 * max(1, B) and np.max(np.abs(g1 - g0)) < 1e-11
+    assert np.max(np.abs(rg[:, -2:])) > 1e-5           # (the Z-type controls' gradients are not zeros)
