@@ -240,7 +240,8 @@ hipError_t rsp_reduce_launch(const double* nzval, long nnz, const long* kptr, co
 
 // ---- xorexp.hip: sparse generator with an XOR-regular pattern: besides offset-0 diagonals, row i holds exactly the entries
 // (i, i ^ xoff[j]), j < R, each XOR-diagonal from one control and of constant magnitude ----
-constexpr int XR_RMAX = 16;  // off-diagonal XOR-diagonals
+constexpr int XR_RMAX = 32;  // off-diagonal XOR-diagonals (table capacity; sign words are 32 bits)
+constexpr int XR_RSMALL = 16; // reverse kernels come with 16 or 32 per-diagonal accumulators (register budget)
 constexpr int XR_DMAX = 16;  // diagonals at offset 0 (one per source matrix that has diagonal entries; any per-row values)
 constexpr int XR_SLOTS = XR_RMAX + XR_DMAX;
 constexpr int XR_QMAX = 6;   // cos / sin polynomial: powers X_1 .. X_{2q+1}

@@ -105,7 +105,7 @@ __device__ __forceinline__ void xr_acc(double* dacc, int j, double s) {
 // one sweep  o += (X - diag) v  with v in LDS image `src`; optional dot products with xm[] (DOT).  The loop over the
 // diagonals is a runtime loop on purpose: unrolled, the compiler hoists sign masks and LDS addresses of all R diagonals out of
 // the column loop, prefetches across diagonals and spills hundreds of registers.
-template <class T, int NT, int RPT, bool SIGN, bool DOT, bool PAIR>
+template <class T, int NT, int RPT, bool SIGN, bool DOT, bool PAIR, int RM = XR_RSMALL>
 __device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, RPT, SIGN>& rw, const T* __restrict__ src, int t, T* o,
                                           const T* xm, double* dacc) {
   // PAIR: two diagonals per trip (16 LDS reads in flight per lane) -- not where that spills (reverse kernel with sign words)
@@ -136,7 +136,7 @@ __device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, 
       T s = 0;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) s = xr_fma(vs[r], xm[r], s);
-      xr_acc<0, XR_RMAX>(dacc, j, (double)s);
+      xr_acc<0, RM>(dacc, j, (double)s);
     }
   };
   int j = 0;
@@ -158,15 +158,15 @@ __device__ __forceinline__ void xr_gather(const XrTab& tab, const XrRows<T, NT, 
 
 // level 0 of the gradient, by lane 0 of the workgroup: xbar_1 (LDS image `src`) pairs with x_0 = e_c, i.e. the entries
 // (c, c ^ x_j) -- sign taken at row c ^ x_j (the diagonals are symmetric)
-template <class T, int J>
+template <class T, int RM, int J>
 __device__ __forceinline__ void xr_level0(const XrTab& tab, const T* __restrict__ src, int c, double* dacc) {
-  if constexpr (J < XR_RMAX) {
+  if constexpr (J < RM) {
     if (J < tab.R) {
       const int row = c ^ tab.xoff[J];
       const unsigned bit = tab.sgn ? (tab.sgn[row] >> J) & 1u : 0u;
       dacc[J] += (double)xr_flip(src[row], bit);
     }
-    xr_level0<T, J + 1>(tab, src, c, dacc);
+    xr_level0<T, RM, J + 1>(tab, src, c, dacc);
   }
 }
 
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(NT, (NT * 2 + 255) / 256) xr_forward_kernel(ty
 // Cache) -- in registers they cost 2 (2q - 1) RPT VGPRs, pin the kernel to 8 waves per CU and q to a template parameter
 // (measured: the same speed).  x_1 is rebuilt from the lookup table.  LDS: four images (the two of the sweeps, cbar, sbar);
 // NT = D / 4 threads (16 waves per CU at D = 4096), one workgroup per CU.
-template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL>
+template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM>
 __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::type* __restrict__ G, long stride, XrTab tab,
                                                                const double* __restrict__ u, int K, double mdt, XrPoly pol,
                                                                double* __restrict__ part, T* __restrict__ xpow) {
@@ -255,9 +255,9 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
   XrRows<T, NT, RPT, SIGN> rw;
   rw.load(tab, u + z * K, mdt, t, xr_lds_raw + 4 * sizeof(T) * D, (T*)(xr_lds_raw + 4 * sizeof(T) * D + D));
   T* xp = xpow + (z * gridDim.x + blockIdx.x) * (long)(npm1 - 1) * D + t;  // [m - 2][r * NT + t]
-  double dacc[XR_RMAX], rowacc[RPT];
+  double dacc[RM], rowacc[RPT];
 #pragma unroll
-  for (int j = 0; j < XR_RMAX; ++j) dacc[j] = 0.0;
+  for (int j = 0; j < RM; ++j) dacc[j] = 0.0;
 #pragma unroll
   for (int r = 0; r < RPT; ++r) rowacc[r] = 0.0;
   int p = 1;
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
         o[r] = xr_fma(cf, add[r * NT + t], rw.dg[r] * cur[r]);
         if (DIAGCTL) rowacc[r] = __builtin_fma((double)cur[r], (double)xmm[r], rowacc[r]);
       }
-      xr_gather<T, NT, RPT, SIGN, true, !DIAGCTL>(tab, rw, lds + p * D, t, o, xmm, dacc);
+      xr_gather<T, NT, RPT, SIGN, true, !DIAGCTL, RM>(tab, rw, lds + p * D, t, o, xmm, dacc);
       p ^= 1;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
       }
       __syncthreads();
     }
-    if (t == 0) xr_level0<T, 0>(tab, lds + p * D, c, dacc);
+    if (t == 0) xr_level0<T, RM, 0>(tab, lds + p * D, c, dacc);
     if (DIAGCTL) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r)
@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
     if (lane == 0) red[wave * XR_SLOTS + slot] = v;
   };
 #pragma unroll
-  for (int j = 0; j < XR_RMAX; ++j) put(j, dacc[j]);
+  for (int j = 0; j < RM; ++j) put(j, dacc[j]);
+  for (int j = RM; j < XR_RMAX; ++j) put(j, 0.0);
   for (int j = 0; j < XR_DMAX; ++j) {
     double v = 0.0;
     if (DIAGCTL && j < tab.nd && tab.dkid[j] >= 0) {
@@ -360,19 +361,21 @@ __global__ void __launch_bounds__(NT) xr_reverse_kernel(const typename Cx<T>::ty
 
 // grad[z][k] (+)= scale * (sum_j [kid_j == k] cmag_j sum_b part[z][b][j] + sum_j [dkid_j == k] sum_b part[z][b][XR_RMAX + j])
 // One workgroup per step: 32 lanes per slot, lane l adds the workgroups l, l + 32, ... in order, then a fixed butterfly.
-__global__ void __launch_bounds__(XR_SLOTS * 32) xr_finish_kernel(const double* __restrict__ part, int nblk, XrTab tab, int K,
-                                                                  double scale, double* __restrict__ grad, int accumulate) {
+__global__ void __launch_bounds__(1024) xr_finish_kernel(const double* __restrict__ part, int nblk, XrTab tab, int K, double scale,
+                                                         double* __restrict__ grad, int accumulate) {
   const long z = blockIdx.x;
-  const int slot = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int l = threadIdx.x & 31;
   __shared__ double s_j[XR_SLOTS];
-  const bool live = slot < XR_RMAX ? slot < tab.R : (slot - XR_RMAX < tab.nd && tab.dkid[slot - XR_RMAX] >= 0);
-  double s = 0.0;
-  if (live)
-    for (int b = l; b < nblk; b += 32) s += part[(z * nblk + b) * XR_SLOTS + slot];
-  for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
-  if (l == 0) s_j[slot] = live ? s * (slot < XR_RMAX ? tab.cmag[slot] : 1.0) : 0.0;
+  for (int slot = threadIdx.x >> 5; slot < XR_SLOTS; slot += 32) {
+    const bool live = slot < XR_RMAX ? slot < tab.R : (slot - XR_RMAX < tab.nd && tab.dkid[slot - XR_RMAX] >= 0);
+    double s = 0.0;
+    if (live)
+      for (int b = l; b < nblk; b += 32) s += part[(z * nblk + b) * XR_SLOTS + slot];
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+    if (l == 0) s_j[slot] = live ? s * (slot < XR_RMAX ? tab.cmag[slot] : 1.0) : 0.0;
+  }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += XR_SLOTS * 32) {
+  for (int k = threadIdx.x; k < K; k += 1024) {
     double g = accumulate ? grad[z * K + k] : 0.0;
     for (int q = 0; q < tab.R; ++q)
       if (tab.kid[q] == k) g += scale * s_j[q];
@@ -431,7 +434,7 @@ hipError_t xr_forward_launch(float2* U, long stride, int d, const XrTab& tab, co
   return xr_forward_t<float>(U, stride, d, tab, u, K, dt, pol, batch, st);
 }
 
-template <class T, int NT, int RPT>
+template <class T, int NT, int RPT, int RM>
 static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, const XrTab& tab, const double* u, int K,
                                        double mdt, const XrPoly& pol, int batch, double* part, const unsigned* zero_sgn, T* xpow,
                                        hipStream_t st) {
@@ -443,7 +446,7 @@ static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, cons
   if (full && !tb.sgn) tb.sgn = zero_sgn;
   if (full && !tb.sgn) return hipErrorInvalidValue;
   void (*kf)(const typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly, double*, T*) =
-      full ? xr_reverse_kernel<T, NT, RPT, true, true> : xr_reverse_kernel<T, NT, RPT, false, false>;
+      full ? xr_reverse_kernel<T, NT, RPT, true, true, RM> : xr_reverse_kernel<T, NT, RPT, false, false, RM>;
   (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tb, u, K, mdt, pol, part, xpow);
   return hipGetLastError();
@@ -462,15 +465,25 @@ static hipError_t xr_reverse_t(const typename Cx<T>::type* G, long stride, int d
   if (batch <= 0) return hipSuccess;
   if (!xr_supported(d, pol.q, tab.R, tab.nd, sizeof(T)) || !xpow) return hipErrorInvalidValue;
   hipError_t e;
-  switch (d) {
-    case 4096: e = xr_reverse_go<T, 1024, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    case 2048: e = xr_reverse_go<T, 512, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    case 1024: e = xr_reverse_go<T, 256, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    case 512: e = xr_reverse_go<T, 128, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
-    default: e = xr_reverse_go<T, 64, 4>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
+  if (tab.R <= XR_RSMALL) {  // 16 accumulators: 4 rows per thread, d / 4 threads
+    switch (d) {
+      case 4096: e = xr_reverse_go<T, 1024, 4, XR_RSMALL>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      case 2048: e = xr_reverse_go<T, 512, 4, XR_RSMALL>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      case 1024: e = xr_reverse_go<T, 256, 4, XR_RSMALL>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      case 512: e = xr_reverse_go<T, 128, 4, XR_RSMALL>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      default: e = xr_reverse_go<T, 64, 4, XR_RSMALL>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
+    }
+  } else {  // up to 32 accumulators (64 VGPRs): 8 rows per thread, d / 8 threads, so that a lane may use 256 registers
+    switch (d) {
+      case 4096: e = xr_reverse_go<T, 512, 8, XR_RMAX>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      case 2048: e = xr_reverse_go<T, 256, 8, XR_RMAX>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      case 1024: e = xr_reverse_go<T, 128, 8, XR_RMAX>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      case 512: e = xr_reverse_go<T, 64, 8, XR_RMAX>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st); break;
+      default: e = xr_reverse_go<T, 64, 4, XR_RMAX>(G, stride, tab, u, K, -dt, pol, batch, part, zero_sgn, xpow, st);
+    }
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d, batch), tab, K, -dt, grad,
+  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(1024), 0, st, part, xr_blocks(d, batch), tab, K, -dt, grad,
                      accumulate);
   return hipGetLastError();
 }
@@ -566,7 +579,7 @@ struct ZxrRows {
 
 // o += s * (A~ - diag) v  with v in the LDS image `src` (interleaved re, im); DOT: dacc[j] += sigma (v_r x_i - v_i x_r) or
 // sigma (v_r x_r + v_i x_i) with x = xm (the thread's own rows)
-template <int NT, int RPT, bool SIGN, bool DOT, bool PAIR = false>
+template <int NT, int RPT, bool SIGN, bool DOT, bool PAIR = false, int RM = XR_RSMALL>
 __device__ __forceinline__ void zxr_gather(const XrTab& tab, const ZxrRows<NT, RPT, SIGN>& rw, const double2* __restrict__ src, int t,
                                            double s, double2* o, const double2* xm, double* dacc) {
   typedef double zxr_v2 __attribute__((ext_vector_type(2)));
@@ -624,7 +637,7 @@ __device__ __forceinline__ void zxr_gather(const XrTab& tab, const ZxrRows<NT, R
 #pragma unroll
         for (int r = 0; r < RPT; ++r) d = __builtin_fma(vr[r], xm[r].y, __builtin_fma(-vi[r], xm[r].x, d));
       }
-      xr_acc<0, XR_RMAX>(dacc, j, d);
+      xr_acc<0, RM>(dacc, j, d);
     }
   };
   int j = 0;
@@ -703,7 +716,7 @@ __global__ void __launch_bounds__(NT) zxr_forward_kernel(double2* __restrict__ U
 
 // part[(z * gridDim.x + blockIdx.x) * XR_SLOTS + j] = this workgroup's share of sum_c sum_a of the level dot products of
 // XOR-diagonal j (before the factors cmag_j and dt); xpow: per workgroup the powers x_1 .. x_{L-1} of the current row
-template <int NT, int RPT, bool SIGN, bool DIAGCTL>
+template <int NT, int RPT, bool SIGN, bool DIAGCTL, int RM>
 __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restrict__ G, long stride, XrTab tab,
                                                          const double* __restrict__ u, int K, double dt, int L,
                                                          double* __restrict__ part, double2* __restrict__ xpow) {
@@ -715,9 +728,9 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
   ZxrRows<NT, RPT, SIGN> rw;
   rw.load(tab, u + z * K, dt, t, xr_lds_raw + 32 * D, (double*)(xr_lds_raw + 32 * D + D));
   double2* xp = xpow + (z * gridDim.x + blockIdx.x) * (long)(L - 1) * D + t;  // [a - 1][r * NT + t], a = 1 .. L - 1
-  double dacc[XR_RMAX], rowacc[DIAGCTL ? RPT : 1];  // rowacc: sum over levels and rows c of Im(conj(y_a[i]) x_a[i]) (diagonal controls)
+  double dacc[RM], rowacc[DIAGCTL ? RPT : 1];  // rowacc: sum over levels and rows c of Im(conj(y_a[i]) x_a[i]) (diagonal controls)
 #pragma unroll
-  for (int j = 0; j < XR_RMAX; ++j) dacc[j] = 0.0;
+  for (int j = 0; j < RM; ++j) dacc[j] = 0.0;
 #pragma unroll
   for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
   int p = 1;
@@ -780,7 +793,7 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
         o[r].y = g.y + rw.dg[r] * cur[r].x;
         if (DIAGCTL) rowacc[r] += cur[r].x * xm[r].y - cur[r].y * xm[r].x;
       }
-      zxr_gather<NT, RPT, SIGN, true>(tab, rw, lds + p * D, t, -1.0, o, xm, dacc);
+      zxr_gather<NT, RPT, SIGN, true, false, RM>(tab, rw, lds + p * D, t, -1.0, o, xm, dacc);
       const double inv = 1.0 / a;
       p ^= 1;
 #pragma unroll
@@ -797,7 +810,7 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
         const double2 v = lds[p * D + (c ^ tab.xoff[j])];
         const unsigned b = tab.sgn ? (tab.sgn[c] >> j) & 1u : 0u;
         const double d = tab.phase[j] ? v.x : -v.y;
-        xr_acc<0, XR_RMAX>(dacc, j, b ? -d : d);
+        xr_acc<0, RM>(dacc, j, b ? -d : d);
       }
     }
     if (DIAGCTL) {  // level 0 of the diagonal controls: x_0 = e_c, Im(conj(y_0[c])) = -Im y_0[c]
@@ -811,7 +824,7 @@ __global__ void __launch_bounds__(NT) zxr_reverse_kernel(const double2* __restri
   const int lane = t & 63, wave = t >> 6;
 #pragma unroll
   for (int j = 0; j < XR_RMAX; ++j) {
-    double v = dacc[j];
+    double v = j < RM ? dacc[j < RM ? j : 0] : 0.0;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0) red[wave * XR_SLOTS + j] = v;
   }
@@ -864,7 +877,7 @@ hipError_t zxr_forward_launch(double2* U, long stride, int d, const XrTab& tab, 
   }
 }
 
-template <int NT, int RPT>
+template <int NT, int RPT, int RM>
 static hipError_t zxr_reverse_go(const double2* G, long stride, const XrTab& tab, const double* u, int K, double dt, int L, int batch,
                                  double* part, double2* xpow, hipStream_t st) {
   const size_t lds = zxr_lds_bytes(NT * RPT);
@@ -873,8 +886,8 @@ static hipError_t zxr_reverse_go(const double2* G, long stride, const XrTab& tab
   for (int j = 0; j < tab.nd; ++j) dc = dc || tab.dkid[j] >= 0;
   if (dc && !tab.sgn) return hipErrorInvalidValue;  // (the full variant reads the sign words; complex tables always carry them)
   void (*kf)(const double2*, long, XrTab, const double*, int, double, int, double*, double2*) =
-      dc ? zxr_reverse_kernel<NT, RPT, true, true>
-         : (tab.sgn ? zxr_reverse_kernel<NT, RPT, true, false> : zxr_reverse_kernel<NT, RPT, false, false>);
+      dc ? zxr_reverse_kernel<NT, RPT, true, true, RM>
+         : (tab.sgn ? zxr_reverse_kernel<NT, RPT, true, false, RM> : zxr_reverse_kernel<NT, RPT, false, false, RM>);
   (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tab, u, K, dt, L, part, xpow);
   return hipGetLastError();
@@ -887,16 +900,26 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
   if (batch <= 0) return hipSuccess;
   if (!zxr_supported(d, L, tab.R, tab.nd) || !xpow) return hipErrorInvalidValue;
   hipError_t e;
-  switch (d) {
-    case 4096: e = zxr_reverse_go<1024, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
-    case 2048: e = zxr_reverse_go<512, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
-    case 1024: e = zxr_reverse_go<256, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
-    case 512: e = zxr_reverse_go<128, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
-    default: e = zxr_reverse_go<64, 4>(G, stride, tab, u, K, dt, L, batch, part, xpow, st);
+  if (tab.R <= XR_RSMALL) {
+    switch (d) {
+      case 4096: e = zxr_reverse_go<1024, 4, XR_RSMALL>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      case 2048: e = zxr_reverse_go<512, 4, XR_RSMALL>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      case 1024: e = zxr_reverse_go<256, 4, XR_RSMALL>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      case 512: e = zxr_reverse_go<128, 4, XR_RSMALL>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      default: e = zxr_reverse_go<64, 4, XR_RSMALL>(G, stride, tab, u, K, dt, L, batch, part, xpow, st);
+    }
+  } else {
+    switch (d) {
+      case 4096: e = zxr_reverse_go<512, 8, XR_RMAX>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      case 2048: e = zxr_reverse_go<256, 8, XR_RMAX>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      case 1024: e = zxr_reverse_go<128, 8, XR_RMAX>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      case 512: e = zxr_reverse_go<64, 8, XR_RMAX>(G, stride, tab, u, K, dt, L, batch, part, xpow, st); break;
+      default: e = zxr_reverse_go<64, 4, XR_RMAX>(G, stride, tab, u, K, dt, L, batch, part, xpow, st);
+    }
   }
   if (e != hipSuccess) return e;
   // dL/du_k = +dt * sum_j [kid_j == k] cmag_j * (sum of the workgroups' parts)
-  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(XR_SLOTS * 32), 0, st, part, xr_blocks(d, batch), tab, K, dt, grad,
+  hipLaunchKernelGGL(xr_finish_kernel, dim3((unsigned)batch), dim3(1024), 0, st, part, xr_blocks(d, batch), tab, K, dt, grad,
                      accumulate);
   return hipGetLastError();
 }

@@ -342,3 +342,27 @@ def test_complex_generator_with_z_controls(oracle, B):
     assert abs(l1 - rl) < TOL * max(1, B / 8) and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
     assert abs(l1 - l0) < 1e-11 * max(1, B) and np.max(np.abs(g1 - g0)) < 1e-11
     assert np.max(np.abs(rg[:, -2:])) > 1e-5           # (the Z-type controls' gradients are not zeros)
+
+
+def test_more_than_sixteen_xor_diagonals(oracle):
+    """17 .. 32 XOR-diagonals take the reverse kernels with 32 accumulators (8 rows per thread): real generator with X_k and
+    X_k X_k+1 controls (18 diagonals), complex generator with X_k and Y_k on every qubit (18 diagonals: full I/Q control)."""
+    n, S, B, dt = 9, 3, 6, 1e-3
+    rng = np.random.default_rng(12)
+    d = 1 << n
+    H0 = np.zeros((d, d))
+    for a in range(n):
+        H0 += rng.standard_normal() * _string(n, {a: "Z"}) + rng.standard_normal() * _string(n, {a: "Z", (a + 1) % n: "Z"})
+    Hr = [_string(n, {k: "X"}) for k in range(n)] + [0.5 * _string(n, {k: "X", (k + 1) % n: "X"}) for k in range(n)]
+    Hc = [_cstring(n, {k: "X"}) for k in range(n)] + [_cstring(n, {k: "Y"}) for k in range(n)]
+    M = rng.standard_normal((d, d))
+    M = ((M + M.T) / 2).astype(complex)
+    psi0 = problems.random_states(d, B, seed=1)
+    for Hs, want in ((np.array(Hr).astype(complex), 1), (np.array(Hc), 2)):
+        u = rng.uniform(-1, 1, (S, len(Hs)))
+        rl, rg, rf = oracle.energy_grad_one_frechet(H0.astype(complex), list(Hs), M, u, dt, psi0)
+        with _engine(H0.astype(complex), Hs, M, **({"sparse_generator": 1} if want == 1 else {})) as e:
+            assert e.info("xor_regular_found") == 18
+            l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+            assert e.info("xor_regular") == want
+        assert abs(l1 - rl) < TOL and np.max(np.abs(g1 - rg)) < TOL and np.max(np.abs(f1 - rf)) < TOL
