@@ -60,7 +60,8 @@ TRAFFIC = {
     "rgemm": (1.81e9, "profiles/r1_bench_v5_realpath_summary.txt"),
     "rsym": (2.68e9, "profiles/r2_bench_dense_real_summary.txt"),    # symmetric-output rgemm 2614 MB + fix-up 64 MB
     "spmm": (8.50e8, "profiles/r2_bench_headline_row_kernels_summary.txt"),     # (2 x 754 MB rsp_mm_slab + 1043 MB rsp_mm_dot_slab) / 3
-    "xr": (2.84e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 315 MB xr_reverse [Ubar read]) / 3
+    "xr": (6.60e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 1441 MB xr_reverse [Ubar
+                                                                     # read + its power scratch written back and re-read]) / 3
 }
 
 
