@@ -104,8 +104,98 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
-def emit(obj):
-    line = (json.dumps(obj) + "\n").encode()
+LINE_LIMIT = 4000   # bytes: the driver keeps an 8000-character tail of stdout; the ONE line must fit with room to spare
+
+
+def _sig(x, nd=6):
+    """Floats to nd significant digits (the line is a summary; the extras file keeps full precision)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("{:.{}g}".format(x, nd))
+
+
+def short_roofline(b):
+    """The contract's roofline object in its short form: numbers and a kernel name of at most 80 characters."""
+    if not b:
+        return None
+    out = {"bound": b["bound"], "kernel": str(b.get("kernel", ""))[:80]}
+    for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "launches", "ms_per_launch"):
+        if k in b:
+            out[k] = _sig(b[k])
+    out.setdefault("traffic", None)
+    return out
+
+
+def compact_line(full):
+    """What rank 0 prints: the contract's fields, `roofline` / `cpu_baseline` in short form, `by_input_structure` as
+    {name: [steps_per_s, roofline_frac]}, and the path of the extras file that holds everything else."""
+    out = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "backend", "trials"):
+        if k in full:
+            v = full[k]
+            out[k] = {kk: _sig(vv) for kk, vv in v.items()} if isinstance(v, dict) else _sig(v)
+    cfg = full.get("config", {})
+    out["config"] = {k: _sig(v) for k, v in cfg.items()
+                     if k == "workload" or (isinstance(v, (int, float, bool)) or (isinstance(v, str) and len(v) <= 48))}
+    out["config"]["workload"] = str(cfg.get("workload", ""))[:200]
+    out["roofline"] = short_roofline(full.get("roofline"))
+    if full.get("roofline_other"):
+        out["roofline_other"] = short_roofline(full["roofline_other"])
+    ee = full.get("end_to_end") or {}
+    if "executed_mfma_frac_of_peak" in ee:
+        out["end_to_end"] = {"executed_mfma_frac_of_peak": _sig(ee["executed_mfma_frac_of_peak"])}
+    if full.get("beside"):
+        out["beside"] = {k: [_sig(x) for x in v] if isinstance(v, (list, tuple)) else _sig(v) for k, v in full["beside"].items()}
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
+        c["sample"] = str(cb.get("sample", ""))[:160]
+        cs = cb.get("c_single_thread")
+        if isinstance(cs, dict) and "forward_steps_per_s_at_sample" in cs:
+            c["c_single_thread"] = {k: _sig(cs[k]) for k in ("forward_steps_per_s_at_sample", "extrapolated_forward_steps_per_s", "cores")}
+        out["cpu_baseline"] = c
+    st = full.get("by_input_structure")
+    if st:
+        out["by_input_structure"] = {k: [_sig(v["value"], 4), _sig((v.get("roofline") or {}).get("frac"), 3)] for k, v in st.items()}
+    for k in ("max_norm_drift",):
+        if k in full:
+            out[k] = _sig(full[k])
+    out["extras"] = full.get("extras")
+    # never exceed the limit: drop the optional objects, least important first
+    for drop in (None, "by_input_structure", "beside", "roofline_other", "trials"):
+        if drop:
+            out.pop(drop, None)
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+    return out
+
+
+def write_extras(full, path):
+    """Everything measured (notes, per-class tables, other configs, the full chain) beside the line; returns the path written
+    (relative to the repo root when inside it), or None when nowhere is writable."""
+    for cand in (path, os.path.join("/tmp", os.path.basename(path))):
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(cand)), exist_ok=True)
+            with open(cand, "w") as f:
+                json.dump(full, f, indent=1)
+            ab = os.path.abspath(cand)
+            return os.path.relpath(ab, ROOT) if ab.startswith(ROOT + os.sep) else ab
+        except OSError:
+            continue
+    return None
+
+
+_EXTRAS_PATH = os.path.join(ROOT, "bench_extras.json")
+
+
+def emit(full):
+    full["extras"] = None
+    full["extras"] = write_extras(full, _EXTRAS_PATH)
+    line = (json.dumps(compact_line(full)) + "\n").encode()
+    assert len(line) <= LINE_LIMIT + 1, len(line)
     if _JSON_FD is None:
         sys.stdout.write(line.decode()); sys.stdout.flush()
     else:
@@ -207,9 +297,10 @@ def cpu_baseline(n, B, seed, dt, u_row):
     t_all = time.perf_counter() - t0
     out = {"value": 1.0 / t_all, "unit": "Trotter steps/s (fwd+adjoint)", "cores": int(cores), "kind": "port",
            "forward_only_steps_per_s": 1.0 / t_fwd,
-           "sample": "1 fwd+adjoint Trotter step of the same workload (n={}, d={}, B={}) through the oracle: dH assembly, "
-                     "scipy.linalg.expm, np.matmul, one scipy.linalg.expm_frechet, {} contractions: {:.1f} s "
-                     "(forward-only step: {:.1f} s)".format(n, 1 << n, B, n, t_all, t_fwd)}
+           "sample": "1 fwd+adjoint step of the same workload (n={}, d={}, B={}) through the oracle (scipy expm, matmul, expm_frechet): "
+                     "{:.1f} s".format(n, 1 << n, B, t_all),
+           "sample_detail": "dH assembly, scipy.linalg.expm, np.matmul, one scipy.linalg.expm_frechet, {} contractions; forward-only "
+                            "step: {:.1f} s".format(n, t_fwd)}
     try:
         out["c_single_thread"] = c_baseline(n, seed, dt)
     except Exception as e:  # noqa: BLE001 -- a reported extra
@@ -269,23 +360,25 @@ def roofline_blocks(prof, info, d):
 
     z, zh, rg, rs, sp = prof["zgemm"], prof["zherm"], prof["rgemm"], prof["rsym"], prof["spmm"]
     alg = "3M: 3 real MFMAs per complex tile step" if three_m else "4M"
+    lin = int(info["zgemm_alg"]) == 2 and d >= 1024
     blocks = {
-        "zgemm": mfma("zgemm", z, ("zgemm_lin_kernel (complex GEMM, linear form: 128x128 tile, 16 waves x 32x32, LDS-DMA staging, 4 waves/SIMD; "
-                                   "operands without a k-major form stay on zgemm_kernel<128,128,8,2,4>), v_mfma_f64_16x16x4_f64, {}"
-                                   if int(info["zgemm_alg"]) == 2 and d >= 1024 else
-                                   "zgemm_kernel<128,128,8,2,4,*,*,{}> (batched complex GEMM, v_mfma_f64_16x16x4_f64, {})".format(int(three_m), "{}")).format(alg),
+        "zgemm": mfma("zgemm", z, "zgemm_lin_kernel<.,0> (complex GEMM, 3M, 16 waves x 32x32, LDS-DMA)" if lin else
+                      "zgemm_kernel<128,128,8,2,4,*,*,{}> (batched complex GEMM, {})".format(int(three_m), "3M" if three_m else "4M"),
                       f3, per(z, "bytes"),
-                      "achieved = EXECUTED MFMA flops (6*M*N*K per launch in the 3M form, 8*M*N*K in 4M) / sum of the launches' HIP-event "
-                      "durations (rank 0); achieved_algorithmic = 8*M*N*K / the same time (can exceed the peak in the 3M form)"),
-        "zherm": mfma("zherm", zh, "{} ((anti-)Hermitian-output complex GEMM: tiles on/above the diagonal + mirror, K-split tail, {})".format(
-                          "zgemm_lin_kernel<.,HERM>" if int(info["zgemm_alg"]) == 2 and d >= 1024 else "zgemm_kernel<...,HERM>", alg),
+                      "v_mfma_f64_16x16x4_f64, {}; linear form: 128x128 tile, 16 waves x 32x32, LDS-DMA staging, 4 waves/SIMD (operands "
+                      "without a k-major form stay on zgemm_kernel<128,128,8,2,4>).  achieved = EXECUTED MFMA flops (6*M*N*K per launch in "
+                      "the 3M form, 8*M*N*K in 4M) / sum of the launches' HIP-event durations (rank 0); achieved_algorithmic = 8*M*N*K / "
+                      "the same time (can exceed the peak in the 3M form)".format(alg)),
+        "zherm": mfma("zherm", zh, "zgemm_lin_kernel<1,1> ((anti-)Hermitian-output complex GEMM, 3M)" if lin else
+                      "zgemm_kernel<...,HERM> ((anti-)Hermitian-output complex GEMM)",
                       f3 * tri, per(zh, "bytes"),
-                      "executed = the {}/{} tiles on and above the diagonal x (6 or 8)*K*128*128; algorithmic = 8*M*N*K of the delivered product".format(
-                          nt * (nt + 1) // 2, nt * nt)),
-        "rsym": mfma("rsym", rs, "rgemm_kernel<128,128,16,4,4,sym> (batched real GEMM, symmetric-output form, LDS-DMA staged; one- and two-product launches)",
+                      "tiles on/above the diagonal + mirror, K-split tail, {}; executed = the {}/{} tiles on and above the diagonal x (6 or "
+                      "8)*K*128*128; algorithmic = 8*M*N*K of the delivered product".format(alg, nt * (nt + 1) // 2, nt * nt)),
+        "rsym": mfma("rsym", rs, "rgemm_kernel<128,128,16,4,4,sym> (symmetric-output real GEMM, LDS-DMA)",
                      1.0, per(rs, "bytes"),
-                     "executed = algorithmic: 2*K*128*128 per tile on/above the diagonal (the mirror half is written, not computed)"),
-        "rgemm": mfma("rgemm", rg, "rgemm_kernel<128,128,16,4,4> (batched real GEMM, full output, LDS-DMA staged)", 1.0, per(rg, "bytes"),
+                     "one- and two-product launches; executed = algorithmic: 2*K*128*128 per tile on/above the diagonal (the mirror "
+                     "half is written, not computed)"),
+        "rgemm": mfma("rgemm", rg, "rgemm_kernel<128,128,16,4,4> (real GEMM, full output, LDS-DMA)", 1.0, per(rg, "bytes"),
                       "executed = algorithmic = 2*M*N*K"),
     }
     if info.get("xor_regular", 0) > 0:
@@ -298,8 +391,9 @@ def roofline_blocks(prof, info, d):
         tr, src = TRAFFIC["xr"]
         use_tr = d == 4096 and sp["launches"] > 0 and tr is not None
         blocks["spmm"] = {
-            "bound": "lds", "kernel": "xr_forward_kernel / xr_reverse_kernel (XOR-regular sparse generator: a column of U = cos X + i sin X, or of its "
-                                      "reverse mode, as a chain of sparse matrix-vector products on a vector held in LDS; partner rows = ds_read_b64 at i ^ x_j)",
+            "bound": "lds", "kernel": "xr_forward_kernel / xr_reverse_kernel (columns of U / of Ubar in LDS)",
+            "kernel_detail": "XOR-regular sparse generator: a column of U = cos X + i sin X, or of its reverse mode, as a chain of sparse "
+                             "matrix-vector products on a vector held in LDS; partner rows = ds_read_b64 at i ^ x_j",
             "achieved": gbps, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": gbps / PEAK_LDS_GBPS,
             "hbm_gbps_algorithmic": sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0,
             "traffic": tr if use_tr else None, "traffic_source": src if use_tr else None,
@@ -313,7 +407,8 @@ def roofline_blocks(prof, info, d):
         use_tr = d == 4096 and sp["launches"] > 0
         gbps = sp["bytes"] / sp["ms"] * 1e-6 if sp["ms"] > 0 else 0.0
         blocks["spmm"] = {
-            "bound": "hbm", "kernel": "rsp_mm_kernel / rsp_mm_dot_kernel (sparse generator x dense matrix: out[i,:] = sum over nnz(X[i,:]) of w X_m[j,:])",
+            "bound": "hbm", "kernel": "rsp_mm_slab_kernel / rsp_mm_dot_slab_kernel (sparse x dense passes)",
+            "kernel_detail": "out[i,:] = sum over nnz(X[i,:]) of w X_m[j,:]",
             "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
             "traffic": tr if use_tr else None, "traffic_source": src if use_tr else None,
             "traffic_over_algorithmic": (tr / per(sp, "bytes")) if (use_tr and sp["bytes"]) else None,
@@ -537,24 +632,25 @@ def measure_config2(dev, seed, S, B, reps=3, first=0):
         e.use_torch_stream()
         e.set_hamiltonians(p["H0"].astype(np.complex128), p["Hs"].astype(np.complex128))
         e.propagate(u, 1.0 / S, psi)
-        best, fin = None, None
+        best, fin, times = None, None, []
         for _ in range(max(1, reps)):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             fin = e.propagate(u, 1.0 / S, psi)
             torch.cuda.synchronize(); el = time.perf_counter() - t0
+            times.append(el)
             best = el if best is None else min(best, el)
         e.profile_enable(True); e.profile_reset()
         e.propagate(u, 1.0 / S, psi)
         prof = e.profile()
         e.profile_enable(False)
         info = {k: e.info(k) for k in INFO_KEYS}
-        return {"steps_per_s": S / best, "wall_s": best, "operator_form": bool(e.info("composed")),
+        return {"steps_per_s": S / best, "wall_s": best, "times": times, "operator_form": bool(e.info("composed")),
                 "max_norm_drift": float((torch.linalg.norm(fin, dim=0) - 1).abs().max().item()),
                 "path": describe_expm(info), "kernel_ms": {k: v["ms"] for k, v in prof.items() if v["launches"]},
                 "kernel_launches": {k: v["launches"] for k, v in prof.items() if v["launches"]}, "_prof": prof, "_info": info}
 
 
-def measure_config5(dev, seed, S, B, dist, n=18, first=0):
+def measure_config5(dev, seed, S, B, dist, n=18, first=0, trials=1):
     """BASELINE configs[4] per GPU: n-qubit Ising + X controls as Pauli strings (never densified), complex64, B states,
     S steps forward and fwd+adjoint on the matrix-free engine; roofline = HBM from the engine's per-pass HIP events."""
     import torch
@@ -576,25 +672,28 @@ def measure_config5(dev, seed, S, B, dist, n=18, first=0):
         e.set_option("profile", 0)
         e.energy_grad(us, 1e-3, st, want_final=False)   # warm-up over the SAME chain: the checkpoint buffers are allocated here
         e.set_option("profile", -1); e.set_option("profile", 1)
-        if dist is not None:
-            dist.fence()
-        t0 = time.perf_counter()
-        loss, grad, _, _ = e.energy_grad(us, 1e-3, st, want_final=False)
-        if dist is not None and dist.on:
-            from diffquantum_amd.distributed import allreduce_loss_grad
-            loss, grad = allreduce_loss_grad(loss, grad, device=dev)
-        if dist is not None:
-            dist.fence()
-        else:
-            torch.cuda.synchronize()
-        el_g = time.perf_counter() - t0
+        times = []
+        for _ in range(max(1, trials)):
+            if dist is not None:
+                dist.fence()
+            t0 = time.perf_counter()
+            loss, grad, _, _ = e.energy_grad(us, 1e-3, st, want_final=False)
+            if dist is not None and dist.on:
+                from diffquantum_amd.distributed import allreduce_loss_grad
+                loss, grad = allreduce_loss_grad(loss, grad, device=dev)
+            if dist is not None:
+                dist.fence()
+            else:
+                torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        el_g = float(np.median(times))
         ms_g, by_g, nl = e.info("prof_ms"), e.info("prof_bytes"), e.info("prof_launches")
         e.set_option("profile", 0)
         gb = by_g / ms_g * 1e-6 if ms_g > 0 else 0.0
         gbf = by_f / ms_f * 1e-6 if ms_f > 0 else 0.0
-        return {"steps_per_s": S / el_g, "seconds": el_g, "fwd_steps_per_s": S / el_f, "degree": int(e.info("degree")),
+        return {"steps_per_s": S / el_g, "seconds": el_g, "times": times, "fwd_steps_per_s": S / el_f, "degree": int(e.info("degree")),
                 "loss": loss, "grad_norm": float(np.linalg.norm(grad)),
-                "roofline": {"bound": "hbm", "kernel": "sapply_kernel / soverlap_kernel (matrix-free H.psi passes: sub-cube of 2^9 rows x 16 columns in LDS)",
+                "roofline": {"bound": "hbm", "kernel": "sapply_kernel / soverlap_kernel (matrix-free H.psi passes, 2^9-row sub-cubes)",
                              "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gb / PEAK_HBM_GBPS, "traffic": None,
                              "launches": int(nl), "ms_in_timed_region": ms_g,
                              "forward_only": {"achieved": gbf, "frac": gbf / PEAK_HBM_GBPS},
@@ -612,23 +711,26 @@ def run_config2(a, D):
     B = a.batch if a.batch is not None else 1024
     measure_config2(D.dev, a.seed, min(S, max(a.warmup, 1) * 10), B, reps=1, first=D.rank * B)   # warm-up (library, allocator)
     D.fence()
-    m = measure_config2(D.dev, a.seed, S, B, reps=1, first=D.rank * B)   # its own warm call, then ONE timed dq_propagate
+    m = measure_config2(D.dev, a.seed, S, B, reps=max(1, a.trials), first=D.rank * B)   # its own warm call, then `trials` timed dq_propagate calls
     D.fence()
-    el = D.max_over_ranks(m["wall_s"])
+    el = D.max_over_ranks(float(np.median(m["times"])))
     if D.rank == 0:
         blocks = roofline_blocks(m["_prof"], m["_info"], 256)
         rk = ranked(blocks)
         W_alg = 8.0 * 256 * 256 * B
         out = {"metric": "Trotter steps/sec (forward), n=8 qubits batch={}".format(B), "value": D.world * S / el,
-               "unit": "Trotter steps/s (each step = forward over one GPU's {}-state batch; aggregate over GPUs)".format(B),
+               "unit": "Trotter steps/s (one step = forward over one GPU's {}-state batch; sum over GPUs)".format(B),
                "n_gpus": D.world, "steps": S, "warmup": a.warmup, "ms_per_step": el / S * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "backend": D.name(),
-               "config": {"workload": "BASELINE configs[1]: 8-qubit ring analog QAOA (d=256, 16 controls = 8 edge ZZ + 8 vertex X), {} Trotter "
-                                      "steps, batch {} per GPU, fp64 complex, forward only; the timed region is ONE dq_propagate over the whole "
-                                      "chain".format(S, B),
+               "trials": {"n": len(m["times"]), "ms_per_step_median": el / S * 1e3, "ms_per_step_min": min(m["times"]) / S * 1e3,
+                          "ms_per_step_max": max(m["times"]) / S * 1e3},
+               "config": {"workload": "BASELINE configs[1]: 8-qubit ring analog QAOA (d=256, 16 controls), {} Trotter steps, batch {} per "
+                                      "GPU, fp64 complex, forward only".format(S, B),
+                          "workload_detail": "16 controls = 8 edge ZZ + 8 vertex X; the timed region is ONE dq_propagate over the whole chain",
                           "n_qubits": 8, "dim": 256, "n_controls": 16, "batch_per_gpu": B, "global_batch": B * D.world, "chain_steps": S,
                           "operator_form": m["operator_form"], "path": m["path"],
-                          "parallelism": "dp{} (independent batch shards, forward only: no collective)".format(D.world)},
+                          "parallelism": "dp{}".format(D.world),
+                          "parallelism_detail": "independent batch shards, forward only: no collective"},
                "roofline": rk[0] if rk else None, "roofline_other": rk[1] if len(rk) > 1 else None,
                "end_to_end": {"algorithmic_flops_per_step": W_alg, "algorithmic_tflops": W_alg * S / el / 1e12,
                               "note": "d = 256: the chain is composed by a log-depth tree of batched d x d products (operator form), "
@@ -645,20 +747,22 @@ def run_config5(a, D):
         raise SystemExit("--batch {} (the WHOLE batch of config 5) must divide over {} ranks".format(total, D.world))
     B = total // D.world
     n = a.qubits if a.qubits != 12 else 18
-    m = measure_config5(D.dev, a.seed, S, B, D, n=n, first=D.rank * B)
+    m = measure_config5(D.dev, a.seed, S, B, D, n=n, first=D.rank * B, trials=a.trials)
     el = D.max_over_ranks(m["seconds"])
     if D.rank == 0:
         out = {"metric": "Trotter steps/sec (fwd+adjoint), n={} qubits batch={} (complex64, matrix-free)".format(n, total),
-               "value": S / el, "unit": "Trotter steps/s (each step = fwd+adjoint over the WHOLE {}-state batch, sharded over the GPUs)".format(total),
+               "value": S / el, "unit": "Trotter steps/s (one step = fwd+adjoint over the WHOLE {}-state batch, sharded over the GPUs)".format(total),
                "n_gpus": D.world, "steps": S, "warmup": a.warmup, "ms_per_step": el / S * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": D.name(),
-               "config": {"workload": "BASELINE configs[4]: {}-qubit Ising drift + X_k controls as Pauli strings (d={}, never densified), "
-                                      "batch {} = {} per GPU, complex64, fwd + adjoint gradient, dt=1e-3; timed chain = {} of the 4000 Trotter "
-                                      "steps".format(n, 1 << n, total, B, S),
+               "trials": {"n": len(m["times"]), "ms_per_step_median": el / S * 1e3, "ms_per_step_min": min(m["times"]) / S * 1e3,
+                          "ms_per_step_max": max(m["times"]) / S * 1e3},
+               "config": {"workload": "BASELINE configs[4]: {}-qubit Ising + X_k as Pauli strings (d={}, never densified), batch {} = {} per "
+                                      "GPU, complex64, fwd+adjoint, dt=1e-3; {} of 4000 Trotter steps timed".format(n, 1 << n, total, B, S),
                           "n_qubits": n, "dim": 1 << n, "n_controls": n, "batch_per_gpu": B, "global_batch": total, "chain_steps": S,
                           "taylor_degree": m["degree"], "loss": m["loss"], "grad_norm": m["grad_norm"],
                           "forward_only_steps_per_s_rank0": m["fwd_steps_per_s"],
-                          "parallelism": "dp{} (batch shards, one all-reduce of loss + dL/du)".format(D.world)},
+                          "parallelism": "dp{}".format(D.world),
+                          "parallelism_detail": "batch shards, one all-reduce of loss + dL/du"},
                "roofline": m["roofline"]}
         emit(out)
 
@@ -727,18 +831,22 @@ def run_config3(a, D):
         grad_dev.copy_(torch.from_numpy(g).to(dev))
         return loss, grad_dev
 
-    # Which multi-GPU form runs.  No exception handling around anything that contains a collective: every rank issues the
-    # same collectives in the same order with the same sizes, and a rank-local failure (OOM, DiffqcError) aborts the job
-    # non-zero instead of leaving the peers in a mismatched collective.
+    # Which multi-GPU form runs.  Default = north_star's partitioning: every rank runs the whole chain on its own
+    # batch shard, ONE all-reduce of (loss, dL/du) -- 'replicated'.  'sliced' / 'propagators' / 'auto' stay as options.  No
+    # exception handling around anything that contains a collective: every rank issues the same collectives in the same order
+    # with the same sizes, and a rank-local failure (OOM, DiffqcError) aborts the job non-zero instead of leaving the peers in
+    # a mismatched collective.
     force = bool(os.environ.get("DQ_FORCE_COLLECTIVES")) and D.on
-    both = (world > 1 or force) and a.multi_gpu == "auto"
+    multi = world > 1 or force
+    both = multi and a.multi_gpu == "auto"
     mode = "sliced" if (a.multi_gpu == "sliced" and D.on) or both else ("propagators" if a.multi_gpu == "propagators" else "replicated")
+    want_beside = multi and a.multi_gpu in ("replicated", "auto") and not a.no_beside
     forms = {}
     sliced_check = None
     if W > 0:
         uw = torch.from_numpy(u_all[:W].copy()).to(dev)
         lr, gr = run_replicated(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
-        if mode == "sliced":
+        if mode == "sliced" or want_beside:
             # the warm-up doubles as the check: same loss and gradient from both forms on every rank
             ls, gs = run_sliced(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
             err = float((gs - gr).abs().max().item())
@@ -752,17 +860,31 @@ def run_config3(a, D):
                     raise SystemExit("sliced form disagrees with the replicated form: {}".format(sliced_check))
                 mode, both = "replicated", False
 
-    # auto: which form is faster on THIS node is measured, not assumed -- both once on the K-step chain, outside the
-    # timed region, max over ranks; the timed region then runs the faster one and the other is reported beside it
-    if both:
+    # beside the timed form (outside the timed region, max over ranks, one trial each on the same K-step chain): the other form,
+    # and -- rank 0 alone -- the WHOLE global batch on one GPU, so that a reader sees what the scaling is worth
+    if both or want_beside:
         for name, fn in (("sliced", run_sliced), ("replicated", run_replicated)):
+            if name == "replicated" and not both:
+                continue
             g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
             D.fence()
             t1 = time.perf_counter()
             l2, g2 = fn(u_t, g2)
             D.fence()
             forms[name] = {"seconds": D.max_over_ranks(time.perf_counter() - t1), "loss": l2, "grad": g2.clone()}
+    if both:
         mode = "replicated" if forms["replicated"]["seconds"] < forms["sliced"]["seconds"] else "sliced"
+    whole = None
+    if want_beside and rank == 0:
+        psi_all = torch.from_numpy(problems.random_states(d, B * world, a.seed, first=0)).to(dev) if world > 1 else psi0
+        eng.set_option("plan_steps", max(a.chain, K))
+        eng.set_option("cache_bytes", 0)
+        g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
+        eng.energy_grad(u_t[:1].contiguous(), a.dt, psi_all, want_final=False, want_energies=False)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        eng.energy_grad(u_t, a.dt, psi_all, want_final=False, want_energies=False, grad_out=g2)
+        torch.cuda.synchronize(); whole = time.perf_counter() - t1
+        del psi_all
     prop_check = None
     if mode == "propagators" and W > 0:   # the warm-up chain doubles as the check against the replicated form
         lp, gp = run_propagators(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
@@ -771,11 +893,16 @@ def run_config3(a, D):
     eng.profile_enable(True)
     eng.profile_reset()
 
-    D.fence()
-    t0 = time.perf_counter()
-    loss, grad = run(u_t, grad_t)
-    D.fence()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    # ---- the timed region: EXACTLY K steps between two fences, `trials` times; the line reports the median trial ----------
+    times = []
+    for _ in range(max(1, a.trials)):
+        D.fence()
+        t0 = time.perf_counter()
+        loss, grad = run(u_t, grad_t)
+        D.fence()
+        times.append(D.max_over_ranks(time.perf_counter() - t0))
+    elapsed = float(np.median(times))
+    elapsed_all = float(np.sum(times))
     prof = eng.profile()
     eng.profile_enable(False)
     info = {k: eng.info(k) for k in INFO_KEYS}
@@ -784,8 +911,9 @@ def run_config3(a, D):
     if forms:
         forms_out = {name: {"value": world * K / f["seconds"], "ms_per_step": f["seconds"] / max(K, 1) * 1e3, "loss": f["loss"]}
                      for name, f in forms.items()}
-        forms_out["max_abs_grad_diff_sliced_vs_replicated"] = float((forms["sliced"]["grad"] - forms["replicated"]["grad"]).abs().max().item())
-        forms_out["abs_loss_diff_sliced_vs_replicated"] = abs(forms["sliced"]["loss"] - forms["replicated"]["loss"])
+        if "replicated" in forms:
+            forms_out["max_abs_grad_diff_sliced_vs_replicated"] = float((forms["sliced"]["grad"] - forms["replicated"]["grad"]).abs().max().item())
+            forms_out["abs_loss_diff_sliced_vs_replicated"] = abs(forms["sliced"]["loss"] - forms["replicated"]["loss"])
         forms_out["note"] = "one untimed trial of each form on the same K-step chain (max over ranks); the timed region ran '{}'".format(mode)
 
     if rank != 0:
@@ -798,7 +926,7 @@ def run_config3(a, D):
     rk = ranked(blocks)
     steps_per_s = world * K / elapsed
     W_alg = 8.0 * d * d * B  # one complex (d x d).(d x B) product
-    ex_tf = executed_tflops(blocks, elapsed)
+    ex_tf = executed_tflops(blocks, elapsed_all)
     structure_note = {
         "ising": ("diagonal Ising drift + X_k controls: real, sparse and a sum of Pauli strings -- the engine builds the step exponential column "
                   "by column in LDS (input-structure-specific path; see by_input_structure for the same inputs on the general sparse kernels "
@@ -807,10 +935,18 @@ def run_config3(a, D):
                   "(input-structure-specific path; see by_input_structure for dense inputs of the same size)"),
         "dense-real": "dense random real symmetric H0 / H_k: cos X + i sin X on real symmetric-output MFMA products",
         "dense-complex": "dense random complex Hermitian H0 / H_k: the general complex tape"}[a.workload]
+    beside = None
+    if want_beside:
+        # [aggregate steps/s in the headline's unit (one step = fwd+adjoint over a 4096-state batch), ms per chain step]
+        beside = {}
+        if "sliced" in forms:
+            beside["sliced_form"] = [world * K / forms["sliced"]["seconds"], forms["sliced"]["seconds"] / K * 1e3]
+        if whole is not None:
+            beside["one_gpu_whole_global_batch"] = [world * K / whole, whole / K * 1e3]
     out = {
         "metric": "Trotter steps/sec (fwd+adjoint), n={} qubits batch={}".format(n, B),
         "value": steps_per_s,
-        "unit": "Trotter steps/s (each step = fwd+adjoint over one GPU's {}-state batch; aggregate over GPUs)".format(B),
+        "unit": "Trotter steps/s (one step = fwd+adjoint over one GPU's {}-state batch; sum over GPUs)".format(B),
         "n_gpus": world,
         "steps": K,
         "warmup": W,
@@ -821,23 +957,27 @@ def run_config3(a, D):
         "dtype": "f64",
         "data": "synthetic",
         "backend": D.name(),
+        "trials": {"n": len(times), "ms_per_step_median": elapsed / max(K, 1) * 1e3,
+                   "ms_per_step_min": min(times) / max(K, 1) * 1e3, "ms_per_step_max": max(times) / max(K, 1) * 1e3},
         "config": {
-            "workload": "BASELINE configs[{}]: {}-qubit {} stored dense (d={}), {} controls, B={} states per GPU, fwd + adjoint gradient, "
-                        "fp64 complex, dt={}; timed chain = {} of the {} Trotter steps (batch >= dim: operator-form backward sweep, no state "
-                        "checkpoints, per-step cost independent of the chain length; otherwise the slice uses the checkpoint stride of the "
-                        "full chain)".format(2 if world == 1 else 3, n,
-                                             {"ising": "random Ising H + X_k", "dense-real": "dense random real symmetric H",
-                                              "dense-complex": "dense random complex Hermitian H"}[a.workload], d, n, B, a.dt, K, max(a.chain, K)),
+            "workload": "BASELINE configs[{}]: {}-qubit {} (d={}), {} controls, B={} states per GPU, fwd+adjoint, fp64 complex, "
+                        "{} of {} Trotter steps timed".format(2 if world == 1 else 3, n,
+                                                              {"ising": "random Ising H + X_k", "dense-real": "dense random real symmetric H",
+                                                               "dense-complex": "dense random complex Hermitian H"}[a.workload], d, n, B, K,
+                                                              max(a.chain, K)),
+            "workload_detail": "stored dense; dt={}; batch >= dim: operator-form backward sweep, no state checkpoints, per-step cost "
+                               "independent of the chain length; otherwise the slice uses the checkpoint stride of the full chain".format(a.dt),
             "input_structure": structure_note,
             "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
             "chain_steps": K, "dt": a.dt,
-            "parallelism": ("dp{} (batch shards, one all-reduce of loss+dL/du)".format(world) if mode == "replicated" else
-                            "dp{0} over the batch, the propagators of every window of {0} steps built one per rank and all-gathered; "
-                            "state-form chain, reduce-scatter of the propagators' cotangents (SURVEY 8-F2 as written)".format(world)
-                            if mode == "propagators" else
-                            "dp{0} over the batch x {0} time slices: operator form, each rank builds and sweeps 1/{0} of "
-                            "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
-                            "(d x d) and of dL/du".format(world)),
+            "parallelism": "dp{}".format(world),
+            "parallelism_detail": ("dp{} (batch shards, one all-reduce of loss+dL/du)".format(world) if mode == "replicated" else
+                                   "dp{0} over the batch, the propagators of every window of {0} steps built one per rank and all-gathered; "
+                                   "state-form chain, reduce-scatter of the propagators' cotangents (SURVEY 8-F2 as written)".format(world)
+                                   if mode == "propagators" else
+                                   "dp{0} over the batch x {0} time slices: operator form, each rank builds and sweeps 1/{0} of "
+                                   "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
+                                   "(d x d) and of dL/du".format(world)),
             "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "propagators_warmup_check": prop_check,
             "multi_gpu_forms": forms_out,
             "collectives_forced_at_world_1": force and world == 1,
@@ -851,6 +991,7 @@ def run_config3(a, D):
         "roofline_other": rk[1] if len(rk) > 1 else None,
         "roofline_all_classes": {k: {kk: b[kk] for kk in ("frac", "achieved", "unit", "launches", "ms_per_launch", "share_of_kernel_time")}
                                  for k, b in blocks.items() if b["launches"] > 0},
+        "beside": beside,
         "by_input_structure": structure,
         "end_to_end": {
             "algorithmic_flops_per_step": 3 * W_alg,
@@ -860,7 +1001,7 @@ def run_config3(a, D):
             "note": "algorithmic = SURVEY 8-D4's 3 x 8 d^2 B flops per fwd+adjoint step (state apply, costate apply, outer product) x steps/s per "
                     "GPU -- a work-normalised rate, NOT a fraction of what the chip executed: the sparse-generator scheme runs the exponential "
                     "on HBM-bound passes and the 3M product executes 6 of every 8 flops.  executed_mfma_tflops = the flops the matrix "
-                    "pipe actually executed in the timed region (rank 0, from the per-launch events) / wall time",
+                    "pipe actually executed in the timed trials (rank 0, from the per-launch events) / their wall time",
             "kernel_ms": {k: v["ms"] for k, v in prof.items()},
             "kernel_launches": {k: v["launches"] for k, v in prof.items()},
             "hbm_GBps": {k: (v["bytes"] / v["ms"] * 1e-6 if v["ms"] > 0 else 0.0) for k, v in prof.items()
@@ -907,16 +1048,23 @@ def main():
                     help="length of the full configuration's chain: the timed slice uses ITS checkpoint stride")
     ap.add_argument("--real-path", type=int, default=-1,
                     help="-1 auto (real H -> cos/sin form on real MFMA products), 0 = general complex path only")
-    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated", "propagators"), default="auto",
-                    help="N > 1: 'sliced' = chain split over time across the ranks (operator form; three collectives), "
-                         "'replicated' = every rank runs the whole chain on its batch shard (one all-reduce); "
+    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated", "propagators"), default="replicated",
+                    help="N > 1: 'replicated' (default; north_star / SURVEY 8-E1) = every rank runs the whole chain on its batch shard, one "
+                         "all-reduce of loss + dL/du; 'sliced' = chain split over time across the ranks (operator form; three collectives); "
                          "auto = both checked and tried, the faster one timed; 'propagators' = SURVEY 8-F2 as written: state-form "
                          "chain on propagators built 1/N per rank and all-gathered (never chosen by auto: 0.8 GB of collectives per step)")
+    ap.add_argument("--no-beside", action="store_true",
+                    help="N > 1: do not measure, beside the timed form, the sliced form and the whole global batch on one GPU")
+    ap.add_argument("--trials", type=int, default=3, help="how many times the K-step region is timed (the line reports the median)")
+    ap.add_argument("--extras", default=None, help="where the full record goes (default: bench_extras.json beside bench.py)")
     ap.add_argument("--launch", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
     a = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.launch):
         sys.exit(launch_ranks(a, sys.argv[1:]))
     claim_stdout()
+    if a.extras:
+        global _EXTRAS_PATH
+        _EXTRAS_PATH = os.path.abspath(a.extras)
     D = Dist(a)
     {2: run_config2, 3: run_config3, 5: run_config5}[a.config](a, D)
     D.close()  # (only on success: a failing rank must not enter a barrier its peers will never reach -- it exits non-zero)

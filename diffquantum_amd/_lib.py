@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libdiffqc_hip.so")
 
 DQ_C128, DQ_C64 = 0, 1
 DQ_OK, DQ_ERR_INVALID, DQ_ERR_STATE, DQ_ERR_HIP, DQ_ERR_NO_DEVICE, DQ_ERR_UNSUPPORTED, DQ_ERR_NOMEM = range(7)
-PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other", "rgemm", "rsym", "zherm", "spmm")
+PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other", "rgemm", "rsym", "zherm", "spmm", "statecol")
 
 
 class DiffqcError(RuntimeError):
@@ -28,10 +28,10 @@ class DiffqcNoDevice(DiffqcError):
 
 class DqProfile(C.Structure):
     _fields_ = [
-        ("launches", C.c_longlong * 9),
-        ("ms", C.c_double * 9),
-        ("flops", C.c_double * 9),
-        ("bytes", C.c_double * 9),
+        ("launches", C.c_longlong * len(PROF_CLASSES)),
+        ("ms", C.c_double * len(PROF_CLASSES)),
+        ("flops", C.c_double * len(PROF_CLASSES)),
+        ("bytes", C.c_double * len(PROF_CLASSES)),
     ]
 
 

@@ -285,4 +285,28 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
                               int batch, double* part, const unsigned* zero_sgn, double2* xpow, double* grad, int accumulate,
                               hipStream_t st);  // per step: scratch of the reverse kernel (xpow), in doubles
 
+
+// ---- statecol.hip: whole chains on state columns held in LDS (XOR-regular generators; real or complex tables) ----
+// States are stored column by column ([B][d]).  wt [S][R], wd [S][XR_DMAX], dg0 [d]: per-step weights (xs_weights_launch).
+bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
+int xs_blocks(int d, size_t elem, int B, int n_cu);           // workgroups of a launch over B columns
+int xs_waves(int d);
+int xs_slots(const XrTab& tab);
+size_t xs_park_elems(int d, int L, int nblk);                 // complex elements of the backward kernel's scratch
+size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab);
+int xs_lds_diagonals(int d, const XrTab& tab);                // XOR-diagonals whose partners are LDS reads (the others: registers)
+hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* wd, double* dg0,
+                             hipStream_t st);
+hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* wd,
+                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st);
+hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* wd,
+                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st);
+// psi: psi_S in, psi_0 out;  lam: lambda_S in, lambda_0 out;  grad[s][k] (+)= dL/du_k[s]
+hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+                              int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
+                              int accumulate, hipStream_t st);
+hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+                              int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
+                              hipStream_t st);
+
 }  // namespace dq

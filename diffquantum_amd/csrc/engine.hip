@@ -302,6 +302,11 @@ struct Ctx : dq_ctx {
   bool zxr_ok = false;
   int xor_mode = -1;
   double last_xr = 0;
+  // state-column form (statecol.hip): whole chains on state columns held in LDS; xs_mode: -1 auto, 0 off, 1 whenever supported
+  DevBuf xs_psi, xs_lam, xs_park, xs_part, xs_wt, xs_wd, xs_dg0;
+  int xs_mode = -1;
+  double xs_batch_ratio = 8.0;  // auto: batch <= ratio x dim (beyond it the operator form, whose cost does not grow with the batch, wins)
+  double last_xs = 0;
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
   bool sparse_h = false;   // a CSR exists (controls, and the drift too if sparse_x)
@@ -1291,6 +1296,107 @@ int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
   return cur;
 }
 
+// ---- state-column form (statecol.hip) -------------------------------------------------------------------------------------
+// For XOR-regular (Pauli-string) generators the chain psi <- exp(-i dt H(t)) psi (diffqc.cc:190-200, sim_plain.py:135-150) needs
+// no propagator at all: a workgroup holds one state column in LDS and applies the Taylor polynomial of every step as sweeps of
+// partner reads; the adjoint sweep runs the same way on (psi, lambda) and leaves dL/du as per-diagonal sums.  Cost ~ batch x
+// dim x diagonals per step instead of dim^3: chosen (auto) while the batch is at most xs_batch_ratio x dim.
+template <class T>
+const dq::XrTab* xs_table(Ctx<T>* c) {
+  if (c->xor_mode == 0 || c->xs_mode == 0) return nullptr;
+  if (c->real_h && c->xr_ok && c->sparse_mode != 0 && c->sparse_gen_mode != 0) return &c->xr_tab;
+  if (!c->real_h && c->zxr_ok) return &c->zxr_tab;
+  return nullptr;
+}
+
+// Taylor degree of the whole chain's polynomial (the largest step decides), or 0 when the state-column form is not to be used
+template <class T>
+int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B) {
+  const dq::XrTab* tab = xs_table(c);
+  if (!tab) return 0;
+  // the options that pin another scheme keep it
+  if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || c->compose_mode >= 0) return 0;
+  if (c->xs_mode < 0 && (double)B > c->xs_batch_ratio * (double)c->d) return 0;
+  double th = 0.0;
+  for (int t = 0; t < S; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
+  for (int L = 1; L <= 24; ++L)
+    if (taylor_remainder(th, L) <= c->expm_tol) {
+      if (!dq::xs_supported(c->d, L, tab->R, tab->nd, sizeof(T))) return 0;
+      c->last_theta = th;
+      return L;
+    }
+  return 0;
+}
+
+template <class T>
+struct XsLaunch {
+  int L, nblk, lds_diag;
+  const dq::XrTab* tab;
+};
+
+// per-call set-up: weights of every step, buffers
+template <class T>
+XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward) {
+  typedef TT T2;
+  XsLaunch<T> x;
+  x.L = L;
+  x.tab = xs_table(c);
+  x.nblk = dq::xs_blocks(c->d, sizeof(T), B, c->n_cu);
+  x.lds_diag = dq::xs_lds_diagonals(c->d, *x.tab);
+  const size_t sb = (size_t)c->d * B * sizeof(T2);
+  c->xs_psi.ensure(sb);
+  c->xs_lam.ensure(sb);
+  c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
+  c->xs_wd.ensure(sizeof(double) * std::max<size_t>((size_t)S * dq::XR_DMAX, 1));
+  c->xs_dg0.ensure(sizeof(double) * (size_t)c->d);
+  if (backward) {
+    c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
+    c->xs_part.ensure(sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, S, x.nblk, *x.tab), 1));
+  }
+  const dq::XrTab tb = *x.tab;
+  c->timed(DQ_PROF_OTHER, 0.0, 8.0 * S * (tb.R + dq::XR_DMAX), [&] {
+    return dq::xs_weights_launch(tb, c->u_dev.d(), c->K, S, c->d, dt, c->xs_wt.d(), c->xs_wd.d(), c->xs_dg0.d(), c->st);
+  });
+  c->last_degree = L;
+  c->last_squarings = 0;
+  c->last_products = 0;
+  c->last_real_q = c->real_h ? (L - 1) / 2 : 0;
+  c->last_spx = c->real_h ? 1 : 0;
+  c->last_xr = c->real_h ? 1 : 2;
+  c->last_xs = 1;
+  c->last_chunk = S;
+  c->last_cstride = 0;
+  c->last_composed = 0;
+  c->last_opback = 0;
+  return x;
+}
+
+// flops / LDS bytes of `sweeps` sweeps over B columns (profile class DQ_PROF_STATECOL)
+template <class T>
+void xs_book(Ctx<T>* c, const XsLaunch<T>& x, double sweeps, double dot_sweeps, int B, double* flops, double* lds_bytes) {
+  const double rows = (double)c->d * B;
+  *flops = rows * (sweeps * (4.0 * x.tab->R + 8.0) + dot_sweeps * 4.0 * x.tab->R);
+  *lds_bytes = rows * sweeps * (double)x.lds_diag * 2.0 * sizeof(T);
+}
+
+// psi (dev, [d][B]) -> U_{S-1} ... U_0 psi in c->xs_psi ([B][d]); the result's [d][B] image goes to `out_db` if given
+template <class T>
+void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B, TT* out_db) {
+  typedef TT T2;
+  const int d = c->d;
+  const double by = 2.0 * sizeof(T2) * (double)d * B;
+  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, psi_db, B, 0, d, B, 0, 1, c->st); });
+  double fl, lb;
+  xs_book(c, x, (double)x.L * S, 0.0, B, &fl, &lb);
+  const dq::XrTab tb = *x.tab;
+  c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
+    return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_wd.d(), c->xs_dg0.d(), S, B, x.L,
+                                 x.nblk, c->st);
+  });
+  if (out_db)
+    c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>(out_db, B, 0, (const T2*)c->xs_psi.p, d, 0, B, d, 0, 1, c->st); });
+}
+
 template <class T>
 void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_in, void* psi_out, int B) {
   typedef TT T2;
@@ -1306,6 +1412,15 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
   std::vector<double> uh = fetch_u(c, u, S);
   c->psi[0].ensure(sb);
   c->psi[1].ensure(sb);
+  c->last_xs = 0;
+  if (const int Lx = S > 0 ? xs_degree(c, uh, S, dt, B) : 0) {
+    const XsLaunch<T> x = xs_prepare(c, S, dt, B, Lx, false);
+    const T2* p0 = in_dev(c, psi_in, sb, c->psi[1]);
+    xs_forward(c, x, p0, S, B, (T2*)c->psi[0].p);
+    out_copy(c, psi_out, c->psi[0].p, sb);
+    HIPCK(hipStreamSynchronize(c->st));
+    return;
+  }
   HIPCK(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
   // composing propagators beats applying them one by one as soon as the batch is wider than the dimension
   const bool compose = c->compose_mode == 1 || (c->compose_mode < 0 && (B > d || d <= c->small_dim));
@@ -1581,6 +1696,37 @@ void chunk_vjp(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
 }
 
 template <class T>
+void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, double* loss, double* grad_u, void* psi_final,
+                       double* energies, const void* targets, int L) {
+  typedef TT T2;
+  const int d = c->d, K = c->K;
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  const XsLaunch<T> x = xs_prepare(c, S, dt, B, L, true);
+  c->psi[0].ensure(sb);
+  c->psi[1].ensure(sb);
+  c->lam[0].ensure(sb);
+  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
+  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
+  xs_forward(c, x, p0, S, B, (T2*)c->psi[0].p);
+  terminal_costate(c, (const T2*)c->psi[0].p, B, targets, loss, energies);
+  if (psi_final) out_copy(c, psi_final, c->psi[0].p, sb);
+  if (S > 0) {
+    const double by = 2.0 * sizeof(T2) * (double)d * B;
+    c->timed(DQ_PROF_OTHER, 0.0, by,
+             [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, (const T2*)c->lam[0].p, B, 0, d, B, 0, 1, c->st); });
+    double fl, lb;
+    xs_book(c, x, (3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
+    const dq::XrTab tb = *x.tab;
+    c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
+      return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d(), c->xs_wd.d(), c->xs_dg0.d(), S, B, L, x.nblk,
+                                    (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->st);
+    });
+  }
+  if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
 void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* psi0, int B, double* loss,
                     double* grad_u, void* psi_final, double* energies, const void* targets = nullptr) {
   // targets == null: energy objective L = sum_b <psi_b|M|psi_b>;  else fidelity objective
@@ -1618,6 +1764,11 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   c->last_composed = (opback && compose) ? 1.0 : 0.0;
   c->last_opback = opback ? 1.0 : 0.0;
   std::vector<double> uh = fetch_u(c, u, S);
+  c->last_xs = 0;
+  if (const int Lx = S > 0 ? xs_degree(c, uh, S, dt, B) : 0) {
+    do_energy_grad_xs(c, S, dt, psi0, B, loss, grad_u, psi_final, energies, targets, Lx);
+    return;
+  }
   for (int i = 0; i < 2; ++i) c->psi[i].ensure(sb);
   c->lam[0].ensure(sb);
   c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
@@ -2422,6 +2573,11 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->transpose_fallback = v != 0 ? 1 : 0;
   } else if (s == "xor_regular") {  // column-form kernels for XOR-regular sparse generators: -1 auto (default), 0 off
     c->xor_mode = v != 0 ? -1 : 0;
+  } else if (s == "state_columns") {  // state-column form (statecol.hip): -1 auto (default), 0 off, 1 whenever the kernels exist
+    c->xs_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_batch_ratio") {  // auto: taken while batch <= ratio x dim
+    if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_batch_ratio must be > 0");
+    c->xs_batch_ratio = v;
   } else if (s == "slab_spmm") {  // sparse x dense passes in XCD-slab form (1, default) or one wave per whole row (0)
     c->slab_spmm = v != 0 ? 1 : 0;
   } else if (s == "skew_trick") {
@@ -2452,6 +2608,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "control_nonzeros") return c->sparse_h ? (double)c->sp_nnz_c : -1.0;
   if (s == "sparse_generator") return c->last_spx;
   if (s == "xor_regular") return c->last_xr;
+  if (s == "state_columns") return c->last_xs;
   if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;

@@ -1,0 +1,649 @@
+// State-column form of the chain for XOR-regular (Pauli-string) generators: whole Trotter chains on a state vector that never
+// leaves LDS.
+//
+// The reference's inner loop is `psi <- expm(-1j * dt * H(t)) psi` per step (sim_plain.py:135-150, diffqc.cc:190-200).  When
+// H(t) = H0 + sum_k u_k(t) H_k is a sum of Pauli strings -- the table of xorexp.hip: besides real diagonals, row i holds the
+// entries (i, i ^ x_j), j < R, of magnitude c_j, sign sigma_ij and phase 1 or i -- the step needs no matrix at all:
+//     psi' = sum_{m <= L} A^m psi / m!,   A = -i dt H(t),   (A v)[i] = -i dg_i v[i] + sum_j a_ij v[i ^ x_j]
+// is L sweeps of R partner reads per row on a vector of d complex numbers.  A workgroup owns one state column (d = 4096,
+// complex128: 64 KB; two images fit the 160 KB LDS), a thread the rows r NT + t, partners at offsets with no lane bits are the
+// thread's own registers, the others conflict-free LDS reads at i ^ x_j, the weights dt u_k(t) c_j wave-uniform scalars -- and
+// the workgroup runs ALL the steps of the chain on its column before it touches HBM again (psi_0 in, psi_S out).
+//
+// Backward (adjoint) sweep, per column and step t, from psi_{t+1} and lam = lambda_{t+1} (both in place of the forward data):
+//     psi_t   = sum_m (-A)^m psi_{t+1} / m!                       (U^H = exp(-A): exact reversal up to the Taylor remainder)
+//     x_l     = A^l psi_t / l!,  l < L                             (parked per workgroup in an L2 / Infinity-Cache resident scratch,
+//                                                                  each element written and read back by the same thread)
+//     y_{L-1} = lam / L,   y_{l-1} = (lam - A y_l) / l,   lambda_t = lam - A y_0                  (Horner; = U^H lam)
+//     dL/du_k[t] = Re sum_l <y_l, dA_k x_l>,  dA_k = -i dt H_k
+// -- the exact derivative of the same polynomial; the partner value y_l[i ^ x_j] fetched for the sweep is the factor of the
+// level-l product with the thread's own x_l[i] (one real accumulator per XOR-diagonal, one per row for diagonal controls).
+// 3L - 1 sweeps per step; HBM traffic of a whole gradient evaluation: psi_S and lambda_S in, a few sums per step out.
+// The numpy twin of these recurrences is tests/np_state_column.py (checked against the oracle on the CPU).
+#include "dq_internal.h"
+
+namespace dq {
+
+namespace {
+
+template <class T>
+struct XsV2;
+template <>
+struct XsV2<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct XsV2<float> {
+  typedef float type __attribute__((ext_vector_type(2)));
+};
+
+__device__ inline double xs_flip(double v, unsigned bit) {
+  return __longlong_as_double(__double_as_longlong(v) ^ ((long long)bit << 63));
+}
+__device__ inline float xs_flip(float v, unsigned bit) { return __int_as_float(__float_as_int(v) ^ (int)(bit << 31)); }
+__device__ inline double xs_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float xs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// dacc[j] += s for a wave-uniform j (register arrays need static indices: a binary tree of scalar compares)
+template <int LO, int HI>
+__device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
+  if constexpr (HI - LO == 1) {
+    asm volatile("" : "+v"(dacc[LO]));
+    dacc[LO] += s;
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (j < MID) xs_acc<LO, MID>(dacc, j, s);
+    else xs_acc<MID, HI>(dacc, j, s);
+  }
+}
+
+// One XOR-diagonal's contribution with the partner values in v[]:  o += sg * a_ij v,  a_ij = -i w sigma (phase 0) or
+// w sigma (phase 1); DOT: the level's gradient pairing of the partners with the thread's own rows xm.
+template <class T, int RPT, bool SIGN, bool DOT, int RM>
+__device__ __forceinline__ void xs_use(int j, int ph, T w, const unsigned* sg, typename Cx<T>::type* v, typename Cx<T>::type* o,
+                                       const typename Cx<T>::type* xm, double* dacc) {
+  if (SIGN) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const unsigned b = (sg[r] >> j) & 1u;
+      v[r].x = xs_flip(v[r].x, b);
+      v[r].y = xs_flip(v[r].y, b);
+    }
+  }
+  if (ph) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      o[r].x = xs_fma(w, v[r].x, o[r].x);
+      o[r].y = xs_fma(w, v[r].y, o[r].y);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      o[r].x = xs_fma(w, v[r].y, o[r].x);
+      o[r].y = xs_fma(-w, v[r].x, o[r].y);
+    }
+  }
+  if (DOT) {
+    double s = 0.0;
+    if (ph) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) s -= (double)xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y);
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) s += (double)xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
+    }
+    xs_acc<0, RM>(dacc, j, s);
+  }
+}
+
+template <class T, int RPT, int XH, bool SIGN, bool DOT, int RM>
+__device__ __forceinline__ void xs_local(int xh, int j, int ph, T w, const unsigned* sg, const typename Cx<T>::type* cur,
+                                         typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+  if constexpr (XH < RPT) {
+    if (xh == XH) {
+      typename Cx<T>::type v[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
+      xs_use<T, RPT, SIGN, DOT, RM>(j, ph, w, sg, v, o, xm, dacc);
+    } else {
+      xs_local<T, RPT, XH + 1, SIGN, DOT, RM>(xh, j, ph, w, sg, cur, o, xm, dacc);
+    }
+  }
+}
+
+// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`).  wrow: this step's weights dt u c_j
+// (wave-uniform).  The loop over the diagonals is a runtime loop on purpose (unrolled, the compiler hoists masks and addresses
+// of all R diagonals and spills); LDS reads are volatile so that neighbours are not merged into ds_read2 forms.
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM>
+__device__ __forceinline__ void xs_gather(const XrTab& tab, const double* __restrict__ wrow, const unsigned* sg,
+                                          const typename Cx<T>::type* __restrict__ src, const typename Cx<T>::type* cur, int t, T sgn,
+                                          typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+  typedef typename Cx<T>::type T2;
+  typedef typename XsV2<T>::type V2;
+  typedef const volatile __attribute__((address_space(3))) V2* lds_ptr;
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < tab.R; ++j) {
+    const int xo = tab.xoff[j];
+    const int ph = tab.phase[j];
+    const T w = sgn * (T)wrow[j];
+    const int xl = xo & (NT - 1), xh = xo / NT;
+    if (xl == 0) {  // (wave-uniform) the partner rows are the thread's own registers
+      xs_local<T, RPT, 1, SIGN, DOT, RM>(xh, j, ph, w, sg, cur, o, xm, dacc);
+    } else {
+      T2 v[RPT];
+      lds_ptr base = (lds_ptr)(src + (t ^ xl));
+      if (xh == 0) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const V2 q = base[r * NT];
+          v[r].x = q.x;
+          v[r].y = q.y;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const V2 q = base[(r ^ xh) * NT];
+          v[r].x = q.x;
+          v[r].y = q.y;
+        }
+      }
+      xs_use<T, RPT, SIGN, DOT, RM>(j, ph, w, sg, v, o, xm, dacc);
+    }
+  }
+}
+
+// the thread's diagonal weights of step s: dg0 (the drift's) + the diagonal controls'
+template <class T, int NT, int RPT, bool DIAGCTL>
+__device__ __forceinline__ void xs_diag(const XrTab& tab, const T* dgc, const double* __restrict__ wdrow, int t, T* dg) {
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) dg[r] = dgc[r];
+  if (DIAGCTL) {
+    constexpr int D = NT * RPT;
+    for (int jd = 0; jd < tab.nd; ++jd) {
+      if (tab.dkid[jd] < 0) continue;
+      const double w = wdrow[jd];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) dg[r] += (T)(w * tab.dval[(long)jd * D + r * NT + t]);
+    }
+  }
+}
+
+template <class T, int NT, int RPT>
+__device__ __forceinline__ void xs_put(typename Cx<T>::type* img, int t, const typename Cx<T>::type* v) {
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) img[r * NT + t] = v[r];
+}
+
+}  // namespace
+
+// wt[s][j] = dt u[s][kid_j] cmag_j;  wd[s][jd] = dt u[s][dkid_jd] (0 for the drift's diagonal);  dg0[i] = dt sum of the drift's
+// diagonals.  grid: S + ceil(d / 256) blocks of 256 threads.
+__global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double* __restrict__ u, int K, int S, int d, double dt,
+                                                         double* __restrict__ wt, double* __restrict__ wd, double* __restrict__ dg0) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b < S) {
+    const double* ur = u + (long)b * K;
+    if (t < tab.R) wt[(long)b * tab.R + t] = dt * (tab.kid[t] < 0 ? 1.0 : ur[tab.kid[t]]) * tab.cmag[t];
+    if (t < tab.nd) wd[(long)b * XR_DMAX + t] = tab.dkid[t] < 0 ? 0.0 : dt * ur[tab.dkid[t]];
+  } else {
+    const int i = (b - S) * 256 + t;
+    if (i < d) {
+      double v = 0.0;
+      for (int jd = 0; jd < tab.nd; ++jd)
+        if (tab.dkid[jd] < 0) v += tab.dval[(long)jd * d + i];
+      dg0[i] = dt * v;
+    }
+  }
+}
+
+// psi_out[b][:] = U_{S-1} ... U_0 psi_in[b][:] for the columns b = blockIdx.x, + gridDim.x, ...  (states stored column by
+// column: [B][D]).  ckpt (optional): psi_t of every step t with t % cstride == 0, [t / cstride][B][D].
+template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL>
+__global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
+                                                        typename Cx<T>::type* __restrict__ psi_out, XrTab tab,
+                                                        const double* __restrict__ wt, const double* __restrict__ wd,
+                                                        const double* __restrict__ dg0, int S, int B, int L) {
+  typedef typename Cx<T>::type T2;
+  constexpr int D = NT * RPT;
+  extern __shared__ __align__(16) unsigned char xs_lds_raw[];
+  T2* img = (T2*)xs_lds_raw;  // two images of D
+  const int t = threadIdx.x;
+  unsigned sg[RPT];
+  T dgc[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+    dgc[r] = (T)dg0[r * NT + t];
+  }
+  int p = 0;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    T2 cur[RPT];
+    const T2* in = psi_in + (long)b * D;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) cur[r] = in[r * NT + t];
+    p ^= 1;
+    xs_put<T, NT, RPT>(img + p * D, t, cur);
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+      T dg[RPT];
+      xs_diag<T, NT, RPT, DIAGCTL>(tab, dgc, wd + (long)s * XR_DMAX, t, dg);
+      const double* wrow = wt + (long)s * tab.R;
+      T2 acc[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
+      for (int m = 1; m <= L; ++m) {
+        T2 o[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {  // the diagonal: -i dg v
+          o[r].x = dg[r] * cur[r].y;
+          o[r].y = -dg[r] * cur[r].x;
+        }
+        xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        const T inv = (T)1 / (T)m;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          o[r].x *= inv;
+          o[r].y *= inv;
+          cur[r] = o[r];
+          acc[r].x += o[r].x;
+          acc[r].y += o[r].y;
+        }
+        if (m < L) {
+          p ^= 1;
+          xs_put<T, NT, RPT>(img + p * D, t, o);
+          __syncthreads();
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
+      if (s + 1 < S) {
+        p ^= 1;
+        xs_put<T, NT, RPT>(img + p * D, t, cur);
+        __syncthreads();
+      }
+    }
+    T2* out = psi_out + (long)b * D;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) out[r * NT + t] = cur[r];
+    __syncthreads();  // (every read of this column's images is done before the next column overwrites one)
+  }
+}
+
+// 16 per-lane values -> lane l < 16 holds the wave's total of value l (17 exchanges instead of 96)
+__device__ __forceinline__ double xs_wave_sums16(double* a, int lane) {
+#pragma unroll
+  for (int half = 8; half >= 1; half >>= 1) {
+    const bool up = (lane & half) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const double send = up ? a[i] : a[i + half];
+      const double keep = up ? a[i + half] : a[i];
+      a[i] = keep + __shfl_xor(send, half, 64);
+    }
+  }
+  double v = a[0];
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;  // lane l: total of value (l & 15) in the bit order of the halving: bit 3 chose first, then 2, 1, 0
+}
+
+// Backward sweep of the chain for the columns b = blockIdx.x, + gridDim.x, ...:  psi [b][:] holds psi_S on entry and psi_0 on exit,
+// lam [b][:] holds lambda_S on entry and lambda_0 on exit.  park: per workgroup (L + 1) vectors of D (x_0 .. x_{L-1}, lambda).
+// part[((blockIdx.x * S + s) * NW + wave) * NS + slot]: this workgroup's share, over its columns, of
+//   slot < RM: sum_i of the level pairings of XOR-diagonal `slot` (before the factors cmag and dt);
+//   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
+template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM>
+__global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
+                                                         XrTab tab, const double* __restrict__ wt, const double* __restrict__ wd,
+                                                         const double* __restrict__ dg0, int S, int B, int L,
+                                                         typename Cx<T>::type* __restrict__ park, double* __restrict__ part) {
+  typedef typename Cx<T>::type T2;
+  constexpr int D = NT * RPT;
+  constexpr int NW = NT / 64;
+  constexpr int NS = RM + (DIAGCTL ? XR_DMAX : 0);
+  extern __shared__ __align__(16) unsigned char xs_lds_raw[];
+  T2* img = (T2*)xs_lds_raw;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned sg[RPT];
+  T dgc[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+    dgc[r] = (T)dg0[r * NT + t];
+  }
+  T2* pk = park + (long)blockIdx.x * (L + 1) * D + t;  // [l][r * NT + t]
+  T2* plam = pk + (long)L * D;
+  // the slot a lane reports after xs_wave_sums16 (bit 3 of the lane chose the upper half first, ...): slot = lane & 15
+  // read as (b3 b2 b1 b0) -> value index b3 * 8 + b2 * 4 + b1 * 2 + b0 = lane & 15
+  int p = 0;
+  bool first = true;
+  for (int b = blockIdx.x; b < B; b += gridDim.x, first = false) {
+    T2 cur[RPT];
+    {
+      const T2* in = psi + (long)b * D;
+      const T2* li = lam + (long)b * D;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        cur[r] = in[r * NT + t];
+        plam[r * NT] = li[r * NT + t];
+      }
+    }
+    for (int s = S - 1; s >= 0; --s) {
+      T dg[RPT];
+      xs_diag<T, NT, RPT, DIAGCTL>(tab, dgc, wd + (long)s * XR_DMAX, t, dg);
+      const double* wrow = wt + (long)s * tab.R;
+      // ---- reversal: psi_s = sum_m (-A)^m psi_{s+1} / m! -------------------------------------------------------------
+      p ^= 1;
+      xs_put<T, NT, RPT>(img + p * D, t, cur);
+      __syncthreads();
+      {
+        T2 acc[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
+        for (int m = 1; m <= L; ++m) {
+          T2 o[RPT];
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) {
+            o[r].x = -dg[r] * cur[r].y;
+            o[r].y = dg[r] * cur[r].x;
+          }
+          xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)-1, o, nullptr, nullptr);
+          const T inv = (T)1 / (T)m;
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) {
+            o[r].x *= inv;
+            o[r].y *= inv;
+            cur[r] = o[r];
+            acc[r].x += o[r].x;
+            acc[r].y += o[r].y;
+          }
+          if (m < L) {
+            p ^= 1;
+            xs_put<T, NT, RPT>(img + p * D, t, o);
+            __syncthreads();
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
+      }
+      // ---- the forward terms x_l = A^l psi_s / l! --------------------------------------------------------------------
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) pk[r * NT] = cur[r];
+      if (L > 1) {
+        p ^= 1;
+        xs_put<T, NT, RPT>(img + p * D, t, cur);
+        __syncthreads();
+      }
+      for (int l = 1; l < L; ++l) {
+        T2 o[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          o[r].x = dg[r] * cur[r].y;
+          o[r].y = -dg[r] * cur[r].x;
+        }
+        xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        const T inv = (T)1 / (T)l;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          o[r].x *= inv;
+          o[r].y *= inv;
+          cur[r] = o[r];
+          pk[(long)l * D + r * NT] = o[r];
+        }
+        if (l < L - 1) {
+          p ^= 1;
+          xs_put<T, NT, RPT>(img + p * D, t, o);
+          __syncthreads();
+        }
+      }
+      // ---- Horner on lambda with the level pairings ----------------------------------------------------------------
+      double dacc[RM], rowacc[DIAGCTL ? RPT : 1];
+#pragma unroll
+      for (int j = 0; j < RM; ++j) dacc[j] = 0.0;
+#pragma unroll
+      for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
+      {
+        const T inv = (T)1 / (T)L;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const T2 g = plam[r * NT];
+          cur[r].x = g.x * inv;
+          cur[r].y = g.y * inv;
+        }
+      }
+      p ^= 1;
+      xs_put<T, NT, RPT>(img + p * D, t, cur);
+      __syncthreads();
+      for (int l = L - 1; l >= 0; --l) {  // forms y_{l-1} from y_l (l = 0: lambda_s), pairing y_l with x_l
+        T2 o[RPT], xm[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          xm[r] = pk[(long)l * D + r * NT];
+          const T2 g = plam[r * NT];
+          o[r].x = g.x - dg[r] * cur[r].y;  // lam - (-i dg y)
+          o[r].y = g.y + dg[r] * cur[r].x;
+          if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
+        }
+        xs_gather<T, NT, RPT, SIGN, true, RM>(tab, wrow, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
+        if (l > 0) {
+          const T inv = (T)1 / (T)l;
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) {
+            cur[r].x = o[r].x * inv;
+            cur[r].y = o[r].y * inv;
+          }
+          p ^= 1;
+          xs_put<T, NT, RPT>(img + p * D, t, cur);
+          __syncthreads();
+        } else {
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) plam[r * NT] = o[r];
+        }
+      }
+      // ---- this step's sums: per wave, accumulated over the workgroup's columns --------------------------------------
+      double* prow = part + (((long)blockIdx.x * S + s) * NW + wave) * NS;
+#pragma unroll
+      for (int g0 = 0; g0 < RM; g0 += 16) {
+        const double v = xs_wave_sums16(dacc + g0, lane);
+        if (lane < 16) prow[g0 + lane] = first ? v : prow[g0 + lane] + v;
+      }
+      if (DIAGCTL) {
+        double dv[XR_DMAX];
+#pragma unroll
+        for (int jd = 0; jd < XR_DMAX; ++jd) {
+          double v = 0.0;
+          if (jd < tab.nd && tab.dkid[jd] >= 0) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) v = __builtin_fma(tab.dval[(long)jd * D + r * NT + t], rowacc[r], v);
+          }
+          dv[jd] = v;
+        }
+        const double v = xs_wave_sums16(dv, lane);
+        if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
+      }
+      // psi_s back into the registers for the next (earlier) step
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) cur[r] = pk[r * NT];
+    }
+    {
+      T2* out = psi + (long)b * D;
+      T2* lo = lam + (long)b * D;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        out[r * NT + t] = cur[r];
+        lo[r * NT + t] = plam[r * NT];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// grad[s][k] (+)= dt * (sum_j [kid_j == k] cmag_j sum part[.., j] + sum_jd [dkid_jd == k] sum part[.., RM + jd]); one workgroup
+// per step: lane group q sums slot q over the nblk * nw partial rows in a fixed order
+__global__ void __launch_bounds__(1024) xs_finish_kernel(const double* __restrict__ part, int nblk, int nw, int ns, int rm, int S,
+                                                         XrTab tab, int K, double dt, double* __restrict__ grad, int accumulate) {
+  const long s = blockIdx.x;
+  const int l = threadIdx.x & 31, slot0 = threadIdx.x >> 5;
+  __shared__ double s_j[XR_SLOTS];
+  for (int slot = slot0; slot < ns; slot += 32) {
+    double v = 0.0;
+    for (int q = l; q < nblk * nw; q += 32) {
+      const int bk = q / nw, w = q - bk * nw;
+      v += part[(((long)bk * S + s) * nw + w) * ns + slot];
+    }
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
+    if (l == 0) s_j[slot] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 1024) {
+    double g = accumulate ? grad[s * K + k] : 0.0;
+    for (int j = 0; j < tab.R; ++j)
+      if (tab.kid[j] == k) g += dt * tab.cmag[j] * s_j[j];
+    if (ns > rm)
+      for (int jd = 0; jd < tab.nd; ++jd)
+        if (tab.dkid[jd] == k) g += dt * s_j[rm + jd];
+    grad[s * K + k] = g;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+
+bool xs_supported(int d, int L, int R, int nd, size_t elem) {
+  if (elem != sizeof(double) && elem != sizeof(float)) return false;
+  if (R < 1 || R > XR_RSMALL || nd < 0 || nd > XR_DMAX || L < 1 || L > 24) return false;
+  return d == 256 || d == 512 || d == 1024 || d == 2048 || d == 4096;
+}
+
+size_t xs_lds_bytes(int d, size_t elem) { return (size_t)2 * 2 * elem * (size_t)d; }
+
+// workgroups of a launch over B columns: as many as fit the chip at once (LDS-limited), never more than columns
+int xs_blocks(int d, size_t elem, int B, int n_cu) {
+  const size_t lds = xs_lds_bytes(d, elem);
+  int per_cu = (int)((size_t)160 * 1024 / lds);
+  const int threads = d >= 4096 ? 512 : (d / 8 < 64 ? 64 : d / 8);
+  const int by_waves = 2048 / threads > 0 ? 2048 / threads : 1;  // 32 waves per CU
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu < 1) per_cu = 1;
+  long nb = (long)per_cu * n_cu;
+  if (nb > B) nb = B;
+  // (an even share of columns per workgroup: the largest count <= nb that divides into equal rounds)
+  const long rounds = (B + nb - 1) / nb;
+  nb = (B + rounds - 1) / rounds;
+  return (int)(nb < 1 ? 1 : nb);
+}
+int xs_waves(int d) { return d >= 4096 ? 8 : (d / 8 < 64 ? 1 : d / 8 / 64); }
+int xs_slots(const XrTab& tab) {
+  for (int j = 0; j < tab.nd; ++j)
+    if (tab.dkid[j] >= 0) return XR_RSMALL + XR_DMAX;
+  return XR_RSMALL;
+}
+int xs_lds_diagonals(int d, const XrTab& tab) {
+  const int nt = d >= 4096 ? 512 : (d / 8 < 64 ? 64 : d / 8);
+  int n = 0;
+  for (int j = 0; j < tab.R; ++j)
+    if (tab.xoff[j] & (nt - 1)) ++n;
+  return n;
+}
+size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)(L + 1) * (size_t)d; }
+size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab) { return (size_t)nblk * (size_t)S * (size_t)xs_waves(d) * (size_t)xs_slots(tab); }
+
+hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* wd, double* dg0,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(xs_weights_kernel, dim3((unsigned)(S + (d + 255) / 256)), dim3(256), 0, st, tab, u, K, S, d, dt, wt, wd, dg0);
+  return hipGetLastError();
+}
+
+namespace {
+
+bool xs_diagctl(const XrTab& tab) {
+  for (int j = 0; j < tab.nd; ++j)
+    if (tab.dkid[j] >= 0) return true;
+  return false;
+}
+
+template <class T, int NT, int RPT>
+hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* out, const XrTab& tab, const double* wt, const double* wd,
+                         const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
+  typedef typename Cx<T>::type T2;
+  const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
+  const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
+  void (*kf)(const T2*, T2*, XrTab, const double*, const double*, const double*, int, int, int) =
+      sgn ? (dc ? xs_forward_kernel<T, NT, RPT, true, true> : xs_forward_kernel<T, NT, RPT, true, false>)
+          : (dc ? xs_forward_kernel<T, NT, RPT, false, true> : xs_forward_kernel<T, NT, RPT, false, false>);
+  hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, wt, wd, dg0, S, B, L);
+  return hipGetLastError();
+}
+
+template <class T, int NT, int RPT>
+hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* wd,
+                          const double* dg0, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
+  typedef typename Cx<T>::type T2;
+  const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
+  const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
+  void (*kf)(T2*, T2*, XrTab, const double*, const double*, const double*, int, int, int, T2*, double*) =
+      sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL>)
+          : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL> : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL>);
+  hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, wt, wd, dg0, S, B, L, park, part);
+  return hipGetLastError();
+}
+
+template <class T>
+hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* out, int d, const XrTab& tab, const double* wt,
+                        const double* wd, const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T))) return hipErrorInvalidValue;
+  switch (d) {
+    case 4096: return xs_forward_go<T, 512, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
+    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
+    case 1024: return xs_forward_go<T, 128, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
+    case 512: return xs_forward_go<T, 64, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
+    default: return xs_forward_go<T, 64, 4>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
+  }
+}
+
+template <class T>
+hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
+                         const double* wd, const double* dg0, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
+                         int K, double dt, double* grad, int accumulate, hipStream_t st) {
+  if (B <= 0 || S <= 0) return hipSuccess;
+  if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T)) || !park || !part) return hipErrorInvalidValue;
+  hipError_t e;
+  switch (d) {
+    case 4096: e = xs_backward_go<T, 512, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
+    case 2048: e = xs_backward_go<T, 256, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
+    case 1024: e = xs_backward_go<T, 128, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
+    case 512: e = xs_backward_go<T, 64, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
+    default: e = xs_backward_go<T, 64, 4>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st);
+  }
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d), xs_slots(tab), (int)XR_RSMALL, S,
+                     tab, K, dt, grad, accumulate);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* wd,
+                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
+  return xs_forward_t<double>(in, out, d, tab, wt, wd, dg0, S, B, L, nblk, st);
+}
+hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* wd,
+                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
+  return xs_forward_t<float>(in, out, d, tab, wt, wd, dg0, S, B, L, nblk, st);
+}
+hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+                              int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
+                              int accumulate, hipStream_t st) {
+  return xs_backward_t<double>(psi, lam, d, tab, wt, wd, dg0, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
+}
+hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+                              int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
+                              hipStream_t st) {
+  return xs_backward_t<float>(psi, lam, d, tab, wt, wd, dg0, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
+}
+
+}  // namespace dq

@@ -52,7 +52,9 @@ typedef struct dq_ctx dq_ctx;
 #define DQ_PROF_RSYM 6      /* the same kernel in its symmetric-output form (tiles on/above the diagonal)  */
 #define DQ_PROF_ZHERM 7     /* complex GEMM in its (anti-)Hermitian-output form (tiles on/above the diagonal) */
 #define DQ_PROF_SPMM 8      /* sparse generator x dense matrix passes (drift and controls sparse)                */
-#define DQ_PROF_NCLASS 9
+#define DQ_PROF_STATECOL 9  /* state-column form (statecol.hip): whole chains on state columns held in LDS. For this class
+                               `bytes` counts the LDS bytes the sweeps gather (its HBM traffic is the states in and out) */
+#define DQ_PROF_NCLASS 10
 
 typedef struct dq_profile {
   long long launches[DQ_PROF_NCLASS];

@@ -1,0 +1,158 @@
+"""Test infrastructure: a numpy model of the state-column form (diffquantum_amd/csrc/statecol.hip), row for row the
+recurrences the kernels run -- it fixes the signs and the pairing of the gradient levels before (and beside) the HIP code.
+Never imported by the product.
+
+The chain is the reference's `psi <- expm(-1j * dt * H(t)) psi` (sim_plain.py:135-150, diffqc.cc:190-200) for a Hermitian
+generator that is a sum of Pauli strings, given as the table the engine extracts at dq_set_hamiltonians (engine.hip
+find_xor_regular / find_zxor_regular):  H_src[i, i ^ xoff[j]] = (-1)^sgn[i]_j * cmag[j] * (1j if phase[j] else 1)  for the
+XOR-diagonal j of source kid[j] (-1 = drift), and real diagonals dval[jd][i] of source dkid[jd].
+
+Step:  psi' = sum_{m <= L} A^m psi / m!,  A = -1j dt H(u_t)  (Taylor polynomial; L from the remainder bound).
+Backward step t (lam = lambda_{t+1}, psi1 = psi_{t+1}):
+    psi_t = sum_m (-A)^m psi1 / m!                                   (reversal: U^H = exp(-A))
+    x_l   = A^l psi_t / l!,  l = 0 .. L-1                             (the forward terms of psi_t)
+    y_{L-1} = lam / L,   y_{l-1} = (lam - A y_l) / l                  (Horner, descending)
+    lam_t = lam - A y_0                                               (= U^H lam)
+    dL/du_k[t] = Re sum_l <y_l, dA_k x_l>,   dA_k = -1j dt H_k
+with <y, dA_k x> evaluated diagonal by diagonal from the partner values y[i ^ xoff] that the sweep A y fetches anyway.
+"""
+import numpy as np
+
+
+def table_from_dense(H0, Hs, tol=0.0):
+    """The XOR-regular table of (H0, Hs) or None when the pattern is not of that kind (mirrors find_zxor_regular)."""
+    H0 = np.asarray(H0)
+    d = H0.shape[0]
+    srcs = [(-1, H0)] + [(k, np.asarray(h)) for k, h in enumerate(Hs)]
+    idx = np.arange(d)
+    xoff, kid, cmag, phase, sgn, dkid, dval = [], [], [], [], [], [], []
+    for k, H in srcs:
+        dg = np.diag(H)
+        if np.any(np.abs(dg.imag) > tol):
+            return None
+        if np.any(dg.real != 0):
+            dkid.append(k)
+            dval.append(dg.real.copy())
+        for x in range(1, d):
+            v = H[idx, idx ^ x]
+            if not np.any(v != 0):
+                continue
+            if np.any(v == 0):
+                return None
+            ph = 1 if np.all(v.real == 0) else 0
+            if ph == 0 and np.any(v.imag != 0):
+                return None
+            w = v.imag if ph else v.real
+            if np.any(np.abs(np.abs(w) - abs(w[0])) > tol):
+                return None
+            xoff.append(x); kid.append(k); cmag.append(abs(w[0])); phase.append(ph); sgn.append((w < 0).astype(np.int64))
+    return dict(d=d, xoff=np.array(xoff, dtype=np.int64), kid=np.array(kid, dtype=np.int64), cmag=np.array(cmag),
+                phase=np.array(phase, dtype=np.int64), sgn=np.array(sgn).reshape(len(xoff), d), dkid=np.array(dkid, dtype=np.int64),
+                dval=np.array(dval).reshape(len(dkid), d))
+
+
+def _weights(tab, u_row, dt):
+    uk = lambda k: 1.0 if k < 0 else u_row[k]
+    w = np.array([dt * uk(k) * c for k, c in zip(tab["kid"], tab["cmag"])])
+    dg = np.zeros(tab["d"])
+    for jd, k in enumerate(tab["dkid"]):
+        dg += dt * uk(k) * tab["dval"][jd]
+    return w, dg
+
+
+def apply_A(tab, w, dg, v, sign=1.0, dots=None, xm=None):
+    """o = sign * A v for A = -1j (diag(dg) + sum_j w_j S_j), S_j[i, i ^ x_j] = sigma_ij * (1j if phase_j else 1).
+    dots (list, one accumulator per XOR-diagonal) += the level's gradient pairing of the fetched partners with xm."""
+    idx = np.arange(tab["d"])
+    o = sign * (-1j) * dg * v
+    for j, x in enumerate(tab["xoff"]):
+        sig = 1.0 - 2.0 * tab["sgn"][j]
+        p = v[idx ^ x]                      # the partner value the kernel reads from LDS
+        if tab["phase"][j]:
+            o = o + sign * w[j] * sig * p   # (-1j)(1j) = 1
+        else:
+            o = o + sign * (-1j) * w[j] * sig * p
+        if dots is not None:
+            # Re <y, dA x> for this diagonal, re-indexed onto the row that fetched the partner: entry H[i ^ x, i] = conj(H[i, i ^ x])
+            if tab["phase"][j]:
+                dots[j] += -np.sum(sig * (p.real * xm.real + p.imag * xm.imag))
+            else:
+                dots[j] += np.sum(sig * (p.real * xm.imag - p.imag * xm.real))
+    return o
+
+
+def forward_step(tab, u_row, dt, psi, L):
+    w, dg = _weights(tab, u_row, dt)
+    cur, acc = psi, psi.copy()
+    for m in range(1, L + 1):
+        cur = apply_A(tab, w, dg, cur) / m
+        acc = acc + cur
+    return acc
+
+
+def backward_step(tab, u_row, dt, psi1, lam, L, K):
+    """(psi_t, lam_t, grad_row[K]) from (psi_{t+1}, lam_{t+1})."""
+    w, dg = _weights(tab, u_row, dt)
+    R = len(tab["xoff"])
+    cur, psi = psi1, psi1.copy()
+    for m in range(1, L + 1):                       # reversal
+        cur = apply_A(tab, w, dg, cur, sign=-1.0) / m
+        psi = psi + cur
+    xs = [psi]
+    for l in range(1, L):                           # the forward terms of psi_t
+        xs.append(apply_A(tab, w, dg, xs[-1]) / l)
+    dots = [0.0] * R
+    rowacc = np.zeros(tab["d"])
+    y = lam / L
+    for l in range(L - 1, 0, -1):                   # sweep forming y_{l-1} from y_l pairs y_l with x_l
+        rowacc += y.real * xs[l].imag - y.imag * xs[l].real
+        y = (lam - apply_A(tab, w, dg, y, dots=dots, xm=xs[l])) / l
+    rowacc += y.real * xs[0].imag - y.imag * xs[0].real
+    lam_t = lam - apply_A(tab, w, dg, y, dots=dots, xm=xs[0])
+    g = np.zeros(K)
+    for j in range(R):
+        if tab["kid"][j] >= 0:
+            g[tab["kid"][j]] += dt * tab["cmag"][j] * dots[j]
+    for jd, k in enumerate(tab["dkid"]):
+        if k >= 0:
+            g[k] += dt * np.sum(tab["dval"][jd] * rowacc)
+    return psi, lam_t, g
+
+
+def taylor_degree(theta, tol=1.1102230246251565e-16):
+    for L in range(1, 17):
+        v = 1.0
+        for j in range(1, L + 2):
+            v *= theta / j
+        if v <= tol:
+            return L
+    raise ValueError("step too large for the polynomial alone")
+
+
+def energy_grad(H0, Hs, M, u, dt, psi0, L=None):
+    """(loss, grad[S][K], psi_S) of L = sum_b <psi_b|M|psi_b> through the state-column recurrences."""
+    tab = table_from_dense(H0, Hs)
+    assert tab is not None, "not an XOR-regular generator"
+    u = np.asarray(u, dtype=np.float64)
+    S, K = u.shape
+    if L is None:
+        n1 = lambda A: np.abs(A).sum(axis=0).max()
+        th = max(abs(dt) * (n1(H0) + sum(abs(row[k]) * n1(Hs[k]) for k in range(K))) for row in u) if S else 0.0
+        L = taylor_degree(th)
+    psi0 = np.asarray(psi0, dtype=np.complex128)
+    B = psi0.shape[1]
+    grad = np.zeros((S, K))
+    fin = np.empty_like(psi0)
+    loss = 0.0
+    for b in range(B):
+        psi = psi0[:, b]
+        for t in range(S):
+            psi = forward_step(tab, u[t], dt, psi, L)
+        fin[:, b] = psi
+        mp = M @ psi
+        loss += float(np.real(np.vdot(psi, mp)))
+        lam = 2.0 * mp
+        for t in range(S - 1, -1, -1):
+            psi, lam, g = backward_step(tab, u[t], dt, psi, lam, L, K)
+            grad[t] += g
+    return loss, grad, fin

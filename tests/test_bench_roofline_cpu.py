@@ -65,6 +65,33 @@ def test_column_form_class_is_priced_against_the_lds_array():
     lds = (40 * fwd + 20 * rev) * 4.0 * R / (R + 1.0)
     assert s["bound"] == "lds" and s["peak"] == 256 * 256 * 2.4
     assert abs(s["achieved"] - lds / ((40 * 0.2 + 20 * 0.83) * 1e-3) / 1e9) < 1e-6
-    assert 0.0 < s["frac"] < 1.0 and s["kernel"].startswith("xr_forward_kernel")
+    assert 0.0 < s["frac"] < 1.0 and s["kernel"].startswith("xr_forward_kernel") and len(s["kernel"]) <= 80
     assert abs(s["hbm_gbps_algorithmic"] - 60 * 16 * nn / ((40 * 0.2 + 20 * 0.83) * 1e-3) / 1e9) < 1e-6
     assert bench.executed_tflops(b, 1.0) == 0.0          # (no MFMA class in this synthetic profile)
+
+
+def test_the_one_line_stays_under_4_kb_whatever_the_full_record_holds():
+    """the driver keeps an 8000-character stdout tail; BENCH_r02's 31.5 KB line was lost.  The line is a
+    short form of the full record (which goes to the extras file): built here from round 2's committed 31.5 KB record."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r2_bench_final.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 30000
+    full["extras"] = "bench_extras.json"
+    full["trials"] = {"n": 3, "ms_per_step_median": 16.1, "ms_per_step_min": 16.0, "ms_per_step_max": 16.3}
+    full["beside"] = {"sliced_form": [4115.123456789, 1.9], "one_gpu_whole_global_batch": [70.1, 114.2]}
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 4096
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "extras"):
+        assert key in line, key
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and len(r["kernel"]) <= 80 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert line["cpu_baseline"]["cores"] == 128 and line["cpu_baseline"]["c_single_thread"]["cores"] == 1
+    assert line["by_input_structure"]["dense_complex_hermitian_H"] == [12.78, 0.91]
+    assert all(not isinstance(v, (dict, list)) for v in line["config"].values())
+    # a record that is too big even in short form loses its optional objects, never the contract's fields
+    full["by_input_structure"] = {"case_{:04d}".format(i): {"value": 1.0, "roofline": {"frac": 0.5}} for i in range(400)}
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT and "by_input_structure" not in line and "roofline" in line and "cpu_baseline" in line

@@ -1,0 +1,57 @@
+"""The state-column recurrences (tests/np_state_column.py: the numpy twin of csrc/statecol.hip) against the oracle: forward
+amplitudes, loss and dL/du at 1e-10 for real Pauli sums (Ising + X_k; reference problems: demo_maxcut.py:36-79), complex ones
+(X and Y drives) and Z/ZZ-type controls with diagonal entries."""
+import numpy as np
+import pytest
+
+from diffquantum_amd import problems
+from tests import np_state_column as nsc
+
+
+def _xy(n, seed, n_x, n_y):
+    d = 1 << n
+    H0 = np.diag(problems.ising_diagonal(n, seed)).astype(np.complex128)
+    idx = np.arange(d)
+    Hs = np.zeros((n_x + n_y, d, d), dtype=np.complex128)
+    for q in range(n_x):
+        Hs[q, idx, idx ^ (1 << (n - 1 - q))] = 1.0
+    for j in range(n_y):
+        e = 1 << (n - 1 - (n - n_y + j))
+        bit = ((idx & e) != 0).astype(np.float64)
+        Hs[n_x + j, idx, idx ^ e] = 1j * (2.0 * bit - 1.0)
+    return H0, Hs, H0.copy()
+
+
+def _cases():
+    n = 5
+    yield "ising_x", problems.random_ising(n, 3)
+    yield "xy_drives", _xy(n, 4, 3, 2)
+    p = problems.qaoa_ring(4)
+    yield "qaoa_ring_zz_controls", (p["H0"].astype(np.complex128), p["Hs"].astype(np.complex128), p["H_cost"].astype(np.complex128))
+    # two-body X_a X_b and X_a Z_b terms (signs along an XOR-diagonal, shared offsets) and a Y Z term
+    H0, Hs, M = problems.random_ising(4, 5)
+    X = np.array([[0, 1], [1, 0]], dtype=complex); Y = np.array([[0, -1j], [1j, 0]]); Z = np.diag([1.0 + 0j, -1.0]); I = np.eye(2)
+    kr = lambda *ops: problems.kron_chain(list(ops))
+    Hs = np.stack([kr(X, X, I, I) + 0.5 * kr(X, Z, I, I), kr(I, Y, Z, I), kr(I, I, Z, Z) + kr(I, I, I, X)]).astype(np.complex128)
+    yield "two_body_mixed", (H0, Hs, M)
+
+
+@pytest.mark.parametrize("name,prob", list(_cases()))
+def test_state_column_model_matches_oracle(oracle, name, prob):
+    H0, Hs, M = prob
+    K, d = len(Hs), H0.shape[0]
+    S, B, dt = 5, 3, 0.02
+    u = np.random.default_rng(7).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=1)
+    tab = nsc.table_from_dense(H0, Hs)
+    assert tab is not None and len(tab["xoff"]) >= 1
+    loss, grad, fin = nsc.energy_grad(H0, Hs, M, u, dt, psi0)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    assert np.max(np.abs(fin - rf)) < 1e-12
+    assert abs(loss - rl) < 1e-11
+    assert np.max(np.abs(grad - rg)) < 1e-11
+
+
+def test_table_rejects_what_is_not_a_pauli_sum():
+    H0, Hs, _ = problems.random_hermitian_problem(3, 2, seed=0)
+    assert nsc.table_from_dense(H0, Hs) is None
