@@ -277,6 +277,8 @@ size_t xr_pow_elems(int d, int q, int batch);
 bool zxr_supported(int d, int L, int R, int nd);
 hipError_t zsp_count_launch(const double2* H, int d, int K, int* cnt, hipStream_t st);  // cnt[k * d + i] = nonzeros of row i of H[k]
 hipError_t zsp_fill_launch(const double2* H, int d, int K, const long* base, int* col, double* re, double* im, hipStream_t st);
+hipError_t zsp_count_launch(const float2* H, int d, int K, int* cnt, hipStream_t st);
+hipError_t zsp_fill_launch(const float2* H, int d, int K, const long* base, int* col, double* re, double* im, hipStream_t st);
 hipError_t zxr_forward_launch(double2* U, long stride, int d, const XrTab& tab, const double* u, int K, double dt, int L, int batch,
                               hipStream_t st);
 // xpow: batch * zxr_pow_elems(d, L, batch) double2 of scratch; part as for xr_reverse_launch
@@ -287,7 +289,8 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
 
 
 // ---- statecol.hip: whole chains on state columns held in LDS (XOR-regular generators; real or complex tables) ----
-// States are stored column by column ([B][d]).  wt [S][R], wd [S][XR_DMAX], dg0 [d]: per-step weights (xs_weights_launch).
+// States are stored column by column ([B][d]).  wt [S][R]: per-step weights of the XOR-diagonals; dgs: the rows' diagonal
+// weights, one vector or one per step (xs_weights_launch).
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
 int xs_blocks(int d, size_t elem, int B, int n_cu);           // workgroups of a launch over B columns
 int xs_waves(int d);
@@ -295,17 +298,18 @@ int xs_slots(const XrTab& tab);
 size_t xs_park_elems(int d, int L, int nblk);                 // complex elements of the backward kernel's scratch
 size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab);
 int xs_lds_diagonals(int d, const XrTab& tab);                // XOR-diagonals whose partners are LDS reads (the others: registers)
-hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* wd, double* dg0,
+size_t xs_dgs_doubles(int d, int S, const XrTab& tab);       // doubles of the diagonal-weight table
+hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
                              hipStream_t st);
-hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* wd,
-                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st);
-hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* wd,
-                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st);
+hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                             int S, int B, int L, int nblk, hipStream_t st);
+hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                             int S, int B, int L, int nblk, hipStream_t st);
 // psi: psi_S in, psi_0 out;  lam: lambda_S in, lambda_0 out;  grad[s][k] (+)= dL/du_k[s]
-hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
                               int accumulate, hipStream_t st);
-hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
                               hipStream_t st);
 

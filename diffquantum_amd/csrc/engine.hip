@@ -303,7 +303,7 @@ struct Ctx : dq_ctx {
   int xor_mode = -1;
   double last_xr = 0;
   // state-column form (statecol.hip): whole chains on state columns held in LDS; xs_mode: -1 auto, 0 off, 1 whenever supported
-  DevBuf xs_psi, xs_lam, xs_park, xs_part, xs_wt, xs_wd, xs_dg0;
+  DevBuf xs_psi, xs_lam, xs_park, xs_part, xs_wt, xs_dgs;
   int xs_mode = -1;
   double xs_batch_ratio = 8.0;  // auto: batch <= ratio x dim (beyond it the operator form, whose cost does not grow with the batch, wins)
   double last_xs = 0;
@@ -357,7 +357,7 @@ struct Ctx : dq_ctx {
     // (XOR-regular generators: the column form, xorexp.hip, beats the MFMA products wherever its kernels exist)
     return xr_ok && xor_mode != 0 && dq::xr_supported(d, 1, xr_tab.R, xr_tab.nd, sizeof(T));
   }
-  bool zxr_on() const { return zxr_ok && xor_mode != 0 && real_mode != 0 && force_degree <= 0 && force_s < 0; }
+  bool zxr_on() const { return sizeof(T) == 8 && zxr_ok && xor_mode != 0 && real_mode != 0 && force_degree <= 0 && force_s < 0; }
   bool xr_on(int q) const {
     return xr_ok && xor_mode != 0 && sparse_gen_on() && dq::xr_supported(d, q, xr_tab.R, xr_tab.nd, sizeof(T));
   }
@@ -1331,6 +1331,7 @@ int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B)
 template <class T>
 struct XsLaunch {
   int L, nblk, lds_diag;
+  long dgs_step;
   const dq::XrTab* tab;
 };
 
@@ -1347,16 +1348,17 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->xs_psi.ensure(sb);
   c->xs_lam.ensure(sb);
   c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
-  c->xs_wd.ensure(sizeof(double) * std::max<size_t>((size_t)S * dq::XR_DMAX, 1));
-  c->xs_dg0.ensure(sizeof(double) * (size_t)c->d);
+  c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
   if (backward) {
     c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
     c->xs_part.ensure(sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, S, x.nblk, *x.tab), 1));
   }
   const dq::XrTab tb = *x.tab;
-  c->timed(DQ_PROF_OTHER, 0.0, 8.0 * S * (tb.R + dq::XR_DMAX), [&] {
-    return dq::xs_weights_launch(tb, c->u_dev.d(), c->K, S, c->d, dt, c->xs_wt.d(), c->xs_wd.d(), c->xs_dg0.d(), c->st);
+  long step = 0;
+  c->timed(DQ_PROF_OTHER, 0.0, 8.0 * ((double)S * tb.R + (double)dq::xs_dgs_doubles(c->d, S, tb)), [&] {
+    return dq::xs_weights_launch(tb, c->u_dev.d(), c->K, S, c->d, dt, c->xs_wt.d(), c->xs_dgs.d(), &step, c->st);
   });
+  x.dgs_step = step;
   c->last_degree = L;
   c->last_squarings = 0;
   c->last_products = 0;
@@ -1390,7 +1392,7 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
   xs_book(c, x, (double)x.L * S, 0.0, B, &fl, &lb);
   const dq::XrTab tb = *x.tab;
   c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
-    return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_wd.d(), c->xs_dg0.d(), S, B, x.L,
+    return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, x.L,
                                  x.nblk, c->st);
   });
   if (out_db)
@@ -1718,7 +1720,7 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
     xs_book(c, x, (3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
     const dq::XrTab tb = *x.tab;
     c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
-      return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d(), c->xs_wd.d(), c->xs_dg0.d(), S, B, L, x.nblk,
+      return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, L, x.nblk,
                                     (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->st);
     });
   }
@@ -2171,28 +2173,29 @@ void find_xor_regular(Ctx<T>* c, const std::vector<long>& rowptr, long nnz) {
 template <class T>
 void find_zxor_regular(Ctx<T>* c) {
   c->zxr_ok = false;
-  if (sizeof(T) != 8 || !c->hermitian || c->real_h || c->K <= 0) return;
+  typedef TT T2;
+  if (!c->hermitian || c->real_h || c->K <= 0) return;   // (complex64 engines too: the state-column form takes the table)
   const int d = c->d, K = c->K, NS = K + 1;
   if (!dq::zxr_supported(d, 1, 1, 0)) return;
   DevBuf cnt_dev, base_dev, col_dev, re_dev, im_dev;
   cnt_dev.ensure(sizeof(int) * (size_t)NS * d);
-  HIPCK(dq::zsp_count_launch((const double2*)c->H0.p, d, 1, (int*)cnt_dev.p, c->st));
-  HIPCK(dq::zsp_count_launch((const double2*)c->Hs.p, d, K, (int*)cnt_dev.p + d, c->st));
+  HIPCK(dq::zsp_count_launch((const T2*)c->H0.p, d, 1, (int*)cnt_dev.p, c->st));
+  HIPCK(dq::zsp_count_launch((const T2*)c->Hs.p, d, K, (int*)cnt_dev.p + d, c->st));
   std::vector<int> cnt((size_t)NS * d);
   HIPCK(hipMemcpyAsync(cnt.data(), cnt_dev.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->st));
   HIPCK(hipStreamSynchronize(c->st));
   std::vector<long> base((size_t)NS * d);
   long nnz = 0;
   for (size_t q = 0; q < cnt.size(); ++q) { base[q] = nnz; nnz += cnt[q]; }
-  if (nnz == 0 || nnz > (long)(dq::XR_RMAX + 1) * d) return;
+  if (nnz == 0 || nnz > (long)(dq::XR_RMAX + dq::XR_DMAX) * d) return;  // up to 32 XOR-diagonals + 16 offset-0 ones
   base_dev.ensure(sizeof(long) * base.size());
   col_dev.ensure(sizeof(int) * (size_t)nnz);
   re_dev.ensure(sizeof(double) * (size_t)nnz);
   im_dev.ensure(sizeof(double) * (size_t)nnz);
   HIPCK(hipMemcpyAsync(base_dev.p, base.data(), sizeof(long) * base.size(), hipMemcpyHostToDevice, c->st));
-  HIPCK(dq::zsp_fill_launch((const double2*)c->H0.p, d, 1, (const long*)base_dev.p, (int*)col_dev.p, (double*)re_dev.p,
+  HIPCK(dq::zsp_fill_launch((const T2*)c->H0.p, d, 1, (const long*)base_dev.p, (int*)col_dev.p, (double*)re_dev.p,
                             (double*)im_dev.p, c->st));
-  HIPCK(dq::zsp_fill_launch((const double2*)c->Hs.p, d, K, (const long*)base_dev.p + d, (int*)col_dev.p, (double*)re_dev.p,
+  HIPCK(dq::zsp_fill_launch((const T2*)c->Hs.p, d, K, (const long*)base_dev.p + d, (int*)col_dev.p, (double*)re_dev.p,
                             (double*)im_dev.p, c->st));
   std::vector<int> col((size_t)nnz);
   std::vector<double> re((size_t)nnz), im((size_t)nnz);

@@ -114,7 +114,7 @@ __device__ __forceinline__ void xs_local(int xh, int j, int ph, T w, const unsig
 // o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`).  wrow: this step's weights dt u c_j
 // (wave-uniform).  The loop over the diagonals is a runtime loop on purpose (unrolled, the compiler hoists masks and addresses
 // of all R diagonals and spills); LDS reads are volatile so that neighbours are not merged into ds_read2 forms.
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM>
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool LOCAL = true>
 __device__ __forceinline__ void xs_gather(const XrTab& tab, const double* __restrict__ wrow, const unsigned* sg,
                                           const typename Cx<T>::type* __restrict__ src, const typename Cx<T>::type* cur, int t, T sgn,
                                           typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
@@ -127,12 +127,12 @@ __device__ __forceinline__ void xs_gather(const XrTab& tab, const double* __rest
     const int ph = tab.phase[j];
     const T w = sgn * (T)wrow[j];
     const int xl = xo & (NT - 1), xh = xo / NT;
-    if (xl == 0) {  // (wave-uniform) the partner rows are the thread's own registers
+    if (LOCAL && xl == 0) {  // (wave-uniform) the partner rows are the thread's own registers
       xs_local<T, RPT, 1, SIGN, DOT, RM>(xh, j, ph, w, sg, cur, o, xm, dacc);
     } else {
       T2 v[RPT];
       lds_ptr base = (lds_ptr)(src + (t ^ xl));
-      if (xh == 0) {
+      if (xh == 0 && xl != 0) {
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           const V2 q = base[r * NT];
@@ -152,22 +152,6 @@ __device__ __forceinline__ void xs_gather(const XrTab& tab, const double* __rest
   }
 }
 
-// the thread's diagonal weights of step s: dg0 (the drift's) + the diagonal controls'
-template <class T, int NT, int RPT, bool DIAGCTL>
-__device__ __forceinline__ void xs_diag(const XrTab& tab, const T* dgc, const double* __restrict__ wdrow, int t, T* dg) {
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) dg[r] = dgc[r];
-  if (DIAGCTL) {
-    constexpr int D = NT * RPT;
-    for (int jd = 0; jd < tab.nd; ++jd) {
-      if (tab.dkid[jd] < 0) continue;
-      const double w = wdrow[jd];
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) dg[r] += (T)(w * tab.dval[(long)jd * D + r * NT + t]);
-    }
-  }
-}
-
 template <class T, int NT, int RPT>
 __device__ __forceinline__ void xs_put(typename Cx<T>::type* img, int t, const typename Cx<T>::type* v) {
 #pragma unroll
@@ -176,45 +160,45 @@ __device__ __forceinline__ void xs_put(typename Cx<T>::type* img, int t, const t
 
 }  // namespace
 
-// wt[s][j] = dt u[s][kid_j] cmag_j;  wd[s][jd] = dt u[s][dkid_jd] (0 for the drift's diagonal);  dg0[i] = dt sum of the drift's
-// diagonals.  grid: S + ceil(d / 256) blocks of 256 threads.
+// wt[s][j] = dt u[s][kid_j] cmag_j;  dgs: the rows' diagonal weights dt (H0 + sum_k u_k H_k)[i][i] -- one vector [d] when only
+// the drift has diagonal entries (per_step = 0), else one per step [S][d].  grid: (ceil(d / 256), per_step ? S : 1) + S blocks for wt
 __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double* __restrict__ u, int K, int S, int d, double dt,
-                                                         double* __restrict__ wt, double* __restrict__ wd, double* __restrict__ dg0) {
+                                                         int per_step, double* __restrict__ wt, double* __restrict__ dgs) {
+  const int nbd = (d + 255) / 256, nds = per_step ? S : 1;
   const int b = blockIdx.x, t = threadIdx.x;
-  if (b < S) {
-    const double* ur = u + (long)b * K;
-    if (t < tab.R) wt[(long)b * tab.R + t] = dt * (tab.kid[t] < 0 ? 1.0 : ur[tab.kid[t]]) * tab.cmag[t];
-    if (t < tab.nd) wd[(long)b * XR_DMAX + t] = tab.dkid[t] < 0 ? 0.0 : dt * ur[tab.dkid[t]];
-  } else {
-    const int i = (b - S) * 256 + t;
+  if (b < nbd * nds) {
+    const int s = b / nbd, i = (b - s * nbd) * 256 + t;
     if (i < d) {
+      const double* ur = u + (long)s * K;
       double v = 0.0;
-      for (int jd = 0; jd < tab.nd; ++jd)
-        if (tab.dkid[jd] < 0) v += tab.dval[(long)jd * d + i];
-      dg0[i] = dt * v;
+      for (int jd = 0; jd < tab.nd; ++jd) {
+        const int k = tab.dkid[jd];
+        v += (k < 0 ? 1.0 : ur[k]) * tab.dval[(long)jd * d + i];
+      }
+      dgs[(long)s * d + i] = dt * v;
     }
+  } else {
+    const int s = b - nbd * nds;
+    const double* ur = u + (long)s * K;
+    if (t < tab.R) wt[(long)s * tab.R + t] = dt * (tab.kid[t] < 0 ? 1.0 : ur[tab.kid[t]]) * tab.cmag[t];
   }
 }
 
 // psi_out[b][:] = U_{S-1} ... U_0 psi_in[b][:] for the columns b = blockIdx.x, + gridDim.x, ...  (states stored column by
-// column: [B][D]).  ckpt (optional): psi_t of every step t with t % cstride == 0, [t / cstride][B][D].
-template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL>
+// column: [B][D]).  dgs + s * dgs_step: the rows' diagonal weights of step s.
+template <class T, int NT, int RPT, bool SIGN>
 __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
                                                         typename Cx<T>::type* __restrict__ psi_out, XrTab tab,
-                                                        const double* __restrict__ wt, const double* __restrict__ wd,
-                                                        const double* __restrict__ dg0, int S, int B, int L) {
+                                                        const double* __restrict__ wt, const double* __restrict__ dgs, long dgs_step,
+                                                        int S, int B, int L) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
   T2* img = (T2*)xs_lds_raw;  // two images of D
   const int t = threadIdx.x;
   unsigned sg[RPT];
-  T dgc[RPT];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
-    dgc[r] = (T)dg0[r * NT + t];
-  }
+  for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
   int p = 0;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     T2 cur[RPT];
@@ -225,32 +209,34 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
     xs_put<T, NT, RPT>(img + p * D, t, cur);
     __syncthreads();
     for (int s = 0; s < S; ++s) {
-      T dg[RPT];
-      xs_diag<T, NT, RPT, DIAGCTL>(tab, dgc, wd + (long)s * XR_DMAX, t, dg);
       const double* wrow = wt + (long)s * tab.R;
+      const double* dgr = dgs + (long)s * dgs_step;
       T2 acc[RPT];
 #pragma unroll
       for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
       for (int m = 1; m <= L; ++m) {
         T2 o[RPT];
+        T dg[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {  // the diagonal: -i dg v
-          o[r].x = dg[r] * cur[r].y;
-          o[r].y = -dg[r] * cur[r].x;
+        for (int r = 0; r < RPT; ++r) {
+          dg[r] = (T)dgr[r * NT + t];
+          o[r].x = 0;
+          o[r].y = 0;
         }
         xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)m;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-          o[r].x *= inv;
-          o[r].y *= inv;
-          cur[r] = o[r];
-          acc[r].x += o[r].x;
-          acc[r].y += o[r].y;
+        for (int r = 0; r < RPT; ++r) {  // + the diagonal: -i dg v
+          const T ox = xs_fma(dg[r], cur[r].y, o[r].x) * inv;
+          const T oy = xs_fma(-dg[r], cur[r].x, o[r].y) * inv;
+          cur[r].x = ox;
+          cur[r].y = oy;
+          acc[r].x += ox;
+          acc[r].y += oy;
         }
         if (m < L) {
           p ^= 1;
-          xs_put<T, NT, RPT>(img + p * D, t, o);
+          xs_put<T, NT, RPT>(img + p * D, t, cur);
           __syncthreads();
         }
       }
@@ -269,22 +255,30 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
   }
 }
 
-// 16 per-lane values -> lane l < 16 holds the wave's total of value l (17 exchanges instead of 96)
-__device__ __forceinline__ double xs_wave_sums16(double* a, int lane) {
+// 16 per-lane values -> lane l < 16 holds the wave's total of value l (17 exchanges instead of 96).  Every stage has its own
+// constant-indexed array, so that the values stay in registers.
+__device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
+  double b8[8], b4[4], b2[2];
+  {
+    const bool up = (lane & 8) != 0;
 #pragma unroll
-  for (int half = 8; half >= 1; half >>= 1) {
-    const bool up = (lane & half) != 0;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-      const double send = up ? a[i] : a[i + half];
-      const double keep = up ? a[i + half] : a[i];
-      a[i] = keep + __shfl_xor(send, half, 64);
-    }
+    for (int i = 0; i < 8; ++i) b8[i] = (up ? a[i + 8] : a[i]) + __shfl_xor(up ? a[i] : a[i + 8], 8, 64);
   }
-  double v = a[0];
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b4[i] = (up ? b8[i + 4] : b8[i]) + __shfl_xor(up ? b8[i] : b8[i + 4], 4, 64);
+  }
+  {
+    const bool up = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b2[i] = (up ? b4[i + 2] : b4[i]) + __shfl_xor(up ? b4[i] : b4[i + 2], 2, 64);
+  }
+  const bool up = (lane & 1) != 0;
+  double v = (up ? b2[1] : b2[0]) + __shfl_xor(up ? b2[0] : b2[1], 1, 64);
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
-  return v;  // lane l: total of value (l & 15) in the bit order of the halving: bit 3 chose first, then 2, 1, 0
+  return v;  // lane l: the total of value (l & 15)
 }
 
 // Backward sweep of the chain for the columns b = blockIdx.x, + gridDim.x, ...:  psi [b][:] holds psi_S on entry and psi_0 on exit,
@@ -294,9 +288,9 @@ __device__ __forceinline__ double xs_wave_sums16(double* a, int lane) {
 //   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
 template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM>
 __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
-                                                         XrTab tab, const double* __restrict__ wt, const double* __restrict__ wd,
-                                                         const double* __restrict__ dg0, int S, int B, int L,
-                                                         typename Cx<T>::type* __restrict__ park, double* __restrict__ part) {
+                                                         XrTab tab, const double* __restrict__ wt, const double* __restrict__ dgs,
+                                                         long dgs_step, int S, int B, int L, typename Cx<T>::type* __restrict__ park,
+                                                         double* __restrict__ part) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
   constexpr int NW = NT / 64;
@@ -305,16 +299,10 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   T2* img = (T2*)xs_lds_raw;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   unsigned sg[RPT];
-  T dgc[RPT];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
-    dgc[r] = (T)dg0[r * NT + t];
-  }
-  T2* pk = park + (long)blockIdx.x * (L + 1) * D + t;  // [l][r * NT + t]
+  for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+  T2* pk = park + (long)blockIdx.x * (L + 1) * D;  // [l][r * NT + t] (uniform base, lane index t)
   T2* plam = pk + (long)L * D;
-  // the slot a lane reports after xs_wave_sums16 (bit 3 of the lane chose the upper half first, ...): slot = lane & 15
-  // read as (b3 b2 b1 b0) -> value index b3 * 8 + b2 * 4 + b1 * 2 + b0 = lane & 15
   int p = 0;
   bool first = true;
   for (int b = blockIdx.x; b < B; b += gridDim.x, first = false) {
@@ -325,13 +313,12 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         cur[r] = in[r * NT + t];
-        plam[r * NT] = li[r * NT + t];
+        plam[r * NT + t] = li[r * NT + t];
       }
     }
     for (int s = S - 1; s >= 0; --s) {
-      T dg[RPT];
-      xs_diag<T, NT, RPT, DIAGCTL>(tab, dgc, wd + (long)s * XR_DMAX, t, dg);
       const double* wrow = wt + (long)s * tab.R;
+      const double* dgr = dgs + (long)s * dgs_step;
       // ---- reversal: psi_s = sum_m (-A)^m psi_{s+1} / m! -------------------------------------------------------------
       p ^= 1;
       xs_put<T, NT, RPT>(img + p * D, t, cur);
@@ -342,24 +329,27 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
         for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
         for (int m = 1; m <= L; ++m) {
           T2 o[RPT];
+          T dg[RPT];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {
-            o[r].x = -dg[r] * cur[r].y;
-            o[r].y = dg[r] * cur[r].x;
+            dg[r] = (T)dgr[r * NT + t];
+            o[r].x = 0;
+            o[r].y = 0;
           }
           xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)-1, o, nullptr, nullptr);
           const T inv = (T)1 / (T)m;
 #pragma unroll
-          for (int r = 0; r < RPT; ++r) {
-            o[r].x *= inv;
-            o[r].y *= inv;
-            cur[r] = o[r];
-            acc[r].x += o[r].x;
-            acc[r].y += o[r].y;
+          for (int r = 0; r < RPT; ++r) {  // + i dg v
+            const T ox = xs_fma(-dg[r], cur[r].y, o[r].x) * inv;
+            const T oy = xs_fma(dg[r], cur[r].x, o[r].y) * inv;
+            cur[r].x = ox;
+            cur[r].y = oy;
+            acc[r].x += ox;
+            acc[r].y += oy;
           }
           if (m < L) {
             p ^= 1;
-            xs_put<T, NT, RPT>(img + p * D, t, o);
+            xs_put<T, NT, RPT>(img + p * D, t, cur);
             __syncthreads();
           }
         }
@@ -368,7 +358,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       }
       // ---- the forward terms x_l = A^l psi_s / l! --------------------------------------------------------------------
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) pk[r * NT] = cur[r];
+      for (int r = 0; r < RPT; ++r) pk[r * NT + t] = cur[r];
       if (L > 1) {
         p ^= 1;
         xs_put<T, NT, RPT>(img + p * D, t, cur);
@@ -376,23 +366,27 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       }
       for (int l = 1; l < L; ++l) {
         T2 o[RPT];
+        T dg[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          o[r].x = dg[r] * cur[r].y;
-          o[r].y = -dg[r] * cur[r].x;
+          dg[r] = (T)dgr[r * NT + t];
+          o[r].x = 0;
+          o[r].y = 0;
         }
         xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)l;
+        T2* pl = pk + (long)l * D;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          o[r].x *= inv;
-          o[r].y *= inv;
-          cur[r] = o[r];
-          pk[(long)l * D + r * NT] = o[r];
+          const T ox = xs_fma(dg[r], cur[r].y, o[r].x) * inv;
+          const T oy = xs_fma(-dg[r], cur[r].x, o[r].y) * inv;
+          cur[r].x = ox;
+          cur[r].y = oy;
+          pl[r * NT + t] = cur[r];
         }
         if (l < L - 1) {
           p ^= 1;
-          xs_put<T, NT, RPT>(img + p * D, t, o);
+          xs_put<T, NT, RPT>(img + p * D, t, cur);
           __syncthreads();
         }
       }
@@ -406,7 +400,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
         const T inv = (T)1 / (T)L;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          const T2 g = plam[r * NT];
+          const T2 g = plam[r * NT + t];
           cur[r].x = g.x * inv;
           cur[r].y = g.y * inv;
         }
@@ -416,15 +410,17 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       __syncthreads();
       for (int l = L - 1; l >= 0; --l) {  // forms y_{l-1} from y_l (l = 0: lambda_s), pairing y_l with x_l
         T2 o[RPT], xm[RPT];
+        const T2* pl = pk + (long)l * D;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          xm[r] = pk[(long)l * D + r * NT];
-          const T2 g = plam[r * NT];
-          o[r].x = g.x - dg[r] * cur[r].y;  // lam - (-i dg y)
-          o[r].y = g.y + dg[r] * cur[r].x;
+          xm[r] = pl[r * NT + t];
+          const T dgv = (T)dgr[r * NT + t];
+          const T2 g = plam[r * NT + t];
+          o[r].x = xs_fma(-dgv, cur[r].y, g.x);  // lam - (-i dg y)
+          o[r].y = xs_fma(dgv, cur[r].x, g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
-        xs_gather<T, NT, RPT, SIGN, true, RM>(tab, wrow, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
+        xs_gather<T, NT, RPT, SIGN, true, RM, false>(tab, wrow, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
 #pragma unroll
@@ -437,7 +433,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           __syncthreads();
         } else {
 #pragma unroll
-          for (int r = 0; r < RPT; ++r) plam[r * NT] = o[r];
+          for (int r = 0; r < RPT; ++r) plam[r * NT + t] = o[r];
         }
       }
       // ---- this step's sums: per wave, accumulated over the workgroup's columns --------------------------------------
@@ -450,20 +446,22 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       if (DIAGCTL) {
         double dv[XR_DMAX];
 #pragma unroll
-        for (int jd = 0; jd < XR_DMAX; ++jd) {
+        for (int jd = 0; jd < XR_DMAX; ++jd) dv[jd] = 0.0;
+#pragma clang loop unroll(disable)
+        for (int jd = 0; jd < tab.nd; ++jd) {  // (runtime loop + tree select: unrolled, the 16 x RPT loads are hoisted and spill)
+          if (tab.dkid[jd] < 0) continue;
+          const double* dvr = tab.dval + (long)jd * D;
           double v = 0.0;
-          if (jd < tab.nd && tab.dkid[jd] >= 0) {
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) v = __builtin_fma(tab.dval[(long)jd * D + r * NT + t], rowacc[r], v);
-          }
-          dv[jd] = v;
+          for (int r = 0; r < RPT; ++r) v = __builtin_fma(dvr[r * NT + t], rowacc[r], v);
+          xs_acc<0, XR_DMAX>(dv, jd, v);
         }
         const double v = xs_wave_sums16(dv, lane);
         if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
       }
       // psi_s back into the registers for the next (earlier) step
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) cur[r] = pk[r * NT];
+      for (int r = 0; r < RPT; ++r) cur[r] = pk[r * NT + t];
     }
     {
       T2* out = psi + (long)b * D;
@@ -471,7 +469,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         out[r * NT + t] = cur[r];
-        lo[r * NT + t] = plam[r * NT];
+        lo[r * NT + t] = plam[r * NT + t];
       }
     }
     __syncthreads();
@@ -547,77 +545,87 @@ int xs_lds_diagonals(int d, const XrTab& tab) {
 size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)(L + 1) * (size_t)d; }
 size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab) { return (size_t)nblk * (size_t)S * (size_t)xs_waves(d) * (size_t)xs_slots(tab); }
 
-hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* wd, double* dg0,
+// dgs: d doubles, or S * d when a control has diagonal entries (xs_dgs_doubles); returns the step stride through *dgs_step
+size_t xs_dgs_doubles(int d, int S, const XrTab& tab) { return (size_t)d * (size_t)(xs_slots(tab) > XR_RSMALL ? (S > 0 ? S : 1) : 1); }
+
+hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
                              hipStream_t st) {
-  hipLaunchKernelGGL(xs_weights_kernel, dim3((unsigned)(S + (d + 255) / 256)), dim3(256), 0, st, tab, u, K, S, d, dt, wt, wd, dg0);
+  const int per_step = xs_slots(tab) > XR_RSMALL ? 1 : 0;
+  *dgs_step = per_step ? d : 0;
+  if (S <= 0) return hipSuccess;
+  const int nbd = (d + 255) / 256;
+  hipLaunchKernelGGL(xs_weights_kernel, dim3((unsigned)(nbd * (per_step ? S : 1) + S)), dim3(256), 0, st, tab, u, K, S, d, dt, per_step,
+                     wt, dgs);
   return hipGetLastError();
 }
 
 namespace {
 
-bool xs_diagctl(const XrTab& tab) {
-  for (int j = 0; j < tab.nd; ++j)
-    if (tab.dkid[j] >= 0) return true;
-  return false;
-}
+bool xs_diagctl(const XrTab& tab) { return xs_slots(tab) > XR_RSMALL; }
 
 template <class T, int NT, int RPT>
-hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* out, const XrTab& tab, const double* wt, const double* wd,
-                         const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
+hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* out, const XrTab& tab, const double* wt, const double* dgs,
+                         long dgs_step, int S, int B, int L, int nblk, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
-  const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
-  void (*kf)(const T2*, T2*, XrTab, const double*, const double*, const double*, int, int, int) =
-      sgn ? (dc ? xs_forward_kernel<T, NT, RPT, true, true> : xs_forward_kernel<T, NT, RPT, true, false>)
-          : (dc ? xs_forward_kernel<T, NT, RPT, false, true> : xs_forward_kernel<T, NT, RPT, false, false>);
+  void (*kf)(const T2*, T2*, XrTab, const double*, const double*, long, int, int, int) =
+      tab.sgn ? xs_forward_kernel<T, NT, RPT, true> : xs_forward_kernel<T, NT, RPT, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, wt, wd, dg0, S, B, L);
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, wt, dgs, dgs_step, S, B, L);
   return hipGetLastError();
 }
 
 template <class T, int NT, int RPT>
-hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* wd,
-                          const double* dg0, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
+hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
+                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
-  void (*kf)(T2*, T2*, XrTab, const double*, const double*, const double*, int, int, int, T2*, double*) =
+  void (*kf)(T2*, T2*, XrTab, const double*, const double*, long, int, int, int, T2*, double*) =
       sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL>)
           : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL> : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL>);
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, wt, wd, dg0, S, B, L, park, part);
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, wt, dgs, dgs_step, S, B, L, park, part);
   return hipGetLastError();
 }
 
 template <class T>
 hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* out, int d, const XrTab& tab, const double* wt,
-                        const double* wd, const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
+                        const double* dgs, long dgs_step, int S, int B, int L, int nblk, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T))) return hipErrorInvalidValue;
   switch (d) {
-    case 4096: return xs_forward_go<T, 512, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
-    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
-    case 1024: return xs_forward_go<T, 128, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
-    case 512: return xs_forward_go<T, 64, 8>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
-    default: return xs_forward_go<T, 64, 4>(in, out, tab, wt, wd, dg0, S, B, L, nblk, st);
+    case 4096: return xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+#ifndef XS_PROBE_4096_ONLY
+    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+    case 1024: return xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+    case 512: return xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+    default: return xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+#else
+    default: return hipErrorInvalidValue;
+#endif
   }
 }
 
 template <class T>
 hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
-                         const double* wd, const double* dg0, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
+                         const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
                          int K, double dt, double* grad, int accumulate, hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T)) || !park || !part) return hipErrorInvalidValue;
   hipError_t e;
   switch (d) {
-    case 4096: e = xs_backward_go<T, 512, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
-    case 2048: e = xs_backward_go<T, 256, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
-    case 1024: e = xs_backward_go<T, 128, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
-    case 512: e = xs_backward_go<T, 64, 8>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st); break;
-    default: e = xs_backward_go<T, 64, 4>(psi, lam, tab, wt, wd, dg0, S, B, L, nblk, park, part, st);
+    case 4096: e = xs_backward_go<T, 512, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
+#ifndef XS_PROBE_4096_ONLY
+    case 2048: e = xs_backward_go<T, 256, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
+    case 1024: e = xs_backward_go<T, 128, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
+    case 512: e = xs_backward_go<T, 64, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
+    default: e = xs_backward_go<T, 64, 4>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+#else
+    default: e = hipErrorInvalidValue;
+#endif
   }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d), xs_slots(tab), (int)XR_RSMALL, S,
@@ -627,23 +635,23 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
 
 }  // namespace
 
-hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* wd,
-                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
-  return xs_forward_t<double>(in, out, d, tab, wt, wd, dg0, S, B, L, nblk, st);
+hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                             int S, int B, int L, int nblk, hipStream_t st) {
+  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
 }
-hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* wd,
-                             const double* dg0, int S, int B, int L, int nblk, hipStream_t st) {
-  return xs_forward_t<float>(in, out, d, tab, wt, wd, dg0, S, B, L, nblk, st);
+hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                             int S, int B, int L, int nblk, hipStream_t st) {
+  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
 }
-hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
                               int accumulate, hipStream_t st) {
-  return xs_backward_t<double>(psi, lam, d, tab, wt, wd, dg0, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
+  return xs_backward_t<double>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
 }
-hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* wd, const double* dg0,
+hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
                               hipStream_t st) {
-  return xs_backward_t<float>(psi, lam, d, tab, wt, wd, dg0, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
+  return xs_backward_t<float>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
 }
 
 }  // namespace dq

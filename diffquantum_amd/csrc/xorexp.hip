@@ -970,5 +970,15 @@ hipError_t zsp_fill_launch(const double2* H, int d, int K, const long* base, int
   hipLaunchKernelGGL(zsp_fill_kernel<double2>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, H, d, base, col, re, im);
   return hipGetLastError();
 }
+hipError_t zsp_count_launch(const float2* H, int d, int K, int* cnt, hipStream_t st) {
+  if (d <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(zsp_count_kernel<float2>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, H, d, cnt);
+  return hipGetLastError();
+}
+hipError_t zsp_fill_launch(const float2* H, int d, int K, const long* base, int* col, double* re, double* im, hipStream_t st) {
+  if (d <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(zsp_fill_kernel<float2>, dim3((unsigned)d, (unsigned)K), dim3(64), 0, st, H, d, base, col, re, im);
+  return hipGetLastError();
+}
 
 }  // namespace dq

@@ -46,6 +46,8 @@ SCHEMES = {
     "sparse_controls_dense_drift": ({"sparse_generator": 0}, {"real_path": True, "sparse_generator": False, "sparse_controls": True}),
     "dense_real": ({"sparse_generator": 0, "sparse_controls": 0}, {"real_path": True, "sparse_generator": False, "sparse_controls": False}),
     "complex_tape": ({"real_path": 0}, {"real_path": False}),
+    # the state-column form (statecol.hip): no propagator at all; `compose` is left on auto (an explicit value pins the other forms)
+    "state_columns": ({"state_columns": 1}, {"real_path": True, "sparse_generator": True, "xor_regular": True}),
 }
 
 
@@ -63,9 +65,16 @@ def test_headline_dimension_matches_oracle(ising12, scheme, compose):
         e.set_observable(P["M"])
         for k, v in opts.items():
             e.set_option(k, v)
-        e.set_option("compose", compose)
+        if scheme == "state_columns":
+            if compose:
+                pytest.skip("one form only")
+        else:
+            e.set_option("compose", compose)
+            e.set_option("state_columns", 0)
         fwd = e.propagate(P["u"], dt, P["psi0"])
+        assert e.info("state_columns") == (1 if scheme == "state_columns" else 0)
         loss, grad, fin, en = e.energy_grad(P["u"], dt, P["psi0"])
+        assert e.info("state_columns") == (1 if scheme == "state_columns" else 0)
         assert (e.info("real_path") >= 1) == want["real_path"]
         if "sparse_generator" in want:
             assert (e.info("sparse_generator") >= 1) == want["sparse_generator"]
@@ -73,7 +82,7 @@ def test_headline_dimension_matches_oracle(ising12, scheme, compose):
             assert (e.info("sparse_controls") >= 1) == want["sparse_controls"]
         if "xor_regular" in want:
             assert (e.info("xor_regular") >= 1) == want["xor_regular"]
-        assert e.info("operator_backward") == (1 if compose else 0)
+        assert e.info("operator_backward") == (1 if compose and scheme != "state_columns" else 0)
     assert np.max(np.abs(fwd - P["fin"])) < TOL
     assert np.max(np.abs(fin - P["fin"])) < TOL
     assert abs(loss - P["loss"]) < TOL * N12["B"] and abs(float(en.sum()) - P["loss"]) < TOL * N12["B"]

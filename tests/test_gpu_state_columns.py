@@ -1,0 +1,170 @@
+"""GPU parity of the state-column form (diffquantum_amd/csrc/statecol.hip): the chain `psi <- expm(-1j dt H(t)) psi`
+(sim_plain.py:135-150, diffqc.cc:190-200) and its adjoint gradient with every state column held in LDS for the whole chain,
+for generators that are sums of Pauli strings.  Against the oracle (d = 256 .. 1024 here, d = 4096 in
+test_gpu_baseline_configs.py) and against the engine's other schemes (option state_columns = 0) up to d = 4096.
+
+Tolerance (BASELINE.json north_star): 1e-10 on amplitudes and gradients in fp64, 1e-4 in fp32.
+"""
+import numpy as np
+import pytest
+
+from diffquantum_amd import problems
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _engine(H0, Hs, M, dtype="c128", **opts):
+    from diffquantum_amd.engine import Engine
+    e = Engine(len(H0), len(Hs), dtype=dtype)
+    e.set_hamiltonians(H0, Hs)
+    e.set_observable(M)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    return e
+
+
+def _xy(n, seed, n_x, n_y):
+    import torch
+    H0, Hs, M = problems.xy_drives_torch(n, seed, torch.device("cuda:0"), n_x=n_x, n_y=n_y)
+    return H0.cpu().numpy(), Hs.cpu().numpy(), M.cpu().numpy()
+
+
+def _qaoa(n):
+    p = problems.qaoa_ring(n)
+    return p["H0"].astype(np.complex128), p["Hs"].astype(np.complex128), p["H_cost"].astype(np.complex128)
+
+
+def _mixed(n, seed):
+    """Drift with an off-diagonal term, two-body X X / X Z / Y Z strings (signs, shared offsets), a diagonal control and a
+    control with both kinds of entries: every entry class of the table, real and imaginary phases."""
+    rng = np.random.default_rng(seed)
+    X = np.array([[0, 1], [1, 0]], dtype=complex); Y = np.array([[0, -1j], [1j, 0]]); Z = np.diag([1.0 + 0j, -1.0])
+
+    def s(ops):
+        return problems.kron_chain([ops.get(q, np.eye(2)) for q in range(n)])
+
+    H0 = np.diag(problems.ising_diagonal(n, seed)).astype(complex) + 0.7 * s({0: X})
+    Hs = [s({1: X}), s({2: X}), s({1: X, 4: X}) + 0.5 * s({1: X, 5: Z}), s({3: Y, 6: Z}), 1.5 * s({3: X, 6: Z}), s({4: Z}),
+          s({7: X}) + 0.5 * s({2: Z}), s({n - 1: Y})]
+    M = rng.standard_normal((1 << n, 1 << n))
+    return H0, np.array(Hs), ((M + M.T) / 2).astype(complex)
+
+
+CASES = {
+    "ising_x": lambda n: problems.random_ising(n, 4),
+    "xy_drives": lambda n: _xy(n, 5, n // 2, n - n // 2),
+    "mixed_two_body": lambda n: _mixed(n, 6),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES) + ["qaoa_ring_zz_controls"])
+@pytest.mark.parametrize("n", [8, 9])
+def test_state_columns_match_oracle(oracle, case, n):
+    """d = 256 (one wave per column, 4 rows per lane) and 512 (8 rows per lane): forward amplitudes, loss, dL/du vs the oracle."""
+    H0, Hs, M = _qaoa(n) if case == "qaoa_ring_zz_controls" else CASES[case](n)
+    K, d = len(Hs), 1 << n
+    S, B, dt = 4, 5, 2e-3
+    u = np.random.default_rng(n).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1, "a Pauli-string generator did not take the state-column form"
+        fwd = e.propagate(u, dt, psi0)
+        assert e.info("state_columns") == 1
+        e.set_option("state_columns", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 0
+    assert np.max(np.abs(fin - rf)) < TOL and np.max(np.abs(fwd - rf)) < TOL
+    assert abs(loss - rl) < TOL and abs(float(en.sum()) - rl) < TOL
+    assert np.max(np.abs(grad - rg)) < TOL, np.max(np.abs(grad - rg))
+    assert np.max(np.abs(grad - g0)) < TOL and abs(loss - l0) < TOL and np.max(np.abs(fin - f0)) < TOL
+    assert np.max(np.abs(rg)) > 1e-5
+
+
+@pytest.mark.parametrize("n,B", [(10, 7), (11, 3), (12, 300)])
+def test_state_columns_match_the_other_schemes_at_every_dimension(n, B):
+    """d = 1024, 2048, 4096 (several columns per workgroup at d = 4096: 300 columns on 256 workgroups) against the engine's
+    explicit-propagator schemes, and a negative dt."""
+    H0, Hs, M = problems.random_ising(n, seed=n)
+    S = 3
+    u = np.random.default_rng(n).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=4)
+    for dt in (1.5e-3, -1e-3):
+        with _engine(H0, Hs, M) as e:
+            l1, g1, f1, e1 = e.energy_grad(u, dt, psi0)
+            assert e.info("state_columns") == 1 and e.info("xor_regular") == 1
+            e.set_option("state_columns", 0)
+            l0, g0, f0, e0 = e.energy_grad(u, dt, psi0)
+            assert e.info("state_columns") == 0
+        assert np.max(np.abs(f1 - f0)) < 1e-12 and abs(l1 - l0) < 1e-11 * B
+        assert np.max(np.abs(e1 - e0)) < 1e-12
+        assert np.max(np.abs(g1 - g0)) < 1e-11 * max(1, B / 16), np.max(np.abs(g1 - g0))
+
+
+def test_state_columns_dimension_1024_matches_oracle(oracle):
+    n, S, B, dt = 10, 3, 4, 2e-3
+    H0, Hs, M = _xy(n, 9, 5, 5)
+    u = np.random.default_rng(3).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=6)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1 and e.info("xor_regular") == 2
+    assert np.max(np.abs(fin - rf)) < TOL and abs(loss - rl) < TOL and np.max(np.abs(grad - rg)) < TOL
+
+
+def test_long_chain_reversal_drift(oracle):
+    """200 steps at d = 256: the backward sweep re-derives psi_t = U_t^H psi_{t+1} all the way down; gradient vs the oracle."""
+    n, S, B = 8, 200, 3
+    H0, Hs, M = problems.random_ising(n, seed=2)
+    u = problems.pulse_table(n, S, 0.4, seed=3)
+    psi0 = problems.random_states(1 << n, B, seed=7)
+    dt = 0.4 / S
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M) as e:
+        loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1
+    assert np.max(np.abs(fin - rf)) < TOL and abs(loss - rl) < TOL and np.max(np.abs(grad - rg)) < TOL
+
+
+def test_fidelity_objective_and_fp32(oracle):
+    n, S, B, dt = 8, 5, 6, 3e-3
+    H0, Hs, M = _xy(n, 3, 4, 4)
+    u = np.random.default_rng(5).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=8)
+    tg = problems.random_states(1 << n, B, seed=9)
+    rl, rg = oracle.fidelity_grad(H0, list(Hs), u, dt, psi0, tg)[:2]
+    with _engine(H0, Hs, M) as e:
+        out = e.fidelity_grad(u, dt, psi0, tg)
+        assert e.info("state_columns") == 1
+    assert abs(out[0] - rl) < TOL and np.max(np.abs(out[1] - rg)) < TOL
+    l64, g64, f64 = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0.astype(np.complex64), Hs.astype(np.complex64), M.astype(np.complex64), dtype="c64") as e:
+        loss, grad, fin, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("state_columns") == 1
+    assert np.max(np.abs(fin - f64)) < 1e-4 and abs(loss - l64) < 1e-4 * B and np.max(np.abs(grad - g64)) < 1e-4
+
+
+def test_options_that_pin_another_scheme_keep_it_and_wide_batches_leave():
+    n = 8
+    H0, Hs, M = problems.random_ising(n, seed=1)
+    u = np.random.default_rng(0).uniform(-1, 1, (2, n))
+    psi0 = problems.random_states(1 << n, 4, seed=1)
+    for opt, val in (("compose", 1), ("compose", 0), ("real_path", 0), ("real_path", 2), ("xor_regular", 0), ("sparse_generator", 0),
+                     ("force_degree", 9)):
+        with _engine(H0, Hs, M, **{opt: val}) as e:
+            e.energy_grad(u, 1e-3, psi0)
+            assert e.info("state_columns") == 0, opt
+    wide = problems.random_states(1 << n, 8 * 256 + 1, seed=1)
+    with _engine(H0, Hs, M) as e:
+        e.energy_grad(u, 1e-3, wide)
+        assert e.info("state_columns") == 0               # batch > 8 x dim: the operator form's cost does not grow with the batch
+        e.set_option("state_columns", 1)
+        e.energy_grad(u, 1e-3, wide)
+        assert e.info("state_columns") == 1
+    Hd, Hsd, Md = problems.random_real_symmetric_problem(n, 2, seed=0)
+    with _engine(Hd, Hsd, Md, state_columns=1) as e:
+        e.energy_grad(u[:, :2], 1e-3, psi0)
+        assert e.info("state_columns") == 0               # dense H: no table, the GEMM chain stays

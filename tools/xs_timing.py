@@ -1,0 +1,51 @@
+"""Times the state-column form against the engine's explicit-propagator forms on one GPU (development tool; not a test).
+    python tools/xs_timing.py [n] [B] [S]"""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from diffquantum_amd import problems
+from diffquantum_amd.engine import Engine
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+dev = torch.device("cuda:0")
+d = 1 << n
+H0, Hs, M = problems.random_ising_torch(n, 0, dev)
+u = torch.from_numpy(problems.pulse_table(n, S, 1e-3 * S, seed=0)).to(dev)
+psi0 = torch.from_numpy(problems.random_states(d, B, 0)).to(dev)
+res = {}
+with Engine(d, n) as e:
+    e.use_torch_stream()
+    e.set_hamiltonians(H0, Hs)
+    e.set_observable(M)
+    del H0, Hs, M
+    for name, xs in (("state_columns", 1), ("other", 0)):
+        e.set_option("state_columns", xs)
+        g = torch.zeros((S, n), dtype=torch.float64, device=dev)
+        e.energy_grad(u[:2].contiguous(), 1e-3, psi0, want_final=False, want_energies=False)
+        e.profile_enable(True); e.profile_reset()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            loss, _, _, _ = e.energy_grad(u, 1e-3, psi0, want_final=False, want_energies=False, grad_out=g)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        prof = e.profile(); e.profile_enable(False)
+        el = float(np.median(ts))
+        res[name] = (loss, g.clone())
+        print("{:14s} state_columns={} : {:8.3f} ms/step  {:9.1f} steps/s   loss {:.12f}  degree {}".format(
+            name, int(e.info("state_columns")), el / S * 1e3, S / el, loss, int(e.info("degree"))), flush=True)
+        for k, v in prof.items():
+            if v["launches"]:
+                print("      {:9s} launches {:4d}  ms {:9.3f}  ms/launch {:8.3f}  GB/s(bytes) {:9.1f}  TF/s {:7.2f}".format(
+                    k, v["launches"], v["ms"], v["ms"] / v["launches"], v["bytes"] / v["ms"] * 1e-6, v["flops"] / v["ms"] * 1e-9), flush=True)
+    # forward only
+    for name, xs in (("fwd state_columns", 1), ("fwd other", 0)):
+        e.set_option("state_columns", xs)
+        e.propagate(u, 1e-3, psi0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.propagate(u, 1e-3, psi0)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        print("{:18s}: {:8.3f} ms/step {:9.1f} steps/s".format(name, el / S * 1e3, S / el), flush=True)
+print("max |grad diff|", float((res["state_columns"][1] - res["other"][1]).abs().max()), "loss diff", abs(res["state_columns"][0] - res["other"][0]))
