@@ -292,25 +292,31 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
 // States are stored column by column ([B][d]).  wt [S][R]: per-step weights of the XOR-diagonals; dgs: the rows' diagonal
 // weights, one vector or one per step (xs_weights_launch).
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
-int xs_blocks(int d, size_t elem, int B, int n_cu);           // workgroups of a launch over B columns
-int xs_waves(int d);
+// variant: bit 0 = 1024 threads x 4 rows per workgroup at d = 4096 (default 512 x 8); bit 1 = prefetch of the next diagonal's partners
+int xs_blocks(int d, size_t elem, int B, int n_cu, int variant);   // workgroups of a launch over B columns
+int xs_waves(int d, int variant);
 int xs_slots(const XrTab& tab);
 size_t xs_park_elems(int d, int L, int nblk);                 // complex elements of the backward kernel's scratch
-size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab);
-int xs_lds_diagonals(int d, const XrTab& tab);                // XOR-diagonals whose partners are LDS reads (the others: registers)
+size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant);
+int xs_lds_diagonals(int d, const XrTab& tab, int variant);   // XOR-diagonals whose partners are LDS reads (the others: registers)
+// out[0] = max off-diagonal |entry| of M (zero it first), mdiag[i] = Re M[i][i];  lam = 2 diag(m) psi, e[b] = <psi_b|diag(m)|psi_b>
+hipError_t xs_offdiag_launch(const double2* M, int d, double* out, double* mdiag, hipStream_t st);
+hipError_t xs_offdiag_launch(const float2* M, int d, double* out, double* mdiag, hipStream_t st);
+hipError_t xs_diag_costate_launch(const double2* psi, const double* mdiag, double2* lam, double* e, int d, int B, hipStream_t st);
+hipError_t xs_diag_costate_launch(const float2* psi, const double* mdiag, float2* lam, double* e, int d, int B, hipStream_t st);
 size_t xs_dgs_doubles(int d, int S, const XrTab& tab);       // doubles of the diagonal-weight table
 hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
                              hipStream_t st);
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, hipStream_t st);
+                             int S, int B, int L, int nblk, int variant, hipStream_t st);
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, hipStream_t st);
+                             int S, int B, int L, int nblk, int variant, hipStream_t st);
 // psi: psi_S in, psi_0 out;  lam: lambda_S in, lambda_0 out;  grad[s][k] (+)= dL/du_k[s]
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
-                              int accumulate, hipStream_t st);
+                              int accumulate, int variant, hipStream_t st);
 hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
-                              hipStream_t st);
+                              int variant, hipStream_t st);
 
 }  // namespace dq

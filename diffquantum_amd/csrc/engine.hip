@@ -303,8 +303,9 @@ struct Ctx : dq_ctx {
   int xor_mode = -1;
   double last_xr = 0;
   // state-column form (statecol.hip): whole chains on state columns held in LDS; xs_mode: -1 auto, 0 off, 1 whenever supported
-  DevBuf xs_psi, xs_lam, xs_park, xs_part, xs_wt, xs_dgs;
-  int xs_mode = -1;
+  DevBuf xs_psi, xs_lam, xs_park, xs_part, xs_wt, xs_dgs, m_diag;
+  bool m_is_diag = false;  // the observable is diagonal (set_observable): Lambda_S = 2 M Psi_S elementwise on the state columns
+  int xs_mode = -1, xs_variant = 0;
   double xs_batch_ratio = 8.0;  // auto: batch <= ratio x dim (beyond it the operator form, whose cost does not grow with the batch, wins)
   double last_xs = 0;
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
@@ -1342,8 +1343,8 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   XsLaunch<T> x;
   x.L = L;
   x.tab = xs_table(c);
-  x.nblk = dq::xs_blocks(c->d, sizeof(T), B, c->n_cu);
-  x.lds_diag = dq::xs_lds_diagonals(c->d, *x.tab);
+  x.nblk = dq::xs_blocks(c->d, sizeof(T), B, c->n_cu, c->xs_variant);
+  x.lds_diag = dq::xs_lds_diagonals(c->d, *x.tab, c->xs_variant);
   const size_t sb = (size_t)c->d * B * sizeof(T2);
   c->xs_psi.ensure(sb);
   c->xs_lam.ensure(sb);
@@ -1351,7 +1352,7 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
   if (backward) {
     c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
-    c->xs_part.ensure(sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, S, x.nblk, *x.tab), 1));
+    c->xs_part.ensure(sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, S, x.nblk, *x.tab, c->xs_variant), 1));
   }
   const dq::XrTab tb = *x.tab;
   long step = 0;
@@ -1393,7 +1394,7 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
   const dq::XrTab tb = *x.tab;
   c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
     return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, x.L,
-                                 x.nblk, c->st);
+                                 x.nblk, c->xs_variant, c->st);
   });
   if (out_db)
     c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>(out_db, B, 0, (const T2*)c->xs_psi.p, d, 0, B, d, 0, 1, c->st); });
@@ -1709,19 +1710,35 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
   c->lam[0].ensure(sb);
   c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
   const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
-  xs_forward(c, x, p0, S, B, (T2*)c->psi[0].p);
-  terminal_costate(c, (const T2*)c->psi[0].p, B, targets, loss, energies);
-  if (psi_final) out_copy(c, psi_final, c->psi[0].p, sb);
+  const bool diag_m = !targets && c->m_is_diag;
+  const double by = 2.0 * sizeof(T2) * (double)d * B;
+  if (diag_m) {
+    // diagonal observable: Lambda_S = 2 m .* Psi_S and the energies on the state columns themselves (no product, no transposes)
+    const bool want_fin = psi_final != nullptr;
+    xs_forward(c, x, p0, S, B, want_fin ? (T2*)c->psi[0].p : nullptr);
+    if (want_fin) out_copy(c, psi_final, c->psi[0].p, sb);
+    c->e_dev.ensure(sizeof(double) * ((size_t)B + 1));
+    c->timed(DQ_PROF_OTHER, 6.0 * d * B, by, [&] {
+      return dq::xs_diag_costate_launch((const T2*)c->xs_psi.p, c->m_diag.d(), (T2*)c->xs_lam.p, c->e_dev.d(), d, B, c->st);
+    });
+    c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(c->e_dev.d(), B, c->e_dev.d() + B, c->st); });
+    if (energies) out_copy(c, energies, c->e_dev.p, sizeof(double) * (size_t)B);
+    if (loss) out_copy(c, loss, c->e_dev.d() + B, sizeof(double));
+  } else {
+    xs_forward(c, x, p0, S, B, (T2*)c->psi[0].p);
+    terminal_costate(c, (const T2*)c->psi[0].p, B, targets, loss, energies);
+    if (psi_final) out_copy(c, psi_final, c->psi[0].p, sb);
+    if (S > 0)
+      c->timed(DQ_PROF_OTHER, 0.0, by,
+               [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, (const T2*)c->lam[0].p, B, 0, d, B, 0, 1, c->st); });
+  }
   if (S > 0) {
-    const double by = 2.0 * sizeof(T2) * (double)d * B;
-    c->timed(DQ_PROF_OTHER, 0.0, by,
-             [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, (const T2*)c->lam[0].p, B, 0, d, B, 0, 1, c->st); });
     double fl, lb;
     xs_book(c, x, (3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
     const dq::XrTab tb = *x.tab;
     c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
       return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, L, x.nblk,
-                                    (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->st);
+                                    (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->xs_variant, c->st);
     });
   }
   if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
@@ -2399,6 +2416,16 @@ void do_set_observable(Ctx<T>* c, const void* M) {
   const double nm = norm1_dev(c, (const T2*)c->M.p);
   if (herm_defect_dev(c, (const T2*)c->M.p) > c->herm_tol * std::max(1.0, nm))
     fail(DQ_ERR_INVALID, "observable must be Hermitian");
+  {  // diagonal observables (Ising cost functions): the state-column form applies them elementwise
+    c->m_diag.ensure(sizeof(double) * (size_t)c->d);
+    c->scratch.ensure(sizeof(double) * (size_t)std::max(c->d, 1));
+    HIPCK(hipMemsetAsync(c->scratch.p, 0, sizeof(double), c->st));
+    HIPCK(dq::xs_offdiag_launch((const T2*)c->M.p, c->d, c->scratch.d(), c->m_diag.d(), c->st));
+    double off = 1.0;
+    HIPCK(hipMemcpyAsync(&off, c->scratch.p, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+    c->m_is_diag = off == 0.0;
+  }
   c->have_M = true;
 }
 
@@ -2578,6 +2605,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xor_mode = v != 0 ? -1 : 0;
   } else if (s == "state_columns") {  // state-column form (statecol.hip): -1 auto (default), 0 off, 1 whenever the kernels exist
     c->xs_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_variant") {  // bit 0: 1024 threads x 4 rows at dim 4096 (default 512 x 8); bit 1: prefetch
+    c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_batch_ratio") {  // auto: taken while batch <= ratio x dim
     if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_batch_ratio must be > 0");
     c->xs_batch_ratio = v;

@@ -96,58 +96,101 @@ __device__ __forceinline__ void xs_use(int j, int ph, T w, const unsigned* sg, t
   }
 }
 
-template <class T, int RPT, int XH, bool SIGN, bool DOT, int RM>
-__device__ __forceinline__ void xs_local(int xh, int j, int ph, T w, const unsigned* sg, const typename Cx<T>::type* cur,
-                                         typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+// v[r] = cur[r ^ xh] for a wave-uniform xh in 1 .. RPT - 1 (register arrays need static indices: a chain of scalar compares)
+template <class T, int RPT, int XH>
+__device__ __forceinline__ void xs_local_copy(int xh, const typename Cx<T>::type* cur, typename Cx<T>::type* v) {
   if constexpr (XH < RPT) {
     if (xh == XH) {
-      typename Cx<T>::type v[RPT];
 #pragma unroll
       for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
-      xs_use<T, RPT, SIGN, DOT, RM>(j, ph, w, sg, v, o, xm, dacc);
+      asm volatile("" : "+v"(v[0].x));  // (keeps the chain from being merged into an indexed access to a scratch copy of cur)
     } else {
-      xs_local<T, RPT, XH + 1, SIGN, DOT, RM>(xh, j, ph, w, sg, cur, o, xm, dacc);
+      xs_local_copy<T, RPT, XH + 1>(xh, cur, v);
     }
   }
 }
 
-// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`).  wrow: this step's weights dt u c_j
-// (wave-uniform).  The loop over the diagonals is a runtime loop on purpose (unrolled, the compiler hoists masks and addresses
-// of all R diagonals and spills); LDS reads are volatile so that neighbours are not merged into ds_read2 forms.
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool LOCAL = true>
-__device__ __forceinline__ void xs_gather(const XrTab& tab, const double* __restrict__ wrow, const unsigned* sg,
-                                          const typename Cx<T>::type* __restrict__ src, const typename Cx<T>::type* cur, int t, T sgn,
-                                          typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
-  typedef typename Cx<T>::type T2;
+// the partner values of XOR-offset xo at the thread's rows: registers when the offset has no lane bits, else LDS reads (volatile,
+// so that neighbours are not merged into ds_read2 forms, which the LDS array serves at half the rate)
+template <class T, int NT, int RPT, bool LOCAL>
+__device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __restrict__ src, const typename Cx<T>::type* cur, int t,
+                                         typename Cx<T>::type* v) {
   typedef typename XsV2<T>::type V2;
   typedef const volatile __attribute__((address_space(3))) V2* lds_ptr;
-#pragma clang loop unroll(disable)
-  for (int j = 0; j < tab.R; ++j) {
-    const int xo = tab.xoff[j];
-    const int ph = tab.phase[j];
-    const T w = sgn * (T)wrow[j];
-    const int xl = xo & (NT - 1), xh = xo / NT;
-    if (LOCAL && xl == 0) {  // (wave-uniform) the partner rows are the thread's own registers
-      xs_local<T, RPT, 1, SIGN, DOT, RM>(xh, j, ph, w, sg, cur, o, xm, dacc);
-    } else {
-      T2 v[RPT];
-      lds_ptr base = (lds_ptr)(src + (t ^ xl));
-      if (xh == 0 && xl != 0) {
+  const int xl = xo & (NT - 1), xh = xo / NT;  // (wave-uniform)
+  if (LOCAL && xl == 0) {
+    xs_local_copy<T, RPT, 1>(xh, cur, v);
+  } else {
+    lds_ptr base = (lds_ptr)(src + (t ^ xl));
+    if (xh == 0) {
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-          const V2 q = base[r * NT];
-          v[r].x = q.x;
-          v[r].y = q.y;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-          const V2 q = base[(r ^ xh) * NT];
-          v[r].x = q.x;
-          v[r].y = q.y;
-        }
+      for (int r = 0; r < RPT; ++r) {
+        const V2 q = base[r * NT];
+        v[r].x = q.x;
+        v[r].y = q.y;
       }
-      xs_use<T, RPT, SIGN, DOT, RM>(j, ph, w, sg, v, o, xm, dacc);
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const V2 q = base[(r ^ xh) * NT];
+        v[r].x = q.x;
+        v[r].y = q.y;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ double xs_readlane(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
+// the table and this step's weights, one entry per lane (lane j < R: XOR-diagonal j), read back with v_readlane -- no memory
+// access in the loop over the diagonals
+struct XsCtl {
+  int R;
+  int ent;    // xoff | phase << 16
+  double w;   // dt u c_j of the current step
+  __device__ __forceinline__ void load_table(const XrTab& tab, int lane) {
+    R = tab.R;
+    ent = lane < tab.R ? (tab.xoff[lane] | (tab.phase[lane] << 16)) : 0;
+  }
+  __device__ __forceinline__ void load_step(const double* __restrict__ wrow, int lane) { w = lane < R ? wrow[lane] : 0.0; }
+};
+
+// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`).  The loop over the diagonals is a runtime
+// loop on purpose (unrolled, the compiler hoists masks and addresses of all R diagonals and spills).  PREF: the partners of the
+// next diagonal are fetched while this one's are used (two register buffers).
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool LOCAL, bool PREF>
+__device__ __forceinline__ void xs_gather(const XsCtl ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
+                                          const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
+                                          const typename Cx<T>::type* xm, double* dacc) {
+  typedef typename Cx<T>::type T2;
+  const int R = ctl.R;
+  if (PREF) {
+    T2 va[RPT], vb[RPT];
+    int e0 = __builtin_amdgcn_readlane(ctl.ent, 0), e1 = 0;
+    xs_fetch<T, NT, RPT, LOCAL>(e0 & 0xffff, src, cur, t, va);
+    int j = 0;
+#pragma clang loop unroll(disable)
+    for (; j + 1 < R; j += 2) {
+      e1 = __builtin_amdgcn_readlane(ctl.ent, j + 1);
+      xs_fetch<T, NT, RPT, LOCAL>(e1 & 0xffff, src, cur, t, vb);
+      xs_use<T, RPT, SIGN, DOT, RM>(j, e0 >> 16, sgn * (T)xs_readlane(ctl.w, j), sg, va, o, xm, dacc);
+      if (j + 2 < R) {
+        e0 = __builtin_amdgcn_readlane(ctl.ent, j + 2);
+        xs_fetch<T, NT, RPT, LOCAL>(e0 & 0xffff, src, cur, t, va);
+      }
+      xs_use<T, RPT, SIGN, DOT, RM>(j + 1, e1 >> 16, sgn * (T)xs_readlane(ctl.w, j + 1), sg, vb, o, xm, dacc);
+    }
+    if (j < R) xs_use<T, RPT, SIGN, DOT, RM>(j, e0 >> 16, sgn * (T)xs_readlane(ctl.w, j), sg, va, o, xm, dacc);
+  } else {
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < R; ++j) {
+      const int e = __builtin_amdgcn_readlane(ctl.ent, j);
+      T2 v[RPT];
+      xs_fetch<T, NT, RPT, LOCAL>(e & 0xffff, src, cur, t, v);
+      xs_use<T, RPT, SIGN, DOT, RM>(j, e >> 16, sgn * (T)xs_readlane(ctl.w, j), sg, v, o, xm, dacc);
     }
   }
 }
@@ -186,7 +229,7 @@ __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double
 
 // psi_out[b][:] = U_{S-1} ... U_0 psi_in[b][:] for the columns b = blockIdx.x, + gridDim.x, ...  (states stored column by
 // column: [B][D]).  dgs + s * dgs_step: the rows' diagonal weights of step s.
-template <class T, int NT, int RPT, bool SIGN>
+template <class T, int NT, int RPT, bool SIGN, bool PREF>
 __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
                                                         typename Cx<T>::type* __restrict__ psi_out, XrTab tab,
                                                         const double* __restrict__ wt, const double* __restrict__ dgs, long dgs_step,
@@ -199,6 +242,8 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
   unsigned sg[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+  XsCtl ctl;
+  ctl.load_table(tab, t & 63);
   int p = 0;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     T2 cur[RPT];
@@ -209,7 +254,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
     xs_put<T, NT, RPT>(img + p * D, t, cur);
     __syncthreads();
     for (int s = 0; s < S; ++s) {
-      const double* wrow = wt + (long)s * tab.R;
+      ctl.load_step(wt + (long)s * tab.R, t & 63);
       const double* dgr = dgs + (long)s * dgs_step;
       T2 acc[RPT];
 #pragma unroll
@@ -223,7 +268,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
           o[r].x = 0;
           o[r].y = 0;
         }
-        xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        xs_gather<T, NT, RPT, SIGN, false, 1, true, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)m;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {  // + the diagonal: -i dg v
@@ -286,7 +331,7 @@ __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
 // part[((blockIdx.x * S + s) * NW + wave) * NS + slot]: this workgroup's share, over its columns, of
 //   slot < RM: sum_i of the level pairings of XOR-diagonal `slot` (before the factors cmag and dt);
 //   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
-template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM>
+template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM, bool PREF>
 __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
                                                          XrTab tab, const double* __restrict__ wt, const double* __restrict__ dgs,
                                                          long dgs_step, int S, int B, int L, typename Cx<T>::type* __restrict__ park,
@@ -301,6 +346,8 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   unsigned sg[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+  XsCtl ctl;
+  ctl.load_table(tab, lane);
   T2* pk = park + (long)blockIdx.x * (L + 1) * D;  // [l][r * NT + t] (uniform base, lane index t)
   T2* plam = pk + (long)L * D;
   int p = 0;
@@ -317,7 +364,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       }
     }
     for (int s = S - 1; s >= 0; --s) {
-      const double* wrow = wt + (long)s * tab.R;
+      ctl.load_step(wt + (long)s * tab.R, lane);
       const double* dgr = dgs + (long)s * dgs_step;
       // ---- reversal: psi_s = sum_m (-A)^m psi_{s+1} / m! -------------------------------------------------------------
       p ^= 1;
@@ -336,7 +383,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
             o[r].x = 0;
             o[r].y = 0;
           }
-          xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)-1, o, nullptr, nullptr);
+          xs_gather<T, NT, RPT, SIGN, false, 1, true, PREF>(ctl, sg, img + p * D, cur, t, (T)-1, o, nullptr, nullptr);
           const T inv = (T)1 / (T)m;
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {  // + i dg v
@@ -373,7 +420,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].x = 0;
           o[r].y = 0;
         }
-        xs_gather<T, NT, RPT, SIGN, false, 1>(tab, wrow, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        xs_gather<T, NT, RPT, SIGN, false, 1, true, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)l;
         T2* pl = pk + (long)l * D;
 #pragma unroll
@@ -420,7 +467,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].y = xs_fma(dgv, cur[r].x, g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
-        xs_gather<T, NT, RPT, SIGN, true, RM, false>(tab, wrow, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
+        xs_gather<T, NT, RPT, SIGN, true, RM, false, false>(ctl, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
 #pragma unroll
@@ -504,6 +551,72 @@ __global__ void __launch_bounds__(1024) xs_finish_kernel(const double* __restric
   }
 }
 
+// ---- diagonal observables: Lambda_S = 2 M Psi_S and the energies without a product ---------------------------------------------
+// out[0] = max |M[i][j]|, i != j (0: M is diagonal); mdiag[i] = Re M[i][i].  grid: d blocks of 256
+template <class T2>
+__global__ void __launch_bounds__(256) xs_offdiag_kernel(const T2* __restrict__ M, int d, double* __restrict__ out, double* __restrict__ mdiag) {
+  const int i = blockIdx.x;
+  const T2* row = M + (long)i * d;
+  double mx = 0.0;
+  for (int j = threadIdx.x; j < d; j += 256) {
+    if (j == i) continue;
+    const double a = fabs((double)row[j].x), b = fabs((double)row[j].y);
+    mx = fmax(mx, fmax(a, b));
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    if (mx > 0.0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(mx));  // (non-negative doubles order as integers)
+    mdiag[i] = (double)row[i].x;
+  }
+}
+// lam[b][i] = 2 m_i psi[b][i];  e[b] = sum_i m_i |psi[b][i]|^2   (states column by column: one workgroup per column)
+template <class T>
+__global__ void __launch_bounds__(256) xs_diag_costate_kernel(const typename Cx<T>::type* __restrict__ psi, const double* __restrict__ mdiag,
+                                                              typename Cx<T>::type* __restrict__ lam, double* __restrict__ e, int d) {
+  typedef typename Cx<T>::type T2;
+  const long b = blockIdx.x;
+  const T2* pc = psi + b * d;
+  T2* lc = lam + b * d;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const T2 v = pc[i];
+    const double m = mdiag[i];
+    T2 o;
+    o.x = (T)(2.0 * m * (double)v.x);
+    o.y = (T)(2.0 * m * (double)v.y);
+    lc[i] = o;
+    acc = __builtin_fma(m, (double)v.x * (double)v.x + (double)v.y * (double)v.y, acc);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) e[b] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+hipError_t xs_offdiag_launch(const double2* M, int d, double* out, double* mdiag, hipStream_t st) {
+  hipLaunchKernelGGL(xs_offdiag_kernel<double2>, dim3((unsigned)d), dim3(256), 0, st, M, d, out, mdiag);
+  return hipGetLastError();
+}
+hipError_t xs_offdiag_launch(const float2* M, int d, double* out, double* mdiag, hipStream_t st) {
+  hipLaunchKernelGGL(xs_offdiag_kernel<float2>, dim3((unsigned)d), dim3(256), 0, st, M, d, out, mdiag);
+  return hipGetLastError();
+}
+hipError_t xs_diag_costate_launch(const double2* psi, const double* mdiag, double2* lam, double* e, int d, int B, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(xs_diag_costate_kernel<double>, dim3((unsigned)B), dim3(256), 0, st, psi, mdiag, lam, e, d);
+  return hipGetLastError();
+}
+hipError_t xs_diag_costate_launch(const float2* psi, const double* mdiag, float2* lam, double* e, int d, int B, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(xs_diag_costate_kernel<float>, dim3((unsigned)B), dim3(256), 0, st, psi, mdiag, lam, e, d);
+  return hipGetLastError();
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 
 bool xs_supported(int d, int L, int R, int nd, size_t elem) {
@@ -514,36 +627,44 @@ bool xs_supported(int d, int L, int R, int nd, size_t elem) {
 
 size_t xs_lds_bytes(int d, size_t elem) { return (size_t)2 * 2 * elem * (size_t)d; }
 
+// threads of a workgroup (rows per thread = d / threads). variant bit 0: 1024 threads x 4 rows at d = 4096 instead of 512 x 8
+int xs_threads(int d, int variant) {
+  if (d >= 4096) return (variant & 1) ? 1024 : 512;
+  return d / 8 < 64 ? 64 : d / 8;
+}
+
 // workgroups of a launch over B columns: as many as fit the chip at once (LDS-limited), never more than columns
-int xs_blocks(int d, size_t elem, int B, int n_cu) {
+int xs_blocks(int d, size_t elem, int B, int n_cu, int variant) {
   const size_t lds = xs_lds_bytes(d, elem);
   int per_cu = (int)((size_t)160 * 1024 / lds);
-  const int threads = d >= 4096 ? 512 : (d / 8 < 64 ? 64 : d / 8);
+  const int threads = xs_threads(d, variant);
   const int by_waves = 2048 / threads > 0 ? 2048 / threads : 1;  // 32 waves per CU
   if (per_cu > by_waves) per_cu = by_waves;
   if (per_cu < 1) per_cu = 1;
   long nb = (long)per_cu * n_cu;
   if (nb > B) nb = B;
-  // (an even share of columns per workgroup: the largest count <= nb that divides into equal rounds)
+  // (an even share of columns per workgroup: the smallest count that needs no more rounds)
   const long rounds = (B + nb - 1) / nb;
   nb = (B + rounds - 1) / rounds;
   return (int)(nb < 1 ? 1 : nb);
 }
-int xs_waves(int d) { return d >= 4096 ? 8 : (d / 8 < 64 ? 1 : d / 8 / 64); }
+int xs_waves(int d, int variant) { return xs_threads(d, variant) / 64; }
 int xs_slots(const XrTab& tab) {
   for (int j = 0; j < tab.nd; ++j)
     if (tab.dkid[j] >= 0) return XR_RSMALL + XR_DMAX;
   return XR_RSMALL;
 }
-int xs_lds_diagonals(int d, const XrTab& tab) {
-  const int nt = d >= 4096 ? 512 : (d / 8 < 64 ? 64 : d / 8);
+int xs_lds_diagonals(int d, const XrTab& tab, int variant) {
+  const int nt = xs_threads(d, variant);
   int n = 0;
   for (int j = 0; j < tab.R; ++j)
     if (tab.xoff[j] & (nt - 1)) ++n;
   return n;
 }
 size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)(L + 1) * (size_t)d; }
-size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab) { return (size_t)nblk * (size_t)S * (size_t)xs_waves(d) * (size_t)xs_slots(tab); }
+size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant) {
+  return (size_t)nblk * (size_t)S * (size_t)xs_waves(d, variant) * (size_t)xs_slots(tab);
+}
 
 // dgs: d doubles, or S * d when a control has diagonal entries (xs_dgs_doubles); returns the step stride through *dgs_step
 size_t xs_dgs_doubles(int d, int S, const XrTab& tab) { return (size_t)d * (size_t)(xs_slots(tab) > XR_RSMALL ? (S > 0 ? S : 1) : 1); }
@@ -565,44 +686,69 @@ bool xs_diagctl(const XrTab& tab) { return xs_slots(tab) > XR_RSMALL; }
 
 template <class T, int NT, int RPT>
 hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* out, const XrTab& tab, const double* wt, const double* dgs,
-                         long dgs_step, int S, int B, int L, int nblk, hipStream_t st) {
+                         long dgs_step, int S, int B, int L, int nblk, bool pref, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
+  const bool sgn = tab.sgn != nullptr;
   void (*kf)(const T2*, T2*, XrTab, const double*, const double*, long, int, int, int) =
-      tab.sgn ? xs_forward_kernel<T, NT, RPT, true> : xs_forward_kernel<T, NT, RPT, false>;
+      sgn ? (pref ? xs_forward_kernel<T, NT, RPT, true, true> : xs_forward_kernel<T, NT, RPT, true, false>)
+          : (pref ? xs_forward_kernel<T, NT, RPT, false, true> : xs_forward_kernel<T, NT, RPT, false, false>);
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, wt, dgs, dgs_step, S, B, L);
   return hipGetLastError();
 }
 
-template <class T, int NT, int RPT>
+template <class T, int NT, int RPT, bool PREF>
 hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
                           long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
   void (*kf)(T2*, T2*, XrTab, const double*, const double*, long, int, int, int, T2*, double*) =
-      sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL>)
-          : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL> : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL>);
+      sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF>)
+          : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL, PREF> : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL, PREF>);
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, wt, dgs, dgs_step, S, B, L, park, part);
   return hipGetLastError();
 }
 
+// variant: bit 0 = 1024 threads x 4 rows at d = 4096; bit 1 = prefetch of the next diagonal's partners in the sweeps without pairings
 template <class T>
 hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* out, int d, const XrTab& tab, const double* wt,
-                        const double* dgs, long dgs_step, int S, int B, int L, int nblk, hipStream_t st) {
+                        const double* dgs, long dgs_step, int S, int B, int L, int nblk, int variant, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T))) return hipErrorInvalidValue;
+  const bool pf = (variant & 2) != 0;
   switch (d) {
-    case 4096: return xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+    case 4096:
+      return (variant & 1) ? xs_forward_go<T, 1024, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
+                           : xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
 #ifndef XS_PROBE_4096_ONLY
-    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
-    case 1024: return xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
-    case 512: return xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
-    default: return xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    case 1024: return xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    case 512: return xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    default: return xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+#else
+    default: return hipErrorInvalidValue;
+#endif
+  }
+}
+
+template <class T, bool PREF>
+hipError_t xs_backward_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
+                            const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
+                            int variant, hipStream_t st) {
+  switch (d) {
+    case 4096:
+      return (variant & 1) ? xs_backward_go<T, 1024, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
+                           : xs_backward_go<T, 512, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+#ifndef XS_PROBE_4096_ONLY
+    case 2048: return xs_backward_go<T, 256, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    case 1024: return xs_backward_go<T, 128, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    case 512: return xs_backward_go<T, 64, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    default: return xs_backward_go<T, 64, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
 #else
     default: return hipErrorInvalidValue;
 #endif
@@ -612,46 +758,36 @@ hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* ou
 template <class T>
 hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                          const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
-                         int K, double dt, double* grad, int accumulate, hipStream_t st) {
+                         int K, double dt, double* grad, int accumulate, int variant, hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T)) || !park || !part) return hipErrorInvalidValue;
-  hipError_t e;
-  switch (d) {
-    case 4096: e = xs_backward_go<T, 512, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
-#ifndef XS_PROBE_4096_ONLY
-    case 2048: e = xs_backward_go<T, 256, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
-    case 1024: e = xs_backward_go<T, 128, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
-    case 512: e = xs_backward_go<T, 64, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st); break;
-    default: e = xs_backward_go<T, 64, 4>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
-#else
-    default: e = hipErrorInvalidValue;
-#endif
-  }
+  const hipError_t e = (variant & 2) ? xs_backward_pick<T, true>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st)
+                                     : xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d), xs_slots(tab), (int)XR_RSMALL, S,
-                     tab, K, dt, grad, accumulate);
+  hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d, variant), xs_slots(tab),
+                     (int)XR_RSMALL, S, tab, K, dt, grad, accumulate);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, hipStream_t st) {
-  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+                             int S, int B, int L, int nblk, int variant, hipStream_t st) {
+  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, st);
 }
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, hipStream_t st) {
-  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, st);
+                             int S, int B, int L, int nblk, int variant, hipStream_t st) {
+  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, st);
 }
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
-                              int accumulate, hipStream_t st) {
-  return xs_backward_t<double>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
+                              int accumulate, int variant, hipStream_t st) {
+  return xs_backward_t<double>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, st);
 }
 hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
-                              hipStream_t st) {
-  return xs_backward_t<float>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, st);
+                              int variant, hipStream_t st) {
+  return xs_backward_t<float>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, st);
 }
 
 }  // namespace dq

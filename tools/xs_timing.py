@@ -10,6 +10,8 @@ from diffquantum_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+VARIANTS = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
+OTHER = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 dev = torch.device("cuda:0")
 d = 1 << n
 H0, Hs, M = problems.random_ising_torch(n, 0, dev)
@@ -21,8 +23,10 @@ with Engine(d, n) as e:
     e.set_hamiltonians(H0, Hs)
     e.set_observable(M)
     del H0, Hs, M
-    for name, xs in (("state_columns", 1), ("other", 0)):
+    runs = [("state_columns v{}".format(v), 1, v) for v in VARIANTS] + ([("other", 0, 0)] if OTHER else [])
+    for name, xs, var in runs:
         e.set_option("state_columns", xs)
+        e.set_option("state_columns_variant", var)
         g = torch.zeros((S, n), dtype=torch.float64, device=dev)
         e.energy_grad(u[:2].contiguous(), 1e-3, psi0, want_final=False, want_energies=False)
         e.profile_enable(True); e.profile_reset()
@@ -33,7 +37,7 @@ with Engine(d, n) as e:
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         prof = e.profile(); e.profile_enable(False)
         el = float(np.median(ts))
-        res[name] = (loss, g.clone())
+        res["state_columns" if xs else "other"] = (loss, g.clone())
         print("{:14s} state_columns={} : {:8.3f} ms/step  {:9.1f} steps/s   loss {:.12f}  degree {}".format(
             name, int(e.info("state_columns")), el / S * 1e3, S / el, loss, int(e.info("degree"))), flush=True)
         for k, v in prof.items():
@@ -41,11 +45,13 @@ with Engine(d, n) as e:
                 print("      {:9s} launches {:4d}  ms {:9.3f}  ms/launch {:8.3f}  GB/s(bytes) {:9.1f}  TF/s {:7.2f}".format(
                     k, v["launches"], v["ms"], v["ms"] / v["launches"], v["bytes"] / v["ms"] * 1e-6, v["flops"] / v["ms"] * 1e-9), flush=True)
     # forward only
-    for name, xs in (("fwd state_columns", 1), ("fwd other", 0)):
+    for name, xs, var in [("fwd state_columns v{}".format(v), 1, v) for v in VARIANTS] + ([("fwd other", 0, 0)] if OTHER else []):
         e.set_option("state_columns", xs)
+        e.set_option("state_columns_variant", var)
         e.propagate(u, 1e-3, psi0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         e.propagate(u, 1e-3, psi0)
         torch.cuda.synchronize(); el = time.perf_counter() - t0
-        print("{:18s}: {:8.3f} ms/step {:9.1f} steps/s".format(name, el / S * 1e3, S / el), flush=True)
-print("max |grad diff|", float((res["state_columns"][1] - res["other"][1]).abs().max()), "loss diff", abs(res["state_columns"][0] - res["other"][0]))
+        print("{:24s}: {:8.3f} ms/step {:9.1f} steps/s".format(name, el / S * 1e3, S / el), flush=True)
+if OTHER:
+    print("max |grad diff|", float((res["state_columns"][1] - res["other"][1]).abs().max()), "loss diff", abs(res["state_columns"][0] - res["other"][0]))
