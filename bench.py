@@ -415,6 +415,30 @@ def roofline_blocks(prof, info, d):
             "launches": sp["launches"], "ms_per_launch": per(sp, "ms"), "ms_in_timed_region": sp["ms"],
             "note": "achieved = ALGORITHMIC bytes (operand read once, product written once: 2-3 x 8 d^2) / HIP-event time; the partner "
                     "rows of a row's nonzeros are re-read from L2 / Infinity Cache: `traffic` is the fabric-side PMC figure per launch"}
+    # state-column form (statecol.hip): `bytes` of these classes = LDS bytes gathered by the sweeps (diffqc_hip.h); HBM traffic is
+    # the states in and out (2 x 16 d B per launch) -- negligible, so the kernels are priced against the LDS array
+    for name, kernel, detail in (
+            ("statecol_bwd", "xs_backward_kernel (adjoint sweep of whole chains on state columns in LDS)",
+             "per step and column: reversal psi_t = U_t^H psi_{t+1} (L sweeps), the forward terms x_l (L - 1 sweeps, parked in an L2 / "
+             "Infinity-Cache resident scratch), Horner on lambda with the gradient pairings (L sweeps): 3L - 1 sweeps of R partner reads per row"),
+            ("statecol_fwd", "xs_forward_kernel (whole Trotter chains on state columns in LDS)",
+             "per step and column: L sweeps of R partner reads per row (Taylor polynomial of exp(-i dt H(t)) applied to the column)")):
+        sc = prof.get(name)
+        if not sc:
+            continue
+        gbps = sc["bytes"] / sc["ms"] * 1e-6 if sc["ms"] > 0 else 0.0
+        blocks[name] = {
+            "bound": "lds", "kernel": kernel, "kernel_detail": detail,
+            "achieved": gbps, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": gbps / PEAK_LDS_GBPS,
+            "vector_f64_tflops": rate(sc), "vector_f64_frac_of_peak": rate(sc) / PEAK_F64_MFMA_TFLOPS,
+            "traffic": TRAFFIC.get(name, (None, None))[0] if d == 4096 and sc["launches"] > 0 else None,
+            "traffic_source": TRAFFIC.get(name, (None, None))[1] if d == 4096 and sc["launches"] > 0 else None,
+            "traffic_over_algorithmic": None,
+            "launches": sc["launches"], "ms_per_launch": per(sc, "ms"), "ms_in_timed_region": sc["ms"],
+            "note": "achieved = LDS bytes the sweeps gather (16 B per row, XOR-diagonal with lane bits and sweep; partners at offsets "
+                    "without lane bits come from the thread's own registers) / HIP-event time, against the LDS array's 256 B/clk/CU; "
+                    "vector_f64_* = the kernel's fp64 FMA work against the 78.6 TF/s vector peak (the other resource the sweeps load); "
+                    "algorithmic HBM bytes: the states in and out, once per CALL (not per step)"}
     total = sum(v["ms"] for v in prof.values())
     for b in blocks.values():
         b["share_of_kernel_time"] = b["ms_in_timed_region"] / total if total > 0 else 0.0
@@ -431,10 +455,15 @@ def executed_tflops(blocks, seconds):
 
 
 INFO_KEYS = ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk", "zgemm_alg", "real_path",
-             "real_hamiltonians", "sparse_controls", "sparse_generator", "control_nonzeros", "xor_regular", "xor_regular_found")
+             "real_hamiltonians", "sparse_controls", "sparse_generator", "control_nonzeros", "xor_regular", "xor_regular_found", "state_columns")
 
 
 def describe_expm(info):
+    if info.get("state_columns", 0) > 0:
+        return ("state-column form: H is a sum of Pauli strings ({} XOR-diagonals), so NO propagator is built -- every state column "
+                "stays in LDS for the whole chain and each step applies the Taylor polynomial of degree {} of exp(-i dt H(t)) as sweeps "
+                "of partner reads; adjoint sweep the same way (statecol.hip), theta<={:.3g}".format(
+                    int(info["xor_regular_found"]), int(info["degree"]), info["theta"]))
     if info.get("xor_regular", 0) > 1:
         return ("Taylor degree {0}: H complex Hermitian and a sum of Pauli strings ({1} XOR-diagonals with entries +-c or +-i c, a real "
                 "diagonal): every row of U = exp(-i dt H) is a chain of {0} complex sparse matrix-vector products held in LDS (xorexp.hip, "
@@ -501,6 +530,9 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
     out = {}
     # (1) the headline's own inputs with their structure ignored step by step: gradients must agree to rounding
     for name, opts, note in (
+            ("ising_inputs_gemm_chain", {"state_columns": 0},
+             "same inputs on the explicit-propagator chain (state_columns = 0; what any batch > 8 x dim, and every generator that is "
+             "not a Pauli sum beyond its exponential, runs): U_t column by column in LDS, then the chain's complex MFMA products"),
             ("ising_inputs_sparse_row_kernels", {"xor_regular": 0},
              "same inputs, the XOR-regular (Pauli-string) structure of the generator ignored: the step exponential as 2q sparse x dense "
              "passes over stored dense powers (what any sparse drift + sparse controls get)"),
@@ -510,12 +542,15 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
              "same inputs, drift and controls treated as dense real symmetric matrices"),
             ("ising_inputs_complex_tape", {"real_path": 0},
              "same inputs on the general complex tape (real_path = 0): 11 full + 3 Hermitian-output complex products per step")):
+        if "state_columns" not in opts:
+            eng.set_option("state_columns", 0)   # (the structure-ignoring schemes all concern the propagator chain)
         for k_, v_ in opts.items():
             eng.set_option(k_, v_)
         ent, g = scheme_entry(eng, torch, u_dev, a.dt, psi0, d, K, note)
         ent["max_abs_grad_diff_vs_headline"] = float((g - grad_ref).abs().max().item())
         ent["abs_loss_diff_vs_headline"] = abs(ent["loss"] - loss_ref)
         out[name] = ent
+        eng.set_option("state_columns", -1)
         eng.set_option("xor_regular", -1)
         eng.set_option("sparse_generator", -1)
         eng.set_option("sparse_controls", 1)
@@ -545,10 +580,17 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
         e3.set_observable(M)
         e3.set_option("plan_steps", max(a.chain, K))
         del H0, Hs, M
-        ent, g3 = scheme_entry(e3, torch, u_dev, a.dt, psi0, d, K,
+        ent, g5 = scheme_entry(e3, torch, u_dev, a.dt, psi0, d, K,
                                "random Ising drift, X_k controls on half of the qubits and Y_k controls on the other half (I/Q drives): complex "
-                               "Hermitian and a sum of Pauli strings -- the rows of U = exp(-i dt H) built in LDS (complex column form, xorexp.hip)")
+                               "Hermitian and a sum of Pauli strings -- the state-column form in complex arithmetic (statecol.hip)")
+        ent["state_columns"] = e3.info("state_columns")
+        out["xy_drives_state_columns"] = ent
+        e3.set_option("state_columns", 0)
+        ent, g3 = scheme_entry(e3, torch, u_dev, a.dt, psi0, d, K,
+                               "the same X / Y-drive inputs on the explicit-propagator chain: the rows of U = exp(-i dt H) built in LDS "
+                               "(complex column form, xorexp.hip), then the complex MFMA products")
         ent["xor_regular"] = e3.info("xor_regular")
+        ent["max_abs_grad_diff_vs_state_columns"] = float((g3 - g5).abs().max().item())
         out["xy_drives_complex_pauli_H"] = ent
         e3.set_option("xor_regular", 0)
         ent, g4 = scheme_entry(e3, torch, u_dev, a.dt, psi0, d, K,
@@ -928,7 +970,10 @@ def run_config3(a, D):
     W_alg = 8.0 * d * d * B  # one complex (d x d).(d x B) product
     ex_tf = executed_tflops(blocks, elapsed_all)
     structure_note = {
-        "ising": ("diagonal Ising drift + X_k controls: real, sparse and a sum of Pauli strings -- the engine builds the step exponential column "
+        "ising": ("diagonal Ising drift + X_k controls: a sum of Pauli strings -- the engine keeps every state column in LDS for the whole chain "
+                  "and builds no propagator (input-structure-specific path; by_input_structure has the same inputs on the explicit-"
+                  "propagator GEMM chain and dense inputs of the same size)") if info.get("state_columns", 0) > 0 else
+                 ("diagonal Ising drift + X_k controls: real, sparse and a sum of Pauli strings -- the engine builds the step exponential column "
                   "by column in LDS (input-structure-specific path; see by_input_structure for the same inputs on the general sparse kernels "
                   "and for dense inputs of the same size)") if info.get("xor_regular", 0) > 0 else
                  ("diagonal Ising drift + X_k controls: real AND sparse -- the engine runs the step exponential as sparse x dense passes "
@@ -982,7 +1027,9 @@ def run_config3(a, D):
             "multi_gpu_forms": forms_out,
             "collectives_forced_at_world_1": force and world == 1,
             "expm": describe_expm(info),
-            "path": "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path",
+            "path": ("state-column form (Pauli-string H)" if info.get("state_columns", 0) > 0 else
+                     "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path"),
+            "state_columns": bool(info.get("state_columns", 0) > 0),
             "checkpoint_stride": int(info["checkpoint_stride"]), "operator_backward": opback,
             "trajectory_steps_per_s": steps_per_s * B,
             "loss": loss, "grad_norm": float(torch.linalg.norm(grad).item()) if hasattr(grad, "norm") else float(np.linalg.norm(grad)),

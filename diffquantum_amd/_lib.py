@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libdiffqc_hip.so")
 
 DQ_C128, DQ_C64 = 0, 1
 DQ_OK, DQ_ERR_INVALID, DQ_ERR_STATE, DQ_ERR_HIP, DQ_ERR_NO_DEVICE, DQ_ERR_UNSUPPORTED, DQ_ERR_NOMEM = range(7)
-PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other", "rgemm", "rsym", "zherm", "spmm", "statecol")
+PROF_CLASSES = ("zgemm", "assemble", "lincomb", "gradc", "other", "rgemm", "rsym", "zherm", "spmm", "statecol_fwd", "statecol_bwd")
 
 
 class DiffqcError(RuntimeError):

@@ -19,6 +19,7 @@
 // extras `trotter_batch` / `f_u_table` exist.  diffquantum_amd/diffqc.py is the pure-Python twin (same engine underneath).
 #include <pybind11/complex.h>
 #include <pybind11/numpy.h>
+#include <cstdint>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -114,21 +115,18 @@ void time_grid(double T0, double T, int per_step, std::vector<double>& ts, doubl
   for (int k = 0; k < n; ++k) { ts[k] = t; t += dt; }
 }
 
-void set_H(const std::vector<std::vector<cplx>>& H0, const std::vector<std::vector<std::vector<cplx>>>& Hs,
+// H0: [d][d], Hs: [K][d][d] -- numpy buffers (nested lists convert on the way in: forcecast), read in place: no per-element
+// Python objects, one copy to the device.  The module owns ONE engine context; the Python side borrows it (ctx_handle).
+void set_H(py::array_t<cplx, py::array::c_style | py::array::forcecast> H0,
+           py::array_t<cplx, py::array::c_style | py::array::forcecast> Hs,
            const std::vector<std::vector<std::vector<double>>>& channels, double duration, int func_type) {
-  const int d = (int)H0.size(), K = (int)Hs.size();
-  if (d == 0) throw py::value_error("H0 must be a non-empty square matrix");
-  std::vector<cplx> h0((size_t)d * d), hs((size_t)K * d * d);
-  for (int i = 0; i < d; ++i) {
-    if ((int)H0[i].size() != d) throw py::value_error("H0 must be a non-empty square matrix");
-    for (int j = 0; j < d; ++j) h0[(size_t)i * d + j] = H0[i][j];
-  }
-  for (int k = 0; k < K; ++k) {
-    if ((int)Hs[k].size() != d) throw py::value_error("every control Hamiltonian must have the shape of H0");
-    for (int i = 0; i < d; ++i) {
-      if ((int)Hs[k][i].size() != d) throw py::value_error("every control Hamiltonian must have the shape of H0");
-      for (int j = 0; j < d; ++j) hs[((size_t)k * d + i) * d + j] = Hs[k][i][j];
-    }
+  if (H0.ndim() != 2 || H0.shape(0) != H0.shape(1) || H0.shape(0) == 0) throw py::value_error("H0 must be a non-empty square matrix");
+  const int d = (int)H0.shape(0);
+  int K = 0;
+  if (Hs.size() > 0) {
+    if (Hs.ndim() != 3 || Hs.shape(1) != d || Hs.shape(2) != d)
+      throw py::value_error("every control Hamiltonian must have the shape of H0");
+    K = (int)Hs.shape(0);
   }
   if ((int)channels.size() != K) throw py::value_error("channels must have one entry per control Hamiltonian");
   std::vector<std::vector<Row>> ch(K);
@@ -140,10 +138,16 @@ void set_H(const std::vector<std::vector<cplx>>& H0, const std::vector<std::vect
   if (!(duration != 0.0) || !std::isfinite(duration)) throw py::value_error("duration must be finite and non-zero");
   dq_ctx* ctx = nullptr;
   check(dq_create(&ctx, d, K, 0));
-  const int st = dq_set_hamiltonians(ctx, h0.data(), K ? hs.data() : nullptr);
+  const int st = dq_set_hamiltonians(ctx, H0.data(), K ? Hs.data() : nullptr);
   if (st != DQ_OK) { dq_destroy(ctx); raise_status(st); }
   if (G.ctx) dq_destroy(G.ctx);
   G.ctx = ctx; G.dim = d; G.K = K; G.func_type = func_type; G.duration = duration; G.channels = std::move(ch);
+}
+
+// destroy the engine context (set_H must be called again before trotter)
+void close_ctx() {
+  if (G.ctx) dq_destroy(G.ctx);
+  G.ctx = nullptr;
 }
 
 void need_H() { if (!G.ctx) throw std::runtime_error("set_H must be called before trotter"); }
@@ -214,5 +218,8 @@ PYBIND11_MODULE(_diffqc_native, m) {
   m.def("f_u_table", &f_u_table, py::arg("vv"), py::arg("ts"), py::arg("channels") = py::none(), py::arg("duration") = 1.0,
         py::arg("func_type") = 1);
   m.def("engine_version", [] { return std::string(dq_version()); });
+  // the module's engine context as an integer (0: none): the Python side wraps it (Engine.borrow) instead of opening a second one
+  m.def("ctx_handle", [] { return (std::uintptr_t)G.ctx; });
+  m.def("close", &close_ctx);
   m.attr("__version__") = "dev";
 }

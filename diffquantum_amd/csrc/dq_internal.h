@@ -291,6 +291,11 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
 // ---- statecol.hip: whole chains on state columns held in LDS (XOR-regular generators; real or complex tables) ----
 // States are stored column by column ([B][d]).  wt [S][R]: per-step weights of the XOR-diagonals; dgs: the rows' diagonal
 // weights, one vector or one per step (xs_weights_launch).
+struct XsOrder {                   // the order in which the sweeps walk the table (statecol.hip, XsCtl)
+  unsigned char perm[XR_RSMALL];   // sorted position -> index in the table
+  int n0, n1;                      // LDS partners that keep / permute the thread's row list
+  int nloc[8];                     // partners in the thread's own registers, by offset / threads
+};
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
 // variant: bit 0 = 1024 threads x 4 rows per workgroup at d = 4096 (default 512 x 8); bit 1 = prefetch of the next diagonal's partners
 int xs_blocks(int d, size_t elem, int B, int n_cu, int variant);   // workgroups of a launch over B columns

@@ -305,7 +305,8 @@ struct Ctx : dq_ctx {
   // state-column form (statecol.hip): whole chains on state columns held in LDS; xs_mode: -1 auto, 0 off, 1 whenever supported
   DevBuf xs_psi, xs_lam, xs_park, xs_part, xs_wt, xs_dgs, m_diag;
   bool m_is_diag = false;  // the observable is diagonal (set_observable): Lambda_S = 2 M Psi_S elementwise on the state columns
-  int xs_mode = -1, xs_variant = 0;
+  int xs_mode = -1, xs_variant = 2;  // variant 2: 512 threads x 8 rows at dim 4096, prefetch of the next diagonal's partners (measured best)
+  int xs_min_dim = 512;
   double xs_batch_ratio = 8.0;  // auto: batch <= ratio x dim (beyond it the operator form, whose cost does not grow with the batch, wins)
   double last_xs = 0;
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
@@ -1317,7 +1318,9 @@ int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B)
   if (!tab) return 0;
   // the options that pin another scheme keep it
   if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || c->compose_mode >= 0) return 0;
-  if (c->xs_mode < 0 && (double)B > c->xs_batch_ratio * (double)c->d) return 0;
+  // auto: from dim 512 up (at 256 a column is one wave and the tree-composed operator form is faster: 0.34 M against 0.11 M forward
+  // steps/s on BASELINE configs[1]) and while the batch is at most xs_batch_ratio x dim
+  if (c->xs_mode < 0 && (c->d < c->xs_min_dim || (double)B > c->xs_batch_ratio * (double)c->d)) return 0;
   double th = 0.0;
   for (int t = 0; t < S; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
   for (int L = 1; L <= 24; ++L)
@@ -1374,7 +1377,7 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   return x;
 }
 
-// flops / LDS bytes of `sweeps` sweeps over B columns (profile class DQ_PROF_STATECOL)
+// flops / LDS bytes of `sweeps` sweeps over B columns (profile classes DQ_PROF_STATECOL_FWD / _BWD)
 template <class T>
 void xs_book(Ctx<T>* c, const XsLaunch<T>& x, double sweeps, double dot_sweeps, int B, double* flops, double* lds_bytes) {
   const double rows = (double)c->d * B;
@@ -1392,7 +1395,7 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
   double fl, lb;
   xs_book(c, x, (double)x.L * S, 0.0, B, &fl, &lb);
   const dq::XrTab tb = *x.tab;
-  c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
+  c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
     return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, x.L,
                                  x.nblk, c->xs_variant, c->st);
   });
@@ -1736,7 +1739,7 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
     double fl, lb;
     xs_book(c, x, (3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
     const dq::XrTab tb = *x.tab;
-    c->timed(DQ_PROF_STATECOL, fl, lb, [&] {
+    c->timed(DQ_PROF_STATECOL_BWD, fl, lb, [&] {
       return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, L, x.nblk,
                                     (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->xs_variant, c->st);
     });
@@ -2605,7 +2608,7 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xor_mode = v != 0 ? -1 : 0;
   } else if (s == "state_columns") {  // state-column form (statecol.hip): -1 auto (default), 0 off, 1 whenever the kernels exist
     c->xs_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
-  } else if (s == "state_columns_variant") {  // bit 0: 1024 threads x 4 rows at dim 4096 (default 512 x 8); bit 1: prefetch
+  } else if (s == "state_columns_variant") {  // bit 0: 1024 threads x 4 rows at dim 4096 (default 512 x 8); bit 1: prefetch (default on)
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_batch_ratio") {  // auto: taken while batch <= ratio x dim
     if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_batch_ratio must be > 0");

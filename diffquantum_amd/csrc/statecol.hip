@@ -20,6 +20,8 @@
 // level-l product with the thread's own x_l[i] (one real accumulator per XOR-diagonal, one per row for diagonal controls).
 // 3L - 1 sweeps per step; HBM traffic of a whole gradient evaluation: psi_S and lambda_S in, a few sums per step out.
 // The numpy twin of these recurrences is tests/np_state_column.py (checked against the oracle on the CPU).
+#include <cstring>
+
 #include "dq_internal.h"
 
 namespace dq {
@@ -96,102 +98,114 @@ __device__ __forceinline__ void xs_use(int j, int ph, T w, const unsigned* sg, t
   }
 }
 
-// v[r] = cur[r ^ xh] for a wave-uniform xh in 1 .. RPT - 1 (register arrays need static indices: a chain of scalar compares)
-template <class T, int RPT, int XH>
-__device__ __forceinline__ void xs_local_copy(int xh, const typename Cx<T>::type* cur, typename Cx<T>::type* v) {
-  if constexpr (XH < RPT) {
-    if (xh == XH) {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
-      asm volatile("" : "+v"(v[0].x));  // (keeps the chain from being merged into an indexed access to a scratch copy of cur)
-    } else {
-      xs_local_copy<T, RPT, XH + 1>(xh, cur, v);
-    }
-  }
-}
-
-// the partner values of XOR-offset xo at the thread's rows: registers when the offset has no lane bits, else LDS reads (volatile,
-// so that neighbours are not merged into ds_read2 forms, which the LDS array serves at half the rate)
-template <class T, int NT, int RPT, bool LOCAL>
-__device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __restrict__ src, const typename Cx<T>::type* cur, int t,
-                                         typename Cx<T>::type* v) {
-  typedef typename XsV2<T>::type V2;
-  typedef const volatile __attribute__((address_space(3))) V2* lds_ptr;
-  const int xl = xo & (NT - 1), xh = xo / NT;  // (wave-uniform)
-  if (LOCAL && xl == 0) {
-    xs_local_copy<T, RPT, 1>(xh, cur, v);
-  } else {
-    lds_ptr base = (lds_ptr)(src + (t ^ xl));
-    if (xh == 0) {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const V2 q = base[r * NT];
-        v[r].x = q.x;
-        v[r].y = q.y;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const V2 q = base[(r ^ xh) * NT];
-        v[r].x = q.x;
-        v[r].y = q.y;
-      }
-    }
-  }
-}
-
 __device__ __forceinline__ double xs_readlane(double v, int j) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
   return __hiloint2double(hi, lo);
 }
 
-// the table and this step's weights, one entry per lane (lane j < R: XOR-diagonal j), read back with v_readlane -- no memory
-// access in the loop over the diagonals
+// The table in the order the sweeps walk it, and this step's weights -- one entry per lane (lane q < R), read back with
+// v_readlane: no memory access in the loop over the diagonals.  Order (XsOrder, made on the host): first the n0 diagonals whose
+// partners are LDS reads that keep their place in the thread's row list (offset < NT), then the n1 LDS ones that permute the row
+// list too, then those whose offset has no lane bits (partners = the thread's own registers), grouped by xh = offset / NT.
 struct XsCtl {
-  int R;
-  int ent;    // xoff | phase << 16
+  int R, n0, n1;
+  int nloc[8];
+  int ent;    // xoff | phase << 16 | (index in the table: sign bit, accumulator) << 20
   double w;   // dt u c_j of the current step
-  __device__ __forceinline__ void load_table(const XrTab& tab, int lane) {
+  int perm;   // this lane's index in the table
+  __device__ __forceinline__ void load_table(const XrTab& tab, const XsOrder& ord, int lane) {
     R = tab.R;
-    ent = lane < tab.R ? (tab.xoff[lane] | (tab.phase[lane] << 16)) : 0;
+    n0 = ord.n0;
+    n1 = ord.n1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) nloc[i] = ord.nloc[i];
+    perm = lane < tab.R ? ord.perm[lane] : 0;
+    ent = lane < tab.R ? (tab.xoff[perm] | (tab.phase[perm] << 16) | (perm << 20)) : 0;
   }
-  __device__ __forceinline__ void load_step(const double* __restrict__ wrow, int lane) { w = lane < R ? wrow[lane] : 0.0; }
+  __device__ __forceinline__ void load_step(const double* __restrict__ wrow, int lane) { w = lane < R ? wrow[perm] : 0.0; }
 };
 
-// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`).  The loop over the diagonals is a runtime
-// loop on purpose (unrolled, the compiler hoists masks and addresses of all R diagonals and spills).  PREF: the partners of the
-// next diagonal are fetched while this one's are used (two register buffers).
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool LOCAL, bool PREF>
-__device__ __forceinline__ void xs_gather(const XsCtl ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
-                                          const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
-                                          const typename Cx<T>::type* xm, double* dacc) {
+// partner values by LDS reads (volatile: neighbours are not to be merged into ds_read2 forms, which the LDS array serves at half
+// the rate).  PERM: the offset permutes the thread's row list as well (xh != 0)
+template <class T, int NT, int RPT, bool PERM>
+__device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __restrict__ src, int t, typename Cx<T>::type* v) {
+  typedef typename XsV2<T>::type V2;
+  typedef const volatile __attribute__((address_space(3))) V2* lds_ptr;
+  lds_ptr base = (lds_ptr)(src + (t ^ (xo & (NT - 1))));
+  const int xh = xo / NT;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const V2 q = PERM ? base[(r ^ xh) * NT] : base[r * NT];
+    v[r].x = q.x;
+    v[r].y = q.y;
+  }
+}
+
+// the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF>
+__device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
+                                             const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
+                                             const typename Cx<T>::type* xm, double* dacc) {
   typedef typename Cx<T>::type T2;
-  const int R = ctl.R;
+  if (n <= 0) return;
   if (PREF) {
     T2 va[RPT], vb[RPT];
-    int e0 = __builtin_amdgcn_readlane(ctl.ent, 0), e1 = 0;
-    xs_fetch<T, NT, RPT, LOCAL>(e0 & 0xffff, src, cur, t, va);
-    int j = 0;
+    int e0 = __builtin_amdgcn_readlane(ctl.ent, q0), e1 = 0;
+    xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
+    int q = q0;
+    const int qe = q0 + n;
 #pragma clang loop unroll(disable)
-    for (; j + 1 < R; j += 2) {
-      e1 = __builtin_amdgcn_readlane(ctl.ent, j + 1);
-      xs_fetch<T, NT, RPT, LOCAL>(e1 & 0xffff, src, cur, t, vb);
-      xs_use<T, RPT, SIGN, DOT, RM>(j, e0 >> 16, sgn * (T)xs_readlane(ctl.w, j), sg, va, o, xm, dacc);
-      if (j + 2 < R) {
-        e0 = __builtin_amdgcn_readlane(ctl.ent, j + 2);
-        xs_fetch<T, NT, RPT, LOCAL>(e0 & 0xffff, src, cur, t, va);
+    for (; q + 1 < qe; q += 2) {
+      e1 = __builtin_amdgcn_readlane(ctl.ent, q + 1);
+      xs_fetch<T, NT, RPT, PERM>(e1 & 0xffff, src, t, vb);
+      xs_use<T, RPT, SIGN, DOT, RM>(e0 >> 20, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+      if (q + 2 < qe) {
+        e0 = __builtin_amdgcn_readlane(ctl.ent, q + 2);
+        xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
       }
-      xs_use<T, RPT, SIGN, DOT, RM>(j + 1, e1 >> 16, sgn * (T)xs_readlane(ctl.w, j + 1), sg, vb, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, RM>(e1 >> 20, (e1 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
     }
-    if (j < R) xs_use<T, RPT, SIGN, DOT, RM>(j, e0 >> 16, sgn * (T)xs_readlane(ctl.w, j), sg, va, o, xm, dacc);
+    if (q < qe) xs_use<T, RPT, SIGN, DOT, RM>(e0 >> 20, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
   } else {
 #pragma clang loop unroll(disable)
-    for (int j = 0; j < R; ++j) {
-      const int e = __builtin_amdgcn_readlane(ctl.ent, j);
+    for (int q = q0; q < q0 + n; ++q) {
+      const int e = __builtin_amdgcn_readlane(ctl.ent, q);
       T2 v[RPT];
-      xs_fetch<T, NT, RPT, LOCAL>(e & 0xffff, src, cur, t, v);
-      xs_use<T, RPT, SIGN, DOT, RM>(j, e >> 16, sgn * (T)xs_readlane(ctl.w, j), sg, v, o, xm, dacc);
+      xs_fetch<T, NT, RPT, PERM>(e & 0xffff, src, t, v);
+      xs_use<T, RPT, SIGN, DOT, RM>(e >> 20, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
     }
+  }
+}
+
+// the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class
+template <class T, int RPT, int XH, bool SIGN, bool DOT, int RM>
+__device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
+                                                 typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+  if constexpr (XH < RPT && XH < 8) {
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < ctl.nloc[XH]; ++i, ++q) {
+      const int e = __builtin_amdgcn_readlane(ctl.ent, q);
+      typename Cx<T>::type v[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
+      xs_use<T, RPT, SIGN, DOT, RM>(e >> 20, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+    }
+    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, RM>(ctl, q, sg, cur, sgn, o, xm, dacc);
+  }
+}
+
+// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`), class by class: no per-diagonal branching
+// LOCAL = false: the last group is read from LDS like the others (the caller's copy of v need not stay in registers)
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL = true>
+__device__ __forceinline__ void xs_gather(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
+                                          const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
+                                          const typename Cx<T>::type* xm, double* dacc) {
+  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF>(ctl, 0, ctl.n0, sg, src, t, sgn, o, xm, dacc);
+  if (LOCAL) {
+    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF>(ctl, ctl.n0, ctl.n1, sg, src, t, sgn, o, xm, dacc);
+    xs_local_classes<T, RPT, 1, SIGN, DOT, RM>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
+  } else {
+    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF>(ctl, ctl.n0, ctl.R - ctl.n0, sg, src, t, sgn, o, xm, dacc);
   }
 }
 
@@ -231,7 +245,7 @@ __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double
 // column: [B][D]).  dgs + s * dgs_step: the rows' diagonal weights of step s.
 template <class T, int NT, int RPT, bool SIGN, bool PREF>
 __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
-                                                        typename Cx<T>::type* __restrict__ psi_out, XrTab tab,
+                                                        typename Cx<T>::type* __restrict__ psi_out, XrTab tab, XsOrder ord,
                                                         const double* __restrict__ wt, const double* __restrict__ dgs, long dgs_step,
                                                         int S, int B, int L) {
   typedef typename Cx<T>::type T2;
@@ -243,7 +257,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
 #pragma unroll
   for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
   XsCtl ctl;
-  ctl.load_table(tab, t & 63);
+  ctl.load_table(tab, ord, t & 63);
   int p = 0;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     T2 cur[RPT];
@@ -268,7 +282,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
           o[r].x = 0;
           o[r].y = 0;
         }
-        xs_gather<T, NT, RPT, SIGN, false, 1, true, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        xs_gather<T, NT, RPT, SIGN, false, 1, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)m;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {  // + the diagonal: -i dg v
@@ -331,9 +345,9 @@ __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
 // part[((blockIdx.x * S + s) * NW + wave) * NS + slot]: this workgroup's share, over its columns, of
 //   slot < RM: sum_i of the level pairings of XOR-diagonal `slot` (before the factors cmag and dt);
 //   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
-template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM, bool PREF>
+template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM, bool PREF, bool HPREF = false>
 __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
-                                                         XrTab tab, const double* __restrict__ wt, const double* __restrict__ dgs,
+                                                         XrTab tab, XsOrder ord, const double* __restrict__ wt, const double* __restrict__ dgs,
                                                          long dgs_step, int S, int B, int L, typename Cx<T>::type* __restrict__ park,
                                                          double* __restrict__ part) {
   typedef typename Cx<T>::type T2;
@@ -347,7 +361,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
   for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
   XsCtl ctl;
-  ctl.load_table(tab, lane);
+  ctl.load_table(tab, ord, lane);
   T2* pk = park + (long)blockIdx.x * (L + 1) * D;  // [l][r * NT + t] (uniform base, lane index t)
   T2* plam = pk + (long)L * D;
   int p = 0;
@@ -383,7 +397,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
             o[r].x = 0;
             o[r].y = 0;
           }
-          xs_gather<T, NT, RPT, SIGN, false, 1, true, PREF>(ctl, sg, img + p * D, cur, t, (T)-1, o, nullptr, nullptr);
+          xs_gather<T, NT, RPT, SIGN, false, 1, PREF>(ctl, sg, img + p * D, cur, t, (T)-1, o, nullptr, nullptr);
           const T inv = (T)1 / (T)m;
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {  // + i dg v
@@ -420,7 +434,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].x = 0;
           o[r].y = 0;
         }
-        xs_gather<T, NT, RPT, SIGN, false, 1, true, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        xs_gather<T, NT, RPT, SIGN, false, 1, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)l;
         T2* pl = pk + (long)l * D;
 #pragma unroll
@@ -467,7 +481,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].y = xs_fma(dgv, cur[r].x, g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
-        xs_gather<T, NT, RPT, SIGN, true, RM, false, false>(ctl, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
+        xs_gather<T, NT, RPT, SIGN, true, RM, HPREF, false>(ctl, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
 #pragma unroll
@@ -661,6 +675,21 @@ int xs_lds_diagonals(int d, const XrTab& tab, int variant) {
     if (tab.xoff[j] & (nt - 1)) ++n;
   return n;
 }
+// the order in which the sweeps walk the table (see XsCtl)
+XsOrder xs_make_order(int d, const XrTab& tab, int variant) {
+  XsOrder o;
+  memset(&o, 0, sizeof(o));
+  const int nt = xs_threads(d, variant);
+  int at = 0;
+  for (int j = 0; j < tab.R; ++j)
+    if ((tab.xoff[j] & (nt - 1)) != 0 && tab.xoff[j] < nt) { o.perm[at++] = (unsigned char)j; ++o.n0; }
+  for (int j = 0; j < tab.R; ++j)
+    if ((tab.xoff[j] & (nt - 1)) != 0 && tab.xoff[j] >= nt) { o.perm[at++] = (unsigned char)j; ++o.n1; }
+  for (int xh = 1; xh < 8; ++xh)
+    for (int j = 0; j < tab.R; ++j)
+      if ((tab.xoff[j] & (nt - 1)) == 0 && tab.xoff[j] / nt == xh) { o.perm[at++] = (unsigned char)j; ++o.nloc[xh]; }
+  return o;
+}
 size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)(L + 1) * (size_t)d; }
 size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant) {
   return (size_t)nblk * (size_t)S * (size_t)xs_waves(d, variant) * (size_t)xs_slots(tab);
@@ -690,12 +719,13 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr;
-  void (*kf)(const T2*, T2*, XrTab, const double*, const double*, long, int, int, int) =
+  void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int) =
       sgn ? (pref ? xs_forward_kernel<T, NT, RPT, true, true> : xs_forward_kernel<T, NT, RPT, true, false>)
           : (pref ? xs_forward_kernel<T, NT, RPT, false, true> : xs_forward_kernel<T, NT, RPT, false, false>);
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, wt, dgs, dgs_step, S, B, L);
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0), wt, dgs,
+                     dgs_step, S, B, L);
   return hipGetLastError();
 }
 
@@ -705,12 +735,13 @@ hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
-  void (*kf)(T2*, T2*, XrTab, const double*, const double*, long, int, int, int, T2*, double*) =
+  void (*kf)(T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, T2*, double*) =
       sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF>)
           : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL, PREF> : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL, PREF>);
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, wt, dgs, dgs_step, S, B, L, park, part);
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0), wt, dgs,
+                     dgs_step, S, B, L, park, part);
   return hipGetLastError();
 }
 

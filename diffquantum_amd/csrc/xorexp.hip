@@ -406,7 +406,10 @@ static hipError_t xr_forward_go(typename Cx<T>::type* U, long stride, const XrTa
   const dim3 grid((unsigned)xr_blocks(NT * RPT, batch), (unsigned)batch);
   void (*kf)(typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly) =
       tab.sgn ? xr_forward_kernel<T, NT, RPT, true> : xr_forward_kernel<T, NT, RPT, false>;
-  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    const hipError_t ea = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;  // (a device or partition mode with less LDS: the caller falls back)
+  }
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, U, stride, tab, u, K, mdt, pol);
   return hipGetLastError();
 }
@@ -447,7 +450,10 @@ static hipError_t xr_reverse_go(const typename Cx<T>::type* G, long stride, cons
   if (full && !tb.sgn) return hipErrorInvalidValue;
   void (*kf)(const typename Cx<T>::type*, long, XrTab, const double*, int, double, XrPoly, double*, T*) =
       full ? xr_reverse_kernel<T, NT, RPT, true, true, RM> : xr_reverse_kernel<T, NT, RPT, false, false, RM>;
-  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    const hipError_t ea = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;  // (a device or partition mode with less LDS: the caller falls back)
+  }
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tb, u, K, mdt, pol, part, xpow);
   return hipGetLastError();
 }
@@ -859,7 +865,10 @@ static hipError_t zxr_forward_go(double2* U, long stride, const XrTab& tab, cons
   const dim3 grid((unsigned)xr_blocks(NT * RPT, batch), (unsigned)batch);
   void (*kf)(double2*, long, XrTab, const double*, int, double, int) =
       tab.sgn ? zxr_forward_kernel<NT, RPT, true> : zxr_forward_kernel<NT, RPT, false>;
-  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    const hipError_t ea = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;  // (a device or partition mode with less LDS: the caller falls back)
+  }
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, U, stride, tab, u, K, dt, L);
   return hipGetLastError();
 }
@@ -888,7 +897,10 @@ static hipError_t zxr_reverse_go(const double2* G, long stride, const XrTab& tab
   void (*kf)(const double2*, long, XrTab, const double*, int, double, int, double*, double2*) =
       dc ? zxr_reverse_kernel<NT, RPT, true, true, RM>
          : (tab.sgn ? zxr_reverse_kernel<NT, RPT, true, false, RM> : zxr_reverse_kernel<NT, RPT, false, false, RM>);
-  (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    const hipError_t ea = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;  // (a device or partition mode with less LDS: the caller falls back)
+  }
   hipLaunchKernelGGL(kf, grid, dim3(NT), lds, st, G, stride, tab, u, K, dt, L, part, xpow);
   return hipGetLastError();
 }

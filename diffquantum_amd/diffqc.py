@@ -58,15 +58,26 @@ def test_eigen(v):
 
 
 def _engine():
-    """The Python-side engine handle (built on first use when set_H went through the compiled module)."""
+    """The Python-side engine handle.  When set_H went through the compiled module it BORROWS that module's context (one
+    dq_ctx, one device copy of the Hamiltonians and of their sparsity tables); otherwise it owns one."""
     if _state["engine"] is None:
         if _state["H"] is None:
             raise RuntimeError("set_H must be called first")
-        H0, Hs = _state["H"]
-        eng = Engine(H0.shape[0], Hs.shape[0])
-        eng.set_hamiltonians(H0, Hs)
-        _state["engine"] = eng
+        d, K = _state["H"]
+        if _state["native_set"]:
+            _state["engine"] = Engine.borrow(native.ctx_handle(), d, K)
+        else:
+            raise RuntimeError("set_H must be called first")
     return _state["engine"]
+
+
+def close():
+    """Release the engine context (the compiled module's included); set_H must be called again afterwards."""
+    if _state["engine"] is not None:
+        _state["engine"].close()
+    if native is not None and _state["native_set"]:
+        native.close()
+    _state.update(engine=None, H=None, native_set=False, dim=0)
 
 
 def set_H(H0, Hs, channels, duration, func_type):
@@ -83,14 +94,16 @@ def set_H(H0, Hs, channels, duration, func_type):
             if len(row) < 4:
                 raise ValueError("each channel row needs at least 4 entries (unused, omega, w, idx)")
     if _state["engine"] is not None:
-        _state["engine"].close()
-    _state.update(engine=None, channels=chans, duration=float(duration), func_type=int(func_type), dim=d, H=(H0, Hs),
+        _state["engine"].close()          # (a borrowed handle is only dropped; the module replaces its context below)
+    _state.update(engine=None, channels=chans, duration=float(duration), func_type=int(func_type), dim=d, H=(d, Hs.shape[0]),
                   native_set=False)
     if native is not None:
-        native.set_H(H0.tolist(), Hs.tolist(), chans, float(duration), int(func_type))
+        native.set_H(H0, Hs, chans, float(duration), int(func_type))      # numpy buffers, read in place
         _state["native_set"] = True
     else:
-        _engine()
+        eng = Engine(d, Hs.shape[0])
+        eng.set_hamiltonians(H0, Hs)
+        _state["engine"] = eng
 
 
 def _table(T0, T, per_step, vv):
@@ -110,7 +123,7 @@ def trotter(psi0, T0, T, per_step, vv):
         v = np.asarray(vv, dtype=np.float64)
         if v.ndim != 3 or v.shape[0] != 2:
             raise ValueError("vv must have shape [2][n_param][n_basis]")
-        return native.trotter(psi.tolist(), float(T0), float(T), int(per_step), v.tolist())
+        return native.trotter(psi.tolist(), float(T0), float(T), int(per_step), v.tolist())   # (the reference's list-in / list-out signature)
     u, dt = _table(T0, T, per_step, vv)
     out = _engine().propagate(u, dt, psi.reshape(-1, 1))
     return [complex(z) for z in out[:, 0]]

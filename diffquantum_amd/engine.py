@@ -70,13 +70,30 @@ class Engine:
         _lib.check(self._lib.dq_create_ex(C.byref(self._ctx), self.dim, self.n_controls, self.device,
                                           _lib.DQ_C128 if dtype == "c128" else _lib.DQ_C64))
 
+        self._owns = True
+
+    @classmethod
+    def borrow(cls, handle: int, dim: int, n_controls: int, device: int = 0, dtype: str = "c128"):
+        """Wrap an existing dq_ctx (e.g. the compiled `diffqc` module's, `_diffqc_native.ctx_handle()`) without owning it:
+        one context, one device copy of the Hamiltonians; close() then only drops the reference."""
+        if not handle:
+            raise ValueError("null context handle")
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p(int(handle))
+        self.dim, self.n_controls, self.device, self.dtype = int(dim), int(n_controls), int(device), dtype
+        self.cdtype = np.complex128 if dtype == "c128" else np.complex64
+        self._owns = False
+        return self
+
     def _c(self, x, shape=None, name="array"):
         return _cx(x, shape, name, self.cdtype)
 
     # -- lifetime -----------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
-            self._lib.dq_destroy(self._ctx)
+            if getattr(self, "_owns", True):
+                self._lib.dq_destroy(self._ctx)
             self._ctx = None
 
     def __del__(self):

@@ -52,9 +52,10 @@ typedef struct dq_ctx dq_ctx;
 #define DQ_PROF_RSYM 6      /* the same kernel in its symmetric-output form (tiles on/above the diagonal)  */
 #define DQ_PROF_ZHERM 7     /* complex GEMM in its (anti-)Hermitian-output form (tiles on/above the diagonal) */
 #define DQ_PROF_SPMM 8      /* sparse generator x dense matrix passes (drift and controls sparse)                */
-#define DQ_PROF_STATECOL 9  /* state-column form (statecol.hip): whole chains on state columns held in LDS. For this class
-                               `bytes` counts the LDS bytes the sweeps gather (its HBM traffic is the states in and out) */
-#define DQ_PROF_NCLASS 10
+#define DQ_PROF_STATECOL_FWD 9  /* state-column form (statecol.hip), forward chains: whole chains on state columns held in LDS. For these
+                                   two classes `bytes` counts the LDS bytes the sweeps gather (HBM traffic: the states in and out) */
+#define DQ_PROF_STATECOL_BWD 10 /* state-column form, adjoint sweeps (reversal, forward terms, Horner with the gradient pairings) */
+#define DQ_PROF_NCLASS 11
 
 typedef struct dq_profile {
   long long launches[DQ_PROF_NCLASS];

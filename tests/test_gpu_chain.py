@@ -471,11 +471,18 @@ def test_headline_shape_all_schemes_agree():
         e.use_torch_stream()
         e.set_hamiltonians(H0, Hs)
         e.set_observable(M)
+        # the state-column form (no propagators at all: statecol.hip) is what this shape takes by default
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1
+        res["state_columns"] = (loss, grad, fin)
+        assert abs(float(en.sum()) - loss) < 1e-9 and float((torch.linalg.norm(fin, dim=0) - 1).abs().max()) < 1e-12
+        e.set_option("state_columns", 0)
         for real in (-1, 0):
             for comp in (-1, 0):
                 e.set_option("real_path", real)
                 e.set_option("compose", comp)
                 loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+                assert e.info("state_columns") == 0
                 assert (e.info("real_path") >= 1) == (real == -1) and e.info("operator_backward") == (1 if comp else 0)
                 res[(real, comp)] = (loss, grad, fin)
                 assert abs(float(en.sum()) - loss) < 1e-9

@@ -237,6 +237,7 @@ def test_headline_shape_two_virtual_ranks():
         e.set_hamiltonians(H0, Hs)
         e.set_observable(M)
         e.set_option("cache_bytes", 8 * 2 ** 30)
+        e.set_option("state_columns", 0)                      # (this test is about the operator form and its time slices)
         l0, g0, f0, _ = e.energy_grad(u, dt, full, want_energies=False)
         assert e.info("real_path") >= 1 and e.info("operator_backward") == 1 and e.info("composed") == 1
         res = virtual_time_sliced_energy_grad([e] * world, u, dt, shards)
@@ -266,6 +267,7 @@ def test_headline_dimension_eight_virtual_ranks_narrow_batch():
         e.set_hamiltonians(H0, Hs)
         e.set_observable(M)
         e.set_option("cache_bytes", 8 * 2 ** 30)
+        e.set_option("state_columns", 0)                      # (state form on explicit propagators vs the sliced operator form)
         l0, g0, f0, _ = e.energy_grad(u, dt, full, want_energies=False)
         assert e.info("operator_backward") == 0 and e.info("checkpoint_stride") >= 1
         res = virtual_time_sliced_energy_grad([e] * world, u, dt, shards)

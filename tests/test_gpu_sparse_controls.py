@@ -304,7 +304,7 @@ def test_sparse_generator_with_the_propagator_cache():
     H0, Hs = p["H0"].astype(complex), p["Hs"].astype(complex)
     u = np.random.default_rng(0).uniform(-1, 1, (S, len(Hs)))
     psi0 = problems.random_states(1 << n, B, seed=3)
-    with _engine(H0, Hs, H0, real_min_dim=128, cache_bytes=2e9, sparse_generator=1) as e:
+    with _engine(H0, Hs, H0, real_min_dim=128, cache_bytes=2e9, sparse_generator=1, state_columns=0) as e:
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("sparse_generator") == 1 and e.info("cached_steps") == S
         e.set_option("cache_bytes", -1)

@@ -68,7 +68,7 @@ def test_state_columns_match_oracle(oracle, case, n):
     u = np.random.default_rng(n).uniform(-1, 1, (S, K))
     psi0 = problems.random_states(d, B, seed=2)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M) as e:
+    with _engine(H0, Hs, M, state_columns=1 if n == 8 else -1) as e:     # (auto takes the form from dim 512 up)
         loss, grad, fin, en = e.energy_grad(u, dt, psi0)
         assert e.info("state_columns") == 1, "a Pauli-string generator did not take the state-column form"
         fwd = e.propagate(u, dt, psi0)
@@ -123,7 +123,7 @@ def test_long_chain_reversal_drift(oracle):
     psi0 = problems.random_states(1 << n, B, seed=7)
     dt = 0.4 / S
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M) as e:
+    with _engine(H0, Hs, M, state_columns=1) as e:
         loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
         assert e.info("state_columns") == 1
     assert np.max(np.abs(fin - rf)) < TOL and abs(loss - rl) < TOL and np.max(np.abs(grad - rg)) < TOL
@@ -136,19 +136,19 @@ def test_fidelity_objective_and_fp32(oracle):
     psi0 = problems.random_states(1 << n, B, seed=8)
     tg = problems.random_states(1 << n, B, seed=9)
     rl, rg = oracle.fidelity_grad(H0, list(Hs), u, dt, psi0, tg)[:2]
-    with _engine(H0, Hs, M) as e:
+    with _engine(H0, Hs, M, state_columns=1) as e:
         out = e.fidelity_grad(u, dt, psi0, tg)
         assert e.info("state_columns") == 1
     assert abs(out[0] - rl) < TOL and np.max(np.abs(out[1] - rg)) < TOL
     l64, g64, f64 = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0.astype(np.complex64), Hs.astype(np.complex64), M.astype(np.complex64), dtype="c64") as e:
+    with _engine(H0.astype(np.complex64), Hs.astype(np.complex64), M.astype(np.complex64), dtype="c64", state_columns=1) as e:
         loss, grad, fin, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
         assert e.info("state_columns") == 1
     assert np.max(np.abs(fin - f64)) < 1e-4 and abs(loss - l64) < 1e-4 * B and np.max(np.abs(grad - g64)) < 1e-4
 
 
 def test_options_that_pin_another_scheme_keep_it_and_wide_batches_leave():
-    n = 8
+    n = 9
     H0, Hs, M = problems.random_ising(n, seed=1)
     u = np.random.default_rng(0).uniform(-1, 1, (2, n))
     psi0 = problems.random_states(1 << n, 4, seed=1)
@@ -157,14 +157,21 @@ def test_options_that_pin_another_scheme_keep_it_and_wide_batches_leave():
         with _engine(H0, Hs, M, **{opt: val}) as e:
             e.energy_grad(u, 1e-3, psi0)
             assert e.info("state_columns") == 0, opt
-    wide = problems.random_states(1 << n, 8 * 256 + 1, seed=1)
+    with _engine(H0, Hs, M) as e:
+        e.energy_grad(u, 1e-3, psi0)
+        assert e.info("state_columns") == 1               # auto: dim >= 512, batch <= 8 x dim
+    H8, Hs8, M8 = problems.random_ising(8, seed=1)
+    with _engine(H8, Hs8, M8) as e:
+        e.energy_grad(u[:, :8], 1e-3, problems.random_states(256, 4, seed=1))
+        assert e.info("state_columns") == 0               # dim 256: one wave per column; the operator form is faster there
+    wide = problems.random_states(1 << n, 8 * 512 + 1, seed=1)
     with _engine(H0, Hs, M) as e:
         e.energy_grad(u, 1e-3, wide)
         assert e.info("state_columns") == 0               # batch > 8 x dim: the operator form's cost does not grow with the batch
         e.set_option("state_columns", 1)
         e.energy_grad(u, 1e-3, wide)
         assert e.info("state_columns") == 1
-    Hd, Hsd, Md = problems.random_real_symmetric_problem(n, 2, seed=0)
+    Hd, Hsd, Md = problems.random_real_symmetric_problem(8, 2, seed=0)
     with _engine(Hd, Hsd, Md, state_columns=1) as e:
-        e.energy_grad(u[:, :2], 1e-3, psi0)
+        e.energy_grad(u[:, :2], 1e-3, problems.random_states(256, 4, seed=1))
         assert e.info("state_columns") == 0               # dense H: no table, the GEMM chain stays

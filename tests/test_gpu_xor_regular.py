@@ -52,10 +52,13 @@ def _pauli_problem(n, seed):
 
 
 def _engine(H0, Hs, M, dtype="c128", **opts):
+    """(state_columns = 0: this file is about the column form of the PROPAGATORS, xorexp.hip; the state-column form, which the
+    engine would otherwise take for these generators at narrow batches, has tests/test_gpu_state_columns.py)"""
     from diffquantum_amd.engine import Engine
     e = Engine(len(H0), len(Hs), dtype=dtype)
     e.set_hamiltonians(H0, Hs)
     e.set_observable(M)
+    opts.setdefault("state_columns", 0)
     for k, v in opts.items():
         e.set_option(k, v)
     return e
@@ -132,6 +135,7 @@ def test_column_form_against_row_kernels_up_to_the_headline_dimension(n, B, S):
     with Engine(1 << n, n) as e:
         e.set_hamiltonians(H0, Hs)
         e.set_observable(M)
+        e.set_option("state_columns", 0)
         assert e.info("xor_regular_found") == n
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("sparse_generator") == 1 and e.info("xor_regular") == 1
@@ -170,7 +174,7 @@ def test_column_form_with_the_propagator_cache_and_time_slices():
     H0, Hs, M = problems.random_ising(n, seed=2)
     u = np.random.default_rng(0).uniform(-1, 1, (S, n))
     psi0 = problems.random_states(1 << n, B, seed=3)
-    with _engine(H0, Hs, M, sparse_generator=1, cache_bytes=2e9) as e:
+    with _engine(H0, Hs, M, sparse_generator=1, cache_bytes=2e9, state_columns=0) as e:
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("xor_regular") == 1 and e.info("cached_steps") == S
         e.set_option("cache_bytes", -1)
@@ -300,6 +304,7 @@ def test_complex_column_form_against_the_tape_up_to_the_headline_dimension(n, B,
     with Engine(1 << n, len(Hs)) as e:
         e.set_hamiltonians(H0, Hs)
         e.set_observable(M)
+        e.set_option("state_columns", 0)
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("xor_regular") == 2
         e.set_option("xor_regular", 0)
