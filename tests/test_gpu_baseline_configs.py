@@ -90,6 +90,60 @@ def test_headline_dimension_matches_oracle(ising12, scheme, compose):
     assert np.max(np.abs(P["grad"])) > 1e-4                             # (the comparison is not of zeros)
 
 
+@pytest.fixture(scope="module")
+def xyz12(oracle):
+    """d = 4096 with X, Y and Z drives (a COMPLEX Hermitian Pauli sum: I/Q control plus a detuning): random Ising drift, X_q on
+    five qubits, Y_q on five others, one Z_q control and one two-body X_a Z_b control -- and the oracle's answer, once."""
+    n, S, B, dt = 12, 2, 16, 1e-3
+    d = 1 << n
+    H0 = np.diag(problems.ising_diagonal(n, 7)).astype(np.complex128)
+    idx = np.arange(d)
+    bit = lambda q: 1 << (n - 1 - q)
+    sgn = lambda q: 1.0 - 2.0 * ((idx & bit(q)) != 0)
+    Hs = np.zeros((12, d, d), dtype=np.complex128)
+    for k, q in enumerate(range(0, 5)):
+        Hs[k, idx, idx ^ bit(q)] = 1.0                                   # X_q
+    for k, q in enumerate(range(5, 10)):
+        Hs[5 + k, idx, idx ^ bit(q)] = -1j * sgn(q)                      # Y_q: Y[0,1] = -i, Y[1,0] = +i
+    Hs[10, idx, idx] = sgn(10)                                           # Z_10
+    Hs[11, idx, idx ^ bit(11)] = sgn(3)                                  # X_11 Z_3
+    M = H0.copy()
+    u = np.random.default_rng(11).uniform(-1, 1, (S, 12))
+    psi0 = problems.random_states(d, B, seed=5)
+    loss, grad, fin = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    return dict(H0=H0, Hs=Hs, M=M, u=u, psi0=psi0, loss=loss, grad=grad, fin=fin, dt=dt, B=B)
+
+
+@pytest.mark.parametrize("form", ["state_columns", "column_form_operator", "column_form_state", "complex_tape"])
+def test_headline_dimension_complex_pauli_sum_matches_oracle(xyz12, form):
+    """the COMPLEX column form (zxr_* kernels, xorexp.hip) directly against the oracle at d = 4096 (it was
+    compared with the oracle at d <= 512 and with the engine's own tape above), in operator and in state form; the
+    state-column form (statecol.hip) on the same complex generator; and the tape."""
+    from diffquantum_amd.engine import Engine
+    P = xyz12
+    with Engine(4096, 12) as e:
+        e.set_hamiltonians(P["H0"], P["Hs"])
+        e.set_observable(P["M"])
+        assert e.info("real_hamiltonians") == 0 and e.info("xor_regular_found") == 11
+        if form == "state_columns":
+            e.set_option("state_columns", 1)
+        else:
+            e.set_option("state_columns", 0)
+            e.set_option("compose", 1 if form == "column_form_operator" else 0)
+            if form == "complex_tape":
+                e.set_option("xor_regular", 0)
+        fwd = e.propagate(P["u"], P["dt"], P["psi0"])
+        loss, grad, fin, en = e.energy_grad(P["u"], P["dt"], P["psi0"])
+        assert e.info("state_columns") == (1 if form == "state_columns" else 0)
+        assert e.info("xor_regular") == (0 if form == "complex_tape" else 2)
+        if form != "state_columns":
+            assert e.info("operator_backward") == (1 if form == "column_form_operator" else 0)
+    assert np.max(np.abs(fwd - P["fin"])) < TOL and np.max(np.abs(fin - P["fin"])) < TOL
+    assert abs(loss - P["loss"]) < TOL * P["B"] and abs(float(en.sum()) - P["loss"]) < TOL * P["B"]
+    assert np.max(np.abs(grad - P["grad"])) < TOL, np.max(np.abs(grad - P["grad"]))
+    assert np.max(np.abs(P["grad"])) > 1e-4
+
+
 def test_headline_dimension_complex_hermitian_matches_oracle(oracle):
     """d = 4096 with a dense COMPLEX Hermitian drift and controls (what `set_H`, diffqc.cc:43-67, accepts in general):
     the complex tape with scaling-and-squaring (theta ~ 1) and the Hermitian-output products on truly complex data."""
