@@ -46,6 +46,11 @@ __device__ inline float xs_flip(float v, unsigned bit) { return __int_as_float(_
 __device__ inline double xs_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ inline float xs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// the per-diagonal accumulators of a thread: one LLVM vector, indexed with a wave-uniform index -- the backend addresses the
+// registers indirectly (s_set_gpr_idx / v_movrel); a tree of scalar compares over a plain array costs a dozen register copies per
+// diagonal where its paths merge, an unrolled loop over the diagonals drowns the register allocator
+typedef double xs_acc16 __attribute__((ext_vector_type(16)));
+
 // dacc[j] += s for a wave-uniform j (register arrays need static indices: a binary tree of scalar compares)
 template <int LO, int HI>
 __device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
@@ -61,9 +66,10 @@ __device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
 
 // One XOR-diagonal's contribution with the partner values in v[]:  o += sg * a_ij v,  a_ij = -i w sigma (phase 0) or
 // w sigma (phase 1); DOT: the level's gradient pairing of the partners with the thread's own rows xm.
-template <class T, int RPT, bool SIGN, bool DOT, int RM>
-__device__ __forceinline__ void xs_use(int j, int ph, T w, const unsigned* sg, typename Cx<T>::type* v, typename Cx<T>::type* o,
-                                       const typename Cx<T>::type* xm, double* dacc) {
+template <class T, int RPT, bool SIGN, bool DOT, int RM, bool CPLX = true>
+__device__ __forceinline__ void xs_use(int j, int slot, int ph_in, T w, const unsigned* sg, typename Cx<T>::type* v,
+                                       typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+  const int ph = CPLX ? ph_in : 0;  // (real tables: every phase is 0 -- no branch, no merging of the two updates' registers)
   if (SIGN) {
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -85,16 +91,22 @@ __device__ __forceinline__ void xs_use(int j, int ph, T w, const unsigned* sg, t
       o[r].y = xs_fma(-w, v[r].x, o[r].y);
     }
   }
-  if (DOT) {
-    double s = 0.0;
+  if (DOT) {  // (dacc: an xs_acc16; slot = the diagonal's sorted position, wave-uniform)
+    T sa = 0, sb = 0;  // two chains: the sums over the rows are latency-bound otherwise
     if (ph) {
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) s -= (double)xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y);
+      for (int r = 0; r < RPT; r += 2) {
+        sa -= xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y);
+        if (r + 1 < RPT) sb -= xs_fma(v[r + 1].x, xm[r + 1].x, v[r + 1].y * xm[r + 1].y);
+      }
     } else {
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) s += (double)xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
+      for (int r = 0; r < RPT; r += 2) {
+        sa += xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
+        if (r + 1 < RPT) sb += xs_fma(v[r + 1].x, xm[r + 1].y, -v[r + 1].y * xm[r + 1].x);
+      }
     }
-    xs_acc<0, RM>(dacc, j, s);
+    (*(xs_acc16*)dacc)[slot] += (double)sa + (double)sb;
   }
 }
 
@@ -142,7 +154,7 @@ __device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __r
 }
 
 // the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF>
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, bool CPLX = true>
 __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
                                              const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
                                              const typename Cx<T>::type* xm, double* dacc) {
@@ -158,27 +170,27 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, co
     for (; q + 1 < qe; q += 2) {
       e1 = __builtin_amdgcn_readlane(ctl.ent, q + 1);
       xs_fetch<T, NT, RPT, PERM>(e1 & 0xffff, src, t, vb);
-      xs_use<T, RPT, SIGN, DOT, RM>(e0 >> 20, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e0 >> 20, q, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
       if (q + 2 < qe) {
         e0 = __builtin_amdgcn_readlane(ctl.ent, q + 2);
         xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
       }
-      xs_use<T, RPT, SIGN, DOT, RM>(e1 >> 20, (e1 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e1 >> 20, q + 1, (e1 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
     }
-    if (q < qe) xs_use<T, RPT, SIGN, DOT, RM>(e0 >> 20, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+    if (q < qe) xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e0 >> 20, q, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
   } else {
 #pragma clang loop unroll(disable)
     for (int q = q0; q < q0 + n; ++q) {
       const int e = __builtin_amdgcn_readlane(ctl.ent, q);
       T2 v[RPT];
       xs_fetch<T, NT, RPT, PERM>(e & 0xffff, src, t, v);
-      xs_use<T, RPT, SIGN, DOT, RM>(e >> 20, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e >> 20, q, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
     }
   }
 }
 
 // the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class
-template <class T, int RPT, int XH, bool SIGN, bool DOT, int RM>
+template <class T, int RPT, int XH, bool SIGN, bool DOT, int RM, bool CPLX = true>
 __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
                                                  typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
   if constexpr (XH < RPT && XH < 8) {
@@ -188,24 +200,26 @@ __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, const 
       typename Cx<T>::type v[RPT];
 #pragma unroll
       for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
-      xs_use<T, RPT, SIGN, DOT, RM>(e >> 20, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e >> 20, q, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
     }
-    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, RM>(ctl, q, sg, cur, sgn, o, xm, dacc);
+    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, RM, CPLX>(ctl, q, sg, cur, sgn, o, xm, dacc);
   }
 }
 
 // o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`), class by class: no per-diagonal branching
 // LOCAL = false: the last group is read from LDS like the others (the caller's copy of v need not stay in registers)
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL = true>
+// DOT: the sweep carries the gradient pairings; dacc is then an xs_acc16 indexed by the diagonal's SORTED position
+// (xs_finish_kernel maps back).  CPLX = false: every phase is 0 (real tables), no branch on it.
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL = true, bool CPLX = true>
 __device__ __forceinline__ void xs_gather(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
                                           const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
                                           const typename Cx<T>::type* xm, double* dacc) {
-  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF>(ctl, 0, ctl.n0, sg, src, t, sgn, o, xm, dacc);
+  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, CPLX>(ctl, 0, ctl.n0, sg, src, t, sgn, o, xm, dacc);
   if (LOCAL) {
-    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF>(ctl, ctl.n0, ctl.n1, sg, src, t, sgn, o, xm, dacc);
-    xs_local_classes<T, RPT, 1, SIGN, DOT, RM>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
+    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, CPLX>(ctl, ctl.n0, ctl.n1, sg, src, t, sgn, o, xm, dacc);
+    xs_local_classes<T, RPT, 1, SIGN, DOT, RM, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
   } else {
-    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF>(ctl, ctl.n0, ctl.R - ctl.n0, sg, src, t, sgn, o, xm, dacc);
+    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, CPLX>(ctl, ctl.n0, ctl.R - ctl.n0, sg, src, t, sgn, o, xm, dacc);
   }
 }
 
@@ -271,14 +285,16 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
       ctl.load_step(wt + (long)s * tab.R, t & 63);
       const double* dgr = dgs + (long)s * dgs_step;
       T2 acc[RPT];
+      T dg[RPT];  // the rows' diagonal weights of this step (registers: a load per sweep would sit in the vmcnt queue of every wait)
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
+      for (int r = 0; r < RPT; ++r) {
+        acc[r] = cur[r];
+        dg[r] = (T)dgr[r * NT + t];
+      }
       for (int m = 1; m <= L; ++m) {
         T2 o[RPT];
-        T dg[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          dg[r] = (T)dgr[r * NT + t];
           o[r].x = 0;
           o[r].y = 0;
         }
@@ -340,12 +356,30 @@ __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
   return v;  // lane l: the total of value (l & 15)
 }
 
+#ifdef XS_STAMPS
+// development builds (tools/statecol_probe.hip): shader cycles per phase of the backward kernel, summed over workgroups
+__device__ unsigned long long xs_stamps[8];
+#define XS_STAMP(i)                                    \
+  do {                                                 \
+    const long long now__ = clock64();                 \
+    stamp_acc[i] += now__ - stamp_t;                   \
+    stamp_t = now__;                                   \
+  } while (0)
+#else
+#define XS_STAMP(i) do { } while (0)
+#endif
+
 // Backward sweep of the chain for the columns b = blockIdx.x, + gridDim.x, ...:  psi [b][:] holds psi_S on entry and psi_0 on exit,
-// lam [b][:] holds lambda_S on entry and lambda_0 on exit.  park: per workgroup (L + 1) vectors of D (x_0 .. x_{L-1}, lambda).
+// lam [b][:] holds lambda_S on entry and lambda_0 on exit.
+// LDS: ONE work image W (the vector the sweeps gather from, updated in place between two barriers) and the lambda image Lm --
+// lambda stays in LDS for the whole chain, each row touched by its own thread only (no barrier concerns it).  park: per
+// workgroup the L forward terms x_0 .. x_{L-1} of the current step (device memory, written and read back by the same thread; 134 MB
+// for the whole grid at d = 4096 -- it streams through the Infinity Cache / HBM and is the kernel's memory traffic: 2 L d 16 B per
+// column and step).  The level-l term is prefetched while the sweep of level l + 1 runs.
 // part[((blockIdx.x * S + s) * NW + wave) * NS + slot]: this workgroup's share, over its columns, of
-//   slot < RM: sum_i of the level pairings of XOR-diagonal `slot` (before the factors cmag and dt);
+//   slot < RM: sum_i of the level pairings of the XOR-diagonal at SORTED position `slot` (before the factors cmag and dt);
 //   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
-template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM, bool PREF, bool HPREF = false>
+template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM, bool PREF, bool CPLX>
 __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
                                                          XrTab tab, XsOrder ord, const double* __restrict__ wt, const double* __restrict__ dgs,
                                                          long dgs_step, int S, int B, int L, typename Cx<T>::type* __restrict__ park,
@@ -355,17 +389,25 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   constexpr int NW = NT / 64;
   constexpr int NS = RM + (DIAGCTL ? XR_DMAX : 0);
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
-  T2* img = (T2*)xs_lds_raw;
+  T2* W = (T2*)xs_lds_raw;
+  T2* Lm = W + D;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   unsigned sg[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
   XsCtl ctl;
   ctl.load_table(tab, ord, lane);
-  T2* pk = park + (long)blockIdx.x * (L + 1) * D;  // [l][r * NT + t] (uniform base, lane index t)
-  T2* plam = pk + (long)L * D;
-  int p = 0;
+  T2* pk = park + (long)blockIdx.x * L * D;  // [l][r * NT + t] (uniform base, lane index t)
+  // in-place update of the work image: every read of the sweep that just ran is done before any row is overwritten
+  auto publish = [&](const T2* v) {
+    __syncthreads();
+    xs_put<T, NT, RPT>(W, t, v);
+    __syncthreads();
+  };
   bool first = true;
+#ifdef XS_STAMPS
+  long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = clock64();
+#endif
   for (int b = blockIdx.x; b < B; b += gridDim.x, first = false) {
     T2 cur[RPT];
     {
@@ -374,30 +416,31 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         cur[r] = in[r * NT + t];
-        plam[r * NT + t] = li[r * NT + t];
+        Lm[r * NT + t] = li[r * NT + t];
       }
     }
+    XS_STAMP(0);
     for (int s = S - 1; s >= 0; --s) {
       ctl.load_step(wt + (long)s * tab.R, lane);
       const double* dgr = dgs + (long)s * dgs_step;
+      {  // (scope of dg: the reversal and the forward terms keep the rows' diagonal weights in registers)
+      T dg[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) dg[r] = (T)dgr[r * NT + t];
       // ---- reversal: psi_s = sum_m (-A)^m psi_{s+1} / m! -------------------------------------------------------------
-      p ^= 1;
-      xs_put<T, NT, RPT>(img + p * D, t, cur);
-      __syncthreads();
+      publish(cur);
       {
         T2 acc[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
         for (int m = 1; m <= L; ++m) {
           T2 o[RPT];
-          T dg[RPT];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {
-            dg[r] = (T)dgr[r * NT + t];
             o[r].x = 0;
             o[r].y = 0;
           }
-          xs_gather<T, NT, RPT, SIGN, false, 1, PREF>(ctl, sg, img + p * D, cur, t, (T)-1, o, nullptr, nullptr);
+          xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, W, cur, t, (T)-1, o, nullptr, nullptr);
           const T inv = (T)1 / (T)m;
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {  // + i dg v
@@ -408,33 +451,24 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
             acc[r].x += ox;
             acc[r].y += oy;
           }
-          if (m < L) {
-            p ^= 1;
-            xs_put<T, NT, RPT>(img + p * D, t, cur);
-            __syncthreads();
-          }
+          if (m < L) publish(cur);
         }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
       }
+      XS_STAMP(1);
       // ---- the forward terms x_l = A^l psi_s / l! --------------------------------------------------------------------
 #pragma unroll
       for (int r = 0; r < RPT; ++r) pk[r * NT + t] = cur[r];
-      if (L > 1) {
-        p ^= 1;
-        xs_put<T, NT, RPT>(img + p * D, t, cur);
-        __syncthreads();
-      }
+      if (L > 1) publish(cur);
       for (int l = 1; l < L; ++l) {
         T2 o[RPT];
-        T dg[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          dg[r] = (T)dgr[r * NT + t];
           o[r].x = 0;
           o[r].y = 0;
         }
-        xs_gather<T, NT, RPT, SIGN, false, 1, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, W, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)l;
         T2* pl = pk + (long)l * D;
 #pragma unroll
@@ -445,64 +479,68 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           cur[r].y = oy;
           pl[r * NT + t] = cur[r];
         }
-        if (l < L - 1) {
-          p ^= 1;
-          xs_put<T, NT, RPT>(img + p * D, t, cur);
-          __syncthreads();
-        }
+        if (l < L - 1) publish(cur);
       }
+      }  // (dg)
+      XS_STAMP(2);
       // ---- Horner on lambda with the level pairings ----------------------------------------------------------------
-      double dacc[RM], rowacc[DIAGCTL ? RPT : 1];
-#pragma unroll
-      for (int j = 0; j < RM; ++j) dacc[j] = 0.0;
+      static_assert(RM == 16, "the accumulator vector has 16 lanes");
+      xs_acc16 dacc = 0.0;
+      double rowacc[DIAGCTL ? RPT : 1];
 #pragma unroll
       for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
+      T2 xm[RPT];
       {
+        // x_{L-1} is still in the registers (cur): it is this sweep's pairing partner
         const T inv = (T)1 / (T)L;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          const T2 g = plam[r * NT + t];
+          xm[r] = cur[r];
+          const T2 g = Lm[r * NT + t];
           cur[r].x = g.x * inv;
           cur[r].y = g.y * inv;
         }
       }
-      p ^= 1;
-      xs_put<T, NT, RPT>(img + p * D, t, cur);
-      __syncthreads();
+      publish(cur);
       for (int l = L - 1; l >= 0; --l) {  // forms y_{l-1} from y_l (l = 0: lambda_s), pairing y_l with x_l
-        T2 o[RPT], xm[RPT];
-        const T2* pl = pk + (long)l * D;
+        T2 o[RPT], xn[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          xm[r] = pl[r * NT + t];
-          const T dgv = (T)dgr[r * NT + t];
-          const T2 g = plam[r * NT + t];
+          const T dgv = (T)dgr[r * NT + t];  // (L2-resident table; not kept in registers across the sweep)
+          const T2 g = Lm[r * NT + t];
           o[r].x = xs_fma(-dgv, cur[r].y, g.x);  // lam - (-i dg y)
           o[r].y = xs_fma(dgv, cur[r].x, g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
-        xs_gather<T, NT, RPT, SIGN, true, RM, HPREF, false>(ctl, sg, img + p * D, cur, t, (T)-1, o, xm, dacc);
+        if (l > 0) {  // the next level's term: loaded while this sweep runs
+          const T2* pl = pk + (long)(l - 1) * D;
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) xn[r] = pl[r * NT + t];
+        }
+        xs_gather<T, NT, RPT, SIGN, true, RM, false, false, CPLX>(ctl, sg, W, cur, t, (T)-1, o, xm, (double*)&dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {
             cur[r].x = o[r].x * inv;
             cur[r].y = o[r].y * inv;
+            xm[r] = xn[r];
           }
-          p ^= 1;
-          xs_put<T, NT, RPT>(img + p * D, t, cur);
-          __syncthreads();
+          publish(cur);
         } else {
 #pragma unroll
-          for (int r = 0; r < RPT; ++r) plam[r * NT + t] = o[r];
+          for (int r = 0; r < RPT; ++r) Lm[r * NT + t] = o[r];
         }
       }
+      XS_STAMP(3);
       // ---- this step's sums: per wave, accumulated over the workgroup's columns --------------------------------------
       double* prow = part + (((long)blockIdx.x * S + s) * NW + wave) * NS;
+      {
+        double da[16];
 #pragma unroll
-      for (int g0 = 0; g0 < RM; g0 += 16) {
-        const double v = xs_wave_sums16(dacc + g0, lane);
-        if (lane < 16) prow[g0 + lane] = first ? v : prow[g0 + lane] + v;
+        for (int j = 0; j < 16; ++j) da[j] = dacc[j];
+        const double v = xs_wave_sums16(da, lane);
+        if (lane < 16) prow[lane] = first ? v : prow[lane] + v;
       }
       if (DIAGCTL) {
         double dv[XR_DMAX];
@@ -520,9 +558,10 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
         const double v = xs_wave_sums16(dv, lane);
         if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
       }
-      // psi_s back into the registers for the next (earlier) step
+      // psi_s = x_0 is in the registers (the last sweep's pairing partner): the next (earlier) step starts from it
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) cur[r] = pk[r * NT + t];
+      for (int r = 0; r < RPT; ++r) cur[r] = xm[r];
+      XS_STAMP(4);
     }
     {
       T2* out = psi + (long)b * D;
@@ -530,17 +569,23 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         out[r * NT + t] = cur[r];
-        lo[r * NT + t] = plam[r * NT + t];
+        lo[r * NT + t] = Lm[r * NT + t];
       }
     }
-    __syncthreads();
+    __syncthreads();  // (the last sweep's reads of W are done before the next column overwrites it)
+    XS_STAMP(5);
   }
+#ifdef XS_STAMPS
+  if (t == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&xs_stamps[i], (unsigned long long)stamp_acc[i]);
+#endif
 }
 
 // grad[s][k] (+)= dt * (sum_j [kid_j == k] cmag_j sum part[.., j] + sum_jd [dkid_jd == k] sum part[.., RM + jd]); one workgroup
 // per step: lane group q sums slot q over the nblk * nw partial rows in a fixed order
 __global__ void __launch_bounds__(1024) xs_finish_kernel(const double* __restrict__ part, int nblk, int nw, int ns, int rm, int S,
-                                                         XrTab tab, int K, double dt, double* __restrict__ grad, int accumulate) {
+                                                         XrTab tab, XsOrder ord, int K, double dt, double* __restrict__ grad,
+                                                         int accumulate) {
   const long s = blockIdx.x;
   const int l = threadIdx.x & 31, slot0 = threadIdx.x >> 5;
   __shared__ double s_j[XR_SLOTS];
@@ -556,8 +601,10 @@ __global__ void __launch_bounds__(1024) xs_finish_kernel(const double* __restric
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 1024) {
     double g = accumulate ? grad[s * K + k] : 0.0;
-    for (int j = 0; j < tab.R; ++j)
-      if (tab.kid[j] == k) g += dt * tab.cmag[j] * s_j[j];
+    for (int q = 0; q < tab.R; ++q) {  // slot q = the diagonal at sorted position q
+      const int j = ord.perm[q];
+      if (tab.kid[j] == k) g += dt * tab.cmag[j] * s_j[q];
+    }
     if (ns > rm)
       for (int jd = 0; jd < tab.nd; ++jd)
         if (tab.dkid[jd] == k) g += dt * s_j[rm + jd];
@@ -690,7 +737,7 @@ XsOrder xs_make_order(int d, const XrTab& tab, int variant) {
       if ((tab.xoff[j] & (nt - 1)) == 0 && tab.xoff[j] / nt == xh) { o.perm[at++] = (unsigned char)j; ++o.nloc[xh]; }
   return o;
 }
-size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)(L + 1) * (size_t)d; }
+size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)L * (size_t)d; }
 size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant) {
   return (size_t)nblk * (size_t)S * (size_t)xs_waves(d, variant) * (size_t)xs_slots(tab);
 }
@@ -735,9 +782,16 @@ hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
+  bool cplx = false;
+  for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
+  // real tables (every phase 0): no sign words -> <false, dc, .., false>; complex tables always carry sign words
   void (*kf)(T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, T2*, double*) =
-      sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF>)
-          : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL, PREF> : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL, PREF>);
+      cplx ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF, true> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF, true>)
+           : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF, false>
+                        : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF, false>)
+                  : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL, PREF, false>
+                        : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL, PREF, false>));
+  if (cplx && !tab.sgn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0), wt, dgs,
@@ -792,11 +846,12 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
                          int K, double dt, double* grad, int accumulate, int variant, hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T)) || !park || !part) return hipErrorInvalidValue;
-  const hipError_t e = (variant & 2) ? xs_backward_pick<T, true>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st)
-                                     : xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
+  // (no prefetch in the backward kernel: its sweeps carry more live registers, and the second partner buffer costs more in spills
+  // than it hides in latency -- measured 24.5 against 26.7 ms per 20 steps at d = B = 4096)
+  const hipError_t e = xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d, variant), xs_slots(tab),
-                     (int)XR_RSMALL, S, tab, K, dt, grad, accumulate);
+                     (int)XR_RSMALL, S, tab, xs_make_order(d, tab, variant), K, dt, grad, accumulate);
   return hipGetLastError();
 }
 
