@@ -305,7 +305,7 @@ struct Ctx : dq_ctx {
   // state-column form (statecol.hip): whole chains on state columns held in LDS; xs_mode: -1 auto, 0 off, 1 whenever supported
   DevBuf xs_psi, xs_lam, xs_park, xs_part, xs_wt, xs_dgs, m_diag;
   bool m_is_diag = false;  // the observable is diagonal (set_observable): Lambda_S = 2 M Psi_S elementwise on the state columns
-  int xs_mode = -1, xs_variant = 2;  // variant 2: 512 threads x 8 rows at dim 4096, prefetch of the next diagonal's partners (measured best)
+  int xs_mode = -1, xs_variant = 0;  // variant 0: 512 threads x 8 rows at dim 4096, no partner prefetch (measured best with the branch-free sweeps)
   int xs_min_dim = 512;
   double xs_batch_ratio = 8.0;  // auto: batch <= ratio x dim (beyond it the operator form, whose cost does not grow with the batch, wins)
   double last_xs = 0;
@@ -2608,7 +2608,7 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xor_mode = v != 0 ? -1 : 0;
   } else if (s == "state_columns") {  // state-column form (statecol.hip): -1 auto (default), 0 off, 1 whenever the kernels exist
     c->xs_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
-  } else if (s == "state_columns_variant") {  // bit 0: 1024 threads x 4 rows at dim 4096 (default 512 x 8); bit 1: prefetch (default on)
+  } else if (s == "state_columns_variant") {  // bit 0: 1024 threads x 4 rows at dim 4096 (default 512 x 8); bit 1: prefetch of the next diagonal's partners in the forward kernel
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_batch_ratio") {  // auto: taken while batch <= ratio x dim
     if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_batch_ratio must be > 0");

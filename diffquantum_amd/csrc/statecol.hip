@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double
 
 // psi_out[b][:] = U_{S-1} ... U_0 psi_in[b][:] for the columns b = blockIdx.x, + gridDim.x, ...  (states stored column by
 // column: [B][D]).  dgs + s * dgs_step: the rows' diagonal weights of step s.
-template <class T, int NT, int RPT, bool SIGN, bool PREF>
+template <class T, int NT, int RPT, bool SIGN, bool PREF, bool CPLX>
 __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
                                                         typename Cx<T>::type* __restrict__ psi_out, XrTab tab, XsOrder ord,
                                                         const double* __restrict__ wt, const double* __restrict__ dgs, long dgs_step,
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
           o[r].x = 0;
           o[r].y = 0;
         }
-        xs_gather<T, NT, RPT, SIGN, false, 1, PREF>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
+        xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
         const T inv = (T)1 / (T)m;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {  // + the diagonal: -i dg v
@@ -766,9 +766,13 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr;
+  bool cplx = false;
+  for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
+  if (cplx && !sgn) return hipErrorInvalidValue;  // (complex tables always carry sign words)
   void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int) =
-      sgn ? (pref ? xs_forward_kernel<T, NT, RPT, true, true> : xs_forward_kernel<T, NT, RPT, true, false>)
-          : (pref ? xs_forward_kernel<T, NT, RPT, false, true> : xs_forward_kernel<T, NT, RPT, false, false>);
+      cplx ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, true> : xs_forward_kernel<T, NT, RPT, true, false, true>)
+           : (sgn ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, false> : xs_forward_kernel<T, NT, RPT, true, false, false>)
+                  : (pref ? xs_forward_kernel<T, NT, RPT, false, true, false> : xs_forward_kernel<T, NT, RPT, false, false, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0), wt, dgs,
