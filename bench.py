@@ -60,6 +60,11 @@ TRAFFIC = {
     "rgemm": (1.81e9, "profiles/r1_bench_v5_realpath_summary.txt"),
     "rsym": (2.68e9, "profiles/r2_bench_dense_real_summary.txt"),    # symmetric-output rgemm 2614 MB + fix-up 64 MB
     "spmm": (8.50e8, "profiles/r2_bench_headline_row_kernels_summary.txt"),     # (2 x 754 MB rsp_mm_slab + 1043 MB rsp_mm_dot_slab) / 3
+    # state-column form (profiles/r3_bench_headline_summary.txt): the forward launch moves the states in and out and nothing else
+    # (269 MB read + 268 MB written = 1.0x algorithmic); the adjoint launch streams its per-workgroup scratch of forward terms:
+    # 1.92 GB read + 1.94 GB written PER STEP of the chain on the fabric side (L2 misses; Infinity-Cache hits are counted)
+    "statecol_fwd": (5.376e8, "profiles/r3_bench_headline_summary.txt"),
+    "statecol_bwd_per_step": (3.86e9, "profiles/r3_bench_headline_summary.txt"),
     "xr": (6.60e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 1441 MB xr_reverse [Ubar
                                                                      # read + its power scratch written back and re-read]) / 3
 }
@@ -427,18 +432,29 @@ def roofline_blocks(prof, info, d):
         if not sc:
             continue
         gbps = sc["bytes"] / sc["ms"] * 1e-6 if sc["ms"] > 0 else 0.0
+        # fabric-side bytes per launch (PMC) at the headline shape (d = 4096, 4096 columns, fp64) and the algorithmic HBM bytes: the
+        # states in and out (forward), states and costates in and out (adjoint) -- per launch, whatever the chain length
+        batch = info.get("batch", 0)
+        use_tr = d == 4096 and batch == 4096 and sc["launches"] > 0
+        alg_hbm = 16.0 * d * batch * (2 if name == "statecol_fwd" else 4)
+        if name == "statecol_fwd":
+            tr, src = TRAFFIC["statecol_fwd"]
+        else:
+            tr, src = TRAFFIC["statecol_bwd_per_step"]
+            tr = tr * float(info.get("chain_steps", 0))
         blocks[name] = {
             "bound": "lds", "kernel": kernel, "kernel_detail": detail,
             "achieved": gbps, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": gbps / PEAK_LDS_GBPS,
             "vector_f64_tflops": rate(sc), "vector_f64_frac_of_peak": rate(sc) / PEAK_F64_MFMA_TFLOPS,
-            "traffic": TRAFFIC.get(name, (None, None))[0] if d == 4096 and sc["launches"] > 0 else None,
-            "traffic_source": TRAFFIC.get(name, (None, None))[1] if d == 4096 and sc["launches"] > 0 else None,
-            "traffic_over_algorithmic": None,
+            "traffic": tr if use_tr and tr > 0 else None, "traffic_source": src if use_tr and tr > 0 else None,
+            "traffic_over_algorithmic": (tr / alg_hbm) if use_tr and tr > 0 and alg_hbm > 0 else None,
+            "algorithmic_hbm_bytes_per_launch": alg_hbm if batch else None,
             "launches": sc["launches"], "ms_per_launch": per(sc, "ms"), "ms_in_timed_region": sc["ms"],
             "note": "achieved = LDS bytes the sweeps gather (16 B per row, XOR-diagonal with lane bits and sweep; partners at offsets "
                     "without lane bits come from the thread's own registers) / HIP-event time, against the LDS array's 256 B/clk/CU; "
                     "vector_f64_* = the kernel's fp64 FMA work against the 78.6 TF/s vector peak (the other resource the sweeps load); "
-                    "algorithmic HBM bytes: the states in and out, once per CALL (not per step)"}
+                    "algorithmic HBM bytes: the states (and costates) in and out, once per CALL (not per step); `traffic` of the adjoint "
+                    "launch is its scratch stream of forward terms (2 L d 16 B per column and step)"}
     total = sum(v["ms"] for v in prof.values())
     for b in blocks.values():
         b["share_of_kernel_time"] = b["ms_in_timed_region"] / total if total > 0 else 0.0
@@ -504,6 +520,7 @@ def scheme_entry(eng, torch, u_dev, dt, psi0, d, K, name_note):
     g = torch.zeros((u_dev.shape[0], eng.n_controls), dtype=torch.float64, device=u_dev.device)
     el, loss, prof = timed_chain(eng, torch, u_dev, dt, psi0, g)
     info = {k: eng.info(k) for k in INFO_KEYS}
+    info["batch"], info["chain_steps"] = int(psi0.shape[1]), int(u_dev.shape[0])
     blocks = roofline_blocks(prof, info, d)
     rk = ranked(blocks)
     return {"value": K / el, "unit": "Trotter steps/s (fwd+adjoint)", "ms_per_step": el / K * 1e3, "chain_steps": K,
@@ -948,6 +965,7 @@ def run_config3(a, D):
     prof = eng.profile()
     eng.profile_enable(False)
     info = {k: eng.info(k) for k in INFO_KEYS}
+    info["batch"], info["chain_steps"] = B, K
     opback = bool(eng.info("operator_backward"))
     forms_out = None
     if forms:

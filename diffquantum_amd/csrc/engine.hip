@@ -1377,12 +1377,13 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   return x;
 }
 
-// flops / LDS bytes of `sweeps` sweeps over B columns (profile classes DQ_PROF_STATECOL_FWD / _BWD)
+// flops / LDS bytes of `sweeps` sweeps over B columns, `dot_sweeps` of them carrying the gradient pairings (those read every
+// partner from LDS; the others take the partners at offsets without lane bits from registers)  (classes DQ_PROF_STATECOL_FWD / _BWD)
 template <class T>
 void xs_book(Ctx<T>* c, const XsLaunch<T>& x, double sweeps, double dot_sweeps, int B, double* flops, double* lds_bytes) {
   const double rows = (double)c->d * B;
   *flops = rows * (sweeps * (4.0 * x.tab->R + 8.0) + dot_sweeps * 4.0 * x.tab->R);
-  *lds_bytes = rows * sweeps * (double)x.lds_diag * 2.0 * sizeof(T);
+  *lds_bytes = rows * ((sweeps - dot_sweeps) * (double)x.lds_diag + dot_sweeps * (double)x.tab->R) * 2.0 * sizeof(T);
 }
 
 // psi (dev, [d][B]) -> U_{S-1} ... U_0 psi in c->xs_psi ([B][d]); the result's [d][B] image goes to `out_db` if given

@@ -95,3 +95,26 @@ def test_the_one_line_stays_under_4_kb_whatever_the_full_record_holds():
     full["by_input_structure"] = {"case_{:04d}".format(i): {"value": 1.0, "roofline": {"frac": 0.5}} for i in range(400)}
     line = bench.compact_line(full)
     assert len(json.dumps(line)) <= bench.LINE_LIMIT and "by_input_structure" not in line and "roofline" in line and "cpu_baseline" in line
+
+
+def test_state_column_classes_are_priced_against_the_lds_array_with_the_scratch_stream_as_traffic():
+    """statecol.hip's classes: `bytes` = LDS bytes gathered (booked by the library), `flops` = fp64 vector work; the adjoint
+    launch's PMC traffic is its scratch stream per step x the chain's steps, far above the states in and out."""
+    d, B, K, R, L, lds_diag = 4096, 4096, 20, 12, 7, 9
+    rows = float(d) * B
+    fwd_lds = rows * L * K * lds_diag * 16.0
+    bwd_lds = rows * K * ((2 * L - 1) * lds_diag + L * R) * 16.0
+    prof = _prof()
+    prof["statecol_fwd"] = {"launches": 3, "ms": 3 * 5.25, "flops": 3 * rows * L * K * (4.0 * R + 8.0), "bytes": 3 * fwd_lds}
+    prof["statecol_bwd"] = {"launches": 3, "ms": 3 * 23.9, "flops": 3 * rows * K * ((3 * L - 1) * (4.0 * R + 8.0) + L * 4.0 * R), "bytes": 3 * bwd_lds}
+    b = bench.roofline_blocks(prof, {"zgemm_alg": 2.0, "batch": B, "chain_steps": K}, d)
+    f, w = b["statecol_fwd"], b["statecol_bwd"]
+    assert f["bound"] == "lds" and w["bound"] == "lds" and len(w["kernel"]) <= 80 and len(f["kernel"]) <= 80
+    assert abs(f["achieved"] - fwd_lds / 5.25e-3 / 1e9) < 1e-6 and 0.3 < f["frac"] < 0.5
+    assert 0.15 < w["frac"] < 0.4 and 0.0 < w["vector_f64_frac_of_peak"] < 1.0
+    assert abs(f["traffic_over_algorithmic"] - 1.0) < 0.01                       # states in and out, nothing else
+    assert abs(w["traffic"] - 3.86e9 * K) < 1.0 and w["traffic_over_algorithmic"] > 50   # the scratch stream of forward terms
+    assert os.path.exists(os.path.join(ROOT, w["traffic_source"]))
+    assert bench.ranked(b)[0] is w and bench.ranked(b)[1] is f
+    other = bench.roofline_blocks(prof, {"zgemm_alg": 2.0, "batch": 512, "chain_steps": K}, 1024)
+    assert other["statecol_bwd"]["traffic"] is None                              # PMC constants hold for the headline shape only
