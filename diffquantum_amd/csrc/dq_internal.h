@@ -295,6 +295,7 @@ struct XsOrder {                   // the order in which the sweeps walk the tab
   unsigned char perm[XR_RSMALL];   // sorted position -> index in the table
   int n0, n1;                      // LDS partners that keep / permute the thread's row list
   int nloc[8];                     // partners in the thread's own registers, by offset / threads
+  int n0p1, n1p1, nlocp1[8];       // how many of each class have phase 1 (entries +-i c): every class is ordered phase 0 first
 };
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
 // variant: bit 0 = 1024 threads x 4 rows per workgroup at d = 4096 (default 512 x 8); bit 1 = prefetch of the next diagonal's partners

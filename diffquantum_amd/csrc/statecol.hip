@@ -64,47 +64,38 @@ __device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
   }
 }
 
-// One XOR-diagonal's contribution with the partner values in v[]:  o += sg * a_ij v,  a_ij = -i w sigma (phase 0) or
-// w sigma (phase 1); DOT: the level's gradient pairing of the partners with the thread's own rows xm.
-template <class T, int RPT, bool SIGN, bool DOT, int RM, bool CPLX = true>
-__device__ __forceinline__ void xs_use(int j, int slot, int ph_in, T w, const unsigned* sg, typename Cx<T>::type* v,
-                                       typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
-  const int ph = CPLX ? ph_in : 0;  // (real tables: every phase is 0 -- no branch, no merging of the two updates' registers)
-  if (SIGN) {
+// One XOR-diagonal's contribution with the partner values in v[]:  o += a_ij v,  a_ij = -i w sigma_ij (PH = 0: entries +-c) or
+// w sigma_ij (PH = 1: entries +-i c).  The phase is a template parameter (the host orders every class phase 0 first, so each loop is
+// of one phase: a runtime branch cost 16 register copies per diagonal where its two updates merged).  SIGN: the row's sign
+// sigma_ij goes into the weight (one xor on its high word) instead of into both components of the partner value.
+// DOT: the level's gradient pairing of the partners with the thread's own rows xm, into lane `slot` of the accumulator vector.
+template <class T, int RPT, bool SIGN, bool DOT, int PH>
+__device__ __forceinline__ void xs_use(int j, int slot, T w, const unsigned* sg, const typename Cx<T>::type* v, typename Cx<T>::type* o,
+                                       const typename Cx<T>::type* xm, double* dacc) {
+  T wr[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) wr[r] = SIGN ? xs_flip(w, (sg[r] >> j) & 1u) : w;
+  if (PH) {
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      const unsigned b = (sg[r] >> j) & 1u;
-      v[r].x = xs_flip(v[r].x, b);
-      v[r].y = xs_flip(v[r].y, b);
-    }
-  }
-  if (ph) {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      o[r].x = xs_fma(w, v[r].x, o[r].x);
-      o[r].y = xs_fma(w, v[r].y, o[r].y);
+      o[r].x = xs_fma(wr[r], v[r].x, o[r].x);
+      o[r].y = xs_fma(wr[r], v[r].y, o[r].y);
     }
   } else {
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      o[r].x = xs_fma(w, v[r].y, o[r].x);
-      o[r].y = xs_fma(-w, v[r].x, o[r].y);
+      o[r].x = xs_fma(wr[r], v[r].y, o[r].x);
+      o[r].y = xs_fma(-wr[r], v[r].x, o[r].y);
     }
   }
   if (DOT) {  // (dacc: an xs_acc16; slot = the diagonal's sorted position, wave-uniform)
     T sa = 0, sb = 0;  // two chains: the sums over the rows are latency-bound otherwise
-    if (ph) {
 #pragma unroll
-      for (int r = 0; r < RPT; r += 2) {
-        sa -= xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y);
-        if (r + 1 < RPT) sb -= xs_fma(v[r + 1].x, xm[r + 1].x, v[r + 1].y * xm[r + 1].y);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < RPT; r += 2) {
-        sa += xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
-        if (r + 1 < RPT) sb += xs_fma(v[r + 1].x, xm[r + 1].y, -v[r + 1].y * xm[r + 1].x);
-      }
+    for (int r = 0; r < RPT; ++r) {
+      T p = PH ? -xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y) : xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
+      if (SIGN) p = xs_flip(p, (sg[r] >> j) & 1u);
+      if (r & 1) sb += p;
+      else sa += p;
     }
     (*(xs_acc16*)dacc)[slot] += (double)sa + (double)sb;
   }
@@ -120,8 +111,8 @@ __device__ __forceinline__ double xs_readlane(double v, int j) {
 // partners are LDS reads that keep their place in the thread's row list (offset < NT), then the n1 LDS ones that permute the row
 // list too, then those whose offset has no lane bits (partners = the thread's own registers), grouped by xh = offset / NT.
 struct XsCtl {
-  int R, n0, n1;
-  int nloc[8];
+  int R, n0, n1, n0p1, n1p1;  // (n0p1 / n1p1 / nlocp1: how many of a class's diagonals, its LAST ones, have phase 1)
+  int nloc[8], nlocp1[8];
   int ent;    // xoff | phase << 16 | (index in the table: sign bit, accumulator) << 20
   double w;   // dt u c_j of the current step
   int perm;   // this lane's index in the table
@@ -129,8 +120,13 @@ struct XsCtl {
     R = tab.R;
     n0 = ord.n0;
     n1 = ord.n1;
+    n0p1 = ord.n0p1;
+    n1p1 = ord.n1p1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) nloc[i] = ord.nloc[i];
+    for (int i = 0; i < 8; ++i) {
+      nloc[i] = ord.nloc[i];
+      nlocp1[i] = ord.nlocp1[i];
+    }
     perm = lane < tab.R ? ord.perm[lane] : 0;
     ent = lane < tab.R ? (tab.xoff[perm] | (tab.phase[perm] << 16) | (perm << 20)) : 0;
   }
@@ -154,7 +150,7 @@ __device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __r
 }
 
 // the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, bool CPLX = true>
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH>
 __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
                                              const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
                                              const typename Cx<T>::type* xm, double* dacc) {
@@ -170,57 +166,63 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, co
     for (; q + 1 < qe; q += 2) {
       e1 = __builtin_amdgcn_readlane(ctl.ent, q + 1);
       xs_fetch<T, NT, RPT, PERM>(e1 & 0xffff, src, t, vb);
-      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e0 >> 20, q, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
       if (q + 2 < qe) {
         e0 = __builtin_amdgcn_readlane(ctl.ent, q + 2);
         xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
       }
-      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e1 >> 20, q + 1, (e1 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH>(e1 >> 20, q + 1, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
     }
-    if (q < qe) xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e0 >> 20, q, (e0 >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
   } else {
 #pragma clang loop unroll(disable)
     for (int q = q0; q < q0 + n; ++q) {
       const int e = __builtin_amdgcn_readlane(ctl.ent, q);
       T2 v[RPT];
       xs_fetch<T, NT, RPT, PERM>(e & 0xffff, src, t, v);
-      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e >> 20, q, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
     }
   }
 }
 
-// the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class
-template <class T, int RPT, int XH, bool SIGN, bool DOT, int RM, bool CPLX = true>
+// the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class, phase 0 then phase 1
+template <class T, int RPT, int XH, bool SIGN, bool DOT, int PH>
+__device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
+                                            typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+#pragma clang loop unroll(disable)
+  for (int i = 0; i < n; ++i, ++q) {
+    const int e = __builtin_amdgcn_readlane(ctl.ent, q);
+    typename Cx<T>::type v[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
+    xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+  }
+  return q;
+}
+template <class T, int RPT, int XH, bool SIGN, bool DOT, bool CPLX>
 __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
                                                  typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
   if constexpr (XH < RPT && XH < 8) {
-#pragma clang loop unroll(disable)
-    for (int i = 0; i < ctl.nloc[XH]; ++i, ++q) {
-      const int e = __builtin_amdgcn_readlane(ctl.ent, q);
-      typename Cx<T>::type v[RPT];
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
-      xs_use<T, RPT, SIGN, DOT, RM, CPLX>(e >> 20, q, (e >> 16) & 1, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
-    }
-    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, RM, CPLX>(ctl, q, sg, cur, sgn, o, xm, dacc);
+    q = xs_local_run<T, RPT, XH, SIGN, DOT, 0>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    if constexpr (CPLX) q = xs_local_run<T, RPT, XH, SIGN, DOT, 1>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, CPLX>(ctl, q, sg, cur, sgn, o, xm, dacc);
   }
 }
 
-// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`), class by class: no per-diagonal branching
-// LOCAL = false: the last group is read from LDS like the others (the caller's copy of v need not stay in registers)
-// DOT: the sweep carries the gradient pairings; dacc is then an xs_acc16 indexed by the diagonal's SORTED position
-// (xs_finish_kernel maps back).  CPLX = false: every phase is 0 (real tables), no branch on it.
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL = true, bool CPLX = true>
+// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`), class by class and phase by phase: no
+// per-diagonal branching.  LOCAL = false: the caller's order (xs_make_order with local = false) has no register class -- every
+// partner is read from LDS and the caller's copy of v need not stay in registers.  DOT: the sweep carries the gradient pairings; dacc is then an xs_acc16 indexed by the diagonal's SORTED
+// position (xs_finish_kernel maps back).
+// CPLX = false (real tables: every phase 0): the phase-1 loops are not even instantiated (their code alone cost the real kernels 4 %).
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL, bool CPLX>
 __device__ __forceinline__ void xs_gather(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
                                           const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
                                           const typename Cx<T>::type* xm, double* dacc) {
-  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, CPLX>(ctl, 0, ctl.n0, sg, src, t, sgn, o, xm, dacc);
-  if (LOCAL) {
-    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, CPLX>(ctl, ctl.n0, ctl.n1, sg, src, t, sgn, o, xm, dacc);
-    xs_local_classes<T, RPT, 1, SIGN, DOT, RM, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
-  } else {
-    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, CPLX>(ctl, ctl.n0, ctl.R - ctl.n0, sg, src, t, sgn, o, xm, dacc);
-  }
+  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  if (LOCAL) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
 }
 
 template <class T, int NT, int RPT>
@@ -381,8 +383,9 @@ __device__ unsigned long long xs_stamps[8];
 //   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
 template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM, bool PREF, bool CPLX>
 __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
-                                                         XrTab tab, XsOrder ord, const double* __restrict__ wt, const double* __restrict__ dgs,
-                                                         long dgs_step, int S, int B, int L, typename Cx<T>::type* __restrict__ park,
+                                                         XrTab tab, XsOrder ord, XsOrder ordh, const double* __restrict__ wt,
+                                                         const double* __restrict__ dgs, long dgs_step, int S, int B, int L,
+                                                         typename Cx<T>::type* __restrict__ park,
                                                          double* __restrict__ part) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
@@ -395,8 +398,9 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   unsigned sg[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
-  XsCtl ctl;
+  XsCtl ctl, ctlh;  // (ctlh: the order of the pairing sweeps -- every partner from LDS, phase 0 first)
   ctl.load_table(tab, ord, lane);
+  ctlh.load_table(tab, ordh, lane);
   T2* pk = park + (long)blockIdx.x * L * D;  // [l][r * NT + t] (uniform base, lane index t)
   // in-place update of the work image: every read of the sweep that just ran is done before any row is overwritten
   auto publish = [&](const T2* v) {
@@ -422,6 +426,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
     XS_STAMP(0);
     for (int s = S - 1; s >= 0; --s) {
       ctl.load_step(wt + (long)s * tab.R, lane);
+      ctlh.load_step(wt + (long)s * tab.R, lane);
       const double* dgr = dgs + (long)s * dgs_step;
       {  // (scope of dg: the reversal and the forward terms keep the rows' diagonal weights in registers)
       T dg[RPT];
@@ -517,7 +522,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
           for (int r = 0; r < RPT; ++r) xn[r] = pl[r * NT + t];
         }
-        xs_gather<T, NT, RPT, SIGN, true, RM, false, false, CPLX>(ctl, sg, W, cur, t, (T)-1, o, xm, (double*)&dacc);
+        xs_gather<T, NT, RPT, SIGN, true, RM, false, false, CPLX>(ctlh, sg, W, cur, t, (T)-1, o, xm, (double*)&dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
 #pragma unroll
@@ -723,18 +728,34 @@ int xs_lds_diagonals(int d, const XrTab& tab, int variant) {
   return n;
 }
 // the order in which the sweeps walk the table (see XsCtl)
-XsOrder xs_make_order(int d, const XrTab& tab, int variant) {
+// local = false: offsets without lane bits join the second LDS class (the pairing sweeps' order)
+XsOrder xs_make_order(int d, const XrTab& tab, int variant, bool local) {
   XsOrder o;
   memset(&o, 0, sizeof(o));
   const int nt = xs_threads(d, variant);
   int at = 0;
-  for (int j = 0; j < tab.R; ++j)
-    if ((tab.xoff[j] & (nt - 1)) != 0 && tab.xoff[j] < nt) { o.perm[at++] = (unsigned char)j; ++o.n0; }
-  for (int j = 0; j < tab.R; ++j)
-    if ((tab.xoff[j] & (nt - 1)) != 0 && tab.xoff[j] >= nt) { o.perm[at++] = (unsigned char)j; ++o.n1; }
-  for (int xh = 1; xh < 8; ++xh)
+  for (int ph = 0; ph < 2; ++ph)
     for (int j = 0; j < tab.R; ++j)
-      if ((tab.xoff[j] & (nt - 1)) == 0 && tab.xoff[j] / nt == xh) { o.perm[at++] = (unsigned char)j; ++o.nloc[xh]; }
+      if ((tab.xoff[j] & (nt - 1)) != 0 && tab.xoff[j] < nt && (tab.phase[j] != 0) == (ph != 0)) {
+        o.perm[at++] = (unsigned char)j;
+        ++o.n0;
+        o.n0p1 += ph;
+      }
+  for (int ph = 0; ph < 2; ++ph)
+    for (int j = 0; j < tab.R; ++j)
+      if (((tab.xoff[j] & (nt - 1)) != 0 ? tab.xoff[j] >= nt : !local) && (tab.phase[j] != 0) == (ph != 0)) {
+        o.perm[at++] = (unsigned char)j;
+        ++o.n1;
+        o.n1p1 += ph;
+      }
+  for (int xh = 1; xh < 8 && local; ++xh)
+    for (int ph = 0; ph < 2; ++ph)
+      for (int j = 0; j < tab.R; ++j)
+        if ((tab.xoff[j] & (nt - 1)) == 0 && tab.xoff[j] / nt == xh && (tab.phase[j] != 0) == (ph != 0)) {
+          o.perm[at++] = (unsigned char)j;
+          ++o.nloc[xh];
+          o.nlocp1[xh] += ph;
+        }
   return o;
 }
 size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)L * (size_t)d; }
@@ -775,7 +796,7 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
                   : (pref ? xs_forward_kernel<T, NT, RPT, false, true, false> : xs_forward_kernel<T, NT, RPT, false, false, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0), wt, dgs,
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0, true), wt, dgs,
                      dgs_step, S, B, L);
   return hipGetLastError();
 }
@@ -788,18 +809,17 @@ hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   const bool sgn = tab.sgn != nullptr, dc = xs_diagctl(tab);
   bool cplx = false;
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
-  // real tables (every phase 0): no sign words -> <false, dc, .., false>; complex tables always carry sign words
-  void (*kf)(T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, T2*, double*) =
+  if (cplx && !sgn) return hipErrorInvalidValue;
+  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, T2*, double*) =
       cplx ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF, true> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF, true>)
            : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF, false>
                         : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF, false>)
                   : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL, PREF, false>
                         : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL, PREF, false>));
-  if (cplx && !tab.sgn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0), wt, dgs,
-                     dgs_step, S, B, L, park, part);
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0, true),
+                     xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0, false), wt, dgs, dgs_step, S, B, L, park, part);
   return hipGetLastError();
 }
 
@@ -855,7 +875,7 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
   const hipError_t e = xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d, variant), xs_slots(tab),
-                     (int)XR_RSMALL, S, tab, xs_make_order(d, tab, variant), K, dt, grad, accumulate);
+                     (int)XR_RSMALL, S, tab, xs_make_order(d, tab, variant, false), K, dt, grad, accumulate);
   return hipGetLastError();
 }
 

@@ -12,9 +12,10 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 VARIANTS = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
 OTHER = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+XY = int(sys.argv[6]) if len(sys.argv) > 6 else 0     # 1: X drives on half of the qubits, Y drives on the other half (complex table)
 dev = torch.device("cuda:0")
 d = 1 << n
-H0, Hs, M = problems.random_ising_torch(n, 0, dev)
+H0, Hs, M = problems.xy_drives_torch(n, 0, dev, n_x=n // 2, n_y=n - n // 2) if XY else problems.random_ising_torch(n, 0, dev)
 u = torch.from_numpy(problems.pulse_table(n, S, 1e-3 * S, seed=0)).to(dev)
 psi0 = torch.from_numpy(problems.random_states(d, B, 0)).to(dev)
 res = {}
