@@ -693,9 +693,14 @@ bool xs_supported(int d, int L, int R, int nd, size_t elem) {
 
 size_t xs_lds_bytes(int d, size_t elem) { return (size_t)2 * 2 * elem * (size_t)d; }
 
-// threads of a workgroup (rows per thread = d / threads). variant bit 0: 1024 threads x 4 rows at d = 4096 instead of 512 x 8
+// threads of a workgroup (rows per thread = d / threads).  variant bit 0 = "wide": more threads per column, fewer rows per thread
+// (d = 4096: 1024 x 4 instead of 512 x 8; d = 1024: 256 x 4 instead of 128 x 8; d = 512: 256 x 2 instead of 64 x 8; d = 256:
+// 256 x 1 instead of 64 x 4) -- for narrow batches, where one wave per column leaves the CUs at 2-4 waves and every sweep is a
+// chain of LDS latencies
 int xs_threads(int d, int variant) {
   if (d >= 4096) return (variant & 1) ? 1024 : 512;
+  if (d == 2048) return 256;
+  if (variant & 1) return 256;
   return d / 8 < 64 ? 64 : d / 8;
 }
 
@@ -796,7 +801,7 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
                   : (pref ? xs_forward_kernel<T, NT, RPT, false, true, false> : xs_forward_kernel<T, NT, RPT, false, false, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0, true), wt, dgs,
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true), wt, dgs,
                      dgs_step, S, B, L);
   return hipGetLastError();
 }
@@ -818,8 +823,8 @@ hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
                         : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL, PREF, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0, true),
-                     xs_make_order(NT * RPT, tab, NT == 1024 ? 1 : 0, false), wt, dgs, dgs_step, S, B, L, park, part);
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true),
+                     xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, false), wt, dgs, dgs_step, S, B, L, park, part);
   return hipGetLastError();
 }
 
@@ -836,9 +841,15 @@ hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* ou
                            : xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
 #ifndef XS_PROBE_4096_ONLY
     case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
-    case 1024: return xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
-    case 512: return xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
-    default: return xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    case 1024:
+      return (variant & 1) ? xs_forward_go<T, 256, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
+                           : xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    case 512:
+      return (variant & 1) ? xs_forward_go<T, 256, 2>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
+                           : xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    default:
+      return (variant & 1) ? xs_forward_go<T, 256, 1>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
+                           : xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
 #else
     default: return hipErrorInvalidValue;
 #endif
@@ -855,9 +866,15 @@ hipError_t xs_backward_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam
                            : xs_backward_go<T, 512, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
 #ifndef XS_PROBE_4096_ONLY
     case 2048: return xs_backward_go<T, 256, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
-    case 1024: return xs_backward_go<T, 128, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
-    case 512: return xs_backward_go<T, 64, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
-    default: return xs_backward_go<T, 64, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    case 1024:
+      return (variant & 1) ? xs_backward_go<T, 256, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
+                           : xs_backward_go<T, 128, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    case 512:
+      return (variant & 1) ? xs_backward_go<T, 256, 2, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
+                           : xs_backward_go<T, 64, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    default:
+      return (variant & 1) ? xs_backward_go<T, 256, 1, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
+                           : xs_backward_go<T, 64, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
 #else
     default: return hipErrorInvalidValue;
 #endif

@@ -177,3 +177,22 @@ def test_options_that_pin_another_scheme_keep_it_and_wide_batches_leave():
     with _engine(Hd, Hsd, Md, state_columns=1) as e:
         e.energy_grad(u[:, :2], 1e-3, problems.random_states(256, 4, seed=1))
         assert e.info("state_columns") == 0               # dense H: no table, the GEMM chain stays
+
+
+@pytest.mark.parametrize("n", [8, 9, 10])
+def test_wide_workgroup_variant_matches_oracle(oracle, n):
+    """`state_columns_variant` bit 0: 256 threads per column with 1 / 2 / 4 rows per thread at d = 256 / 512 / 1024 (instead of one
+    or two waves with 4-8 rows): the same recurrences on another workgroup shape (X/Y drives and a Z control: signs, both phases,
+    a diagonal control), against the oracle."""
+    H0, Hs, M = _mixed(n, seed=n)
+    K, d = len(Hs), 1 << n
+    S, B, dt = 3, 5, 2e-3
+    u = np.random.default_rng(n).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=2)
+    rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, state_columns=1, state_columns_variant=1) as e:
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+        fwd = e.propagate(u, dt, psi0)
+        assert e.info("state_columns") == 1
+    assert np.max(np.abs(fin - rf)) < TOL and np.max(np.abs(fwd - rf)) < TOL and abs(loss - rl) < TOL
+    assert np.max(np.abs(grad - rg)) < TOL, np.max(np.abs(grad - rg))

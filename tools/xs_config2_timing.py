@@ -18,8 +18,9 @@ with Engine(256, 16) as e:
     e.set_hamiltonians(p["H0"].astype(np.complex128), p["Hs"].astype(np.complex128))
     e.set_observable(p["H_cost"].astype(np.complex128))
     outs = {}
-    for xs in (1, 0):
+    for xs, var in ((1, 0), (1, 1), (1, 3), (0, 0)):
         e.set_option("state_columns", xs)
+        e.set_option("state_columns_variant", var)
         e.propagate(u, 1.0 / S, psi)
         ts = []
         for _ in range(3):
@@ -28,11 +29,12 @@ with Engine(256, 16) as e:
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         el = float(np.median(ts))
         outs[xs] = fin.clone()
-        print("forward   state_columns={} (took {}): {:8.3f} ms  {:10.0f} steps/s  degree {}".format(xs, int(e.info("state_columns")), el * 1e3, S / el, int(e.info("degree"))), flush=True)
+        print("forward   state_columns={} variant {} (took {}): {:8.3f} ms  {:10.0f} steps/s  degree {}".format(xs, var, int(e.info("state_columns")), el * 1e3, S / el, int(e.info("degree"))), flush=True)
     print("max |diff| of the two forward results", float((outs[1] - outs[0]).abs().max()))
     Sg = min(S, 200)
-    for xs in (1, 0):
+    for xs, var in ((1, 0), (1, 1), (0, 0)):
         e.set_option("state_columns", xs)
+        e.set_option("state_columns_variant", var)
         e.energy_grad(u[:Sg], 1.0 / S, psi, want_final=False, want_energies=False)
         ts = []
         for _ in range(3):
@@ -41,5 +43,5 @@ with Engine(256, 16) as e:
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         el = float(np.median(ts))
         outs[xs] = (l, g)
-        print("fwd+adj   state_columns={} (took {}): {:8.3f} ms  {:10.0f} steps/s".format(xs, int(e.info("state_columns")), el * 1e3, Sg / el), flush=True)
+        print("fwd+adj   state_columns={} variant {} (took {}): {:8.3f} ms  {:10.0f} steps/s".format(xs, var, int(e.info("state_columns")), el * 1e3, Sg / el), flush=True)
     print("grad diff", float(np.max(np.abs(outs[1][1] - outs[0][1]))), "loss diff", abs(outs[1][0] - outs[0][0]))
