@@ -269,6 +269,7 @@ template <class T>
 struct Ctx : dq_ctx {
   typedef typename dq::Cx<T>::type T2;
   int d = 0, K = 0, dev = 0, n_cu = 256;
+  size_t max_lds = 160 * 1024;  // dynamic LDS a workgroup may ask for on this device (the column forms fall back when it is too small)
   hipStream_t st = nullptr;
   // cache of the real path's per-chunk propagator intermediates (X, Y_1..Y_{q-1}, P, U): what the backward sweep would
   // otherwise rebuild with q + 1 products per step; filled in the forward pass as far as the budget reaches
@@ -359,9 +360,17 @@ struct Ctx : dq_ctx {
     // (XOR-regular generators: the column form, xorexp.hip, beats the MFMA products wherever its kernels exist)
     return xr_ok && xor_mode != 0 && dq::xr_supported(d, 1, xr_tab.R, xr_tab.nd, sizeof(T));
   }
-  bool zxr_on() const { return sizeof(T) == 8 && zxr_ok && xor_mode != 0 && real_mode != 0 && force_degree <= 0 && force_s < 0; }
+  // (the column forms need up to 4 real / 2 complex images of a column in LDS plus tables: a device or partition mode that
+  // grants less falls back to the row-wise / tape schemes instead of failing at launch)
+  bool column_lds_ok() const {
+    const size_t images = std::max<size_t>((size_t)4 * sizeof(T) * d, sizeof(T) == 8 ? (size_t)32 * d : 0);
+    return images + (size_t)d + 1024 <= max_lds;
+  }
+  bool zxr_on() const {
+    return sizeof(T) == 8 && zxr_ok && xor_mode != 0 && real_mode != 0 && force_degree <= 0 && force_s < 0 && column_lds_ok();
+  }
   bool xr_on(int q) const {
-    return xr_ok && xor_mode != 0 && sparse_gen_on() && dq::xr_supported(d, q, xr_tab.R, xr_tab.nd, sizeof(T));
+    return xr_ok && xor_mode != 0 && sparse_gen_on() && dq::xr_supported(d, q, xr_tab.R, xr_tab.nd, sizeof(T)) && column_lds_ok();
   }
   size_t nn() const { return (size_t)d * d; }
   size_t mat_bytes() const { return nn() * sizeof(T2); }
@@ -1323,6 +1332,7 @@ int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B)
   if (c->xs_mode < 0 && (c->d < c->xs_min_dim || (double)B > c->xs_batch_ratio * (double)c->d)) return 0;
   double th = 0.0;
   for (int t = 0; t < S; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
+  if ((size_t)4 * sizeof(T) * (size_t)c->d > c->max_lds) return 0;  // two images of a column must fit the device's LDS
   for (int L = 1; L <= 24; ++L)
     if (taylor_remainder(th, L) <= c->expm_tol) {
       if (!dq::xs_supported(c->d, L, tab->R, tab->nd, sizeof(T))) return 0;
@@ -2720,6 +2730,9 @@ int dq_create_ex(dq_ctx** out, int dim, int n_controls, int device_id, int dtype
       c->dev = device_id;
       int ncu = 0;
       if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) c->n_cu = ncu;
+      else (void)hipGetLastError();
+      int lds = 0;
+      if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0) c->max_lds = (size_t)lds;
       else (void)hipGetLastError();
       c->nHk.assign(n_controls, 0.0);
       *out = c;

@@ -224,7 +224,10 @@ int dq_propagator_vjp(dq_ctx* ctx, const double* u, int n_steps, double dt, cons
 /* C = alpha*op(A)*op(B) + beta*C, batched; op: 0 = N, 1 = conjugate transpose; strides in complex elements.
  * opA may also be 2 / 3 / 4: A as stored (like 0), square, and KNOWN by the caller to be complex symmetric (A^T = A) /
  * Hermitian / anti-Hermitian -- a hint that lets the kernel read A k-major (linear-form kernel); the result is the same
- * as with opA = 0 for operands that have the stated property. */
+ * as with opA = 0 for operands that have the stated property.  For an operand that has it only up to a defect (rounding, or the
+ * engine's herm_tol), the result is that of op(A') with A' = A^T / A^H / -A^H: it differs from opA = 0 by the product of the
+ * defect with B, and whether the hint takes effect depends on the shape (whole 128-tiles, K >= 1024, batch 1) -- the hint is
+ * never checked. */
 int dq_zgemm(dq_ctx* ctx, int opA, int opB, int M, int N, int K, double alpha, const void* A, long lda, long strideA,
              const void* B, long ldb, long strideB, double beta, void* C, long ldc, long strideC, int batch);
 /* The same with herm = +1 / -1: the caller asserts that the product is Hermitian / anti-Hermitian (e.g. X^H W X for an
