@@ -292,7 +292,7 @@ hipError_t zxr_reverse_launch(const double2* G, long stride, int d, const XrTab&
 // States are stored column by column ([B][d]).  wt [S][R]: per-step weights of the XOR-diagonals; dgs: the rows' diagonal
 // weights, one vector or one per step (xs_weights_launch).
 struct XsOrder {                   // the order in which the sweeps walk the table (statecol.hip, XsCtl)
-  unsigned char perm[XR_RSMALL];   // sorted position -> index in the table
+  unsigned char perm[XR_RMAX];     // sorted position -> index in the table
   int n0, n1;                      // LDS partners that keep / permute the thread's row list
   int nloc[8];                     // partners in the thread's own registers, by offset / threads
   int n0p1, n1p1, nlocp1[8];       // how many of each class have phase 1 (entries +-i c): every class is ordered phase 0 first
@@ -302,6 +302,7 @@ bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(r
 int xs_blocks(int d, size_t elem, int B, int n_cu, int variant);   // workgroups of a launch over B columns
 int xs_waves(int d, int variant);
 int xs_slots(const XrTab& tab);
+int xs_rm(const XrTab& tab);       // per-thread accumulators of the adjoint kernel: 16, or 32 for more than 16 XOR-diagonals
 size_t xs_park_elems(int d, int L, int nblk);                 // complex elements of the backward kernel's scratch
 size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant);
 int xs_lds_diagonals(int d, const XrTab& tab, int variant);   // XOR-diagonals whose partners are LDS reads (the others: registers)

@@ -150,10 +150,10 @@ __device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __r
 }
 
 // the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH>
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0>
 __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
                                              const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
-                                             const typename Cx<T>::type* xm, double* dacc) {
+                                             const typename Cx<T>::type* xm, double* dacc) {  // (SB: accumulator lane = position - SB)
   typedef typename Cx<T>::type T2;
   if (n <= 0) return;
   if (PREF) {
@@ -166,23 +166,49 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, co
     for (; q + 1 < qe; q += 2) {
       e1 = __builtin_amdgcn_readlane(ctl.ent, q + 1);
       xs_fetch<T, NT, RPT, PERM>(e1 & 0xffff, src, t, vb);
-      xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
       if (q + 2 < qe) {
         e0 = __builtin_amdgcn_readlane(ctl.ent, q + 2);
         xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
       }
-      xs_use<T, RPT, SIGN, DOT, PH>(e1 >> 20, q + 1, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH>(e1 >> 20, q + 1 - SB, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
     }
-    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
   } else {
 #pragma clang loop unroll(disable)
     for (int q = q0; q < q0 + n; ++q) {
       const int e = __builtin_amdgcn_readlane(ctl.ent, q);
       T2 v[RPT];
       xs_fetch<T, NT, RPT, PERM>(e & 0xffff, src, t, v);
-      xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
     }
   }
+}
+
+// a class of a pairing sweep with up to 32 diagonals: positions below 16 accumulate into the first accumulator vector, the others
+// into the second -- two instantiations of the loop, no per-diagonal choice of the vector
+template <class T, int NT, int RPT, bool SIGN, int RM, bool PERM, int PH>
+__device__ __forceinline__ void xs_pair_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
+                                              const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
+                                              const typename Cx<T>::type* xm, xs_acc16* dacc) {
+  const int qe = q0 + n;
+  const int lo_end = qe < 16 ? qe : 16;
+  xs_lds_class<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 0>(ctl, q0, lo_end - q0, sg, src, t, sgn, o, xm, (double*)&dacc[0]);
+  if constexpr (RM > 16) {
+    const int hi0 = q0 > 16 ? q0 : 16;
+    xs_lds_class<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 16>(ctl, hi0, qe - hi0, sg, src, t, sgn, o, xm, (double*)&dacc[1]);
+  }
+}
+
+// the pairing sweep (Horner on lambda): o += sgn (A - diag) v with every partner from LDS, in the order of ctl (no register class)
+template <class T, int NT, int RPT, bool SIGN, int RM, bool CPLX>
+__device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
+                                                   int t, T sgn, typename Cx<T>::type* o, const typename Cx<T>::type* xm,
+                                                   xs_acc16* dacc) {
+  xs_pair_class<T, NT, RPT, SIGN, RM, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_pair_class<T, NT, RPT, SIGN, RM, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  xs_pair_class<T, NT, RPT, SIGN, RM, true, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_pair_class<T, NT, RPT, SIGN, RM, true, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
 }
 
 // the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class, phase 0 then phase 1
@@ -463,8 +489,10 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       }
       XS_STAMP(1);
       // ---- the forward terms x_l = A^l psi_s / l! --------------------------------------------------------------------
+#ifndef XS_NOPARK
 #pragma unroll
       for (int r = 0; r < RPT; ++r) pk[r * NT + t] = cur[r];
+#endif
       if (L > 1) publish(cur);
       for (int l = 1; l < L; ++l) {
         T2 o[RPT];
@@ -482,15 +510,19 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           const T oy = xs_fma(-dg[r], cur[r].x, o[r].y) * inv;
           cur[r].x = ox;
           cur[r].y = oy;
+#ifndef XS_NOPARK
           pl[r * NT + t] = cur[r];
+#endif
         }
         if (l < L - 1) publish(cur);
       }
       }  // (dg)
       XS_STAMP(2);
       // ---- Horner on lambda with the level pairings ----------------------------------------------------------------
-      static_assert(RM == 16, "the accumulator vector has 16 lanes");
-      xs_acc16 dacc = 0.0;
+      static_assert(RM == 16 || RM == 32, "one or two accumulator vectors of 16 lanes");
+      xs_acc16 dacc[RM / 16];
+#pragma unroll
+      for (int g = 0; g < RM / 16; ++g) dacc[g] = 0.0;
       double rowacc[DIAGCTL ? RPT : 1];
 #pragma unroll
       for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
@@ -517,19 +549,30 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].y = xs_fma(dgv, cur[r].x, g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
-        if (l > 0) {  // the next level's term: loaded while this sweep runs
+        if (RM > 16 && l < L - 1) {  // (two accumulator vectors: no room for the prefetch buffer -- this level's term, now)
+          const T2* pl = pk + (long)l * D;
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) xm[r] = pl[r * NT + t];
+        }
+        if (RM == 16 && l > 0) {  // the next level's term: loaded while this sweep runs
           const T2* pl = pk + (long)(l - 1) * D;
+#ifndef XS_NOPARK
 #pragma unroll
           for (int r = 0; r < RPT; ++r) xn[r] = pl[r * NT + t];
+#else
+          (void)pl;
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) xn[r] = xm[r];
+#endif
         }
-        xs_gather<T, NT, RPT, SIGN, true, RM, false, false, CPLX>(ctlh, sg, W, cur, t, (T)-1, o, xm, (double*)&dacc);
+        xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, xm, dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {
             cur[r].x = o[r].x * inv;
             cur[r].y = o[r].y * inv;
-            xm[r] = xn[r];
+            if (RM == 16) xm[r] = xn[r];
           }
           publish(cur);
         } else {
@@ -540,12 +583,13 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       XS_STAMP(3);
       // ---- this step's sums: per wave, accumulated over the workgroup's columns --------------------------------------
       double* prow = part + (((long)blockIdx.x * S + s) * NW + wave) * NS;
-      {
+#pragma unroll
+      for (int g = 0; g < RM / 16; ++g) {
         double da[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) da[j] = dacc[j];
+        for (int j = 0; j < 16; ++j) da[j] = dacc[g][j];
         const double v = xs_wave_sums16(da, lane);
-        if (lane < 16) prow[lane] = first ? v : prow[lane] + v;
+        if (lane < 16) prow[g * 16 + lane] = first ? v : prow[g * 16 + lane] + v;
       }
       if (DIAGCTL) {
         double dv[XR_DMAX];
@@ -687,7 +731,7 @@ hipError_t xs_diag_costate_launch(const float2* psi, const double* mdiag, float2
 
 bool xs_supported(int d, int L, int R, int nd, size_t elem) {
   if (elem != sizeof(double) && elem != sizeof(float)) return false;
-  if (R < 1 || R > XR_RSMALL || nd < 0 || nd > XR_DMAX || L < 1 || L > 24) return false;
+  if (R < 1 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || L < 1 || L > 24) return false;
   return d == 256 || d == 512 || d == 1024 || d == 2048 || d == 4096;
 }
 
@@ -720,11 +764,14 @@ int xs_blocks(int d, size_t elem, int B, int n_cu, int variant) {
   return (int)(nb < 1 ? 1 : nb);
 }
 int xs_waves(int d, int variant) { return xs_threads(d, variant) / 64; }
-int xs_slots(const XrTab& tab) {
+// accumulators per thread of the adjoint kernel: one vector of 16 for up to 16 XOR-diagonals, two for up to 32
+int xs_rm(const XrTab& tab) { return tab.R > XR_RSMALL ? 2 * XR_RSMALL : XR_RSMALL; }
+static bool xs_has_diag_controls(const XrTab& tab) {
   for (int j = 0; j < tab.nd; ++j)
-    if (tab.dkid[j] >= 0) return XR_RSMALL + XR_DMAX;
-  return XR_RSMALL;
+    if (tab.dkid[j] >= 0) return true;
+  return false;
 }
+int xs_slots(const XrTab& tab) { return xs_rm(tab) + (xs_has_diag_controls(tab) ? XR_DMAX : 0); }
 int xs_lds_diagonals(int d, const XrTab& tab, int variant) {
   const int nt = xs_threads(d, variant);
   int n = 0;
@@ -769,11 +816,11 @@ size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant) {
 }
 
 // dgs: d doubles, or S * d when a control has diagonal entries (xs_dgs_doubles); returns the step stride through *dgs_step
-size_t xs_dgs_doubles(int d, int S, const XrTab& tab) { return (size_t)d * (size_t)(xs_slots(tab) > XR_RSMALL ? (S > 0 ? S : 1) : 1); }
+size_t xs_dgs_doubles(int d, int S, const XrTab& tab) { return (size_t)d * (size_t)(xs_has_diag_controls(tab) ? (S > 0 ? S : 1) : 1); }
 
 hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
                              hipStream_t st) {
-  const int per_step = xs_slots(tab) > XR_RSMALL ? 1 : 0;
+  const int per_step = xs_has_diag_controls(tab) ? 1 : 0;
   *dgs_step = per_step ? d : 0;
   if (S <= 0) return hipSuccess;
   const int nbd = (d + 255) / 256;
@@ -784,7 +831,7 @@ hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, in
 
 namespace {
 
-bool xs_diagctl(const XrTab& tab) { return xs_slots(tab) > XR_RSMALL; }
+bool xs_diagctl(const XrTab& tab) { return xs_has_diag_controls(tab); }
 
 template <class T, int NT, int RPT>
 hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* out, const XrTab& tab, const double* wt, const double* dgs,
@@ -806,8 +853,8 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
   return hipGetLastError();
 }
 
-template <class T, int NT, int RPT, bool PREF>
-hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
+template <class T, int NT, int RPT, bool PREF, int RM>
+hipError_t xs_backward_rm(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
                           long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
@@ -816,16 +863,24 @@ hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
   if (cplx && !sgn) return hipErrorInvalidValue;
   void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, T2*, double*) =
-      cplx ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF, true> : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF, true>)
-           : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, XR_RSMALL, PREF, false>
-                        : xs_backward_kernel<T, NT, RPT, true, false, XR_RSMALL, PREF, false>)
-                  : (dc ? xs_backward_kernel<T, NT, RPT, false, true, XR_RSMALL, PREF, false>
-                        : xs_backward_kernel<T, NT, RPT, false, false, XR_RSMALL, PREF, false>));
+      cplx ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, RM, PREF, true> : xs_backward_kernel<T, NT, RPT, true, false, RM, PREF, true>)
+           : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, RM, PREF, false>
+                        : xs_backward_kernel<T, NT, RPT, true, false, RM, PREF, false>)
+                  : (dc ? xs_backward_kernel<T, NT, RPT, false, true, RM, PREF, false>
+                        : xs_backward_kernel<T, NT, RPT, false, false, RM, PREF, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true),
                      xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, false), wt, dgs, dgs_step, S, B, L, park, part);
   return hipGetLastError();
+}
+
+template <class T, int NT, int RPT, bool PREF>
+hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
+                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
+  return xs_rm(tab) > XR_RSMALL
+             ? xs_backward_rm<T, NT, RPT, PREF, 2 * XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
+             : xs_backward_rm<T, NT, RPT, PREF, XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
 }
 
 // variant: bit 0 = 1024 threads x 4 rows at d = 4096; bit 1 = prefetch of the next diagonal's partners in the sweeps without pairings
@@ -892,7 +947,7 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
   const hipError_t e = xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d, variant), xs_slots(tab),
-                     (int)XR_RSMALL, S, tab, xs_make_order(d, tab, variant, false), K, dt, grad, accumulate);
+                     xs_rm(tab), S, tab, xs_make_order(d, tab, variant, false), K, dt, grad, accumulate);
   return hipGetLastError();
 }
 

@@ -140,7 +140,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      dq_get_info("xor_regular_found") = number of XOR-diagonals found (-1: not of that class),
  *                      ("xor_regular") = 1 if the last call ran the column form
  *   state_columns      -1 (default, auto) / 0 / 1: the STATE-COLUMN form (csrc/statecol.hip) for the same class of generators (real
- *                      or complex tables, both dtypes, up to 16 XOR-diagonals, dim 256 .. 4096): no propagator is built -- every state
+ *                      or complex tables, both dtypes, up to 32 XOR-diagonals, dim 256 .. 4096): no propagator is built -- every state
  *                      column (dim complex numbers: 64 KB at dim 4096) stays in LDS for the WHOLE chain, a step is L sweeps of
  *                      partner reads (the Taylor polynomial of exp(-i dt H(t)) applied to the column), the adjoint sweep runs the
  *                      same way on (psi, lambda) with psi_t re-derived as U_t^H psi_{t+1} and leaves dL/du as per-diagonal sums.
@@ -148,8 +148,9 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      state_columns_batch_ratio (8) x dim and no option pins another scheme (compose >= 0, real_path != -1,
  *                      force_degree, force_squarings, xor_regular = 0, sparse_generator = 0); 1 = whenever the kernels exist.
  *                      dq_get_info("state_columns") = 1 if the last call ran it ("xor_regular" then reports the table's kind, 1 / 2)
- *   state_columns_variant   kernel configuration at dim 4096 (bit 0: 1024 threads x 4 rows instead of 512 x 8; bit 1: partner
- *                      prefetch in the forward kernel); default 0 (measured best)
+ *   state_columns_variant   kernel configuration: bit 0 = "wide" workgroups (dim 4096: 1024 threads x 4 rows instead of 512 x 8;
+ *                      dim <= 1024: 256 threads per column instead of one or two waves -- +20 % at dim 512 with narrow batches);
+ *                      bit 1 = partner prefetch in the forward kernel; default 0
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",

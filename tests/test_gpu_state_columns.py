@@ -196,3 +196,32 @@ def test_wide_workgroup_variant_matches_oracle(oracle, n):
         assert e.info("state_columns") == 1
     assert np.max(np.abs(fin - rf)) < TOL and np.max(np.abs(fwd - rf)) < TOL and abs(loss - rl) < TOL
     assert np.max(np.abs(grad - rg)) < TOL, np.max(np.abs(grad - rg))
+
+
+def test_more_than_sixteen_xor_diagonals_on_state_columns(oracle):
+    """17 .. 32 XOR-diagonals: the adjoint kernel with two accumulator vectors.  A real generator with X_k and X_k X_k+1 controls
+    (18 diagonals, shared low / high offsets) and full I/Q control (X_k and Y_k on every qubit: 18 diagonals, both phases, sign
+    words), at d = 512, against the oracle."""
+    n, S, B, dt = 9, 3, 6, 1e-3
+    rng = np.random.default_rng(12)
+    d = 1 << n
+    X = np.array([[0, 1], [1, 0]], dtype=complex); Y = np.array([[0, -1j], [1j, 0]]); Z = np.diag([1.0 + 0j, -1.0])
+
+    def s(ops):
+        return problems.kron_chain([ops.get(q, np.eye(2)) for q in range(n)])
+
+    H0 = np.diag(problems.ising_diagonal(n, 3)).astype(complex)
+    Hr = [s({k: X}) for k in range(n)] + [0.5 * s({k: X, (k + 1) % n: X}) for k in range(n)]
+    Hc = [s({k: X}) for k in range(n)] + [s({k: Y}) for k in range(n)]
+    M = rng.standard_normal((d, d))
+    M = ((M + M.T) / 2).astype(complex)
+    psi0 = problems.random_states(d, B, seed=1)
+    for Hs, want in ((np.array(Hr), 1), (np.array(Hc), 2)):
+        u = rng.uniform(-1, 1, (S, len(Hs)))
+        rl, rg, rf = oracle.energy_grad_one_frechet(H0, list(Hs), M, u, dt, psi0)
+        with _engine(H0, Hs, M) as e:
+            assert e.info("xor_regular_found") == 18
+            loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
+            assert e.info("state_columns") == 1 and e.info("xor_regular") == want
+        assert abs(loss - rl) < TOL and np.max(np.abs(grad - rg)) < TOL and np.max(np.abs(fin - rf)) < TOL
+        assert np.max(np.abs(rg)) > 1e-5
