@@ -403,7 +403,7 @@ __device__ unsigned long long xs_stamps[8];
 // lambda stays in LDS for the whole chain, each row touched by its own thread only (no barrier concerns it).  park: per
 // workgroup the L forward terms x_0 .. x_{L-1} of the current step (device memory, written and read back by the same thread; 134 MB
 // for the whole grid at d = 4096 -- it streams through the Infinity Cache / HBM and is the kernel's memory traffic: 2 L d 16 B per
-// column and step).  The level-l term is prefetched while the sweep of level l + 1 runs.
+// column and step).
 // part[((blockIdx.x * S + s) * NW + wave) * NS + slot]: this workgroup's share, over its columns, of
 //   slot < RM: sum_i of the level pairings of the XOR-diagonal at SORTED position `slot` (before the factors cmag and dt);
 //   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
@@ -540,7 +540,16 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       }
       publish(cur);
       for (int l = L - 1; l >= 0; --l) {  // forms y_{l-1} from y_l (l = 0: lambda_s), pairing y_l with x_l
-        T2 o[RPT], xn[RPT];
+        T2 o[RPT];
+        if (l < L - 1) {  // this level's forward term (x_{L-1} is still in the registers).  No prefetch of the next one: its buffer
+          const T2* pl = pk + (long)l * D;  // costs more in spills than the load's latency (22.9 against 24.8 ms per 20 steps)
+#ifndef XS_NOPARK
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) xm[r] = pl[r * NT + t];
+#else
+          (void)pl;
+#endif
+        }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           const T dgv = (T)dgr[r * NT + t];  // (L2-resident table; not kept in registers across the sweep)
@@ -549,22 +558,6 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].y = xs_fma(dgv, cur[r].x, g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
-        if (RM > 16 && l < L - 1) {  // (two accumulator vectors: no room for the prefetch buffer -- this level's term, now)
-          const T2* pl = pk + (long)l * D;
-#pragma unroll
-          for (int r = 0; r < RPT; ++r) xm[r] = pl[r * NT + t];
-        }
-        if (RM == 16 && l > 0) {  // the next level's term: loaded while this sweep runs
-          const T2* pl = pk + (long)(l - 1) * D;
-#ifndef XS_NOPARK
-#pragma unroll
-          for (int r = 0; r < RPT; ++r) xn[r] = pl[r * NT + t];
-#else
-          (void)pl;
-#pragma unroll
-          for (int r = 0; r < RPT; ++r) xn[r] = xm[r];
-#endif
-        }
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, xm, dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
@@ -572,7 +565,6 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           for (int r = 0; r < RPT; ++r) {
             cur[r].x = o[r].x * inv;
             cur[r].y = o[r].y * inv;
-            if (RM == 16) xm[r] = xn[r];
           }
           publish(cur);
         } else {
