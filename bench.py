@@ -62,9 +62,9 @@ TRAFFIC = {
     "spmm": (8.50e8, "profiles/r2_bench_headline_row_kernels_summary.txt"),     # (2 x 754 MB rsp_mm_slab + 1043 MB rsp_mm_dot_slab) / 3
     # state-column form (profiles/r3_bench_headline_summary.txt): the forward launch moves the states in and out and nothing else
     # (269 MB read + 268 MB written = 1.0x algorithmic); the adjoint launch streams its per-workgroup scratch of forward terms:
-    # 1.92 GB read + 1.94 GB written PER STEP of the chain on the fabric side (L2 misses; Infinity-Cache hits are counted)
+    # 1.67 GB read + 1.93 GB written PER STEP of the chain on the fabric side (L2 misses; Infinity-Cache hits are counted)
     "statecol_fwd": (5.376e8, "profiles/r3_bench_headline_summary.txt"),
-    "statecol_bwd_per_step": (3.86e9, "profiles/r3_bench_headline_summary.txt"),
+    "statecol_bwd_per_step": (3.60e9, "profiles/r3_bench_headline_summary.txt"),
     "xr": (6.60e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 1441 MB xr_reverse [Ubar
                                                                      # read + its power scratch written back and re-read]) / 3
 }

@@ -113,7 +113,7 @@ def test_state_column_classes_are_priced_against_the_lds_array_with_the_scratch_
     assert abs(f["achieved"] - fwd_lds / 5.25e-3 / 1e9) < 1e-6 and 0.3 < f["frac"] < 0.5
     assert 0.15 < w["frac"] < 0.4 and 0.0 < w["vector_f64_frac_of_peak"] < 1.0
     assert abs(f["traffic_over_algorithmic"] - 1.0) < 0.01                       # states in and out, nothing else
-    assert abs(w["traffic"] - 3.86e9 * K) < 1.0 and w["traffic_over_algorithmic"] > 50   # the scratch stream of forward terms
+    assert abs(w["traffic"] - bench.TRAFFIC["statecol_bwd_per_step"][0] * K) < 1.0 and w["traffic_over_algorithmic"] > 50   # the scratch stream of forward terms
     assert os.path.exists(os.path.join(ROOT, w["traffic_source"]))
     assert bench.ranked(b)[0] is w and bench.ranked(b)[1] is f
     other = bench.roofline_blocks(prof, {"zgemm_alg": 2.0, "batch": 512, "chain_steps": K}, 1024)
