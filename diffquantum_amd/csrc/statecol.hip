@@ -724,7 +724,8 @@ hipError_t xs_diag_costate_launch(const float2* psi, const double* mdiag, float2
 bool xs_supported(int d, int L, int R, int nd, size_t elem) {
   if (elem != sizeof(double) && elem != sizeof(float)) return false;
   if (R < 1 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || L < 1 || L > 24) return false;
-  return d == 256 || d == 512 || d == 1024 || d == 2048 || d == 4096;
+  // (d = 8192: a column is 64 KB in complex64 -- two images fit the LDS as at d = 4096 in complex128; in complex128 they do not)
+  return d == 256 || d == 512 || d == 1024 || d == 2048 || d == 4096 || (d == 8192 && elem == sizeof(float));
 }
 
 size_t xs_lds_bytes(int d, size_t elem) { return (size_t)2 * 2 * elem * (size_t)d; }
@@ -734,6 +735,7 @@ size_t xs_lds_bytes(int d, size_t elem) { return (size_t)2 * 2 * elem * (size_t)
 // 256 x 1 instead of 64 x 4) -- for narrow batches, where one wave per column leaves the CUs at 2-4 waves and every sweep is a
 // chain of LDS latencies
 int xs_threads(int d, int variant) {
+  if (d >= 8192) return 1024;
   if (d >= 4096) return (variant & 1) ? 1024 : 512;
   if (d == 2048) return 256;
   if (variant & 1) return 256;
@@ -882,6 +884,9 @@ hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* ou
   if (B <= 0) return hipSuccess;
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T))) return hipErrorInvalidValue;
   const bool pf = (variant & 2) != 0;
+  if constexpr (sizeof(T) == sizeof(float)) {
+    if (d == 8192) return xs_forward_go<T, 1024, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+  }
   switch (d) {
     case 4096:
       return (variant & 1) ? xs_forward_go<T, 1024, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
@@ -907,6 +912,9 @@ template <class T, bool PREF>
 hipError_t xs_backward_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                             const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
                             int variant, hipStream_t st) {
+  if constexpr (sizeof(T) == sizeof(float)) {
+    if (d == 8192) return xs_backward_go<T, 1024, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+  }
   switch (d) {
     case 4096:
       return (variant & 1) ? xs_backward_go<T, 1024, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)

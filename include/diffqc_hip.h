@@ -140,7 +140,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      dq_get_info("xor_regular_found") = number of XOR-diagonals found (-1: not of that class),
  *                      ("xor_regular") = 1 if the last call ran the column form
  *   state_columns      -1 (default, auto) / 0 / 1: the STATE-COLUMN form (csrc/statecol.hip) for the same class of generators (real
- *                      or complex tables, both dtypes, up to 32 XOR-diagonals, dim 256 .. 4096): no propagator is built -- every state
+ *                      or complex tables, both dtypes, up to 32 XOR-diagonals, dim 256 .. 4096, and 8192 in complex64): no propagator is built -- every state
  *                      column (dim complex numbers: 64 KB at dim 4096) stays in LDS for the WHOLE chain, a step is L sweeps of
  *                      partner reads (the Taylor polynomial of exp(-i dt H(t)) applied to the column), the adjoint sweep runs the
  *                      same way on (psi, lambda) with psi_t re-derived as U_t^H psi_{t+1} and leaves dL/du as per-diagonal sums.

@@ -225,3 +225,36 @@ def test_more_than_sixteen_xor_diagonals_on_state_columns(oracle):
             assert e.info("state_columns") == 1 and e.info("xor_regular") == want
         assert abs(loss - rl) < TOL and np.max(np.abs(grad - rg)) < TOL and np.max(np.abs(fin - rf)) < TOL
         assert np.max(np.abs(rg)) > 1e-5
+
+
+def test_thirteen_qubits_in_complex64():
+    """d = 8192 exists in complex64 only (a column is 64 KB there; two images fit the LDS): n = 13 Ising drift + X_k, against the
+    engine's explicit-propagator scheme in the same precision (the oracle's expm at d = 8192 is out of reach of a test), 1e-4."""
+    import torch
+    from diffquantum_amd.engine import Engine
+    n, S, B, dt = 13, 2, 24, 1e-3
+    d = 1 << n
+    dev = torch.device("cuda:0")
+    diag = torch.from_numpy(problems.ising_diagonal(n, 2)).to(dev)
+    H0 = torch.zeros((d, d), dtype=torch.complex64, device=dev)
+    H0.diagonal().copy_(diag.to(torch.complex64))
+    Hs = torch.zeros((n, d, d), dtype=torch.complex64, device=dev)
+    idx = torch.arange(d, device=dev)
+    for q in range(n):
+        Hs[q, idx, idx ^ (1 << (n - 1 - q))] = 1.0
+    u = np.random.default_rng(4).uniform(-1, 1, (S, n))
+    psi0 = torch.from_numpy(problems.random_states(d, B, seed=5).astype(np.complex64)).to(dev)
+    with Engine(d, n, dtype="c64") as e:
+        e.set_hamiltonians(H0, Hs)
+        e.set_observable(H0)
+        del Hs
+        assert e.info("xor_regular_found") == n
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1
+        e.set_option("state_columns", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 0
+    gs = float(np.max(np.abs(g0)))
+    assert gs > 1e-4                                                      # (gradients of this problem are ~5e-4)
+    assert float((f1 - f0).abs().max()) < 1e-5 and abs(l1 - l0) < 1e-4 * B
+    assert np.max(np.abs(g1 - g0)) < 1e-3 * gs, (np.max(np.abs(g1 - g0)), gs)   # fp32: both schemes carry ~1e-6 relative rounding
