@@ -118,6 +118,7 @@ struct SApply {
   const DTerm* oterms;
   int n_ovl;
   double* part;     // [nblocks * waves][n_ovl][2]
+  const int* omap;  // DMA form: applied string m -> its index among the overlap strings, or -1 (the strings' partner rows are shared)
 };
 
 template <class T2, int V>
@@ -289,6 +290,282 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
   }
 }
 
+// ---- LDS-DMA forms of the passes (round 3): complex64, 2^9-row tiles, batch a multiple of 16 ---------------------------------
+// The kernels above run ONE tile per workgroup: load -> barrier -> LDS work -> store, with whatever a second workgroup on the CU
+// overlaps (3.6-4.6 TB/s at B = 512; soverlap_kernel, at 80 VGPRs alone on its CU, 2.8 TB/s).  Here a workgroup is persistent and
+// walks its tiles with TWO tile buffers (128 KB of LDS): while it works on tile t, tile t + 1 streams into the other buffer by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers; one wave instruction moves 8 rows x 128 B = 1 KiB -- four per wave and tile --, every lane with
+// its own global address), so the HBM pipe of the CU never drains.  One barrier per tile: a wave reaches it only after its LDS
+// work on the previous tile, so the buffer the next DMA overwrites is free.  vmcnt is in issue order: the wait in front of the
+// barrier leaves exactly the previous tile's stores in flight (they are younger than the DMA it waits for).
+// (inline asm, as in zgemm_lin.hip: for the builtin hipcc drains vmcnt in front of every LDS read)
+#define S_DMA16(gp_, lds_) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp_), "s"(lds_) : "memory")
+
+constexpr int SD_P = 9, SD_ROWS = 1 << SD_P, SD_RSTEP = 128, SD_RPT = SD_ROWS / SD_RSTEP;  // 1024 threads = 128 rows x 8 column pairs; 4 rows per thread
+static_assert(STHREADS == 1024 && SBC == 16, "the DMA forms assume 1024 threads and 16 batch columns per tile");
+
+// tile units: unit u = column chunk (u % nchunks) of row tile (u / nchunks).  Chunk-fastest on purpose: the workgroups that run at
+// the same time then cover whole rows (contiguous B * 8 bytes) of a few tiles, not the same 128-byte column chunk of 256 tiles --
+// accesses whose addresses all agree in the bits below the row stride and land on a fraction of the HBM channels.
+struct SDmaWalk {
+  unsigned nchunks, nunits;
+  __host__ __device__ unsigned tile(unsigned u) const { return u / nchunks; }
+  __host__ __device__ unsigned chunk(unsigned u) const { return u % nchunks; }
+};
+
+// Register operands of a tile (prev / add / acc rows, diagonal entries) are requested by inline asm as well: vmcnt counts in issue
+// order, and a load the compiler knows about makes it wait with vmcnt(0) at the first use -- i.e. for the next tile's DMA, which
+// was issued behind it (the first version of this kernel did exactly that and ran no faster than the one-tile kernel).  Order per
+// tile: operand requests -> DMA of tile t + 1 -> LDS gathers of tile t (no vector-memory wait) -> vmcnt(4): operands in, the four
+// DMA instructions still in flight -> combine, store.
+typedef float sd_f4 __attribute__((ext_vector_type(4)));
+#define S_GLOAD16(dst_, gp_) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst_) : "v"(gp_) : "memory")
+#define S_GLOAD4(dst_, gp_) asm volatile("global_load_dword %0, %1, off" : "=&v"(dst_) : "v"(gp_) : "memory")
+#define S_PIN(x_) asm volatile("" : "+v"(x_))
+
+// SIMPLE: every string of the group is a pure X-string (no Z factor: no row-dependent sign, real coefficient) and there are at most
+// SD_SIMPLE_T of them -- offsets and coefficients sit in scalar registers, a gather is one v_xor + ds_read_b128 + two packed FMAs
+// (the general loop issues ~3x the instructions per tile, and at 16 waves per CU the passes were bound by instruction issue:
+// ~900 wave-instructions per tile and wave = 6 us of the 9.7 us a tile took).
+constexpr int SD_SIMPLE_T = 10;
+
+// OVL (SIMPLE only, at most SD_OVL_T strings): the pass also forms the overlaps <y, P_m zo> of the group's control strings -- they are
+// among the applied strings, so the partner rows of y are gathered once for both; zo is one more register operand per row.
+constexpr int SD_OVL_T = 10;
+
+template <int FLAGS, bool SIMPLE, bool OVL = false>
+__global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, SDmaWalk wk) {
+  static_assert(!OVL || SIMPLE, "fused overlaps exist for the pure X-string form only");
+  constexpr bool HAS_PREV = FLAGS & 1, HAS_ADD = FLAGS & 2, HAS_ACC = FLAGS & 4, HAS_DIAG = FLAGS & 8;
+  constexpr int NSTORE = SD_RPT * (1 + (HAS_ACC ? 1 : 0));  // vector-memory stores a thread issues per tile
+  typedef float2 T2;
+  extern __shared__ __align__(16) unsigned char sd_raw[];
+  T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
+  __shared__ DTerm tt[SMAXT];
+  __shared__ T2 tc[SMAXT];
+  const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
+  if (!SIMPLE)
+    for (int m = threadIdx.x; m < a.nterms; m += STHREADS) { tt[m] = a.terms[m]; tc[m] = a.coef[a.terms[m].slot]; }
+  unsigned xl[SIMPLE ? SD_SIMPLE_T : 1];  // byte offset of the partner row (XOR on the row's LDS address), per string: uniform
+  float cr[SIMPLE ? SD_SIMPLE_T : 1];
+  unsigned omask = 0;  // applied strings whose overlap is wanted
+  float px[OVL ? SD_OVL_T : 1], py[OVL ? SD_OVL_T : 1];
+  if (OVL) {
+#pragma unroll
+    for (int m = 0; m < SD_OVL_T; ++m) {
+      px[m] = 0.f; py[m] = 0.f;
+      if (m < a.nterms && a.omap[m] >= 0) omask |= 1u << m;
+    }
+    omask = __builtin_amdgcn_readfirstlane(omask);
+  }
+  if (SIMPLE) {
+#pragma unroll
+    for (int m = 0; m < SD_SIMPLE_T; ++m) {
+      xl[m] = 0; cr[m] = 0.f;
+      if (m < a.nterms) {  // uniform (a group may have no strings at all: its table is then unset)
+        const DTerm t = a.terms[m];
+        xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * 8));
+        cr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.coef[t.slot].x)));
+      }
+    }
+  }
+  const int c = (threadIdx.x % 8) * 2;
+  const int rbase = threadIdx.x / 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned dep[SD_RPT];
+#pragma unroll
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
+  auto issue = [&](unsigned u, int buf) {  // tile unit u -> buffer buf (this wave's 4 pieces of 1 KiB)
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const T2* gp = a.y + (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      S_DMA16(gp, ld);
+    }
+  };
+  unsigned u = blockIdx.x;
+  if (u < wk.nunits) issue(u, 0);
+  int buf = 0;
+  bool first = true;
+  for (; u < wk.nunits; u += gridDim.x, buf ^= 1, first = false) {
+    if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+    sd_f4 pv[SD_RPT], ad[SD_RPT], ac[SD_RPT], zo[OVL ? SD_RPT : 1];
+    float dg[SD_RPT];
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const unsigned i = base | dep[q];
+      const size_t off = (size_t)i * a.B + c0 + c;
+      if (OVL) S_GLOAD16(zo[q], a.zo + off);
+      if (HAS_PREV) S_GLOAD16(pv[q], a.prev + off);
+      if (HAS_ADD) S_GLOAD16(ad[q], a.add + off);
+      if (HAS_ACC) S_GLOAD16(ac[q], a.acc + off);
+      if (HAS_DIAG) S_GLOAD4(dg[q], a.diag + i);
+    }
+    const bool more = u + gridDim.x < wk.nunits;  // uniform
+    if (more) issue(u + gridDim.x, buf ^ 1);
+    const T2* tile = tiles + (size_t)buf * (SD_ROWS * SBC);
+    sd_f4 s[SD_RPT];   // (re, im) of the thread's two columns, per row
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) s[q] = (sd_f4)(0.f);
+    if (OVL) {  // zo is needed inside the gathers: the operands are waited for here (the next tile's DMA stays in flight)
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < SD_RPT; ++q) {
+        S_PIN(zo[q]);
+        if (HAS_PREV) { S_PIN(pv[q]); s[q] = pv[q]; }  // the sums start from the earlier groups' partial sums: no registers of their own
+      }
+    }
+    if (SIMPLE) {
+      const unsigned char* tb = (const unsigned char*)tile;
+      const unsigned ra = (unsigned)(rbase * SBC + c) * 8u;  // own row and columns; the rows q * 128 above it are bits 14-15
+#pragma unroll
+      for (int m = 0; m < SD_SIMPLE_T; ++m)
+        if (m < a.nterms) {  // uniform
+          // (opaque per tile: otherwise hipcc hoists all strings x rows partner addresses out of the tile loop -- 48 to 64 VGPRs)
+          asm volatile("" : "+s"(xl[m]));
+#pragma unroll
+          for (int q = 0; q < SD_RPT; ++q) {
+            const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+            s[q] += cr[m] * v;
+            if (OVL && m < SD_OVL_T && (omask >> m & 1u)) {  // uniform; conj(y[i ^ x]) * zo[i]
+              px[m < SD_OVL_T ? m : 0] += (v.x * zo[q].x + v.y * zo[q].y) + (v.z * zo[q].z + v.w * zo[q].w);
+              py[m < SD_OVL_T ? m : 0] += (v.x * zo[q].y - v.y * zo[q].x) + (v.z * zo[q].w - v.w * zo[q].z);
+            }
+          }
+        }
+    } else {
+      for (int m = 0; m < a.nterms; ++m) {
+        const DTerm t = tt[m];
+        const T2 cf0 = tc[m];
+#pragma unroll
+        for (int q = 0; q < SD_RPT; ++q) {
+          const int r = rbase + q * SD_RSTEP;
+          const sd_f4 v = *(const sd_f4*)(tile + (r ^ t.xloc) * SBC + c);
+          T2 cf = cf0;
+          if (t.zmask != 0 && (__popc(((base | dep[q]) ^ t.xmask) & t.zmask) & 1)) { cf.x = -cf.x; cf.y = -cf.y; }
+          s[q].x = fmaf(cf.x, v.x, s[q].x); s[q].x = fmaf(-cf.y, v.y, s[q].x);
+          s[q].y = fmaf(cf.x, v.y, s[q].y); s[q].y = fmaf(cf.y, v.x, s[q].y);
+          s[q].z = fmaf(cf.x, v.z, s[q].z); s[q].z = fmaf(-cf.y, v.w, s[q].z);
+          s[q].w = fmaf(cf.x, v.w, s[q].w); s[q].w = fmaf(cf.y, v.z, s[q].w);
+        }
+      }
+    }
+    // the operands: everything but the next tile's four DMA instructions has to be in
+    if (FLAGS != 0) {
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < SD_RPT; ++q) {
+        if (HAS_PREV && !OVL) S_PIN(pv[q]);
+        if (HAS_ADD) S_PIN(ad[q]);
+        if (HAS_ACC) S_PIN(ac[q]);
+        if (HAS_DIAG) S_PIN(dg[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const int r = rbase + q * SD_RSTEP;
+      const size_t off = (size_t)(base | dep[q]) * a.B + c0 + c;
+      sd_f4 w = s[q];
+      if (HAS_DIAG) {
+        const sd_f4 v = *(const sd_f4*)(tile + r * SBC + c);
+        w.x = fmaf(dg[q], v.x, w.x); w.y = fmaf(dg[q], v.y, w.y); w.z = fmaf(dg[q], v.z, w.z); w.w = fmaf(dg[q], v.w, w.w);
+      }
+      if (HAS_PREV && !OVL) w += pv[q];
+      sd_f4 o;
+      o.x = a.sr * w.x - a.si * w.y; o.y = a.sr * w.y + a.si * w.x;
+      o.z = a.sr * w.z - a.si * w.w; o.w = a.sr * w.w + a.si * w.z;
+      if (HAS_ADD) o += ad[q];
+      *(sd_f4*)(a.out + off) = o;
+      if (HAS_ACC) *(sd_f4*)(a.acc + off) = ac[q] + o;
+    }
+  }
+  if (OVL) {  // one sum per wave and string over ALL tiles of the workgroup; soverlap_finish_kernel adds them in a fixed order
+    const int lane = threadIdx.x & 63;
+    const size_t blk = (size_t)blockIdx.x * (STHREADS / 64) + wave;
+#pragma unroll
+    for (int m = 0; m < SD_OVL_T; ++m)
+      if (omask >> m & 1u) {
+        const double tx = s_wave_sum<float>(px[m]), ty = s_wave_sum<float>(py[m]);
+        if (lane == 0) {
+          const int mm = a.omap[m];
+          a.part[(blk * a.n_ovl + mm) * 2 + 0] = tx;
+          a.part[(blk * a.n_ovl + mm) * 2 + 1] = ty;
+        }
+      }
+  }
+}
+
+// can this pass take the DMA form?  (complex64 only: the template below exists for float)
+template <class T>
+bool sdma_ok(int p, int B, int nterms, int mode) {
+  return mode != 0 && sizeof(T) == sizeof(float) && p == SD_P && (B % SBC) == 0 && nterms <= SMAXT;
+}
+inline int sdma_blocks(unsigned nunits, int n_cu) {  // one persistent workgroup per CU (128 KB of LDS), equal rounds
+  unsigned nb = (unsigned)n_cu < nunits ? (unsigned)n_cu : nunits;
+  const unsigned rounds = (nunits + nb - 1) / nb;
+  nb = (nunits + rounds - 1) / rounds;
+  return (int)(nb < 1 ? 1 : nb);
+}
+template <int F>
+void sapply_dma_launch_f(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st, bool simple) {
+  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
+  if (simple) {
+    (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((sapply_dma_kernel<F, true>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+  } else {
+    (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((sapply_dma_kernel<F, false>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+  }
+}
+template <int F>
+void sapply_dma_launch_ovl(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st) {
+  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
+  (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<F, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((sapply_dma_kernel<F, true, true>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+}
+inline bool sapply_ovl_flags_ok(int f);
+inline void sapply_dma_launch(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st, bool simple) {
+  const int f = (a.prev ? 1 : 0) | (a.add ? 2 : 0) | (a.acc ? 4 : 0) | (a.diag ? 8 : 0);
+  if (a.zo) {  // fused overlaps: the caller has checked simple && sapply_ovl_flags_ok(f)
+    switch (f) {
+      case 0: sapply_dma_launch_ovl<0>(a, wk, nblk, st); break;
+      case 1: sapply_dma_launch_ovl<1>(a, wk, nblk, st); break;
+      case 4: sapply_dma_launch_ovl<4>(a, wk, nblk, st); break;
+      case 5: sapply_dma_launch_ovl<5>(a, wk, nblk, st); break;
+      case 8: sapply_dma_launch_ovl<8>(a, wk, nblk, st); break;
+      default: sapply_dma_launch_ovl<12>(a, wk, nblk, st); break;
+    }
+    return;
+  }
+  switch (f) {
+    case 0: sapply_dma_launch_f<0>(a, wk, nblk, st, simple); break;
+    case 1: sapply_dma_launch_f<1>(a, wk, nblk, st, simple); break;
+    case 2: sapply_dma_launch_f<2>(a, wk, nblk, st, simple); break;
+    case 3: sapply_dma_launch_f<3>(a, wk, nblk, st, simple); break;
+    case 4: sapply_dma_launch_f<4>(a, wk, nblk, st, simple); break;
+    case 5: sapply_dma_launch_f<5>(a, wk, nblk, st, simple); break;
+    case 6: sapply_dma_launch_f<6>(a, wk, nblk, st, simple); break;
+    case 7: sapply_dma_launch_f<7>(a, wk, nblk, st, simple); break;
+    case 8: sapply_dma_launch_f<8>(a, wk, nblk, st, simple); break;
+    case 9: sapply_dma_launch_f<9>(a, wk, nblk, st, simple); break;
+    case 10: sapply_dma_launch_f<10>(a, wk, nblk, st, simple); break;
+    case 11: sapply_dma_launch_f<11>(a, wk, nblk, st, simple); break;
+    case 12: sapply_dma_launch_f<12>(a, wk, nblk, st, simple); break;
+    case 13: sapply_dma_launch_f<13>(a, wk, nblk, st, simple); break;
+    case 14: sapply_dma_launch_f<14>(a, wk, nblk, st, simple); break;
+    default: sapply_dma_launch_f<15>(a, wk, nblk, st, simple); break;
+  }
+}
+// (the double-typed engine never takes these paths: sdma_ok is false for it)
+inline void sapply_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t, bool) {}
 template <class T, int F>
 void sapply_launch_f(const SApply<T>& a, dim3 grid, hipStream_t st) {
   if ((a.B & 1) == 0) hipLaunchKernelGGL((sapply_kernel<T, F, 2>), grid, dim3(STHREADS), 0, st, a);
@@ -446,6 +723,97 @@ __global__ void __launch_bounds__(STHREADS) soverlap_kernel(SOverlap<T> a) {
   }
 }
 
+// part[blk][m] as soverlap_kernel (blk = blockIdx.x; at most SOVL_TCH strings).  The cotangent rows of tile t + 1 are requested one
+// tile ahead as well (registers), so neither operand's latency is exposed.
+__global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<float> a, SDmaWalk wk) {
+  typedef float2 T2;
+  typedef CVec<T2, 2> VT;
+  extern __shared__ __align__(16) unsigned char sd_raw[];
+  T2* tiles = (T2*)sd_raw;
+  __shared__ DTerm tt[SOVL_TCH];
+  __shared__ double red[2][SOVL_TCH][STHREADS / 64];
+  const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
+  for (int m = threadIdx.x; m < a.nterms; m += STHREADS) tt[m] = a.terms[m];
+  const int c = (threadIdx.x % 8) * 2;
+  const int rbase = threadIdx.x / 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  unsigned dep[SD_RPT];
+#pragma unroll
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
+  auto issue = [&](unsigned u, int buf) {
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const T2* gp = a.zb + (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      S_DMA16(gp, ld);
+    }
+  };
+  auto load_u = [&](unsigned u, VT* dst) {
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) dst[q] = *(const VT*)(a.za + (size_t)(base | dep[q]) * a.B + c0 + c);
+  };
+  float px[SOVL_TCH], py[SOVL_TCH];
+#pragma unroll
+  for (int mm = 0; mm < SOVL_TCH; ++mm) { px[mm] = 0; py[mm] = 0; }
+  VT un[SD_RPT];
+  unsigned u = blockIdx.x;
+  if (u < wk.nunits) { issue(u, 0); load_u(u, un); }
+  int buf = 0;
+  for (; u < wk.nunits; u += gridDim.x, buf ^= 1) {
+    VT uc[SD_RPT];
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) uc[q] = un[q];  // (waits for this tile's cotangent rows: requested a tile ago)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile u has landed in every wave's pieces
+    if (u + gridDim.x < wk.nunits) { issue(u + gridDim.x, buf ^ 1); load_u(u + gridDim.x, un); }
+    const T2* tile = tiles + (size_t)buf * (SD_ROWS * SBC);
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+#pragma unroll
+    for (int mm = 0; mm < SOVL_TCH; ++mm)
+      if (mm < a.nterms) {  // uniform
+        const DTerm t = tt[mm];
+#pragma unroll
+        for (int q = 0; q < SD_RPT; ++q) {
+          const int r = rbase + q * SD_RSTEP;
+          const VT v = *(const VT*)(tile + (r ^ t.xloc) * SBC + c);
+          float qx = 0, qy = 0;
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            qx += uc[q].v[w].x * v.v[w].x + uc[q].v[w].y * v.v[w].y;   // conj(u) * v
+            qy += uc[q].v[w].x * v.v[w].y - uc[q].v[w].y * v.v[w].x;
+          }
+          if (t.zmask != 0 && (__popc(((base | dep[q]) ^ t.xmask) & t.zmask) & 1)) { qx = -qx; qy = -qy; }
+          px[mm] += qx; py[mm] += qy;
+        }
+      }
+  }
+#pragma unroll
+  for (int mm = 0; mm < SOVL_TCH; ++mm)
+    if (mm < a.nterms) {
+      float vx = px[mm], vy = py[mm];
+      for (int off = 32; off > 0; off >>= 1) { vx += __shfl_down(vx, off, 64); vy += __shfl_down(vy, off, 64); }
+      if (lane == 0) { red[0][mm][wave] = (double)vx; red[1][mm][wave] = (double)vy; }
+    }
+  __syncthreads();
+  if ((int)threadIdx.x < a.nterms) {
+    double tx = 0, ty = 0;
+    for (int w = 0; w < STHREADS / 64; ++w) { tx += red[0][threadIdx.x][w]; ty += red[1][threadIdx.x][w]; }
+    a.part[((size_t)blockIdx.x * a.nterms + threadIdx.x) * 2 + 0] = tx;
+    a.part[((size_t)blockIdx.x * a.nterms + threadIdx.x) * 2 + 1] = ty;
+  }
+}
+
+inline void soverlap_dma_launch(const SOverlap<float>& o, SDmaWalk wk, int nblk, hipStream_t st) {
+  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
+  (void)hipFuncSetAttribute((const void*)soverlap_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(soverlap_dma_kernel, dim3((unsigned)nblk), dim3(STHREADS), lds, st, o, wk);
+}
+inline void soverlap_dma_launch(const SOverlap<double>&, SDmaWalk, int, hipStream_t) {}
+
 // grad[k(slot)] += fac * Im( phase_slot * sum_blk part[blk][m] ) * weight_slot      (fixed-order sum: deterministic)
 __global__ void __launch_bounds__(256) soverlap_finish_kernel(const double* part, int nblk, int nterms, const int* slots,
                                                               const int* owner, const double* wre, const double* wim,
@@ -508,6 +876,10 @@ struct Group {
   int p = 0;
   std::vector<DTerm> apply;   // off-diagonal strings applied in this pass
   std::vector<DTerm> ovl;     // strings whose overlaps are taken in this pass (control strings, incl. diagonal ones)
+  bool simple = false;        // every applied string is a pure X-string (z = 0: real coefficient, no sign) and they are few
+  bool ovl_fusable = false;   // simple, and every overlap string is one of the (at most SD_OVL_T) applied strings: DMA-form fusion
+  SBuf d_omap;                // applied string -> index among the overlap strings, or -1
+  int last_nblk = 0;          // workgroup-wave partial sums the last fused pass wrote per string
   SBuf d_apply, d_ovl, d_ovl_slots;
 };
 
@@ -541,7 +913,8 @@ struct SCtx : dq_sctx {
   double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
-  int fuse_overlaps = 0;  // measured slower: kept as an option and under test
+  int fuse_overlaps = 0;  // 1: always (the one-tile kernels pay a workgroup per CU for it); 0: only in the DMA form, where it is free; -1: never
+  int dma = 1, n_cu = 256;  // dma: LDS-DMA double-buffered passes where the shapes allow (complex64, 2^9-row tiles, batch % 16 == 0); 0 = off
   // profile of the streaming passes
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> recs;
@@ -643,6 +1016,18 @@ void build_groups(SCtx<T>* c, const std::vector<int>& slots, std::vector<Group>&
       }
   }
   for (auto& g : groups) {
+    g.simple = (int)g.apply.size() <= SD_SIMPLE_T;
+    for (auto& t : g.apply) if (t.zmask != 0) g.simple = false;
+    {
+      std::vector<int> omap(std::max<size_t>(1, g.apply.size()), -1);
+      size_t found = 0;
+      for (size_t o = 0; o < g.ovl.size(); ++o)
+        for (size_t m = 0; m < g.apply.size(); ++m)
+          if (g.apply[m].slot == g.ovl[o].slot) { omap[m] = (int)o; ++found; break; }
+      g.ovl_fusable = g.simple && !g.ovl.empty() && found == g.ovl.size() && (int)g.apply.size() <= SD_OVL_T;
+      g.d_omap.ensure(omap.size() * sizeof(int));
+      SHIP(hipMemcpy(g.d_omap.p, omap.data(), omap.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     g.d_apply.ensure(std::max<size_t>(1, g.apply.size()) * sizeof(DTerm));
     if (!g.apply.empty()) SHIP(hipMemcpy(g.d_apply.p, g.apply.data(), g.apply.size() * sizeof(DTerm), hipMemcpyHostToDevice));
     g.d_ovl.ensure(std::max<size_t>(1, g.ovl.size()) * sizeof(DTerm));
@@ -786,15 +1171,26 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
     T2* dst = last ? out : (T2*)c->tmp[g & 1].p;
     a.out = dst;
     dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
+    const bool dma = sdma_ok<T>(a.p, B, a.nterms, c->dma);
+    a.omap = nullptr;
     if (zo && !groups[g].ovl.empty()) {
       a.zo = zo;
       a.oterms = (const DTerm*)groups[g].d_ovl.p;
       a.n_ovl = (int)groups[g].ovl.size();
+      a.omap = (const int*)groups[g].d_omap.p;
       (*parts)[g].ensure((size_t)grid.x * grid.y * (STHREADS / 64) * a.n_ovl * 16);
       a.part = (double*)(*parts)[g].p;
+      groups[g].last_nblk = (int)(grid.x * grid.y) * (STHREADS / 64);
     }
     const double units = 2.0 + (prev ? 1 : 0) + (a.add ? 1 : 0) + (a.acc ? 2 : 0) + (a.zo ? 1 : 0);
-    c->timed(units * sb, [&] { sapply_launch<T>(a, grid, c->st); });
+    if (dma && (!a.zo || groups[g].ovl_fusable)) {
+      SDmaWalk wk{grid.y, grid.x * grid.y};
+      const int nblk = sdma_blocks(wk.nunits, c->n_cu);
+      if (a.zo) groups[g].last_nblk = nblk * (STHREADS / 64);
+      c->timed(units * sb, [&] { sapply_dma_launch(a, wk, nblk, c->st, groups[g].simple); });
+    } else {
+      c->timed(units * sb, [&] { sapply_launch<T>(a, grid, c->st); });
+    }
     c->last_passes += 1;
     c->last_bytes += units * sb;
     prev = dst;
@@ -996,7 +1392,15 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     // option fuse_overlaps = 1: the reverse apply of a group also forms that group's overlaps (zbar_{j-1} is its tile, z_j read
     // at the own rows) -- one state-unit less per group and Horner stage, but the fused kernel's accumulators cost the second
     // workgroup per CU (64-VGPR limit): 256 -> 231-242 steps/s at n = 18, B = 64.  Default: separate overlap passes.
-    bool fuse = c->fuse_overlaps != 0;
+    // With the DMA form (one workgroup per CU, 128 VGPRs to spend) the fusion is free of that cost: taken whenever every group's
+    // control strings are among its applied pure X-strings (fuse_overlaps = -1 forbids it).
+    bool fuse = c->fuse_overlaps > 0;
+    if (c->fuse_overlaps == 0 && c->dma != 0) {
+      bool all = true;
+      for (auto& g : c->hgroups)
+        if (!sdma_ok<T>(g.p, B, (int)g.apply.size(), c->dma) || (!g.ovl.empty() && !g.ovl_fusable)) all = false;
+      fuse = all;
+    }
     for (size_t g = 0; g < c->hgroups.size(); ++g) {
       if ((int)c->hgroups[g].ovl.size() > SOVL_TCH) fuse = false;
       const int f = (g > 0 ? 1 : 0) | (g + 1 == c->hgroups.size() ? 4 : 0) | (g == 0 && step_diag(c) ? 8 : 0);
@@ -1014,11 +1418,14 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         const unsigned ychunks = (B + SBC - 1) / SBC;
         o.tpw = (int)std::max(1u, std::min(8u, (o.ntiles * ychunks) / 512u));  // keep >= ~512 workgroups (2 per CU)
         dim3 grid((o.ntiles + o.tpw - 1) / o.tpw, ychunks);
-        const int nblk = grid.x * grid.y;
+        const bool use_dma = sdma_ok<T>(o.p, B, o.nterms, c->dma) && o.nterms <= SOVL_TCH;
+        SDmaWalk wk{ychunks, o.ntiles * ychunks};
+        const int nblk = use_dma ? sdma_blocks(wk.nunits, c->n_cu) : (int)(grid.x * grid.y);
         c->part.ensure((size_t)nblk * o.nterms * 16);
         o.part = (double*)c->part.p;
         c->timed(2.0 * sb, [&] {
-          if ((B & 1) == 0) hipLaunchKernelGGL((soverlap_kernel<T, 2>), grid, dim3(STHREADS), 0, c->st, o);
+          if (use_dma) soverlap_dma_launch(o, wk, nblk, c->st);
+          else if ((B & 1) == 0) hipLaunchKernelGGL((soverlap_kernel<T, 2>), grid, dim3(STHREADS), 0, c->st, o);
           else hipLaunchKernelGGL((soverlap_kernel<T, 1>), grid, dim3(STHREADS), 0, c->st, o);
         });
         c->last_passes += 1; c->last_bytes += 2.0 * sb;
@@ -1036,7 +1443,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         for (size_t gi = 0; gi < c->hgroups.size(); ++gi) {
           auto& g = c->hgroups[gi];
           if (g.ovl.empty()) continue;
-          const int nblk = (int)((c->d >> g.p) * ((B + SBC - 1) / SBC)) * (STHREADS / 64);
+          const int nblk = g.last_nblk;
           hipLaunchKernelGGL(soverlap_finish_kernel, dim3((unsigned)g.ovl.size()), dim3(256), 0, c->st,
                              (const double*)c->oparts[gi].p, nblk, (int)g.ovl.size(), (const int*)g.d_ovl_slots.p,
                              (const int*)c->d_owner.p, (const double*)c->d_wre.p, (const double*)c->d_wim.p, dt / j,
@@ -1090,7 +1497,13 @@ int dq_sctx_create(dq_sctx** out, int n_qubits, int n_controls, int device_id, i
     }
     if (device_id < 0 || device_id >= ndev) sfail(DQ_ERR_INVALID, "device_id out of range");
     SHIP(hipSetDevice(device_id));
-    auto init = [&](auto* c) { c->n = n_qubits; c->d = 1u << n_qubits; c->K = n_controls; c->dev = device_id; *out = c; };
+    auto init = [&](auto* c) {
+      c->n = n_qubits; c->d = 1u << n_qubits; c->K = n_controls; c->dev = device_id;
+      int ncu = 0;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) c->n_cu = ncu;
+      else (void)hipGetLastError();
+      *out = c;
+    };
     if (dtype == DQ_C128) init(new SCtx<double>()); else init(new SCtx<float>());
   });
 }
@@ -1116,7 +1529,8 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     if (s == "tol") { if (!(v > 0)) sfail(DQ_ERR_INVALID, "tol must be > 0"); t->tol = v; }
     else if (s == "force_degree") t->force_degree = (int)v;
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
-    else if (s == "fuse_overlaps") t->fuse_overlaps = v != 0 ? 1 : 0;
+    else if (s == "fuse_overlaps") t->fuse_overlaps = v > 0 ? 1 : (v < 0 ? -1 : 0);
+    else if (s == "dma") t->dma = v != 0 ? 1 : 0;
     else if (s == "profile") { t->collect(); t->prof_on = v != 0; if (v < 0) { t->prof_ms = 0; t->prof_bytes = 0; t->prof_launches = 0; } }
     else sfail(DQ_ERR_INVALID, "unknown option '" + s + "'");
   });
