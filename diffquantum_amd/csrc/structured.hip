@@ -119,6 +119,7 @@ struct SApply {
   int n_ovl;
   double* part;     // [nblocks * waves][n_ovl][2]
   const int* omap;  // DMA form: applied string m -> its index among the overlap strings, or -1 (the strings' partner rows are shared)
+  T2* out2;         // chain form (schain_dma_kernel): the next application's partial sums, see there
 };
 
 template <class T2, int V>
@@ -502,6 +503,121 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
       }
   }
 }
+
+// ---- chain form: two applications share one pass ---------------------------------------------------------------------------------
+// A Horner chain z_{j-1} = in + s_j (H z_j) over two string groups A, B walks the groups in alternating order: A B | B A | A B ...
+// The pass that FINISHES an application on group g (z' = add + s (prev + H_g y): prev holds D y + H_other y) has z' complete, and the
+// next application may start on the same group g with the tile it has: after a barrier the tile's rows are overwritten in place
+// with z', and out2 = D z' + H_g z' goes out as the next pass's `prev`.  Per application 5 state-units (y, prev, add in; z', out2
+// out) instead of 2 + 4, and m + 1 tile walks for m applications instead of 2 m.  Pure X-string groups only (scalar tables).
+__global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, SDmaWalk wk) {
+  constexpr int NSTORE = 2 * SD_RPT;
+  typedef float2 T2;
+  extern __shared__ __align__(16) unsigned char sd_raw[];
+  T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
+  const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
+  unsigned xl[SD_SIMPLE_T];
+  float cr[SD_SIMPLE_T];
+#pragma unroll
+  for (int m = 0; m < SD_SIMPLE_T; ++m) {
+    xl[m] = 0; cr[m] = 0.f;
+    if (m < a.nterms) {
+      const DTerm t = a.terms[m];
+      xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * 8));
+      cr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.coef[t.slot].x)));
+    }
+  }
+  const bool has_diag = a.diag != nullptr;  // uniform
+  const int c = (threadIdx.x % 8) * 2;
+  const int rbase = threadIdx.x / 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned dep[SD_RPT];
+#pragma unroll
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
+  auto issue = [&](unsigned u, int buf) {
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const T2* gp = a.y + (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      S_DMA16(gp, ld);
+    }
+  };
+  const unsigned ra = (unsigned)(rbase * SBC + c) * 8u;
+  unsigned u = blockIdx.x;
+  if (u < wk.nunits) issue(u, 0);
+  int buf = 0;
+  bool first = true;
+  for (; u < wk.nunits; u += gridDim.x, buf ^= 1, first = false) {
+    if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+    sd_f4 pv[SD_RPT], ad[SD_RPT];
+    float dg[SD_RPT];
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const unsigned i = base | dep[q];
+      const size_t off = (size_t)i * a.B + c0 + c;
+      S_GLOAD16(pv[q], a.prev + off);
+      S_GLOAD16(ad[q], a.add + off);
+      dg[q] = 0.f;
+      if (has_diag) S_GLOAD4(dg[q], a.diag + i);
+    }
+    const bool more = u + gridDim.x < wk.nunits;  // uniform
+    if (more) issue(u + gridDim.x, buf ^ 1);
+    unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (SD_ROWS * SBC));
+    sd_f4 s[SD_RPT];
+    auto gather = [&]() {
+#pragma unroll
+      for (int q = 0; q < SD_RPT; ++q) s[q] = (sd_f4)(0.f);
+#pragma unroll
+      for (int m = 0; m < SD_SIMPLE_T; ++m)
+        if (m < a.nterms) {  // uniform
+          asm volatile("" : "+s"(xl[m]));
+#pragma unroll
+          for (int q = 0; q < SD_RPT; ++q) {
+            const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+            s[q] += cr[m] * v;
+          }
+        }
+    };
+    gather();  // H_g y
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sd_f4 z[SD_RPT];
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      S_PIN(pv[q]); S_PIN(ad[q]);
+      if (has_diag) S_PIN(dg[q]);
+      const size_t off = (size_t)(base | dep[q]) * a.B + c0 + c;
+      const sd_f4 w = s[q] + pv[q];
+      z[q].x = a.sr * w.x - a.si * w.y + ad[q].x; z[q].y = a.sr * w.y + a.si * w.x + ad[q].y;
+      z[q].z = a.sr * w.z - a.si * w.w + ad[q].z; z[q].w = a.sr * w.w + a.si * w.z + ad[q].w;
+      *(sd_f4*)(a.out + off) = z[q];
+    }
+    // every wave is done with the rows of y: the tile becomes z' in place (LDS-only waits: the DMA and the stores stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) *(sd_f4*)(tb + (ra | (unsigned)(q * SD_RSTEP * SBC * 8))) = z[q];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    gather();  // H_g z'
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const size_t off = (size_t)(base | dep[q]) * a.B + c0 + c;
+      *(sd_f4*)(a.out2 + off) = s[q] + dg[q] * z[q];
+    }
+  }
+}
+
+inline void schain_dma_launch(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st) {
+  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
+  (void)hipFuncSetAttribute((const void*)schain_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(schain_dma_kernel, dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+}
+inline void schain_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t) {}
 
 // can this pass take the DMA form?  (complex64 only: the template below exists for float)
 template <class T>
@@ -910,9 +1026,10 @@ struct SCtx : dq_sctx {
   std::vector<double> wsumk;        // per control
   double tol = 0, checkpoint_bytes = 0;
   int force_degree = 0;
-  double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0;
+  double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0, last_dma_passes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
+  int chain = 1;          // 1: Horner chains over two pure X-string groups in the chain form (schain_dma_kernel); 0: one application = one pass per group
   int fuse_overlaps = 0;  // 1: always (the one-tile kernels pay a workgroup per CU for it); 0: only in the DMA form, where it is free; -1: never
   int dma = 1, n_cu = 256;  // dma: LDS-DMA double-buffered passes where the shapes allow (complex64, 2^9-row tiles, batch % 16 == 0); 0 = off
   // profile of the streaming passes
@@ -1157,7 +1274,7 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
   for (int g = 0; g < ng; ++g) {
     const bool last = (g == ng - 1);
     SApply<T> a;
-    a.zo = nullptr; a.oterms = nullptr; a.n_ovl = 0; a.part = nullptr;
+    a.zo = nullptr; a.oterms = nullptr; a.n_ovl = 0; a.part = nullptr; a.out2 = nullptr;
     a.y = y; a.prev = prev;
     a.add = last ? add : nullptr;
     a.acc = last ? acc : nullptr;
@@ -1187,6 +1304,7 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
       SDmaWalk wk{grid.y, grid.x * grid.y};
       const int nblk = sdma_blocks(wk.nunits, c->n_cu);
       if (a.zo) groups[g].last_nblk = nblk * (STHREADS / 64);
+      c->last_dma_passes += 1;
       c->timed(units * sb, [&] { sapply_dma_launch(a, wk, nblk, c->st, groups[g].simple); });
     } else {
       c->timed(units * sb, [&] { sapply_launch<T>(a, grid, c->st); });
@@ -1254,6 +1372,65 @@ int plan_degree(SCtx<T>* c, const std::vector<double>& uh, int S, double dt) {
   return m;
 }
 
+// ---- Horner chain in the chain form -------------------------------------------------------------------------------------------------
+template <class T>
+bool chain_ok(SCtx<T>* c, int B) {
+  if (!c->chain || c->hgroups.size() != 2) return false;
+  for (auto& g : c->hgroups)
+    if (!g.simple || g.apply.empty() || !sdma_ok<T>(g.p, B, (int)g.apply.size(), c->dma)) return false;
+  return true;
+}
+
+// one pass of the chain over group g: which = 0 start (out = D y + H_g y), 1 link (out = add + s (prev + H_g y); out2 = D out + H_g out),
+// 2 finish (out = add + s (prev + H_g y))
+template <class T>
+void chain_pass(SCtx<T>* c, int g, int which, const typename SCtx<T>::T2* y, const typename SCtx<T>::T2* prev,
+                const typename SCtx<T>::T2* add, typename SCtx<T>::T2* out, typename SCtx<T>::T2* out2, double sr, double si, int B) {
+  const size_t sb = c->state_bytes(B);
+  Group& G = c->hgroups[g];
+  SApply<T> a;
+  a.zo = nullptr; a.oterms = nullptr; a.n_ovl = 0; a.part = nullptr; a.omap = nullptr; a.acc = nullptr;
+  a.y = y; a.prev = prev; a.add = add; a.out = out; a.out2 = out2;
+  a.diag = (which == 2) ? nullptr : step_diag(c);
+  a.terms = (const DTerm*)G.d_apply.p;
+  a.coef = (const typename SCtx<T>::T2*)c->d_coef.p;
+  a.nterms = (int)G.apply.size();
+  a.n = c->n; a.p = G.p; a.lmask = G.lmask; a.B = B;
+  a.sr = which == 0 ? (T)1 : (T)sr; a.si = which == 0 ? (T)0 : (T)si;
+  dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
+  SDmaWalk wk{grid.y, grid.x * grid.y};
+  const int nblk = sdma_blocks(wk.nunits, c->n_cu);
+  const double units = which == 0 ? 2.0 : (which == 1 ? 5.0 : 4.0);
+  if (which == 1) c->timed(units * sb, [&] { schain_dma_launch(a, wk, nblk, c->st); });
+  else c->timed(units * sb, [&] { sapply_dma_launch(a, wk, nblk, c->st, true); });
+  c->last_passes += 1;
+  c->last_dma_passes += 1;
+  c->last_bytes += units * sb;
+}
+
+// z_{j-1} = in + (0, -sign dt / j) H z_j  for j = jhi .. jlo  (z_jhi = zhi); dst(j - 1) names where z_{j-1} goes
+template <class T, class Dst>
+void taylor_chain(SCtx<T>* c, int jhi, int jlo, double dt, double sign, const typename SCtx<T>::T2* in,
+                  const typename SCtx<T>::T2* zhi, int B, Dst dst) {
+  typedef typename SCtx<T>::T2 T2;
+  const size_t sb = c->state_bytes(B);
+  c->tmp[0].ensure(sb); c->tmp[1].ensure(sb);
+  int g = 0, pb = 0;
+  chain_pass<T>(c, g, 0, zhi, nullptr, nullptr, (T2*)c->tmp[pb].p, nullptr, 1.0, 0.0, B);
+  const T2* zj = zhi;
+  for (int j = jhi; j >= jlo; --j) {
+    g ^= 1;  // the application is finished on the other group ...
+    T2* znew = dst(j - 1);
+    if (j > jlo) {  // ... which also starts the next one
+      chain_pass<T>(c, g, 1, zj, (const T2*)c->tmp[pb].p, in, znew, (T2*)c->tmp[pb ^ 1].p, 0.0, -sign * dt / j, B);
+      pb ^= 1;
+    } else {
+      chain_pass<T>(c, g, 2, zj, (const T2*)c->tmp[pb].p, in, znew, nullptr, 0.0, -sign * dt / j, B);
+    }
+    zj = znew;
+  }
+}
+
 // z_out = T_m(sign * A_t) z_in  (Horner); if zs_store != null keeps the iterates z_m..z_1 there (z_j in zs_store[j])
 template <class T>
 void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx<T>::T2* in, typename SCtx<T>::T2* out,
@@ -1261,6 +1438,15 @@ void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx
   typedef typename SCtx<T>::T2 T2;
   const size_t sb = c->state_bytes(B);
   // z_m = in;  z_{j-1} = in + (A z_j)/j,  A = -i dt H * sign  ->  scale = (0, -sign*dt/j)
+  if (m >= 1 && chain_ok(c, B)) {
+    taylor_chain<T>(c, m, 1, dt, sign, in, in, B, [&](int jm1) -> T2* {
+      if (jm1 == 0) return out;
+      if (store) { (*store)[jm1].ensure(sb); return (T2*)(*store)[jm1].p; }
+      c->zbar[(jm1 + 1) & 1].ensure(sb);
+      return (T2*)c->zbar[(jm1 + 1) & 1].p;
+    });
+    return;
+  }
   const T2* zj = in;
   for (int j = m; j >= 1; --j) {
     T2* dst;
@@ -1291,7 +1477,7 @@ void s_propagate(SCtx<T>* c, const double* u, int S, double dt, const void* psi_
   const int m = plan_degree(c, uh, S, dt);
   c->psi[0].ensure(sb); c->psi[1].ensure(sb);
   SHIP(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
-  c->last_passes = 0; c->last_bytes = 0;
+  c->last_passes = 0; c->last_bytes = 0; c->last_dma_passes = 0;
   int cur = 0;
   for (int t = 0; t < S; ++t) {
     step_coefficients(c, t);
@@ -1346,7 +1532,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   if ((int)c->zs.size() < m + 1) c->zs.resize(m + 1);
   c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * 8);
   SHIP(hipMemsetAsync(c->grad_dev.p, 0, std::max<size_t>((size_t)S * K, 1) * 8, c->st));
-  c->last_passes = 0; c->last_bytes = 0;
+  c->last_passes = 0; c->last_bytes = 0; c->last_dma_passes = 0;
 
   // ---- forward ----
   SHIP(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
@@ -1375,7 +1561,13 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     // Horner iterates z_m = psi_t, ..., z_1 (z_0 = psi_{t+1} is not needed)
     std::vector<const T2*> z(m + 1);
     z[m] = psi_t;
-    {
+    if (m >= 2 && chain_ok(c, B)) {
+      taylor_chain<T>(c, m, 2, dt, 1.0, psi_t, psi_t, B, [&](int jm1) -> T2* {
+        c->zs[jm1].ensure(sb);
+        z[jm1] = (const T2*)c->zs[jm1].p;
+        return (T2*)c->zs[jm1].p;
+      });
+    } else {
       const T2* zj = psi_t;
       for (int j = m; j >= 2; --j) {
         c->zs[j - 1].ensure(sb);
@@ -1424,7 +1616,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         c->part.ensure((size_t)nblk * o.nterms * 16);
         o.part = (double*)c->part.p;
         c->timed(2.0 * sb, [&] {
-          if (use_dma) soverlap_dma_launch(o, wk, nblk, c->st);
+          if (use_dma) { c->last_dma_passes += 1; soverlap_dma_launch(o, wk, nblk, c->st); }
           else if ((B & 1) == 0) hipLaunchKernelGGL((soverlap_kernel<T, 2>), grid, dim3(STHREADS), 0, c->st, o);
           else hipLaunchKernelGGL((soverlap_kernel<T, 1>), grid, dim3(STHREADS), 0, c->st, o);
         });
@@ -1529,8 +1721,10 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     if (s == "tol") { if (!(v > 0)) sfail(DQ_ERR_INVALID, "tol must be > 0"); t->tol = v; }
     else if (s == "force_degree") t->force_degree = (int)v;
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
+    else if (s == "chain") t->chain = v != 0 ? 1 : 0;
     else if (s == "fuse_overlaps") t->fuse_overlaps = v > 0 ? 1 : (v < 0 ? -1 : 0);
     else if (s == "dma") t->dma = v != 0 ? 1 : 0;
+    else if (s == "dma_workgroups") { if (v < 1 || v > 65535) sfail(DQ_ERR_INVALID, "dma_workgroups must be 1..65535"); t->n_cu = (int)v; }
     else if (s == "profile") { t->collect(); t->prof_on = v != 0; if (v < 0) { t->prof_ms = 0; t->prof_bytes = 0; t->prof_launches = 0; } }
     else sfail(DQ_ERR_INVALID, "unknown option '" + s + "'");
   });
@@ -1545,6 +1739,7 @@ int dq_sctx_get_info(dq_sctx* c, const char* name, double* v) {
     else if (s == "groups") *v = (double)t->hgroups.size();
     else if (s == "checkpoint_stride") *v = t->last_cstride;
     else if (s == "passes") *v = t->last_passes;
+    else if (s == "dma_passes") *v = t->last_dma_passes;
     else if (s == "pass_bytes") *v = t->last_bytes;
     else if (s == "prof_ms") { t->collect(); *v = t->prof_ms; }
     else if (s == "prof_bytes") { t->collect(); *v = t->prof_bytes; }

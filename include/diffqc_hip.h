@@ -267,8 +267,13 @@ int dq_sctx_destroy(dq_sctx* ctx);
 int dq_sctx_set_stream(dq_sctx* ctx, void* hip_stream);
 int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigned* xmask, const unsigned* zmask,
                       const double* weight);
-/* options: "tol" (Taylor remainder bound), "force_degree", "checkpoint_bytes", "fuse_overlaps" (1: the reverse-mode apply pass of a group
- * also forms that group's control overlaps; 0, default: separate overlap passes -- faster, the fused kernel loses occupancy), "profile" (1 on, 0 off, -1 reset) */
+/* options: "tol" (Taylor remainder bound), "force_degree", "checkpoint_bytes", "profile" (1 on, 0 off, -1 reset);
+ *   "dma" (1, default: complex64 passes over 2^9-row tiles with batch % 16 == 0 run as persistent LDS-DMA kernels; 0: one tile per workgroup),
+ *   "dma_workgroups" (persistent workgroups per pass; default = the device's CU count),
+ *   "chain" (1, default: a Horner chain over two pure X-string groups finishes one application and starts the next in one pass),
+ *   "fuse_overlaps" (1: the reverse-mode apply pass of a group also forms that group's control overlaps, in every kernel form;
+ *                    0, default: only in the DMA form, where it costs no occupancy; -1: never).
+ * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "pass_bytes", "prof_ms", "prof_bytes", "prof_launches", "dtype" */
 int dq_sctx_set_option(dq_sctx* ctx, const char* name, double value);
 int dq_sctx_get_info(dq_sctx* ctx, const char* name, double* value);
 int dq_sctx_propagate(dq_sctx* ctx, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out,

@@ -165,3 +165,69 @@ def test_structured_errors():
         e.set_terms([(DRIFT, "ZII", 1.0), (0, "IXI", 1.0)])
         with pytest.raises(DiffqcError):
             e.energy_grad(np.zeros((1, 1)), 0.1, np.ones((8, 1)))  # no observable
+
+
+def _dense_reference(terms, n, K, u, dt, psi0):
+    from diffquantum_amd.engine import Engine
+    H0, Hs, M = terms_to_dense(terms, n, K)
+    with Engine(1 << n, K) as de:
+        de.set_hamiltonians(H0, Hs)
+        de.set_observable(M)
+        return de.energy_grad(u, dt, psi0.astype(np.complex128))
+
+
+@pytest.mark.parametrize("workgroups", [0, 3])
+@pytest.mark.parametrize("kind,n,B", [("ising", 10, 16), ("ising", 11, 48), ("random", 10, 32), ("random", 12, 16)])
+def test_dma_forms_match_dense_and_one_tile_kernels(kind, n, B, workgroups):
+    """The persistent LDS-DMA passes (complex64, 2^9-row tiles, batch % 16 == 0) against the dense engine in complex128 and against
+    the one-tile-per-workgroup kernels.  `ising`: pure X-strings -> scalar string tables, the chain form (one pass finishes an
+    application and starts the next) and overlaps fused into the reverse apply; `random`: X / Y / Z strings -> the general DMA loop,
+    separate DMA overlap passes.  dma_workgroups = 3 makes every workgroup walk several tiles (uneven counts) at these small sizes,
+    which is what the kernels do at n = 18."""
+    K = n if kind == "ising" else 3
+    S, dt = 5, 0.02
+    terms = ising_x_terms(n, seed=6) if kind == "ising" else random_terms(n, K, seed=12) + [(0, "Z" + "I" * (n - 1), 0.7)]
+    u = problems.pulse_table(K, S, S * dt, seed=3)
+    psi0 = problems.random_states(1 << n, B, seed=4).astype(np.complex64)
+    rl, rg, rf, _ = _dense_reference(terms, n, K, u, dt, psi0)
+    with StructuredEngine(n, K, dtype="c64") as e:
+        e.set_terms(terms)
+        if workgroups:
+            e.set_option("dma_workgroups", workgroups)
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("dma_passes") == e.info("passes") > 0
+        p1 = e.info("passes")
+        o1 = e.propagate(u, dt, psi0)
+        e.set_option("chain", 0)
+        e.set_option("fuse_overlaps", -1)
+        l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
+        p2 = e.info("passes")
+        e.set_option("dma", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("dma_passes") == 0
+        o0 = e.propagate(u, dt, psi0)
+    if kind == "ising":
+        assert p1 < p2                    # chain form + fused overlaps: fewer walks over the state
+    tol = 2e-5
+    for l, g, f in ((l1, g1, f1), (l2, g2, f2), (l0, g0, f0)):
+        assert np.max(np.abs(f - rf)) < tol and abs(l - rl) < tol * B * 4 and np.max(np.abs(g - rg)) < tol * B * 4
+    assert np.max(np.abs(o1 - f1)) < 1e-6 and np.max(np.abs(o1 - o0)) < tol
+    assert np.max(np.abs(g1 - g0)) < tol * B and np.max(np.abs(rg)) > 1e-3
+
+
+def test_dma_forms_many_tiles_per_workgroup():
+    """n = 14, B = 128: 32 row tiles x 8 column chunks = 256 tile units over 40 workgroups (six or seven tiles each, both LDS buffers
+    in turn); against the one-tile kernels, which the tests above tie to the dense engine."""
+    n, B, S, dt = 14, 128, 3, 0.01
+    terms = ising_x_terms(n, seed=2)
+    u = problems.pulse_table(n, S, S * dt, seed=5)
+    psi0 = problems.random_states(1 << n, B, seed=6).astype(np.complex64)
+    with StructuredEngine(n, n, dtype="c64") as e:
+        e.set_terms(terms)
+        e.set_option("dma_workgroups", 40)
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("dma_passes") == e.info("passes")
+        e.set_option("dma", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+    assert np.max(np.abs(f1 - f0)) < 2e-6 and abs(l1 - l0) < 2e-5 * B and np.max(np.abs(g1 - g0)) < 2e-5 * B
+    assert np.max(np.abs(np.linalg.norm(f1.astype(np.complex128), axis=0) - 1)) < 1e-5 and np.max(np.abs(g1)) > 1e-3
