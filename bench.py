@@ -747,12 +747,16 @@ def measure_config5(dev, seed, S, B, dist, n=18, first=0, trials=1):
             times.append(time.perf_counter() - t0)
         el_g = float(np.median(times))
         ms_g, by_g, nl = e.info("prof_ms"), e.info("prof_bytes"), e.info("prof_launches")
+        passes, dma_passes = int(e.info("passes")), int(e.info("dma_passes"))
         e.set_option("profile", 0)
         gb = by_g / ms_g * 1e-6 if ms_g > 0 else 0.0
         gbf = by_f / ms_f * 1e-6 if ms_f > 0 else 0.0
         return {"steps_per_s": S / el_g, "seconds": el_g, "times": times, "fwd_steps_per_s": S / el_f, "degree": int(e.info("degree")),
                 "loss": loss, "grad_norm": float(np.linalg.norm(grad)),
-                "roofline": {"bound": "hbm", "kernel": "sapply_kernel / soverlap_kernel (matrix-free H.psi passes, 2^9-row sub-cubes)",
+                "roofline": {"bound": "hbm",
+                             "kernel": ("sapply_dma_kernel / schain_dma_kernel (matrix-free passes, LDS-DMA tiles)" if dma_passes
+                                        else "sapply_kernel / soverlap_kernel (matrix-free H.psi passes, 2^9-row sub-cubes)"),
+                             "passes_per_step": passes / max(S, 1), "dma_passes_per_step": dma_passes / max(S, 1),
                              "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gb / PEAK_HBM_GBPS, "traffic": None,
                              "launches": int(nl), "ms_in_timed_region": ms_g,
                              "forward_only": {"achieved": gbf, "frac": gbf / PEAK_HBM_GBPS},

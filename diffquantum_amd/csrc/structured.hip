@@ -103,7 +103,8 @@ struct SApply {
   const T2* prev;   // partial sums of earlier groups (may be null)
   const T2* add;    // addend of the final pass (may be null)
   T2* out;
-  T2* acc;          // optional: acc += out (lambda_t = sum_j zbar_j)
+  T2* acc;          // optional: acc = acc_in + out (lambda_t = lambda_{t+1} + sum_j zbar_j)
+  const T2* acc_in; // the sum so far: acc itself, or another buffer for the first term (no copy of lambda_{t+1} into lambda_t)
   const T* diag;    // per-step real diagonal (first group only) or null
   const DTerm* terms;
   const T2* coef;   // per-slot complex coefficient for this step (weight * u_k * i^{nY})
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
     const size_t off = (size_t)rowidx[r] * a.B + c0 + c;
     if (HAS_PREV) pv[q] = *(const VT*)(a.prev + off);
     if (HAS_ADD) ad[q] = *(const VT*)(a.add + off);
-    if (HAS_ACC) ac[q] = *(const VT*)(a.acc + off);
+    if (HAS_ACC) ac[q] = *(const VT*)(a.acc_in + off);
     if (HAS_DIAG) dg[q] = a.diag[rowidx[r]];
     if (OVL) zo[q] = *(const VT*)(a.zo + off);
   }
@@ -405,7 +406,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
       if (OVL) S_GLOAD16(zo[q], a.zo + off);
       if (HAS_PREV) S_GLOAD16(pv[q], a.prev + off);
       if (HAS_ADD) S_GLOAD16(ad[q], a.add + off);
-      if (HAS_ACC) S_GLOAD16(ac[q], a.acc + off);
+      if (HAS_ACC) S_GLOAD16(ac[q], a.acc_in + off);
       if (HAS_DIAG) S_GLOAD4(dg[q], a.diag + i);
     }
     const bool more = u + gridDim.x < wk.nunits;  // uniform
@@ -1266,7 +1267,7 @@ template <class T>
 void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>::T2* coef, const T* diag,
                   const typename SCtx<T>::T2* y, const typename SCtx<T>::T2* add, typename SCtx<T>::T2* out,
                   typename SCtx<T>::T2* acc, double sr, double si, int B, const typename SCtx<T>::T2* zo = nullptr,
-                  std::vector<SBuf>* parts = nullptr) {
+                  std::vector<SBuf>* parts = nullptr, const typename SCtx<T>::T2* acc_in = nullptr) {
   typedef typename SCtx<T>::T2 T2;
   const size_t sb = c->state_bytes(B);
   const int ng = (int)groups.size();
@@ -1278,6 +1279,7 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
     a.y = y; a.prev = prev;
     a.add = last ? add : nullptr;
     a.acc = last ? acc : nullptr;
+    a.acc_in = last ? (acc_in ? acc_in : acc) : nullptr;
     a.diag = (g == 0) ? diag : nullptr;
     a.terms = (const DTerm*)groups[g].d_apply.p;
     a.coef = coef;
@@ -1389,7 +1391,7 @@ void chain_pass(SCtx<T>* c, int g, int which, const typename SCtx<T>::T2* y, con
   const size_t sb = c->state_bytes(B);
   Group& G = c->hgroups[g];
   SApply<T> a;
-  a.zo = nullptr; a.oterms = nullptr; a.n_ovl = 0; a.part = nullptr; a.omap = nullptr; a.acc = nullptr;
+  a.zo = nullptr; a.oterms = nullptr; a.n_ovl = 0; a.part = nullptr; a.omap = nullptr; a.acc = nullptr; a.acc_in = nullptr;
   a.y = y; a.prev = prev; a.add = add; a.out = out; a.out2 = out2;
   a.diag = (which == 2) ? nullptr : step_diag(c);
   a.terms = (const DTerm*)G.d_apply.p;
@@ -1578,8 +1580,8 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       }
     }
     // reverse: zbar_0 = lambda_{t+1}; lambda_t = sum_j zbar_j; overlaps <zbar_{j-1}, P z_j>
-    T2* lam_new = (T2*)c->lam[lcur ^ 1].p;
-    SHIP(hipMemcpyAsync(lam_new, c->lam[lcur].p, sb, hipMemcpyDeviceToDevice, c->st));
+    T2* lam_new = (T2*)c->lam[lcur ^ 1].p;   // = lambda_{t+1} + zbar_1 + ... + zbar_m: the first term reads lambda_{t+1} where it is
+    if (m < 1) SHIP(hipMemcpyAsync(lam_new, c->lam[lcur].p, sb, hipMemcpyDeviceToDevice, c->st));
     const T2* zb_prev = (const T2*)c->lam[lcur].p;
     // option fuse_overlaps = 1: the reverse apply of a group also forms that group's overlaps (zbar_{j-1} is its tile, z_j read
     // at the own rows) -- one state-unit less per group and Horner stage, but the fused kernel's accumulators cost the second
@@ -1630,7 +1632,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       c->zbar[j & 1].ensure(sb);
       T2* zb_new = (T2*)c->zbar[j & 1].p;
       apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zb_prev, (const T2*)nullptr, zb_new, lam_new, 0.0,
-                   dt / j, B, fuse ? z[j] : (const T2*)nullptr, &c->oparts);
+                   dt / j, B, fuse ? z[j] : (const T2*)nullptr, &c->oparts, j == 1 ? (const T2*)c->lam[lcur].p : (const T2*)nullptr);
       if (fuse)
         for (size_t gi = 0; gi < c->hgroups.size(); ++gi) {
           auto& g = c->hgroups[gi];
