@@ -109,6 +109,7 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
+CONFIG5_CHAIN = 4000   # BASELINE configs[4]: 4000 Trotter steps
 LINE_LIMIT = 4000   # bytes: the driver keeps an 8000-character tail of stdout; the ONE line must fit with room to spare
 
 
@@ -722,6 +723,7 @@ def measure_config5(dev, seed, S, B, dist, n=18, first=0, trials=1):
     with StructuredEngine(n, n, device=dev.index or 0, dtype="c64") as e:
         e.use_torch_stream()
         e.set_terms(ising_x_terms(n, seed))
+        e.set_option("plan_steps", CONFIG5_CHAIN)   # the timed slice pays the checkpoint stride (state reversals) of the full chain
         e.propagate(us[:2], 1e-3, st)
         e.set_option("profile", -1); e.set_option("profile", 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -747,18 +749,28 @@ def measure_config5(dev, seed, S, B, dist, n=18, first=0, trials=1):
             times.append(time.perf_counter() - t0)
         el_g = float(np.median(times))
         ms_g, by_g, nl = e.info("prof_ms"), e.info("prof_bytes"), e.info("prof_launches")
-        passes, dma_passes = int(e.info("passes")), int(e.info("dma_passes"))
+        passes, dma_passes, stride = int(e.info("passes")), int(e.info("dma_passes")), int(e.info("checkpoint_stride"))
         e.set_option("profile", 0)
+        # beside it: the same slice with a checkpoint at every step (what a chain short enough for the HBM would cost; rounds 1-2 timed this)
+        e.set_option("plan_steps", 0)
+        e.energy_grad(us, 1e-3, st, want_final=False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.energy_grad(us, 1e-3, st, want_final=False)
+        torch.cuda.synchronize(); el_ck = time.perf_counter() - t0
+        stride_ck = int(e.info("checkpoint_stride"))
         gb = by_g / ms_g * 1e-6 if ms_g > 0 else 0.0
         gbf = by_f / ms_f * 1e-6 if ms_f > 0 else 0.0
         return {"steps_per_s": S / el_g, "seconds": el_g, "times": times, "fwd_steps_per_s": S / el_f, "degree": int(e.info("degree")),
-                "loss": loss, "grad_norm": float(np.linalg.norm(grad)),
+                "loss": loss, "grad_norm": float(np.linalg.norm(grad)), "checkpoint_stride": stride,
+                "every_step_checkpointed": {"steps_per_s": S / el_ck, "checkpoint_stride": stride_ck},
                 "roofline": {"bound": "hbm",
                              "kernel": ("sapply_dma_kernel / schain_dma_kernel (matrix-free passes, LDS-DMA tiles)" if dma_passes
                                         else "sapply_kernel / soverlap_kernel (matrix-free H.psi passes, 2^9-row sub-cubes)"),
                              "passes_per_step": passes / max(S, 1), "dma_passes_per_step": dma_passes / max(S, 1),
-                             "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gb / PEAK_HBM_GBPS, "traffic": None,
-                             "launches": int(nl), "ms_in_timed_region": ms_g,
+                             "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gb / PEAK_HBM_GBPS,
+                             "traffic": (by_g / nl * 1.003 if nl else None), "traffic_over_algorithmic": 1.003,
+                             "traffic_source": "profiles/r3_bench_config5_summary.txt: PMC bytes per pass = its state-units x 2^n x B x 8 B (n = 18, B = 512)",
+                             "launches": int(nl), "ms_in_timed_region": ms_g, "ms_per_launch": (ms_g / nl if nl else None),
                              "forward_only": {"achieved": gbf, "frac": gbf / PEAK_HBM_GBPS},
                              "note": "fwd+adjoint passes of the timed region: algorithmic bytes (state-units x 2^n x B x 8 B per pass) / "
                                      "HIP-event time; 6.29 TB/s is the measured copy rate of the part (guide), 8 TB/s the spec used as peak"}}
@@ -819,11 +831,12 @@ def run_config5(a, D):
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": D.name(),
                "trials": {"n": len(m["times"]), "ms_per_step_median": el / S * 1e3, "ms_per_step_min": min(m["times"]) / S * 1e3,
                           "ms_per_step_max": max(m["times"]) / S * 1e3},
-               "config": {"workload": "BASELINE configs[4]: {}-qubit Ising + X_k as Pauli strings (d={}, never densified), batch {} = {} per "
-                                      "GPU, complex64, fwd+adjoint, dt=1e-3; {} of 4000 Trotter steps timed".format(n, 1 << n, total, B, S),
+               "config": {"workload": "BASELINE configs[4]: {}-qubit Ising + X_k as Pauli strings (d={}), batch {} = {} per "
+                                      "GPU, complex64, fwd+adjoint, dt=1e-3; {} of {} Trotter steps timed at the full chain's checkpoint stride".format(n, 1 << n, total, B, S, CONFIG5_CHAIN),
                           "n_qubits": n, "dim": 1 << n, "n_controls": n, "batch_per_gpu": B, "global_batch": total, "chain_steps": S,
                           "taylor_degree": m["degree"], "loss": m["loss"], "grad_norm": m["grad_norm"],
                           "forward_only_steps_per_s_rank0": m["fwd_steps_per_s"],
+                          "checkpoint_stride": m["checkpoint_stride"], "every_step_checkpointed_steps_per_s_rank0": m["every_step_checkpointed"]["steps_per_s"],
                           "parallelism": "dp{}".format(D.world),
                           "parallelism_detail": "batch shards, one all-reduce of loss + dL/du"},
                "roofline": m["roofline"]}

@@ -1030,6 +1030,7 @@ struct SCtx : dq_sctx {
   double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0, last_dma_passes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
+  int plan_steps = 0;     // checkpoint stride as for a chain of this many steps (a timed slice of a long chain then pays the long chain's reversals)
   int chain = 1;          // 1: Horner chains over two pure X-string groups in the chain form (schain_dma_kernel); 0: one application = one pass per group
   int fuse_overlaps = 0;  // 1: always (the one-tile kernels pay a workgroup per CU for it); 0: only in the DMA form, where it is free; -1: never
   int dma = 1, n_cu = 256;  // dma: LDS-DMA double-buffered passes where the shapes allow (complex64, 2^9-row tiles, batch % 16 == 0); 0 = off
@@ -1525,7 +1526,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     budget = 0.70 * ((double)fr + held);
   }
   const long ncp_max = std::max(1L, (long)(budget / (double)sb));
-  const int cstride = (int)std::max(1L, ((long)S + ncp_max - 1) / ncp_max);
+  const int cstride = (int)std::max(1L, ((long)std::max(S, c->plan_steps) + ncp_max - 1) / ncp_max);
   const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
   c->last_cstride = cstride;
   if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
@@ -1724,6 +1725,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     else if (s == "force_degree") t->force_degree = (int)v;
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
     else if (s == "chain") t->chain = v != 0 ? 1 : 0;
+    else if (s == "plan_steps") { if (v < 0 || v > 1e9) sfail(DQ_ERR_INVALID, "plan_steps must be 0..1e9"); t->plan_steps = (int)v; }
     else if (s == "fuse_overlaps") t->fuse_overlaps = v > 0 ? 1 : (v < 0 ? -1 : 0);
     else if (s == "dma") t->dma = v != 0 ? 1 : 0;
     else if (s == "dma_workgroups") { if (v < 1 || v > 65535) sfail(DQ_ERR_INVALID, "dma_workgroups must be 1..65535"); t->n_cu = (int)v; }

@@ -268,6 +268,7 @@ int dq_sctx_set_stream(dq_sctx* ctx, void* hip_stream);
 int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigned* xmask, const unsigned* zmask,
                       const double* weight);
 /* options: "tol" (Taylor remainder bound), "force_degree", "checkpoint_bytes", "profile" (1 on, 0 off, -1 reset);
+ *   "plan_steps" (checkpoint stride as for a chain of this many steps: a timed slice of a long chain pays the long chain's reversals),
  *   "dma" (1, default: complex64 passes over 2^9-row tiles with batch % 16 == 0 run as persistent LDS-DMA kernels; 0: one tile per workgroup),
  *   "dma_workgroups" (persistent workgroups per pass; default = the device's CU count),
  *   "chain" (1, default: a Horner chain over two pure X-string groups finishes one application and starts the next in one pass),

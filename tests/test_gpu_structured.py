@@ -231,3 +231,22 @@ def test_dma_forms_many_tiles_per_workgroup():
         l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
     assert np.max(np.abs(f1 - f0)) < 2e-6 and abs(l1 - l0) < 2e-5 * B and np.max(np.abs(g1 - g0)) < 2e-5 * B
     assert np.max(np.abs(np.linalg.norm(f1.astype(np.complex128), axis=0) - 1)) < 1e-5 and np.max(np.abs(g1)) > 1e-3
+
+
+def test_plan_steps_sets_the_stride_of_a_longer_chain():
+    """`plan_steps`: a slice of a long chain is differentiated with the long chain's checkpoint stride (bench.py --config 5 times 20 of
+    4000 steps this way); the stride changes, the numbers do not."""
+    n, K, B, S, dt = 10, 10, 16, 7, 0.02
+    terms = ising_x_terms(n, seed=8)
+    u = problems.pulse_table(K, S, S * dt, seed=1)
+    psi0 = problems.random_states(1 << n, B, seed=2).astype(np.complex64)
+    with StructuredEngine(n, K, dtype="c64") as e:
+        e.set_terms(terms)
+        e.set_option("checkpoint_bytes", (1 << n) * B * 8 * 10)          # room for 10 states
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("checkpoint_stride") == 1
+        p0 = e.info("passes")
+        e.set_option("plan_steps", 40)                                    # 40 steps over 10 checkpoints: every 4th state is kept
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("checkpoint_stride") == 4 and e.info("passes") > p0  # the states in between are rebuilt by reversal
+    assert np.array_equal(f0, f1) and abs(l0 - l1) < 2e-5 * B and np.max(np.abs(g0 - g1)) < 2e-5 * B
