@@ -177,7 +177,7 @@ def _dense_reference(terms, n, K, u, dt, psi0):
 
 
 @pytest.mark.parametrize("workgroups", [0, 3])
-@pytest.mark.parametrize("kind,n,B", [("ising", 10, 16), ("ising", 11, 48), ("random", 10, 32), ("random", 12, 16)])
+@pytest.mark.parametrize("kind,n,B", [("ising", 9, 16), ("ising", 10, 16), ("ising", 11, 48), ("random", 9, 32), ("random", 10, 32), ("random", 12, 16)])
 def test_dma_forms_match_dense_and_one_tile_kernels(kind, n, B, workgroups):
     """The persistent LDS-DMA passes (complex64, 2^9-row tiles, batch % 16 == 0) against the dense engine in complex128 and against
     the one-tile-per-workgroup kernels.  `ising`: pure X-strings -> scalar string tables, the chain form (one pass finishes an
@@ -207,7 +207,7 @@ def test_dma_forms_match_dense_and_one_tile_kernels(kind, n, B, workgroups):
         assert e.info("dma_passes") == 0
         o0 = e.propagate(u, dt, psi0)
     if kind == "ising":
-        assert p1 < p2                    # chain form + fused overlaps: fewer walks over the state
+        assert p1 < p2                    # (chain form at two groups) + fused overlaps: fewer walks over the state
     tol = 2e-5
     for l, g, f in ((l1, g1, f1), (l2, g2, f2), (l0, g0, f0)):
         assert np.max(np.abs(f - rf)) < tol and abs(l - rl) < tol * B * 4 and np.max(np.abs(g - rg)) < tol * B * 4
