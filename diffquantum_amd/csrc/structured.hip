@@ -121,6 +121,8 @@ struct SApply {
   double* part;     // [nblocks * waves][n_ovl][2]
   const int* omap;  // DMA form: applied string m -> its index among the overlap strings, or -1 (the strings' partner rows are shared)
   T2* out2;         // chain form (schain_dma_kernel): the next application's partial sums, see there
+  const T2* zo2;    // reverse chain form (srchain_dma_kernel): cotangent operand of the NEXT stage's overlaps, and their weight
+  T ovl2_scale;     //   relative to this stage's (the two stages' sums share one accumulator set)
 };
 
 template <class T2, int V>
@@ -301,19 +303,29 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
 // work on the previous tile, so the buffer the next DMA overwrites is free.  vmcnt is in issue order: the wait in front of the
 // barrier leaves exactly the previous tile's stores in flight (they are younger than the DMA it waits for).
 // (inline asm, as in zgemm_lin.hip: for the builtin hipcc drains vmcnt in front of every LDS read)
-#define S_DMA16(gp_, lds_) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp_), "s"(lds_) : "memory")
+// (addresses as uniform base pointer in SGPRs + one 32-bit byte offset per row, shared by every operand of the row: per-thread 64-bit
+// pointers for eight arrays cost 16 VGPRs and spilled the reverse chain kernel; the DMA forms therefore need states below 4 GB)
+// (s_nop 4 in front of every one of these: under SGPR pressure hipcc restores the base pointer with v_readlane_b32 right before the asm
+// block, and a VMEM instruction that reads an SGPR written by a VALU instruction needs 5 wait states -- the hazard recognizer does not
+// look inside inline asm.  Without it the reverse chain kernel read a half-restored pointer and faulted.)
+#define S_DMA16(base_, off_, lds_) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off_), "s"(base_), "s"(lds_) : "memory")
 
 constexpr int SD_P = 9, SD_ROWS = 1 << SD_P, SD_RSTEP = 128, SD_RPT = SD_ROWS / SD_RSTEP;  // 1024 threads = 128 rows x 8 column pairs; 4 rows per thread
 static_assert(STHREADS == 1024 && SBC == 16, "the DMA forms assume 1024 threads and 16 batch columns per tile");
 
-// tile units: unit u = column chunk (u % nchunks) of row tile (u / nchunks).  Chunk-fastest on purpose: the workgroups that run at
-// the same time then cover whole rows (contiguous B * 8 bytes) of a few tiles, not the same 128-byte column chunk of 256 tiles --
-// accesses whose addresses all agree in the bits below the row stride and land on a fraction of the HBM channels.
+// tile units.  Chunk-fastest by default: the workgroups that run at the same time then cover whole rows (contiguous B * 8 bytes) of a
+// few tiles, not the same 128-byte column chunk of 256 tiles (2-unit pass at B = 512: 621 -> 554 us).  Groups with high local bits (a
+// tile's rows lie 2^k rows apart) and narrow batches (rows under 2 KB) walk tile-fastest instead: neighbouring tiles are neighbouring
+// rows of the same regions, which the concurrent workgroups then share (B = 64: 316 -> 322 steps/s; B = 512: 36.3 -> 34.6, hence the
+// width condition).
 struct SDmaWalk {
-  unsigned nchunks, nunits;
-  __host__ __device__ unsigned tile(unsigned u) const { return u / nchunks; }
-  __host__ __device__ unsigned chunk(unsigned u) const { return u % nchunks; }
+  unsigned nchunks, nunits, ntiles, tile_fast;
+  __host__ __device__ unsigned tile(unsigned u) const { return tile_fast ? u % ntiles : u / nchunks; }
+  __host__ __device__ unsigned chunk(unsigned u) const { return tile_fast ? u / ntiles : u % nchunks; }
 };
+inline SDmaWalk sdma_walk(unsigned ntiles, unsigned nchunks, unsigned lmask) {
+  return SDmaWalk{nchunks, ntiles * nchunks, ntiles, ((lmask & 1u) == 0 && nchunks < 16) ? 1u : 0u};
+}
 
 // Register operands of a tile (prev / add / acc rows, diagonal entries) are requested by inline asm as well: vmcnt counts in issue
 // order, and a load the compiler knows about makes it wait with vmcnt(0) at the first use -- i.e. for the next tile's DMA, which
@@ -321,8 +333,8 @@ struct SDmaWalk {
 // tile: operand requests -> DMA of tile t + 1 -> LDS gathers of tile t (no vector-memory wait) -> vmcnt(4): operands in, the four
 // DMA instructions still in flight -> combine, store.
 typedef float sd_f4 __attribute__((ext_vector_type(4)));
-#define S_GLOAD16(dst_, gp_) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst_) : "v"(gp_) : "memory")
-#define S_GLOAD4(dst_, gp_) asm volatile("global_load_dword %0, %1, off" : "=&v"(dst_) : "v"(gp_) : "memory")
+#define S_GLOAD16(dst_, base_, off_) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst_) : "v"(off_), "s"(base_) : "memory")
+#define S_GLOAD4(dst_, base_, off_) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(dst_) : "v"(off_), "s"(base_) : "memory")
 #define S_PIN(x_) asm volatile("" : "+v"(x_))
 
 // SIMPLE: every string of the group is a pure X-string (no Z factor: no row-dependent sign, real coefficient) and there are at most
@@ -383,9 +395,9 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const T2* gp = a.y + (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
       const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
-      S_DMA16(gp, ld);
+      S_DMA16(a.y, off, ld);
     }
   };
   unsigned u = blockIdx.x;
@@ -402,12 +414,12 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned i = base | dep[q];
-      const size_t off = (size_t)i * a.B + c0 + c;
-      if (OVL) S_GLOAD16(zo[q], a.zo + off);
-      if (HAS_PREV) S_GLOAD16(pv[q], a.prev + off);
-      if (HAS_ADD) S_GLOAD16(ad[q], a.add + off);
-      if (HAS_ACC) S_GLOAD16(ac[q], a.acc_in + off);
-      if (HAS_DIAG) S_GLOAD4(dg[q], a.diag + i);
+      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;   // byte offset: the same for every operand
+      if (OVL) S_GLOAD16(zo[q], a.zo, off);
+      if (HAS_PREV) S_GLOAD16(pv[q], a.prev, off);
+      if (HAS_ADD) S_GLOAD16(ad[q], a.add, off);
+      if (HAS_ACC) S_GLOAD16(ac[q], a.acc_in, off);
+      if (HAS_DIAG) S_GLOAD4(dg[q], a.diag, i * 4u);
     }
     const bool more = u + gridDim.x < wk.nunits;  // uniform
     if (more) issue(u + gridDim.x, buf ^ 1);
@@ -474,7 +486,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const int r = rbase + q * SD_RSTEP;
-      const size_t off = (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
       sd_f4 w = s[q];
       if (HAS_DIAG) {
         const sd_f4 v = *(const sd_f4*)(tile + r * SBC + c);
@@ -485,8 +497,8 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
       o.x = a.sr * w.x - a.si * w.y; o.y = a.sr * w.y + a.si * w.x;
       o.z = a.sr * w.z - a.si * w.w; o.w = a.sr * w.w + a.si * w.z;
       if (HAS_ADD) o += ad[q];
-      *(sd_f4*)(a.out + off) = o;
-      if (HAS_ACC) *(sd_f4*)(a.acc + off) = ac[q] + o;
+      *(sd_f4*)((unsigned char*)a.out + off) = o;
+      if (HAS_ACC) *(sd_f4*)((unsigned char*)a.acc + off) = ac[q] + o;
     }
   }
   if (OVL) {  // one sum per wave and string over ALL tiles of the workgroup; soverlap_finish_kernel adds them in a fixed order
@@ -541,9 +553,9 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const T2* gp = a.y + (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
       const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
-      S_DMA16(gp, ld);
+      S_DMA16(a.y, off, ld);
     }
   };
   const unsigned ra = (unsigned)(rbase * SBC + c) * 8u;
@@ -561,11 +573,11 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned i = base | dep[q];
-      const size_t off = (size_t)i * a.B + c0 + c;
-      S_GLOAD16(pv[q], a.prev + off);
-      S_GLOAD16(ad[q], a.add + off);
+      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;   // byte offset: the same for every operand
+      S_GLOAD16(pv[q], a.prev, off);
+      S_GLOAD16(ad[q], a.add, off);
       dg[q] = 0.f;
-      if (has_diag) S_GLOAD4(dg[q], a.diag + i);
+      if (has_diag) S_GLOAD4(dg[q], a.diag, i * 4u);
     }
     const bool more = u + gridDim.x < wk.nunits;  // uniform
     if (more) issue(u + gridDim.x, buf ^ 1);
@@ -593,11 +605,11 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
     for (int q = 0; q < SD_RPT; ++q) {
       S_PIN(pv[q]); S_PIN(ad[q]);
       if (has_diag) S_PIN(dg[q]);
-      const size_t off = (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
       const sd_f4 w = s[q] + pv[q];
       z[q].x = a.sr * w.x - a.si * w.y + ad[q].x; z[q].y = a.sr * w.y + a.si * w.x + ad[q].y;
       z[q].z = a.sr * w.z - a.si * w.w + ad[q].z; z[q].w = a.sr * w.w + a.si * w.z + ad[q].w;
-      *(sd_f4*)(a.out + off) = z[q];
+      *(sd_f4*)((unsigned char*)a.out + off) = z[q];
     }
     // every wave is done with the rows of y: the tile becomes z' in place (LDS-only waits: the DMA and the stores stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -607,8 +619,8 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
     gather();  // H_g z'
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const size_t off = (size_t)(base | dep[q]) * a.B + c0 + c;
-      *(sd_f4*)(a.out2 + off) = s[q] + dg[q] * z[q];
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
+      *(sd_f4*)((unsigned char*)a.out2 + off) = s[q] + dg[q] * z[q];
     }
   }
 }
@@ -620,10 +632,171 @@ inline void schain_dma_launch(const SApply<float>& a, SDmaWalk wk, int nblk, hip
 }
 inline void schain_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t) {}
 
+// ---- chain form of the reverse sweep ----------------------------------------------------------------------------------------------
+// zbar_j = s_j H zbar_{j-1} (s_j = i dt / j), lambda_t = lambda_{t+1} + sum_j zbar_j, overlaps <zbar_{j-1}, P_m z_j> per stage j and
+// control string m.  Same walk A B | B A | ...: the pass that finishes stage j on group g (out = s_j (prev + H_g y), acc = acc_in +
+// out, stage-j overlaps of g's strings against zo = z_j) rewrites its tile with zbar_j and starts stage j + 1 there (out2 = D zbar_j
+// + H_g zbar_j; stage-(j+1) overlaps of g's strings against zo2 = z_{j+1}, weighted ovl2_scale = j / (j+1) into the SAME sums, which
+// soverlap_finish_kernel then scales by dt / j).  8 state-units per stage instead of 3 + 6, m + 1 walks instead of 2 m.
+__global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, SDmaWalk wk) {
+  constexpr int NSTORE = 3 * SD_RPT;
+  typedef float2 T2;
+  extern __shared__ __align__(16) unsigned char sd_raw[];
+  T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
+  const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
+  unsigned xl[SD_OVL_T];
+  float cr[SD_OVL_T];
+  unsigned omask = 0;
+  float px[SD_OVL_T], py[SD_OVL_T];
+#pragma unroll
+  for (int m = 0; m < SD_OVL_T; ++m) {
+    xl[m] = 0; cr[m] = 0.f; px[m] = 0.f; py[m] = 0.f;
+    if (m < a.nterms) {
+      const DTerm t = a.terms[m];
+      xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * 8));
+      cr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.coef[t.slot].x)));
+      if (a.omap[m] >= 0) omask |= 1u << m;
+    }
+  }
+  omask = __builtin_amdgcn_readfirstlane(omask);
+  const bool has_diag = a.diag != nullptr;  // uniform
+  const int c = (threadIdx.x % 8) * 2;
+  const int rbase = threadIdx.x / 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned dep[SD_RPT];
+#pragma unroll
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
+  auto issue = [&](unsigned u, int buf) {
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
+      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      S_DMA16(a.y, off, ld);
+    }
+  };
+  const unsigned ra = (unsigned)(rbase * SBC + c) * 8u;
+  unsigned u = blockIdx.x;
+  if (u < wk.nunits) issue(u, 0);
+  int buf = 0;
+  bool first = true;
+  for (; u < wk.nunits; u += gridDim.x, buf ^= 1, first = false) {
+    if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
+    const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
+    const int c0 = (int)wk.chunk(u) * SBC;
+    sd_f4 s[SD_RPT], ac[SD_RPT], zo[SD_RPT];
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const unsigned i = base | dep[q];
+      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;   // byte offset: the same for every operand
+      S_GLOAD16(zo[q], a.zo, off);
+      S_GLOAD16(s[q], a.prev, off);
+      S_GLOAD16(ac[q], a.acc_in, off);
+    }
+    const bool more = u + gridDim.x < wk.nunits;  // uniform
+    if (more) issue(u + gridDim.x, buf ^ 1);
+    unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (SD_ROWS * SBC));
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      S_PIN(zo[q]); S_PIN(s[q]); S_PIN(ac[q]);
+    }
+    // stage j on the tile of zbar_{j-1}: H_g y on top of prev, overlaps against z_j
+#pragma unroll
+    for (int m = 0; m < SD_OVL_T; ++m)
+      if (m < a.nterms) {  // uniform
+        asm volatile("" : "+s"(xl[m]));
+#pragma unroll
+        for (int q = 0; q < SD_RPT; ++q) {
+          const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+          s[q] += cr[m] * v;
+          if (omask >> m & 1u) {
+            px[m] += (v.x * zo[q].x + v.y * zo[q].y) + (v.z * zo[q].z + v.w * zo[q].w);
+            py[m] += (v.x * zo[q].y - v.y * zo[q].x) + (v.z * zo[q].w - v.w * zo[q].z);
+          }
+        }
+      }
+    // the next stage's cotangent rows take the registers of this stage's (requested now, needed after the tile is rewritten; the
+    // eight stores below are younger, the next tile's DMA older: by then it has had the whole first stage to arrive)
+    sd_f4 zn[SD_RPT];
+    float dg[SD_RPT];
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      S_GLOAD16(zn[q], a.zo2, ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u);
+      dg[q] = 0.f;
+      if (has_diag) S_GLOAD4(dg[q], a.diag, (base | dep[q]) * 4u);
+    }
+    sd_f4 z[SD_RPT];
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
+      z[q].x = a.sr * s[q].x - a.si * s[q].y; z[q].y = a.sr * s[q].y + a.si * s[q].x;
+      z[q].z = a.sr * s[q].z - a.si * s[q].w; z[q].w = a.sr * s[q].w + a.si * s[q].z;
+      *(sd_f4*)((unsigned char*)a.out + off) = z[q];
+      *(sd_f4*)((unsigned char*)a.acc + off) = ac[q] + z[q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) *(sd_f4*)(tb + (ra | (unsigned)(q * SD_RSTEP * SBC * 8))) = z[q];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // stage j + 1 starts on the same tile, now zbar_j
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SD_RPT) : "memory");
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      S_PIN(zn[q]);
+      if (has_diag) S_PIN(dg[q]);
+      s[q] = dg[q] * z[q]; zn[q] *= a.ovl2_scale;
+    }
+#pragma unroll
+    for (int m = 0; m < SD_OVL_T; ++m)
+      if (m < a.nterms) {  // uniform
+        asm volatile("" : "+s"(xl[m]));
+#pragma unroll
+        for (int q = 0; q < SD_RPT; ++q) {
+          const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+          s[q] += cr[m] * v;
+          if (omask >> m & 1u) {
+            px[m] += (v.x * zn[q].x + v.y * zn[q].y) + (v.z * zn[q].z + v.w * zn[q].w);
+            py[m] += (v.x * zn[q].y - v.y * zn[q].x) + (v.z * zn[q].w - v.w * zn[q].z);
+          }
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < SD_RPT; ++q) {
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
+      *(sd_f4*)((unsigned char*)a.out2 + off) = s[q];
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const size_t blk = (size_t)blockIdx.x * (STHREADS / 64) + wave;
+#pragma unroll
+  for (int m = 0; m < SD_OVL_T; ++m)
+    if (omask >> m & 1u) {
+      const double tx = s_wave_sum<float>(px[m]), ty = s_wave_sum<float>(py[m]);
+      if (lane == 0) {
+        const int mm = a.omap[m];
+        a.part[(blk * a.n_ovl + mm) * 2 + 0] = tx;
+        a.part[(blk * a.n_ovl + mm) * 2 + 1] = ty;
+      }
+    }
+}
+
+inline void srchain_dma_launch(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st) {
+  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
+  (void)hipFuncSetAttribute((const void*)srchain_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(srchain_dma_kernel, dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+}
+inline void srchain_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t) {}
+
 // can this pass take the DMA form?  (complex64 only: the template below exists for float)
 template <class T>
-bool sdma_ok(int p, int B, int nterms, int mode) {
-  return mode != 0 && sizeof(T) == sizeof(float) && p == SD_P && (B % SBC) == 0 && nterms <= SMAXT;
+bool sdma_ok(int p, int B, int nterms, int mode, int n) {
+  return mode != 0 && sizeof(T) == sizeof(float) && p == SD_P && (B % SBC) == 0 && nterms <= SMAXT &&
+         ((double)B * 8.0 * (double)(1ull << n) < 4294967296.0);   // 32-bit byte offsets
 }
 inline int sdma_blocks(unsigned nunits, int n_cu) {  // one persistent workgroup per CU (128 KB of LDS), equal rounds
   unsigned nb = (unsigned)n_cu < nunits ? (unsigned)n_cu : nunits;
@@ -863,9 +1036,9 @@ __global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<float> 
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const T2* gp = a.zb + (size_t)(base | dep[q]) * a.B + c0 + c;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
       const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
-      S_DMA16(gp, ld);
+      S_DMA16(a.zb, off, ld);
     }
   };
   auto load_u = [&](unsigned u, VT* dst) {
@@ -1031,6 +1204,7 @@ struct SCtx : dq_sctx {
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
   int plan_steps = 0;     // checkpoint stride as for a chain of this many steps (a timed slice of a long chain then pays the long chain's reversals)
+  int reverse_chain = 1;  // 1: the reverse sweep in the chain form too (srchain_dma_kernel) when chain applies and the overlaps are fused
   int chain = 1;          // 1: Horner chains over two pure X-string groups in the chain form (schain_dma_kernel); 0: one application = one pass per group
   int fuse_overlaps = 0;  // 1: always (the one-tile kernels pay a workgroup per CU for it); 0: only in the DMA form, where it is free; -1: never
   int dma = 1, n_cu = 256;  // dma: LDS-DMA double-buffered passes where the shapes allow (complex64, 2^9-row tiles, batch % 16 == 0); 0 = off
@@ -1291,7 +1465,7 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
     T2* dst = last ? out : (T2*)c->tmp[g & 1].p;
     a.out = dst;
     dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
-    const bool dma = sdma_ok<T>(a.p, B, a.nterms, c->dma);
+    const bool dma = sdma_ok<T>(a.p, B, a.nterms, c->dma, c->n);
     a.omap = nullptr;
     if (zo && !groups[g].ovl.empty()) {
       a.zo = zo;
@@ -1304,7 +1478,7 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
     }
     const double units = 2.0 + (prev ? 1 : 0) + (a.add ? 1 : 0) + (a.acc ? 2 : 0) + (a.zo ? 1 : 0);
     if (dma && (!a.zo || groups[g].ovl_fusable)) {
-      SDmaWalk wk{grid.y, grid.x * grid.y};
+      SDmaWalk wk = sdma_walk(grid.x, grid.y, a.lmask);
       const int nblk = sdma_blocks(wk.nunits, c->n_cu);
       if (a.zo) groups[g].last_nblk = nblk * (STHREADS / 64);
       c->last_dma_passes += 1;
@@ -1380,7 +1554,7 @@ template <class T>
 bool chain_ok(SCtx<T>* c, int B) {
   if (!c->chain || c->hgroups.size() != 2) return false;
   for (auto& g : c->hgroups)
-    if (!g.simple || g.apply.empty() || !sdma_ok<T>(g.p, B, (int)g.apply.size(), c->dma)) return false;
+    if (!g.simple || g.apply.empty() || !sdma_ok<T>(g.p, B, (int)g.apply.size(), c->dma, c->n)) return false;
   return true;
 }
 
@@ -1401,7 +1575,7 @@ void chain_pass(SCtx<T>* c, int g, int which, const typename SCtx<T>::T2* y, con
   a.n = c->n; a.p = G.p; a.lmask = G.lmask; a.B = B;
   a.sr = which == 0 ? (T)1 : (T)sr; a.si = which == 0 ? (T)0 : (T)si;
   dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
-  SDmaWalk wk{grid.y, grid.x * grid.y};
+  SDmaWalk wk = sdma_walk(grid.x, grid.y, a.lmask);
   const int nblk = sdma_blocks(wk.nunits, c->n_cu);
   const double units = which == 0 ? 2.0 : (which == 1 ? 5.0 : 4.0);
   if (which == 1) c->timed(units * sb, [&] { schain_dma_launch(a, wk, nblk, c->st); });
@@ -1431,6 +1605,67 @@ void taylor_chain(SCtx<T>* c, int jhi, int jlo, double dt, double sign, const ty
       chain_pass<T>(c, g, 2, zj, (const T2*)c->tmp[pb].p, in, znew, nullptr, 0.0, -sign * dt / j, B);
     }
     zj = znew;
+  }
+}
+
+// The reverse sweep of one step in the chain form (srchain_dma_kernel): lambda_new = lambda_old + sum_j zbar_j and the control
+// overlaps of all stages into grad_row.  z[j] are the forward Horner iterates (z[m] = psi_t).
+template <class T>
+void reverse_chain(SCtx<T>* c, int m, double dt, int B, const std::vector<const typename SCtx<T>::T2*>& z,
+                   const typename SCtx<T>::T2* lam_old, typename SCtx<T>::T2* lam_new, double* grad_row) {
+  typedef typename SCtx<T>::T2 T2;
+  const size_t sb = c->state_bytes(B);
+  c->tmp[0].ensure(sb); c->tmp[1].ensure(sb);
+  if (c->oparts.size() < c->hgroups.size()) c->oparts.resize(c->hgroups.size());
+  auto pass = [&](int g, int which, const T2* y, const T2* prev, const T2* acc_in, const T2* zo, const T2* zo2, T2* out, T2* out2,
+                  double si, double ovl2) {
+    Group& G = c->hgroups[g];
+    SApply<T> a;
+    a.add = nullptr; a.oterms = (const DTerm*)G.d_ovl.p; a.n_ovl = (int)G.ovl.size(); a.omap = (const int*)G.d_omap.p;
+    a.y = y; a.prev = prev; a.out = out; a.out2 = out2; a.zo = zo; a.zo2 = zo2; a.ovl2_scale = (T)ovl2;
+    a.acc = which == 0 ? nullptr : lam_new; a.acc_in = acc_in;
+    a.diag = (which == 2) ? nullptr : step_diag(c);
+    a.terms = (const DTerm*)G.d_apply.p;
+    a.coef = (const T2*)c->d_coef.p;
+    a.nterms = (int)G.apply.size();
+    a.n = c->n; a.p = G.p; a.lmask = G.lmask; a.B = B;
+    a.sr = which == 0 ? (T)1 : (T)0; a.si = which == 0 ? (T)0 : (T)si;
+    dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
+    SDmaWalk wk = sdma_walk(grid.x, grid.y, a.lmask);
+    const int nblk = sdma_blocks(wk.nunits, c->n_cu);
+    c->oparts[g].ensure((size_t)nblk * (STHREADS / 64) * std::max(1, a.n_ovl) * 16);
+    a.part = (double*)c->oparts[g].p;
+    G.last_nblk = nblk * (STHREADS / 64);
+    const double units = which == 0 ? 3.0 : (which == 1 ? 8.0 : 6.0);
+    if (which == 1) c->timed(units * sb, [&] { srchain_dma_launch(a, wk, nblk, c->st); });
+    else c->timed(units * sb, [&] { sapply_dma_launch(a, wk, nblk, c->st, true); });
+    c->last_passes += 1; c->last_dma_passes += 1; c->last_bytes += units * sb;
+  };
+  auto finish = [&](int g, double fac) {
+    Group& G = c->hgroups[g];
+    if (G.ovl.empty()) return;
+    hipLaunchKernelGGL(soverlap_finish_kernel, dim3((unsigned)G.ovl.size()), dim3(256), 0, c->st, (const double*)c->oparts[g].p,
+                       G.last_nblk, (int)G.ovl.size(), (const int*)G.d_ovl_slots.p, (const int*)c->d_owner.p,
+                       (const double*)c->d_wre.p, (const double*)c->d_wim.p, fac, grad_row);
+    SHIP(hipGetLastError());
+  };
+  int g = 0, pb = 0;
+  pass(g, 0, lam_old, nullptr, nullptr, z[1], nullptr, (T2*)c->tmp[pb].p, nullptr, 0.0, 0.0);   // stage 1 starts on group 0
+  finish(g, dt);
+  const T2* zprev = lam_old;
+  for (int j = 1; j <= m; ++j) {
+    g ^= 1;
+    c->zbar[j & 1].ensure(sb);
+    T2* zb_new = (T2*)c->zbar[j & 1].p;
+    const T2* acc_in = j == 1 ? lam_old : (const T2*)lam_new;
+    if (j < m) {
+      pass(g, 1, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], z[j + 1], zb_new, (T2*)c->tmp[pb ^ 1].p, dt / j, (double)j / (j + 1));
+      pb ^= 1;
+    } else {
+      pass(g, 2, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], nullptr, zb_new, nullptr, dt / j, 0.0);
+    }
+    finish(g, dt / j);
+    zprev = zb_new;
   }
 }
 
@@ -1593,7 +1828,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     if (c->fuse_overlaps == 0 && c->dma != 0) {
       bool all = true;
       for (auto& g : c->hgroups)
-        if (!sdma_ok<T>(g.p, B, (int)g.apply.size(), c->dma) || (!g.ovl.empty() && !g.ovl_fusable)) all = false;
+        if (!sdma_ok<T>(g.p, B, (int)g.apply.size(), c->dma, c->n) || (!g.ovl.empty() && !g.ovl_fusable)) all = false;
       fuse = all;
     }
     for (size_t g = 0; g < c->hgroups.size(); ++g) {
@@ -1602,7 +1837,10 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       if (!c->hgroups[g].ovl.empty() && !sapply_ovl_flags_ok(f)) fuse = false;
     }
     if (c->oparts.size() < c->hgroups.size()) c->oparts.resize(c->hgroups.size());
-    for (int j = 1; j <= m; ++j) {
+    bool rchain = fuse && m >= 1 && c->reverse_chain && chain_ok(c, B);
+    for (auto& g : c->hgroups) if (!g.ovl.empty() && !g.ovl_fusable) rchain = false;
+    if (rchain) reverse_chain<T>(c, m, dt, B, z, (const T2*)c->lam[lcur].p, lam_new, (double*)c->grad_dev.p + (size_t)t * K);
+    for (int j = 1; j <= m && !rchain; ++j) {
       for (auto& g : c->hgroups) {
         if (fuse || g.ovl.empty()) continue;
         SOverlap<T> o;
@@ -1613,8 +1851,8 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         const unsigned ychunks = (B + SBC - 1) / SBC;
         o.tpw = (int)std::max(1u, std::min(8u, (o.ntiles * ychunks) / 512u));  // keep >= ~512 workgroups (2 per CU)
         dim3 grid((o.ntiles + o.tpw - 1) / o.tpw, ychunks);
-        const bool use_dma = sdma_ok<T>(o.p, B, o.nterms, c->dma) && o.nterms <= SOVL_TCH;
-        SDmaWalk wk{ychunks, o.ntiles * ychunks};
+        const bool use_dma = sdma_ok<T>(o.p, B, o.nterms, c->dma, c->n) && o.nterms <= SOVL_TCH;
+        SDmaWalk wk = sdma_walk(o.ntiles, ychunks, o.lmask);
         const int nblk = use_dma ? sdma_blocks(wk.nunits, c->n_cu) : (int)(grid.x * grid.y);
         c->part.ensure((size_t)nblk * o.nterms * 16);
         o.part = (double*)c->part.p;
@@ -1725,6 +1963,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     else if (s == "force_degree") t->force_degree = (int)v;
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
     else if (s == "chain") t->chain = v != 0 ? 1 : 0;
+    else if (s == "reverse_chain") t->reverse_chain = v != 0 ? 1 : 0;
     else if (s == "plan_steps") { if (v < 0 || v > 1e9) sfail(DQ_ERR_INVALID, "plan_steps must be 0..1e9"); t->plan_steps = (int)v; }
     else if (s == "fuse_overlaps") t->fuse_overlaps = v > 0 ? 1 : (v < 0 ? -1 : 0);
     else if (s == "dma") t->dma = v != 0 ? 1 : 0;

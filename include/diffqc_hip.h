@@ -272,6 +272,7 @@ int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigne
  *   "dma" (1, default: complex64 passes over 2^9-row tiles with batch % 16 == 0 run as persistent LDS-DMA kernels; 0: one tile per workgroup),
  *   "dma_workgroups" (persistent workgroups per pass; default = the device's CU count),
  *   "chain" (1, default: a Horner chain over two pure X-string groups finishes one application and starts the next in one pass),
+ *   "reverse_chain" (1, default: so does the reverse sweep, overlaps of both stages included),
  *   "fuse_overlaps" (1: the reverse-mode apply pass of a group also forms that group's control overlaps, in every kernel form;
  *                    0, default: only in the DMA form, where it costs no occupancy; -1: never).
  * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "pass_bytes", "prof_ms", "prof_bytes", "prof_launches", "dtype" */

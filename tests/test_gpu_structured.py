@@ -198,6 +198,9 @@ def test_dma_forms_match_dense_and_one_tile_kernels(kind, n, B, workgroups):
         assert e.info("dma_passes") == e.info("passes") > 0
         p1 = e.info("passes")
         o1 = e.propagate(u, dt, psi0)
+        e.set_option("reverse_chain", 0)          # the reverse sweep as one fused pass per group and stage
+        l3, g3, f3, _ = e.energy_grad(u, dt, psi0)
+        p3 = e.info("passes")
         e.set_option("chain", 0)
         e.set_option("fuse_overlaps", -1)
         l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
@@ -208,8 +211,9 @@ def test_dma_forms_match_dense_and_one_tile_kernels(kind, n, B, workgroups):
         o0 = e.propagate(u, dt, psi0)
     if kind == "ising":
         assert p1 < p2                    # (chain form at two groups) + fused overlaps: fewer walks over the state
+        assert (p1 < p3 < p2) if n > 9 else (p1 == p3)     # two groups: the reverse sweep is a chain as well
     tol = 2e-5
-    for l, g, f in ((l1, g1, f1), (l2, g2, f2), (l0, g0, f0)):
+    for l, g, f in ((l1, g1, f1), (l3, g3, f3), (l2, g2, f2), (l0, g0, f0)):
         assert np.max(np.abs(f - rf)) < tol and abs(l - rl) < tol * B * 4 and np.max(np.abs(g - rg)) < tol * B * 4
     assert np.max(np.abs(o1 - f1)) < 1e-6 and np.max(np.abs(o1 - o0)) < tol
     assert np.max(np.abs(g1 - g0)) < tol * B and np.max(np.abs(rg)) > 1e-3
