@@ -273,6 +273,8 @@ int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigne
  *   "dma_workgroups" (persistent workgroups per pass; default = the device's CU count),
  *   "chain" (1, default: a Horner chain over two pure X-string groups finishes one application and starts the next in one pass),
  *   "reverse_chain" (1, default: so does the reverse sweep, overlaps of both stages included),
+ *   "interleave_groups" (set before dq_sctx_set_terms; 2, default: two groups of single-qubit flips get the qubits in turn, so that
+ *                    both tiles touch few 2 MB regions; 0: low qubits to one group, high qubits to the other),
  *   "fuse_overlaps" (1: the reverse-mode apply pass of a group also forms that group's control overlaps, in every kernel form;
  *                    0, default: only in the DMA form, where it costs no occupancy; -1: never).
  * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "pass_bytes", "prof_ms", "prof_bytes", "prof_launches", "dtype" */

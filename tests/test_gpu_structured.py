@@ -254,3 +254,25 @@ def test_plan_steps_sets_the_stride_of_a_longer_chain():
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("checkpoint_stride") == 4 and e.info("passes") > p0  # the states in between are rebuilt by reversal
     assert np.array_equal(f0, f1) and abs(l0 - l1) < 2e-5 * B and np.max(np.abs(g0 - g1)) < 2e-5 * B
+
+
+@pytest.mark.parametrize("dtype,n,B,tol", [("c128", 10, 6, 1e-11), ("c64", 11, 32, 2e-5)])
+def test_group_interleaving_changes_the_tiling_not_the_numbers(dtype, n, B, tol):
+    """`interleave_groups` (set before set_terms): which qubits are local to which of the two string groups is a tiling decision."""
+    K, S, dt = n, 4, 0.02
+    terms = ising_x_terms(n, seed=5)
+    u = problems.pulse_table(K, S, S * dt, seed=1)
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    if dtype == "c64":
+        psi0 = psi0.astype(np.complex64)
+    res = []
+    for v in (0, 1, 2, 3):
+        with StructuredEngine(n, K, dtype=dtype) as e:
+            e.set_option("interleave_groups", v)
+            e.set_terms(terms)
+            assert e.info("groups") == 2
+            res.append(e.energy_grad(u, dt, psi0))
+    l0, g0, f0, _ = res[0]
+    for l, g, f, _ in res[1:]:
+        assert abs(l - l0) <= tol * B and np.max(np.abs(g - g0)) < tol * B and np.max(np.abs(f - f0)) < tol
+    assert np.max(np.abs(g0)) > 1e-3
