@@ -313,18 +313,19 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
 constexpr int SD_P = 9, SD_ROWS = 1 << SD_P, SD_RSTEP = 128, SD_RPT = SD_ROWS / SD_RSTEP;  // 1024 threads = 128 rows x 8 column pairs; 4 rows per thread
 static_assert(STHREADS == 1024 && SBC == 16, "the DMA forms assume 1024 threads and 16 batch columns per tile");
 
-// tile units.  Chunk-fastest by default: the workgroups that run at the same time then cover whole rows (contiguous B * 8 bytes) of a
-// few tiles, not the same 128-byte column chunk of 256 tiles (2-unit pass at B = 512: 621 -> 554 us).  Groups with high local bits (a
-// tile's rows lie 2^k rows apart) and narrow batches (rows under 2 KB) walk tile-fastest instead: neighbouring tiles are neighbouring
-// rows of the same regions, which the concurrent workgroups then share (B = 64: 316 -> 322 steps/s; B = 512: 36.3 -> 34.6, hence the
-// width condition).
+// tile units.  A group whose local bits are exactly the low row bits (a tile = 2^9 consecutive rows) walks chunk-fastest: the workgroups
+// that run at the same time then cover whole rows of a few tiles, not the same 128-byte column chunk of 256 tiles (2-unit pass at
+// B = 512: 621 -> 554 us).  Every other group (rows of a tile spread out; the interleaved groups of Ising-type inputs) walks
+// tile-fastest: neighbouring tiles are neighbouring rows of the same regions, which the concurrent workgroups then share
+// (n = 18, interleaved groups, ms per step at B = 512 / 64: tile-fastest 23.6 / 3.07, chunk-fastest 24.6 / 3.23).
 struct SDmaWalk {
   unsigned nchunks, nunits, ntiles, tile_fast;
   __host__ __device__ unsigned tile(unsigned u) const { return tile_fast ? u % ntiles : u / nchunks; }
   __host__ __device__ unsigned chunk(unsigned u) const { return tile_fast ? u / ntiles : u % nchunks; }
 };
 inline SDmaWalk sdma_walk(unsigned ntiles, unsigned nchunks, unsigned lmask) {
-  return SDmaWalk{nchunks, ntiles * nchunks, ntiles, ((lmask & 1u) == 0 && nchunks < 16) ? 1u : 0u};
+  const bool low_block = (lmask & (lmask + 1u)) == 0;   // the local bits are exactly the low row bits: a tile = consecutive rows
+  return SDmaWalk{nchunks, ntiles * nchunks, ntiles, low_block ? 0u : 1u};
 }
 
 // Register operands of a tile (prev / add / acc rows, diagonal entries) are requested by inline asm as well: vmcnt counts in issue
