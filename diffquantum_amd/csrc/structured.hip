@@ -336,6 +336,9 @@ inline SDmaWalk sdma_walk(unsigned ntiles, unsigned nchunks, unsigned lmask) {
 typedef float sd_f4 __attribute__((ext_vector_type(4)));
 #define S_GLOAD16(dst_, base_, off_) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst_) : "v"(off_), "s"(base_) : "memory")
 #define S_GLOAD4(dst_, base_, off_) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(dst_) : "v"(off_), "s"(base_) : "memory")
+// S_PIN: for the compiler the asm load DEFINES its destination at issue; the empty asm after the vmcnt wait makes every use depend
+// on the wait.  Between the two the registers must stay where they are: the kernels below are kept free of VGPR spills (hipcc
+// -Rpass-analysis=kernel-resource-usage: ScratchSize 0 for every sapply_dma / schain / srchain instance that is launched).
 #define S_PIN(x_) asm volatile("" : "+v"(x_))
 
 // SIMPLE: every string of the group is a pure X-string (no Z factor: no row-dependent sign, real coefficient) and there are at most
