@@ -1207,6 +1207,10 @@ struct SCtx : dq_sctx {
   double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0, last_dma_passes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
+  int two_level = 1;      // 1: when the states of a chain do not all fit, keep every s-th and rebuild a segment at a time WITH its Horner iterates (below)
+  double last_two_level = 0;
+  std::vector<SBuf> segpsi;
+  std::vector<std::vector<SBuf>> segz;
   int plan_steps = 0;     // checkpoint stride as for a chain of this many steps (a timed slice of a long chain then pays the long chain's reversals)
   int interleave_groups = 2;  // v > 0: two groups of single-qubit flips share the low and the high qubits (set before dq_sctx_set_terms)
   int reverse_chain = 1;  // 1: the reverse sweep in the chain form too (srchain_dma_kernel) when chain applies and the overlaps are fused
@@ -1796,10 +1800,23 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     SHIP(hipMemGetInfo(&fr, &tot));
     double held = 0.0;
     for (const auto& b : c->ck) held += (double)b.bytes;
+    for (const auto& b : c->segpsi) held += (double)b.bytes;
+    for (const auto& v : c->segz) for (const auto& b : v) held += (double)b.bytes;
     budget = 0.70 * ((double)fr + held);
   }
   const long ncp_max = std::max(1L, (long)(budget / (double)sb));
-  const int cstride = (int)std::max(1L, ((long)std::max(S, c->plan_steps) + ncp_max - 1) / ncp_max);
+  const long Splan = std::max(S, c->plan_steps);
+  int cstride = (int)std::max(1L, (Splan + ncp_max - 1) / ncp_max);
+  // Two levels.  With stride > 1 a step's psi_t costs a reversal chain (5m + 1 state-units) and its Horner iterates another chain
+  // (5m - 4).  Where memory allows, keep every s-th state instead and, a segment at a time, recompute the segment forward once
+  // WITH the iterates of every step stored (m states per step): the recomputation costs what the reversal did, the iterates chain
+  // is gone (n = 18, m = 5: 113 -> 92 units per step).  s = sqrt(steps / m) minimises the memory: steps / s + m s states.
+  bool two_level = false;
+  if (c->two_level && cstride > 1 && m >= 2) {
+    const long s2 = std::max(2L, (long)std::lround(std::sqrt((double)Splan / m)));
+    if ((Splan + s2 - 1) / s2 + (long)m * s2 <= ncp_max) { two_level = true; cstride = (int)s2; }
+  }
+  c->last_two_level = two_level ? 1 : 0;
   const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
   c->last_cstride = cstride;
   if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
@@ -1824,35 +1841,8 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
 
   // ---- backward ----
   int lcur = 0;
-  for (int t = S - 1; t >= 0; --t) {
-    step_coefficients(c, t);
-    // psi_t: checkpoint, or T_m(-A_t) psi_{t+1}
-    const T2* psi_t;
-    if (t % cstride == 0) psi_t = (const T2*)c->ck[t / cstride].p;
-    else {
-      taylor_apply(c, m, dt, -1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
-      cur ^= 1;
-      psi_t = (const T2*)c->psi[cur].p;
-    }
-    // Horner iterates z_m = psi_t, ..., z_1 (z_0 = psi_{t+1} is not needed)
-    std::vector<const T2*> z(m + 1);
-    z[m] = psi_t;
-    if (m >= 2 && chain_ok(c, B)) {
-      taylor_chain<T>(c, m, 2, dt, 1.0, psi_t, psi_t, B, [&](int jm1) -> T2* {
-        c->zs[jm1].ensure(sb);
-        z[jm1] = (const T2*)c->zs[jm1].p;
-        return (T2*)c->zs[jm1].p;
-      });
-    } else {
-      const T2* zj = psi_t;
-      for (int j = m; j >= 2; --j) {
-        c->zs[j - 1].ensure(sb);
-        T2* dst = (T2*)c->zs[j - 1].p;
-        apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, psi_t, dst, (T2*)nullptr, 0.0, -dt / j, B);
-        z[j - 1] = dst;
-        zj = dst;
-      }
-    }
+  // the reverse sweep of step t: lambda_{t+1} -> lambda_t and dL/du[t]; z[m] = psi_t, z[j] its Horner iterates
+  auto reverse_step = [&](int t, const std::vector<const T2*>& z) {
     // reverse: zbar_0 = lambda_{t+1}; lambda_t = sum_j zbar_j; overlaps <zbar_{j-1}, P z_j>
     T2* lam_new = (T2*)c->lam[lcur ^ 1].p;   // = lambda_{t+1} + zbar_1 + ... + zbar_m: the first term reads lambda_{t+1} where it is
     if (m < 1) SHIP(hipMemcpyAsync(lam_new, c->lam[lcur].p, sb, hipMemcpyDeviceToDevice, c->st));
@@ -1924,6 +1914,74 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       zb_prev = zb_new;
     }
     lcur ^= 1;
+  };
+  if (two_level) {
+    if ((int)c->segpsi.size() < cstride) c->segpsi.resize(cstride);
+    if ((int)c->segz.size() < cstride) c->segz.resize(cstride);
+    for (int seg = ncp - 1; seg >= 0; --seg) {
+      const int t0 = seg * cstride, t1 = std::min(S, t0 + cstride);
+      auto psi_of = [&](int t) -> T2* { return t == t0 ? (T2*)c->ck[seg].p : (T2*)c->segpsi[t - t0].p; };
+      for (int t = t0; t < t1; ++t) {  // the segment once more, iterates kept (the last step needs no psi_{t1}: iterates only)
+        auto& zs = c->segz[t - t0];
+        if ((int)zs.size() < m + 1) zs.resize(m + 1);
+        step_coefficients(c, t);
+        if (t + 1 < t1) {
+          c->segpsi[t + 1 - t0].ensure(sb);
+          taylor_apply(c, m, dt, 1.0, (const T2*)psi_of(t), psi_of(t + 1), B, &zs);
+        } else if (chain_ok(c, B)) {
+          taylor_chain<T>(c, m, 2, dt, 1.0, (const T2*)psi_of(t), (const T2*)psi_of(t), B, [&](int jm1) -> T2* {
+            zs[jm1].ensure(sb);
+            return (T2*)zs[jm1].p;
+          });
+        } else {
+          const T2* zj = psi_of(t);
+          for (int j = m; j >= 2; --j) {
+            zs[j - 1].ensure(sb);
+            apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, (const T2*)psi_of(t), (T2*)zs[j - 1].p, (T2*)nullptr, 0.0,
+                         -dt / j, B);
+            zj = (const T2*)zs[j - 1].p;
+          }
+        }
+      }
+      for (int t = t1 - 1; t >= t0; --t) {
+        step_coefficients(c, t);
+        std::vector<const T2*> z(m + 1);
+        z[m] = psi_of(t);
+        for (int j = 1; j < m; ++j) z[j] = (const T2*)c->segz[t - t0][j].p;
+        reverse_step(t, z);
+      }
+    }
+  }
+  for (int t = S - 1; t >= 0 && !two_level; --t) {
+    step_coefficients(c, t);
+    // psi_t: checkpoint, or T_m(-A_t) psi_{t+1}
+    const T2* psi_t;
+    if (t % cstride == 0) psi_t = (const T2*)c->ck[t / cstride].p;
+    else {
+      taylor_apply(c, m, dt, -1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
+      cur ^= 1;
+      psi_t = (const T2*)c->psi[cur].p;
+    }
+    // Horner iterates z_m = psi_t, ..., z_1 (z_0 = psi_{t+1} is not needed)
+    std::vector<const T2*> z(m + 1);
+    z[m] = psi_t;
+    if (m >= 2 && chain_ok(c, B)) {
+      taylor_chain<T>(c, m, 2, dt, 1.0, psi_t, psi_t, B, [&](int jm1) -> T2* {
+        c->zs[jm1].ensure(sb);
+        z[jm1] = (const T2*)c->zs[jm1].p;
+        return (T2*)c->zs[jm1].p;
+      });
+    } else {
+      const T2* zj = psi_t;
+      for (int j = m; j >= 2; --j) {
+        c->zs[j - 1].ensure(sb);
+        T2* dst = (T2*)c->zs[j - 1].p;
+        apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, psi_t, dst, (T2*)nullptr, 0.0, -dt / j, B);
+        z[j - 1] = dst;
+        zj = dst;
+      }
+    }
+    reverse_step(t, z);
     if (t % cstride == 0 && t > 0) {
       // next iteration rebuilds psi_{t-1} from psi_t = this checkpoint
       SHIP(hipMemcpyAsync(c->psi[cur].p, c->ck[t / cstride].p, sb, hipMemcpyDeviceToDevice, c->st));
@@ -2000,6 +2058,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     if (s == "tol") { if (!(v > 0)) sfail(DQ_ERR_INVALID, "tol must be > 0"); t->tol = v; }
     else if (s == "force_degree") t->force_degree = (int)v;
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
+    else if (s == "two_level") t->two_level = v != 0 ? 1 : 0;
     else if (s == "chain") t->chain = v != 0 ? 1 : 0;
     else if (s == "reverse_chain") t->reverse_chain = v != 0 ? 1 : 0;
     else if (s == "interleave_groups") t->interleave_groups = v > 0 ? (int)v : 0;
@@ -2022,6 +2081,7 @@ int dq_sctx_get_info(dq_sctx* c, const char* name, double* v) {
     else if (s == "checkpoint_stride") *v = t->last_cstride;
     else if (s == "passes") *v = t->last_passes;
     else if (s == "dma_passes") *v = t->last_dma_passes;
+    else if (s == "two_level") *v = t->last_two_level;
     else if (s == "pass_bytes") *v = t->last_bytes;
     else if (s == "prof_ms") { t->collect(); *v = t->prof_ms; }
     else if (s == "prof_bytes") { t->collect(); *v = t->prof_bytes; }

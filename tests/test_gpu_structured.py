@@ -276,3 +276,34 @@ def test_group_interleaving_changes_the_tiling_not_the_numbers(dtype, n, B, tol)
     for l, g, f, _ in res[1:]:
         assert abs(l - l0) <= tol * B and np.max(np.abs(g - g0)) < tol * B and np.max(np.abs(f - f0)) < tol
     assert np.max(np.abs(g0)) > 1e-3
+
+
+@pytest.mark.parametrize("dtype,B,tol", [("c128", 6, 1e-11), ("c64", 16, 2e-5)])
+def test_two_level_checkpoints(dtype, B, tol):
+    """When the states of a chain do not all fit but steps / s + m s of them do, every s-th state is kept and a segment at a time is
+    recomputed forward WITH the Horner iterates of its steps stored: no reversal chain, no separate iterates chain."""
+    n, K, S, dt = 10, 10, 120, 0.01
+    terms = ising_x_terms(n, seed=11)
+    u = problems.pulse_table(K, S, S * dt, seed=1)
+    psi0 = problems.random_states(1 << n, B, seed=2)
+    if dtype == "c64":
+        psi0 = psi0.astype(np.complex64)
+    sb = (1 << n) * B * (16 if dtype == "c128" else 8)
+    with StructuredEngine(n, K, dtype=dtype) as e:
+        e.set_terms(terms)
+        la, ga, fa, _ = e.energy_grad(u, dt, psi0)                 # everything fits: a checkpoint per step
+        assert e.info("checkpoint_stride") == 1 and e.info("two_level") == 0
+        m = int(e.info("degree"))
+        s2 = max(2, round((S / m) ** 0.5))
+        need = -(-S // s2) + m * s2                                 # kept states + one segment with its iterates
+        assert need + 1 < S
+        e.set_option("checkpoint_bytes", sb * (need + 1))
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("two_level") == 1 and e.info("checkpoint_stride") == s2
+        p1 = e.info("passes")
+        e.set_option("two_level", 0)
+        l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("two_level") == 0 and e.info("checkpoint_stride") == -(-S // (need + 1)) and e.info("passes") > p1
+    for l, g, f in ((l1, g1, f1), (l0, g0, f0)):
+        assert abs(l - la) <= tol * B and np.max(np.abs(g - ga)) < tol * B and np.max(np.abs(f - fa)) < tol
+    assert np.max(np.abs(ga)) > 1e-3
