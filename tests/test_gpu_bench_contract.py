@@ -189,4 +189,4 @@ def test_graft_entry_smoke():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.count("smoke ok") == 6
+    assert out.stdout.count("smoke ok") == 7
