@@ -340,6 +340,12 @@ typedef float sd_f4 __attribute__((ext_vector_type(4)));
 // on the wait.  Between the two the registers must stay where they are: the kernels below are kept free of VGPR spills (hipcc
 // -Rpass-analysis=kernel-resource-usage: ScratchSize 0 for every sapply_dma / schain / srchain instance that is launched).
 #define S_PIN(x_) asm volatile("" : "+v"(x_))
+// (-DSD_NT_STORES: nontemporal stores; measured on one box: B = 64 2.69 against 2.74 ms per step, B = 512 no difference -- left off)
+#ifdef SD_NT_STORES
+#define S_STORE16(p_, v_) __builtin_nontemporal_store((v_), (sd_f4*)(p_))
+#else
+#define S_STORE16(p_, v_) (*(sd_f4*)(p_) = (v_))
+#endif
 
 // SIMPLE: every string of the group is a pure X-string (no Z factor: no row-dependent sign, real coefficient) and there are at most
 // SD_SIMPLE_T of them -- offsets and coefficients sit in scalar registers, a gather is one v_xor + ds_read_b128 + two packed FMAs
@@ -501,8 +507,8 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
       o.x = a.sr * w.x - a.si * w.y; o.y = a.sr * w.y + a.si * w.x;
       o.z = a.sr * w.z - a.si * w.w; o.w = a.sr * w.w + a.si * w.z;
       if (HAS_ADD) o += ad[q];
-      *(sd_f4*)((unsigned char*)a.out + off) = o;
-      if (HAS_ACC) *(sd_f4*)((unsigned char*)a.acc + off) = ac[q] + o;
+      S_STORE16((unsigned char*)a.out + off, o);
+      if (HAS_ACC) S_STORE16((unsigned char*)a.acc + off, ac[q] + o);
     }
   }
   if (OVL) {  // one sum per wave and string over ALL tiles of the workgroup; soverlap_finish_kernel adds them in a fixed order
@@ -613,7 +619,7 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
       const sd_f4 w = s[q] + pv[q];
       z[q].x = a.sr * w.x - a.si * w.y + ad[q].x; z[q].y = a.sr * w.y + a.si * w.x + ad[q].y;
       z[q].z = a.sr * w.z - a.si * w.w + ad[q].z; z[q].w = a.sr * w.w + a.si * w.z + ad[q].w;
-      *(sd_f4*)((unsigned char*)a.out + off) = z[q];
+      S_STORE16((unsigned char*)a.out + off, z[q]);
     }
     // every wave is done with the rows of y: the tile becomes z' in place (LDS-only waits: the DMA and the stores stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -624,7 +630,7 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      *(sd_f4*)((unsigned char*)a.out2 + off) = s[q] + dg[q] * z[q];
+      S_STORE16((unsigned char*)a.out2 + off, s[q] + dg[q] * z[q]);
     }
   }
 }
@@ -740,8 +746,8 @@ __global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, 
       const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
       z[q].x = a.sr * s[q].x - a.si * s[q].y; z[q].y = a.sr * s[q].y + a.si * s[q].x;
       z[q].z = a.sr * s[q].z - a.si * s[q].w; z[q].w = a.sr * s[q].w + a.si * s[q].z;
-      *(sd_f4*)((unsigned char*)a.out + off) = z[q];
-      *(sd_f4*)((unsigned char*)a.acc + off) = ac[q] + z[q];
+      S_STORE16((unsigned char*)a.out + off, z[q]);
+      S_STORE16((unsigned char*)a.acc + off, ac[q] + z[q]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
@@ -772,7 +778,7 @@ __global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, 
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      *(sd_f4*)((unsigned char*)a.out2 + off) = s[q];
+      S_STORE16((unsigned char*)a.out2 + off, s[q]);
     }
   }
   const int lane = threadIdx.x & 63;
