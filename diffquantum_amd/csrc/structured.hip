@@ -1633,20 +1633,26 @@ void chain_pass(SCtx<T>* c, int g, int which, const typename SCtx<T>::T2* y, con
   c->last_bytes += units * sb;
 }
 
-// z_{j-1} = in + (0, -sign dt / j) H z_j  for j = jhi .. jlo  (z_jhi = zhi); dst(j - 1) names where z_{j-1} goes
+// A chain may hand its last tile walk to the chain that follows on its result: the finishing pass then also STARTS that chain
+// (out2 = D z + H_g z on the group g it is on, in tmp[pb]) -- the reversal of psi_t hands over to the chain of psi_t's Horner iterates.
+struct ChainLink { int g = 0, pb = 0; bool set = false; };
+
+// z_{j-1} = in + (0, -sign dt / j) H z_j  for j = jhi .. jlo  (z_jhi = zhi); dst(j - 1) names where z_{j-1} goes.
+// from: the start of this chain was done by the chain before (zhi = its result); to: start the next chain in this one's last pass.
 template <class T, class Dst>
 void taylor_chain(SCtx<T>* c, int jhi, int jlo, double dt, double sign, const typename SCtx<T>::T2* in,
-                  const typename SCtx<T>::T2* zhi, int B, Dst dst) {
+                  const typename SCtx<T>::T2* zhi, int B, Dst dst, const ChainLink* from = nullptr, ChainLink* to = nullptr) {
   typedef typename SCtx<T>::T2 T2;
   const size_t sb = c->state_bytes(B);
   c->tmp[0].ensure(sb); c->tmp[1].ensure(sb);
   int g = 0, pb = 0;
-  chain_pass<T>(c, g, 0, zhi, nullptr, nullptr, (T2*)c->tmp[pb].p, nullptr, 1.0, 0.0, B);
+  if (from && from->set) { g = from->g; pb = from->pb; }
+  else chain_pass<T>(c, g, 0, zhi, nullptr, nullptr, (T2*)c->tmp[pb].p, nullptr, 1.0, 0.0, B);
   const T2* zj = zhi;
   for (int j = jhi; j >= jlo; --j) {
     g ^= 1;  // the application is finished on the other group ...
     T2* znew = dst(j - 1);
-    if (j > jlo) {  // ... which also starts the next one
+    if (j > jlo || to) {  // ... which also starts the next one (of this chain, or of the chain that follows)
       chain_pass<T>(c, g, 1, zj, (const T2*)c->tmp[pb].p, in, znew, (T2*)c->tmp[pb ^ 1].p, 0.0, -sign * dt / j, B);
       pb ^= 1;
     } else {
@@ -1654,6 +1660,7 @@ void taylor_chain(SCtx<T>* c, int jhi, int jlo, double dt, double sign, const ty
     }
     zj = znew;
   }
+  if (to) { to->g = g; to->pb = pb; to->set = true; }
 }
 
 // The reverse sweep of one step in the chain form (srchain_dma_kernel): lambda_new = lambda_old + sum_j zbar_j and the control
@@ -1720,7 +1727,7 @@ void reverse_chain(SCtx<T>* c, int m, double dt, int B, const std::vector<const 
 // z_out = T_m(sign * A_t) z_in  (Horner); if zs_store != null keeps the iterates z_m..z_1 there (z_j in zs_store[j])
 template <class T>
 void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx<T>::T2* in, typename SCtx<T>::T2* out,
-                  int B, std::vector<SBuf>* store) {
+                  int B, std::vector<SBuf>* store, ChainLink* to = nullptr) {
   typedef typename SCtx<T>::T2 T2;
   const size_t sb = c->state_bytes(B);
   // z_m = in;  z_{j-1} = in + (A z_j)/j,  A = -i dt H * sign  ->  scale = (0, -sign*dt/j)
@@ -1730,7 +1737,7 @@ void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx
       if (store) { (*store)[jm1].ensure(sb); return (T2*)(*store)[jm1].p; }
       c->zbar[(jm1 + 1) & 1].ensure(sb);
       return (T2*)c->zbar[(jm1 + 1) & 1].p;
-    });
+    }, nullptr, to);
     return;
   }
   const T2* zj = in;
@@ -1962,9 +1969,11 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     step_coefficients(c, t);
     // psi_t: checkpoint, or T_m(-A_t) psi_{t+1}
     const T2* psi_t;
+    ChainLink handover;
     if (t % cstride == 0) psi_t = (const T2*)c->ck[t / cstride].p;
     else {
-      taylor_apply(c, m, dt, -1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
+      // (in the chain form the reversal's last pass also starts the chain of psi_t's Horner iterates: one tile walk less)
+      taylor_apply(c, m, dt, -1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr, m >= 2 ? &handover : nullptr);
       cur ^= 1;
       psi_t = (const T2*)c->psi[cur].p;
     }
@@ -1976,7 +1985,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         c->zs[jm1].ensure(sb);
         z[jm1] = (const T2*)c->zs[jm1].p;
         return (T2*)c->zs[jm1].p;
-      });
+      }, &handover);
     } else {
       const T2* zj = psi_t;
       for (int j = m; j >= 2; --j) {
