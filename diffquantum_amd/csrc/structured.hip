@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -62,6 +63,43 @@ struct SBuf {
     bytes = n;
   }
 };
+
+struct SHostBuf {  // pinned host memory (checkpoints of the first level when the HBM has room for one segment only)
+  void* p = nullptr;
+  size_t bytes = 0;
+  SHostBuf() = default;
+  SHostBuf(const SHostBuf&) = delete;
+  SHostBuf& operator=(const SHostBuf&) = delete;
+  SHostBuf(SHostBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  ~SHostBuf() { if (p) (void)hipHostFree(p); }
+  bool ensure(size_t n) {  // false (and no exception) when the host will not pin that much
+    if (n <= bytes) return true;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; bytes = 0;
+    if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+    bytes = n;
+    return true;
+  }
+};
+
+// how much host memory the first-level checkpoints may pin: 60 % of what this process may still use (cgroup limit or MemAvailable)
+double s_host_budget() {
+  double lim = 1e30;
+  for (const char* f : {"/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"}) {
+    if (FILE* fp = fopen(f, "r")) {
+      double v = 0;
+      if (fscanf(fp, "%lf", &v) == 1 && v > 0) lim = std::min(lim, v);
+      fclose(fp);
+    }
+  }
+  if (FILE* fp = fopen("/proc/meminfo", "r")) {
+    char key[64]; double kb = 0; char unit[16];
+    while (fscanf(fp, "%63s %lf %15s", key, &kb, unit) >= 2)
+      if (strcmp(key, "MemAvailable:") == 0) { lim = std::min(lim, kb * 1024.0); break; }
+    fclose(fp);
+  }
+  return lim > 1e29 ? 0.0 : 0.6 * lim;
+}
 
 bool s_is_device_ptr(const void* p) {
   if (!p) return false;
@@ -1213,6 +1251,9 @@ struct SCtx : dq_sctx {
   double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0, last_dma_passes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
+  int host_checkpoints = 1;  // 1: the kept states of the two-level plan may live in pinned host memory when the HBM holds one segment only
+  double last_host_ck = 0;
+  std::vector<SHostBuf> ckh;
   int two_level = 1;      // 1: when the states of a chain do not all fit, keep every s-th and rebuild a segment at a time WITH its Horner iterates (below)
   double last_two_level = 0;
   std::vector<SBuf> segpsi;
@@ -1824,16 +1865,30 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   // (5m - 4).  Where memory allows, keep every s-th state instead and, a segment at a time, recompute the segment forward once
   // WITH the iterates of every step stored (m states per step): the recomputation costs what the reversal did, the iterates chain
   // is gone (n = 18, m = 5: 113 -> 92 units per step).  s = sqrt(steps / m) minimises the memory: steps / s + m s states.
-  bool two_level = false;
+  bool two_level = false, host_ck = false;
   if (c->two_level && cstride > 1 && m >= 2) {
     const long s2 = std::max(2L, (long)std::lround(std::sqrt((double)Splan / m)));
     if ((Splan + s2 - 1) / s2 + (long)m * s2 <= ncp_max) { two_level = true; cstride = (int)s2; }
+    else if (c->host_checkpoints && (long)m * s2 + 1 <= ncp_max) {
+      // the segment fits, the kept states do not: they go to pinned host memory (one state down per s steps on the way forward,
+      // one up per segment on the way back: 1 / s of a step's traffic over the host link) -- if the host pins that much
+      const int need = S > 0 ? (S + (int)s2 - 1) / (int)s2 : 0;
+      if ((int)c->ckh.size() < need) c->ckh.resize(need);
+      double pinned = 0.0;
+      for (const auto& b : c->ckh) pinned += (double)b.bytes;
+      bool ok = (double)need * (double)sb <= s_host_budget() + pinned;
+      for (int i = 0; i < need && ok; ++i) ok = c->ckh[i].ensure(sb);
+      if (ok) { two_level = true; host_ck = true; cstride = (int)s2; }
+    }
   }
   c->last_two_level = two_level ? 1 : 0;
+  c->last_host_ck = host_ck ? 1 : 0;
   const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
   c->last_cstride = cstride;
-  if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
-  for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
+  if (!host_ck) {
+    if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
+    for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
+  }
   c->psi[0].ensure(sb); c->psi[1].ensure(sb); c->lam[0].ensure(sb); c->lam[1].ensure(sb);
   if ((int)c->zs.size() < m + 1) c->zs.resize(m + 1);
   c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * 8);
@@ -1844,7 +1899,10 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   SHIP(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
   int cur = 0;
   for (int t = 0; t < S; ++t) {
-    if (t % cstride == 0) SHIP(hipMemcpyAsync(c->ck[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToDevice, c->st));
+    if (t % cstride == 0) {
+      if (host_ck) SHIP(hipMemcpyAsync(c->ckh[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToHost, c->st));
+      else SHIP(hipMemcpyAsync(c->ck[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToDevice, c->st));
+    }
     step_coefficients(c, t);
     taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
     cur ^= 1;
@@ -1933,7 +1991,11 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
     if ((int)c->segz.size() < cstride) c->segz.resize(cstride);
     for (int seg = ncp - 1; seg >= 0; --seg) {
       const int t0 = seg * cstride, t1 = std::min(S, t0 + cstride);
-      auto psi_of = [&](int t) -> T2* { return t == t0 ? (T2*)c->ck[seg].p : (T2*)c->segpsi[t - t0].p; };
+      if (host_ck) {  // the segment's first state comes back up
+        c->segpsi[0].ensure(sb);
+        SHIP(hipMemcpyAsync(c->segpsi[0].p, c->ckh[seg].p, sb, hipMemcpyHostToDevice, c->st));
+      }
+      auto psi_of = [&](int t) -> T2* { return (t == t0 && !host_ck) ? (T2*)c->ck[seg].p : (T2*)c->segpsi[t - t0].p; };
       for (int t = t0; t < t1; ++t) {  // the segment once more, iterates kept (the last step needs no psi_{t1}: iterates only)
         auto& zs = c->segz[t - t0];
         if ((int)zs.size() < m + 1) zs.resize(m + 1);
@@ -2074,6 +2136,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     else if (s == "force_degree") t->force_degree = (int)v;
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
     else if (s == "two_level") t->two_level = v != 0 ? 1 : 0;
+    else if (s == "host_checkpoints") t->host_checkpoints = v != 0 ? 1 : 0;
     else if (s == "chain") t->chain = v != 0 ? 1 : 0;
     else if (s == "reverse_chain") t->reverse_chain = v != 0 ? 1 : 0;
     else if (s == "interleave_groups") t->interleave_groups = v > 0 ? (int)v : 0;
@@ -2097,6 +2160,7 @@ int dq_sctx_get_info(dq_sctx* c, const char* name, double* v) {
     else if (s == "passes") *v = t->last_passes;
     else if (s == "dma_passes") *v = t->last_dma_passes;
     else if (s == "two_level") *v = t->last_two_level;
+    else if (s == "host_checkpoints") *v = t->last_host_ck;
     else if (s == "pass_bytes") *v = t->last_bytes;
     else if (s == "prof_ms") { t->collect(); *v = t->prof_ms; }
     else if (s == "prof_bytes") { t->collect(); *v = t->prof_bytes; }

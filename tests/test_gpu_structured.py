@@ -301,9 +301,17 @@ def test_two_level_checkpoints(dtype, B, tol):
         l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
         assert e.info("two_level") == 1 and e.info("checkpoint_stride") == s2
         p1 = e.info("passes")
+        assert e.info("host_checkpoints") == 0
+        e.set_option("checkpoint_bytes", sb * (m * s2 + 2))          # room for one segment, not for the kept states: those go to the host
+        l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("two_level") == 1 and e.info("host_checkpoints") == 1 and e.info("checkpoint_stride") == s2 and e.info("passes") == p1
+        e.set_option("host_checkpoints", 0)
+        l3, g3, f3, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("two_level") == 0 and e.info("checkpoint_stride") == -(-S // (m * s2 + 2))
+        e.set_option("checkpoint_bytes", sb * (need + 1))
         e.set_option("two_level", 0)
         l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
         assert e.info("two_level") == 0 and e.info("checkpoint_stride") == -(-S // (need + 1)) and e.info("passes") > p1
-    for l, g, f in ((l1, g1, f1), (l0, g0, f0)):
+    for l, g, f in ((l1, g1, f1), (l2, g2, f2), (l3, g3, f3), (l0, g0, f0)):
         assert abs(l - la) <= tol * B and np.max(np.abs(g - ga)) < tol * B and np.max(np.abs(f - fa)) < tol
     assert np.max(np.abs(ga)) > 1e-3
