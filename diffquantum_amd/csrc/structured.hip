@@ -1275,8 +1275,22 @@ struct SCtx : dq_sctx {
     dtype = sizeof(T) == 8 ? DQ_C128 : DQ_C64;
     tol = sizeof(T) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-08;
   }
+  // host checkpoints move on a stream of their own: down from a staged copy while the chain goes on, up one segment ahead
+  hipStream_t copy_st = nullptr;
+  hipEvent_t ev_staged = nullptr, ev_down = nullptr, ev_up = nullptr, ev_used = nullptr;
+  SBuf stage;
+  void copy_stream_ready() {
+    if (copy_st) return;
+    SHIP(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&ev_staged, &ev_down, &ev_up, &ev_used}) SHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
   ~SCtx() override {
     for (auto& r : recs) { (void)hipEventDestroy(r.first); (void)hipEventDestroy(r.second); }
+    if (copy_st) {
+      (void)hipStreamSynchronize(copy_st);
+      for (hipEvent_t e : {ev_staged, ev_down, ev_up, ev_used}) if (e) (void)hipEventDestroy(e);
+      (void)hipStreamDestroy(copy_st);
+    }
   }
   size_t state_bytes(int B) const { return (size_t)d * B * sizeof(T2); }
 
@@ -1878,7 +1892,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       for (const auto& b : c->ckh) pinned += (double)b.bytes;
       bool ok = (double)need * (double)sb <= s_host_budget() + pinned;
       for (int i = 0; i < need && ok; ++i) ok = c->ckh[i].ensure(sb);
-      if (ok) { two_level = true; host_ck = true; cstride = (int)s2; }
+      if (ok) { two_level = true; host_ck = true; cstride = (int)s2; c->copy_stream_ready(); c->stage.ensure(sb); }
     }
   }
   c->last_two_level = two_level ? 1 : 0;
@@ -1900,8 +1914,14 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   int cur = 0;
   for (int t = 0; t < S; ++t) {
     if (t % cstride == 0) {
-      if (host_ck) SHIP(hipMemcpyAsync(c->ckh[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToHost, c->st));
-      else SHIP(hipMemcpyAsync(c->ck[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToDevice, c->st));
+      if (host_ck) {  // snapshot on the chain's stream (a device copy), the way down on the copy stream behind it
+        if (t > 0) SHIP(hipStreamWaitEvent(c->st, c->ev_down, 0));               // the previous state has left the staging buffer
+        SHIP(hipMemcpyAsync(c->stage.p, c->psi[cur].p, sb, hipMemcpyDeviceToDevice, c->st));
+        SHIP(hipEventRecord(c->ev_staged, c->st));
+        SHIP(hipStreamWaitEvent(c->copy_st, c->ev_staged, 0));
+        SHIP(hipMemcpyAsync(c->ckh[t / cstride].p, c->stage.p, sb, hipMemcpyDeviceToHost, c->copy_st));
+        SHIP(hipEventRecord(c->ev_down, c->copy_st));
+      } else SHIP(hipMemcpyAsync(c->ck[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToDevice, c->st));
     }
     step_coefficients(c, t);
     taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
@@ -1989,11 +2009,22 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   if (two_level) {
     if ((int)c->segpsi.size() < cstride) c->segpsi.resize(cstride);
     if ((int)c->segz.size() < cstride) c->segz.resize(cstride);
+    if (host_ck && ncp > 0) {  // the last segment's first state comes back up (behind the copies that went down: same stream)
+      SHIP(hipMemcpyAsync(c->stage.p, c->ckh[ncp - 1].p, sb, hipMemcpyHostToDevice, c->copy_st));
+      SHIP(hipEventRecord(c->ev_up, c->copy_st));
+    }
     for (int seg = ncp - 1; seg >= 0; --seg) {
       const int t0 = seg * cstride, t1 = std::min(S, t0 + cstride);
-      if (host_ck) {  // the segment's first state comes back up
+      if (host_ck) {  // take the state that was brought up, then let the one of the segment before follow while this one is worked on
         c->segpsi[0].ensure(sb);
-        SHIP(hipMemcpyAsync(c->segpsi[0].p, c->ckh[seg].p, sb, hipMemcpyHostToDevice, c->st));
+        SHIP(hipStreamWaitEvent(c->st, c->ev_up, 0));
+        SHIP(hipMemcpyAsync(c->segpsi[0].p, c->stage.p, sb, hipMemcpyDeviceToDevice, c->st));
+        SHIP(hipEventRecord(c->ev_used, c->st));
+        if (seg > 0) {
+          SHIP(hipStreamWaitEvent(c->copy_st, c->ev_used, 0));
+          SHIP(hipMemcpyAsync(c->stage.p, c->ckh[seg - 1].p, sb, hipMemcpyHostToDevice, c->copy_st));
+          SHIP(hipEventRecord(c->ev_up, c->copy_st));
+        }
       }
       auto psi_of = [&](int t) -> T2* { return (t == t0 && !host_ck) ? (T2*)c->ck[seg].p : (T2*)c->segpsi[t - t0].p; };
       for (int t = t0; t < t1; ++t) {  // the segment once more, iterates kept (the last step needs no psi_{t1}: iterates only)
