@@ -298,6 +298,19 @@ struct XsOrder {                   // the order in which the sweeps walk the tab
   int n0p1, n1p1, nlocp1[8];       // how many of each class have phase 1 (entries +-i c): every class is ordered phase 0 first
 };
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
+// Quadrature form of the adjoint sweep (xs_backward_q_kernel): a Gauss-Lobatto rule on [0, 1] with ni interior nodes.
+// c1[m][i] = s_i^m, c2[m][i] = -w_i s_i^m, w0 / w1 = minus the weights of the end points.
+constexpr int XS_LMAX = 24;   // largest Taylor degree of the state-column kernels
+constexpr int XS_NIMAX = 3;
+struct XsQuad {
+  int ni;
+  double w0, w1;
+  double c1[XS_LMAX + 1][XS_NIMAX], c2[XS_LMAX + 1][XS_NIMAX];
+};
+// the rule for a step of size theta (bound of ||A||): the fewest interior nodes whose error bound e (2 theta)^(2 ni + 2) stays below
+// tol (relative to ||dA_k|| ||lambda|| ||psi||); false when no rule the kernels are built for reaches it (ni_max <= XS_NIMAX)
+bool xs_quad_make(double theta, double tol, int ni_max, XsQuad* qd);
+bool xs_quad_supported(const XrTab& tab, int ni);  // the table / rule combinations xs_backward_q_kernel is instantiated for
 // variant: bit 0 = 1024 threads x 4 rows per workgroup at d = 4096 (default 512 x 8); bit 1 = prefetch of the next diagonal's partners
 int xs_blocks(int d, size_t elem, int B, int n_cu, int variant);   // workgroups of a launch over B columns
 int xs_waves(int d, int variant);
@@ -321,9 +334,9 @@ hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& 
 // psi: psi_S in, psi_0 out;  lam: lambda_S in, lambda_0 out;  grad[s][k] (+)= dL/du_k[s]
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
-                              int accumulate, int variant, hipStream_t st);
+                              int accumulate, int variant, const XsQuad* quad, hipStream_t st);  // quad != null: the quadrature form (park unused)
 hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
-                              int variant, hipStream_t st);
+                              int variant, const XsQuad* quad, hipStream_t st);
 
 }  // namespace dq

@@ -310,6 +310,11 @@ struct Ctx : dq_ctx {
   int xs_min_dim = 512;
   double xs_batch_ratio = 8.0;  // auto: batch <= ratio x dim (beyond it the operator form, whose cost does not grow with the batch, wins)
   double last_xs = 0;
+  // adjoint sweep of the state-column form: -1 auto / 1 = the quadrature form (xs_backward_q_kernel) whenever a rule the kernels are
+  // built for keeps its error bound below xs_quad_tol at this chain's theta, 0 = always the exact derivative of the polynomial
+  int xs_adjoint = -1;
+  double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
+  double last_xs_nodes = 0;                    // interior nodes of the rule the last adjoint sweep ran (0: the exact form)
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
   bool sparse_h = false;   // a CSR exists (controls, and the drift too if sparse_x)
@@ -1347,6 +1352,8 @@ struct XsLaunch {
   int L, nblk, lds_diag;
   long dgs_step;
   const dq::XrTab* tab;
+  bool quad_ok;      // the adjoint sweep runs the quadrature form with the rule `quad`
+  dq::XsQuad quad;
 };
 
 // per-call set-up: weights of every step, buffers
@@ -1363,8 +1370,11 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->xs_lam.ensure(sb);
   c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
   c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
+  x.quad_ok = false;
+  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, &x.quad) && dq::xs_quad_supported(*x.tab, x.quad.ni);
+  c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
   if (backward) {
-    c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
+    if (!x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
     c->xs_part.ensure(sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, S, x.nblk, *x.tab, c->xs_variant), 1));
   }
   const dq::XrTab tb = *x.tab;
@@ -1748,11 +1758,13 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
   }
   if (S > 0) {
     double fl, lb;
-    xs_book(c, x, (3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
+    // sweeps per step: the exact form runs 3 L - 1 (L of them with the pairings), the quadrature form 2 L (L with the pairings)
+    xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
     const dq::XrTab tb = *x.tab;
     c->timed(DQ_PROF_STATECOL_BWD, fl, lb, [&] {
       return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, L, x.nblk,
-                                    (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->xs_variant, c->st);
+                                    x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->xs_variant,
+                                    x.quad_ok ? &x.quad : nullptr, c->st);
     });
   }
   if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
@@ -2621,6 +2633,11 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "state_columns_variant") {  // bit 0: 1024 threads x 4 rows at dim 4096 (default 512 x 8); bit 1: prefetch of the next diagonal's partners in the forward kernel
     c->xs_variant = (int)v & 3;
+  } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
+    c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_quad_tol") {  // bound of the rule's error per step, relative to ||dA_k|| ||lambda|| ||psi||
+    if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_quad_tol must be > 0");
+    c->xs_quad_tol = v;
   } else if (s == "state_columns_batch_ratio") {  // auto: taken while batch <= ratio x dim
     if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_batch_ratio must be > 0");
     c->xs_batch_ratio = v;
@@ -2655,6 +2672,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "sparse_generator") return c->last_spx;
   if (s == "xor_regular") return c->last_xr;
   if (s == "state_columns") return c->last_xs;
+  if (s == "state_columns_quad_nodes") return c->last_xs_nodes;
   if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;

@@ -14,6 +14,7 @@
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 12, B = argc > 2 ? atoi(argv[2]) : 4096, S = argc > 3 ? atoi(argv[3]) : 20;
   const int L = argc > 4 ? atoi(argv[4]) : 7, variant = argc > 5 ? atoi(argv[5]) : 2;
+  const int forms = argc > 6 ? atoi(argv[6]) : 3;   // bit 0: the exact adjoint form, bit 1: the quadrature form
   const int d = 1 << n, K = n;
   dq::XrTab tab;
   memset(&tab, 0, sizeof(tab));
@@ -51,6 +52,11 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  dq::XsQuad quad;
+  if (!dq::xs_quad_make(0.04, 9.1e-13, 2, &quad)) { printf("no quadrature rule\n"); return 1; }
+  std::vector<double> g_exact((size_t)S * K), g_quad((size_t)S * K);
+  for (int form = 0; form < 2; ++form) {
+  if (!((forms >> form) & 1)) continue;
   for (int rep = 0; rep < 3; ++rep) {
     float msf = 0, msb = 0;
     CK(hipEventRecord(e0));
@@ -64,11 +70,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(dq::xs_stamps), zero, sizeof(zero)));
 #endif
     CK(hipEventRecord(e0));
-    CK(dq::xs_backward_launch(d_psi, d_lam, d, tab, d_wt, d_dgs, step, S, B, L, nblk, d_park, d_part, K, 1e-3, d_grad, 0, variant, nullptr));
+    CK(dq::xs_backward_launch(d_psi, d_lam, d, tab, d_wt, d_dgs, step, S, B, L, nblk, d_park, d_part, K, 1e-3, d_grad, 0, variant,
+                              form ? &quad : nullptr, nullptr));
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&msb, e0, e1));
-    printf("n=%d B=%d S=%d L=%d variant=%d nblk=%d: forward %.3f ms (%.4f ms/step)  backward %.3f ms (%.4f ms/step)\n", n, B, S, L, variant,
+    printf("%s n=%d B=%d S=%d L=%d variant=%d nblk=%d: forward %.3f ms (%.4f ms/step)  backward %.3f ms (%.4f ms/step)\n", form ? "quadrature" : "exact     ", n, B, S, L, variant,
            nblk, msf, msf / S, msb, msb / S);
 #ifdef XS_STAMPS
     unsigned long long st[8];
@@ -77,6 +84,13 @@ int main(int argc, char** argv) {
     printf("   cycles per column-step: load %.0f | reversal %.0f | forward terms %.0f | horner %.0f | reduce %.0f | store %.0f\n",
            st[0] * per * S, st[1] * per, st[2] * per, st[3] * per, st[4] * per, st[5] * per * S);
 #endif
+  }
+  CK(hipMemcpy((form ? g_quad : g_exact).data(), d_grad, sizeof(double) * S * K, hipMemcpyDeviceToHost));
+  }
+  if (forms == 3) {
+    double gd = 0, gm = 0;
+    for (size_t i = 0; i < g_exact.size(); ++i) { gd = fmax(gd, fabs(g_exact[i] - g_quad[i])); gm = fmax(gm, fabs(g_exact[i])); }
+    printf("max |grad (quadrature) - grad (exact form)| = %.3e  (max |grad| %.3e)\n", gd, gm);
   }
   // reversal check: the backward kernel leaves psi_0 in d_psi
   std::vector<double2> back(psi.size());
