@@ -21,6 +21,7 @@
 // 3L - 1 sweeps per step; HBM traffic of a whole gradient evaluation: psi_S and lambda_S in, a few sums per step out.
 // The numpy twin of these recurrences is tests/np_state_column.py (checked against the oracle on the CPU).
 #include <cstring>
+#include <type_traits>
 
 #include "dq_internal.h"
 
@@ -149,6 +150,151 @@ __device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __r
   }
 }
 
+// Ring form of a class's loop (complex128, 8 rows per thread): the partner buffer v[] is a ring over the rows -- as soon as row r
+// of diagonal q has been used, its slot takes the read of row r of diagonal q + 1, so 8 reads stay in flight all the time, in the
+// SAME 32 registers (the plain loop drains to zero at the end of every diagonal and pays the LDS latency again at the start of the
+// next; a second buffer does not fit the adjoint kernels' register budget).  hipcc will not keep such a schedule by itself (it
+// hoists the next diagonal's reads into a second buffer or sinks the uses behind them), so the reads and the counted waits are
+// inline asm: a wait is tied to its slot (in/out operand: the uses follow it), a read overwrites its slot (in/out: the uses
+// precede it), and volatile asm statements keep their order -- everything else (the arithmetic) is plain C++ between the two.
+// LDS returns in order, so before row r is used all but the 7 youngest reads must be done: s_waitcnt lgkmcnt(7) every time.
+// Measured at d = B = 4096 (tools/statecol_probe.hip, profiles/r4_probe_ring*.txt): the pairing sweeps (4 FMAs per partner value)
+// gain 25 % from the ring, best at 4 - 6 reads in flight (8: the queue in front of the LDS holds up the other wave's issue); the
+// plain sweeps (2 FMAs per partner value: LDS-bound) lose 10 - 30 % at every depth against the compiler's burst loop -> off there.
+#ifndef XS_RING_PLAIN
+#define XS_RING_PLAIN 0
+#endif
+#ifndef XS_RING_PAIR
+#define XS_RING_PAIR 1
+#endif
+#ifndef XS_PAIR_LOCAL
+#define XS_PAIR_LOCAL 1   // quadrature form: the pairing sweeps take the partners at offsets without lane bits from registers
+#endif
+#ifndef XS_RING_DEPTH_PLAIN
+#define XS_RING_DEPTH_PLAIN 8
+#endif
+#ifndef XS_RING_DEPTH_PAIR
+#define XS_RING_DEPTH_PAIR 4
+#endif
+typedef double xs_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned xs_lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void xs_ds_read_first(xs_d2& q, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void xs_ds_read_next(xs_d2& q, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(q) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void xs_ds_wait(xs_d2& q) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q) : "n"(N));
+}
+template <int R0, int R1, class F>
+__device__ __forceinline__ void xs_rows(F&& f) {
+  if constexpr (R0 < R1) {
+    f(std::integral_constant<int, R0>{});
+    xs_rows<R0 + 1, R1>(f);
+  }
+}
+// one row's share of a diagonal: o += a_ij v and, with DOT, the pairing sums in four chains s[0..3]
+template <bool SIGN, bool DOT, int PH, int R>
+__device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, double2& o, const double2* xm, double* s) {
+  if (SIGN && DOT) {  // the row's sign goes into the partner value (both uses take it from there)
+    v.x = xs_flip(v.x, sbit);
+    v.y = xs_flip(v.y, sbit);
+  } else if (SIGN) {
+    w = xs_flip(w, sbit);
+  }
+  if (PH) {
+    o.x = __builtin_fma(w, v.x, o.x);
+    o.y = __builtin_fma(w, v.y, o.y);
+  } else {
+    o.x = __builtin_fma(w, v.y, o.x);
+    o.y = __builtin_fma(-w, v.x, o.y);
+  }
+  if (DOT) {
+    constexpr int c = (R & 1) * 2;
+    if (PH) {
+      s[c] = __builtin_fma(v.x, xm[R].x, s[c]);
+      s[c + 1] = __builtin_fma(v.y, xm[R].y, s[c + 1]);
+    } else {
+      s[c] = __builtin_fma(v.x, xm[R].y, s[c]);
+      s[c + 1] = __builtin_fma(v.y, xm[R].x, s[c + 1]);
+    }
+  }
+}
+// DEPTH = reads in flight (the read of element k + DEPTH of the class's (diagonal, row) sequence is issued right after element k
+// has been used; DEPTH = RPT: a slot is refilled with the same row of the next diagonal)
+template <int NT, int RPT, bool SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH>
+__device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, const unsigned* sg, const double2* __restrict__ src, int t,
+                                            double sgn, double2* o, const double2* xm, double* dacc) {
+  static_assert(DEPTH >= 1 && DEPTH <= RPT, "ring depth");
+  if (n <= 0) return;
+  xs_d2 v[RPT];
+  const unsigned base = xs_lds_addr(src);
+  int e = __builtin_amdgcn_readlane(ctl.ent, q0);
+  unsigned a = base + (unsigned)((t ^ (e & (NT - 1))) << 4);
+  int xh = (e & 0xffff) / NT;
+  xs_rows<0, DEPTH>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if constexpr (PERM) xs_ds_read_first<0>(v[r], a + (unsigned)(((r ^ xh) * NT) << 4));
+    else xs_ds_read_first<r * NT * 16>(v[r], a);
+  });
+  xs_rows<DEPTH, RPT>([&](auto rc) { v[decltype(rc)::value] = 0.0; });  // (defined before their first in/out use)
+  const int qe = q0 + n;
+  auto finish = [&](int q, const double* s) {
+    if (DOT) {
+      const double tot = PH ? -((s[0] + s[1]) + (s[2] + s[3])) : (s[0] - s[1]) + (s[2] - s[3]);
+      (*(xs_acc16*)dacc)[q - SB] += tot;
+    }
+  };
+#pragma clang loop unroll(disable)
+  for (int q = q0; q + 1 < qe; ++q) {
+    const int en = __builtin_amdgcn_readlane(ctl.ent, q + 1);
+    const unsigned an = base + (unsigned)((t ^ (en & (NT - 1))) << 4);
+    const int xhn = (en & 0xffff) / NT;
+    const double w = sgn * xs_readlane(ctl.w, q);
+    const int j = e >> 20;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    xs_rows<0, RPT>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      xs_ds_wait<DEPTH - 1>(v[r]);
+      xs_ring_use<SIGN, DOT, PH, r>(w, SIGN ? (sg[r] >> j) & 1u : 0u, v[r], o[r], xm, s);
+      constexpr int k = r + DEPTH;  // the element whose read goes out now
+      if constexpr (k < RPT) {
+        if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
+        else xs_ds_read_next<k * NT * 16>(v[k], a);
+      } else {
+        if constexpr (PERM) xs_ds_read_next<0>(v[k - RPT], an + (unsigned)((((k - RPT) ^ xhn) * NT) << 4));
+        else xs_ds_read_next<(k - RPT) * NT * 16>(v[k - RPT], an);
+      }
+    });
+    finish(q, s);
+    e = en;
+    a = an;
+    xh = xhn;
+  }
+  {
+    const double w = sgn * xs_readlane(ctl.w, qe - 1);
+    const int j = e >> 20;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    xs_rows<0, RPT>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      xs_ds_wait<(RPT - 1 - r < DEPTH - 1 ? RPT - 1 - r : DEPTH - 1)>(v[r]);
+      xs_ring_use<SIGN, DOT, PH, r>(w, SIGN ? (sg[r] >> j) & 1u : 0u, v[r], o[r], xm, s);
+      constexpr int k = r + DEPTH;
+      if constexpr (k < RPT) {
+        if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
+        else xs_ds_read_next<k * NT * 16>(v[k], a);
+      }
+    });
+    finish(qe - 1, s);
+  }
+}
+
 // the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
 template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0>
 __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
@@ -156,6 +302,10 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, co
                                              const typename Cx<T>::type* xm, double* dacc) {  // (SB: accumulator lane = position - SB)
   typedef typename Cx<T>::type T2;
   if (n <= 0) return;
+  if constexpr (!PREF && RPT == 8 && sizeof(T) == sizeof(double) && ((DOT && XS_RING_PAIR) || (!DOT && XS_RING_PLAIN))) {
+    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
+    return;
+  }
   if (PREF) {
     T2 va[RPT], vb[RPT];
     int e0 = __builtin_amdgcn_readlane(ctl.ent, q0), e1 = 0;
@@ -665,6 +815,9 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
     __syncthreads();
   };
   bool first = true;
+#ifdef XS_STAMPS
+  long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = clock64();
+#endif
   for (int b = blockIdx.x; b < B; b += gridDim.x, first = false) {
     T2 cur[RPT];  // psi_{s+1}: the thread's rows, in registers between steps
     {
@@ -676,6 +829,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         Lm[r * NT + t] = li[r * NT + t];
       }
     }
+    XS_STAMP(0);
     for (int s = S - 1; s >= 0; --s) {
       ctl.load_step(wt + (long)s * tab.R, lane);
       ctlh.load_step(wt + (long)s * tab.R, lane);
@@ -740,6 +894,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           Lm[r * NT + t] = acc[r];  // lambda_s (own rows only: no barrier concerns it)
         }
       }
+      XS_STAMP(1);
       // ---- phase 2: psi_s = sum_m r_m with the level pairings -----------------------------------------------------------------
       xs_acc16 dacc[1];
       dacc[0] = 0.0;
@@ -777,7 +932,19 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           o[r].y = dgv * cur[r].x;
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)q[r].y - (double)cur[r].y * (double)q[r].x;
         }
+#if XS_PAIR_LOCAL
+        // the partners at offsets without lane bits are the thread's own rows of r_m: those diagonals FIRST, while cur is still
+        // live and the partner ring of the LDS classes is not yet (the two share registers in time), then the LDS classes
+        xs_local_classes<T, RPT, 1, SIGN, true, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, (T)-1, o, q, (double*)&dacc[0]);
+        xs_lds_class<T, NT, RPT, SIGN, true, RM, false, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+        if constexpr (CPLX)
+          xs_lds_class<T, NT, RPT, SIGN, true, RM, false, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+        xs_lds_class<T, NT, RPT, SIGN, true, RM, true, false, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+        if constexpr (CPLX)
+          xs_lds_class<T, NT, RPT, SIGN, true, RM, true, false, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+#else
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, q, dacc);
+#endif
         const T inv = (T)1 / (T)(m + 1);
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
@@ -790,6 +957,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       }
 #pragma unroll
       for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
+      XS_STAMP(3);
       // ---- this step's sums: per wave, accumulated over the workgroup's columns --------------------------------------
       double* prow = part + (((long)blockIdx.x * S + s) * NW + wave) * NS;
       {
@@ -815,6 +983,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         const double v = xs_wave_sums16(dv, lane);
         if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
       }
+      XS_STAMP(4);
     }
     {
       T2* out = psi + (long)b * D;
@@ -826,7 +995,12 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       }
     }
     __syncthreads();  // (the last sweep's reads of W are done before the next column overwrites it)
+    XS_STAMP(5);
   }
+#ifdef XS_STAMPS
+  if (t == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&xs_stamps[i], (unsigned long long)stamp_acc[i]);
+#endif
 }
 
 // grad[s][k] (+)= dt * (sum_j [kid_j == k] cmag_j sum part[.., j] + sum_jd [dkid_jd == k] sum part[.., RM + jd]); one workgroup
@@ -1249,7 +1423,7 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
                             : xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d, variant), xs_slots(tab),
-                     xs_rm(tab), S, tab, xs_make_order(d, tab, variant, false), K, dt, grad, accumulate);
+                     xs_rm(tab), S, tab, xs_make_order(d, tab, variant, quad && XS_PAIR_LOCAL), K, dt, grad, accumulate);
   return hipGetLastError();
 }
 

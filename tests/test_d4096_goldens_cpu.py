@@ -1,6 +1,7 @@
 """tests/golden/oracle_d4096.npz (the oracle's answers at the headline dimension, tests/d4096_cases.py): present, complete, and
-made for the inputs the GPU tests build -- checked here for the case that is cheapest to build on the CPU box."""
+made for the inputs the GPU tests build -- checked here for all three cases (a few seconds and up to 3.5 GB of host memory each)."""
 import numpy as np
+import pytest
 
 import d4096_cases
 
@@ -15,6 +16,7 @@ def test_fixture_is_complete():
         assert abs(float(z[name + "/loss"]) - float(np.sum(z[name + "/energies"]))) < 1e-9
 
 
-def test_fixture_was_made_for_the_inputs_the_tests_build():
-    P, a = d4096_cases.answer("xyz12", oracle=None)      # (oracle=None: a signature mismatch would fail loudly instead of recomputing)
+@pytest.mark.parametrize("case", list(d4096_cases.CASES))
+def test_fixture_was_made_for_the_inputs_the_tests_build(case):
+    P, a = d4096_cases.answer(case, oracle=None)      # (oracle=None: a signature mismatch would fail loudly instead of recomputing)
     assert a["stored"] and a["grad"].shape == P["u"].shape and a["energies"].shape == (P["B"],)

@@ -258,3 +258,24 @@ def test_thirteen_qubits_in_complex64():
     assert gs > 1e-4                                                      # (gradients of this problem are ~5e-4)
     assert float((f1 - f0).abs().max()) < 1e-5 and abs(l1 - l0) < 1e-4 * B
     assert np.max(np.abs(g1 - g0)) < 1e-3 * gs, (np.max(np.abs(g1 - g0)), gs)   # fp32: both schemes carry ~1e-6 relative rounding
+
+
+# ---- the chain length BASELINE states: S = 2000 (tests/s2000_cases.py; fixture tests/golden/oracle_s2000.npz) --------------------
+@pytest.mark.parametrize("adjoint", [1, 0], ids=["quadrature", "exact_polynomial"])
+@pytest.mark.parametrize("case,variant", [("ising8", 0), ("ising8", 1), ("ising9", 0), ("ising9", 1), ("xyz9", 0), ("xyz9", 1)])
+def test_full_2000_step_chain_matches_the_oracle_fixture(case, variant, adjoint):
+    """The whole 2000-step chain (configs[2]'s step count; reference loop diffqc.cc:190-200) on state columns against the oracle's
+    answer (scipy expm + expm_frechet per step, committed fixture): final amplitudes, energies, loss and dL/du at 1e-10 -- both
+    workgroup shapes (variant 1: 256 threads per column) and both forms of the adjoint sweep.  The sweep re-derives psi_t from
+    psi_{t+1} over all 2000 steps without a checkpoint: this is the check that the drift stays inside the tolerance."""
+    import s2000_cases
+    P, a = s2000_cases.answer(case)
+    with _engine(P["H0"], P["Hs"], P["M"], state_columns=1, state_columns_variant=variant, state_columns_adjoint=adjoint) as e:
+        loss, grad, fin, en = e.energy_grad(P["u"], P["dt"], P["psi0"])
+        assert e.info("state_columns") == 1
+        assert (e.info("state_columns_quad_nodes") > 0) == (adjoint == 1), "the requested form of the adjoint sweep did not run"
+        fwd = e.propagate(P["u"], P["dt"], P["psi0"])
+    assert np.max(np.abs(fin - a["fin"])) < TOL and np.max(np.abs(fwd - a["fin"])) < TOL
+    assert np.max(np.abs(en - a["energies"])) < TOL and abs(loss - a["loss"]) < TOL
+    assert np.max(np.abs(grad - a["grad"])) < TOL, np.max(np.abs(grad - a["grad"]))
+    assert np.max(np.abs(a["grad"])) > 1e-4
