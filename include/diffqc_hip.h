@@ -151,10 +151,18 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   state_columns_variant   kernel configuration: bit 0 = "wide" workgroups (dim 4096: 1024 threads x 4 rows instead of 512 x 8;
  *                      dim <= 1024: 256 threads per column instead of one or two waves -- +20 % at dim 512 with narrow batches);
  *                      bit 1 = partner prefetch in the forward kernel; default 0
+ *   state_columns_adjoint   -1 (default) / 1: the adjoint sweep of the state-column form in its QUADRATURE form whenever a rule the
+ *                      kernels are built for keeps its error bound below state_columns_quad_tol at the chain's largest step: with
+ *                      phi(s) = exp(-s A_t) phi_{t+1}, dL/du_k[t] = Re int_0^1 <lambda(s), dA_k psi(s)> ds by a 4-point Gauss-Lobatto
+ *                      rule whose node values are sums of the Taylor terms the propagation of lambda produces anyway (2 L sweeps per
+ *                      step, no scratch; up to 16 XOR-diagonals, bound e (2 theta)^6 <= tol: theta <= 0.05 at the default);
+ *                      0 = always the exact derivative of the step polynomial (3 L - 1 sweeps, forward terms parked in a scratch).
+ *                      dq_get_info("state_columns_quad_nodes") = interior nodes of the rule the last adjoint sweep used (0: exact form)
+ *   state_columns_quad_tol  bound of the rule's error per step relative to ||dA_k|| ||lambda|| ||psi|| (default 2^-40)
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",
  * "real_hamiltonians", "real_path" (q used by the last call, 0 = complex tape), "composed", "operator_backward",
- * "time_parallel", "cached_steps", "slice_skew", "sparse_controls", "control_nonzeros" (-1 = dense), "sparse_generator", "sparse_drift", "xor_regular", "xor_regular_found", "state_columns", "zgemm_alg", "norm_H0", "dim",
+ * "time_parallel", "cached_steps", "slice_skew", "sparse_controls", "control_nonzeros" (-1 = dense), "sparse_generator", "sparse_drift", "xor_regular", "xor_regular_found", "state_columns", "state_columns_quad_nodes", "zgemm_alg", "norm_H0", "dim",
  * "n_controls", "dtype". */
 int dq_set_option(dq_ctx* ctx, const char* name, double value);
 int dq_get_info(dq_ctx* ctx, const char* name, double* value);
