@@ -76,6 +76,9 @@ def main():
                     help="length of the full configuration's chain: the timed slice uses ITS checkpoint stride")
     ap.add_argument("--real-path", type=int, default=-1,
                     help="-1 auto (real H -> cos/sin form on real MFMA products), 0 = general complex path only")
+    ap.add_argument("--state-columns", type=int, default=-1, choices=(-1, 0, 1),
+                    help="config 3: -1 auto (Pauli-sum generators run the state-column form), 0 = the explicit-propagator GEMM chain as the "
+                         "timed workload (profiling the north-star kernel on the headline's inputs), 1 = whenever the kernels exist")
     ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated", "propagators"), default="replicated",
                     help="N > 1: 'replicated' (default; north_star / SURVEY 8-E1) = every rank runs the whole chain on its batch shard, one "
                          "all-reduce of loss + dL/du; 'sliced' = chain split over time across the ranks (operator form; three collectives); "

@@ -461,6 +461,7 @@ def run_config3(a, D):
     M_dev = M if a.multi_gpu == "propagators" else None
     del H0, Hs, M
     eng.set_option("real_path", a.real_path)
+    eng.set_option("state_columns", a.state_columns)
     eng.set_option("plan_steps", max(a.chain, K))  # checkpoint/rebuild ratio of the full 2000-step chain
     u_t = torch.from_numpy(u_all[:K].copy()).to(dev)
     grad_t = torch.zeros((K, n), dtype=torch.float64, device=dev)

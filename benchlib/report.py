@@ -27,7 +27,9 @@ TRAFFIC = {
     "statecol_fwd": (5.376e8, "profiles/r3_bench_headline_summary.txt"),
     "statecol_bwd_per_step": (3.60e9, "profiles/r3_bench_headline_summary.txt"),     # exact form (xs_backward_kernel)
     # quadrature form (xs_backward_q_kernel, round 4): no forward-term scratch; what is left per step is register spill traffic
-    "statecol_bwdq_per_step": (None, "profiles/r4_bench_headline_summary.txt"),
+    # (profiles/r4_bench_headline_summary.txt: 703 MB read + 643 MB written per average launch of 11 steps = the states and costates in
+    # and out, 1074 MB, + 24.8 MB per step)
+    "statecol_bwdq_per_step": (2.48e7, "profiles/r4_bench_headline_summary.txt"),
     "xr": (6.60e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 1441 MB xr_reverse [Ubar
                                                                      # read + its power scratch written back and re-read]) / 3
 }
@@ -269,6 +271,8 @@ def roofline_blocks(prof, info, d):
         else:
             tr, src = TRAFFIC["statecol_bwdq_per_step" if quad else "statecol_bwd_per_step"]
             tr = tr * float(info.get("chain_steps", 0)) if tr is not None else 0.0
+            if quad and tr > 0:
+                tr += alg_hbm   # (the PMC figure of the quadrature form is the states in and out + the per-step remainder)
         blocks[name] = {
             "bound": "lds", "kernel": kernel, "kernel_detail": detail,
             "achieved": gbps, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": gbps / PEAK_LDS_GBPS,
