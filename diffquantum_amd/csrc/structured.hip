@@ -346,7 +346,16 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
 // (s_nop 4 in front of every one of these: under SGPR pressure hipcc restores the base pointer with v_readlane_b32 right before the asm
 // block, and a VMEM instruction that reads an SGPR written by a VALU instruction needs 5 wait states -- the hazard recognizer does not
 // look inside inline asm.  Without it the reverse chain kernel read a half-restored pointer and faulted.)
-#define S_DMA16(base_, off_, lds_) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off_), "s"(base_), "s"(lds_) : "memory")
+// (m0 is saved and restored inside the block: it is a reserved register that cannot be named as a clobber, and the compiler may
+// hold its own value there -- s_set_gpr_idx / LDS-DMA builtins elsewhere in a kernel)
+#define S_DMA16(base_, off_, lds_)                                                                                               \
+  do {                                                                                                                           \
+    unsigned m0_keep_;                                                                                                           \
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(m0_keep_)                                                                                               \
+                 : "v"(off_), "s"(base_), "s"(lds_)                                                                              \
+                 : "memory");                                                                                                    \
+  } while (0)
 
 constexpr int SD_P = 9, SD_ROWS = 1 << SD_P, SD_RSTEP = 128, SD_RPT = SD_ROWS / SD_RSTEP;  // 1024 threads = 128 rows x 8 column pairs; 4 rows per thread
 static_assert(STHREADS == 1024 && SBC == 16, "the DMA forms assume 1024 threads and 16 batch columns per tile");

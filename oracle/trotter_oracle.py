@@ -10,9 +10,12 @@ Pinning status
     ``compute_energy_grad_MC``, the demo's training trace) is PINNED: ``tests/test_oracle_golden.py``
     checks this file against golden vectors captured by importing /root/reference/sim_plain.py in
     place (``tests/golden/make_goldens.py``; fixtures ``tests/golden/*.npz``).
-  * The ``diffqc.cc`` pulse model ``f_u`` (carrier cos/sin channels) is restated from the source;
-    the reference cannot be compiled here (Eigen absent) and has no tests -> that part is
-    "parity unpinned" except through its equivalence with ``generate_u`` (one channel, w=0, vv[1]=0).
+  * The ``diffqc.cc`` pulse model ``f_u`` (carrier cos/sin channels) is PINNED since round 3:
+    ``tests/golden/make_fu_goldens.py`` slices ``my_expit`` / ``bspline`` / ``f_u`` out of
+    /root/reference/diffqc.cc at generation time, compiles them with g++ beside a driver and stores
+    the tables only (``tests/golden/fu_goldens.npz``: carrier w != 0, both quadratures, several
+    channels, the 1e-6 cutoff, the clamp at 32); ``tests/test_oracle_golden.py`` checks ``f_u`` here
+    against them at 2e-15.  (The whole of diffqc.cc cannot be compiled here: Eigen is absent.)
   * The adjoint gradient does not exist in the reference; its oracle is the exact derivative of the
     reference's discrete chain via ``scipy.linalg.expm_frechet``, cross-checked against central
     finite differences of the (pinned) forward path (golden G6).
