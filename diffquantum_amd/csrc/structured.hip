@@ -62,6 +62,10 @@ struct SBuf {
     SHIP(hipMalloc(&p, n));
     bytes = n;
   }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+  }
 };
 
 struct SHostBuf {  // pinned host memory (checkpoints of the first level when the HBM has room for one segment only)
@@ -1871,11 +1875,17 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   const int K = c->K;
   std::vector<double> uh = s_fetch_u(c, u, S);
   const int m = plan_degree(c, uh, S, dt);
+  // (a call that failed half-way may have left checkpoint copies in flight on the copy stream: none may land in `stage` or leave
+  // the pinned buffers while this call takes its first snapshots)
+  if (c->copy_st) SHIP(hipStreamSynchronize(c->copy_st));
   double budget = c->checkpoint_bytes;
-  if (budget <= 0) {  // default: 70 % of the free HBM plus the checkpoints this context already holds
+  if (budget <= 0) {
+    // default: 70 % of the free HBM plus everything the checkpoint pools of this context hold already -- ALL of it is at the plan's
+    // disposal, because the pools the plan does not use are released below before anything new is allocated (a context that ran
+    // the two-level plan keeps ~m s states in segz / segpsi; a one-level plan sized from that memory must not allocate on top of it)
     size_t fr = 0, tot = 0;
     SHIP(hipMemGetInfo(&fr, &tot));
-    double held = 0.0;
+    double held = (double)c->stage.bytes;
     for (const auto& b : c->ck) held += (double)b.bytes;
     for (const auto& b : c->segpsi) held += (double)b.bytes;
     for (const auto& v : c->segz) for (const auto& b : v) held += (double)b.bytes;
@@ -1908,6 +1918,15 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   c->last_host_ck = host_ck ? 1 : 0;
   const int ncp = S > 0 ? (S + cstride - 1) / cstride : 0;
   c->last_cstride = cstride;
+  // release the pools this plan does not use (or uses less of) before it allocates its own
+  if (host_ck) c->ck.clear();
+  else if ((int)c->ck.size() > ncp) c->ck.resize(ncp);
+  if (!host_ck) c->stage.release();
+  if (!two_level) { c->segpsi.clear(); c->segz.clear(); }
+  else {
+    if ((int)c->segpsi.size() > cstride + 1) c->segpsi.resize(cstride + 1);
+    if ((int)c->segz.size() > cstride + 1) c->segz.resize(cstride + 1);
+  }
   if (!host_ck) {
     if ((int)c->ck.size() < ncp) c->ck.resize(ncp);
     for (int i = 0; i < ncp; ++i) c->ck[i].ensure(sb);
@@ -2202,6 +2221,13 @@ int dq_sctx_get_info(dq_sctx* c, const char* name, double* v) {
     else if (s == "two_level") *v = t->last_two_level;
     else if (s == "host_checkpoints") *v = t->last_host_ck;
     else if (s == "pass_bytes") *v = t->last_bytes;
+    else if (s == "checkpoint_pool_bytes") {  // device memory the checkpoint pools hold now (kept states, segment states + iterates, staging)
+      double h = (double)t->stage.bytes;
+      for (const auto& b : t->ck) h += (double)b.bytes;
+      for (const auto& b : t->segpsi) h += (double)b.bytes;
+      for (const auto& z : t->segz) for (const auto& b : z) h += (double)b.bytes;
+      *v = h;
+    }
     else if (s == "prof_ms") { t->collect(); *v = t->prof_ms; }
     else if (s == "prof_bytes") { t->collect(); *v = t->prof_bytes; }
     else if (s == "prof_launches") { t->collect(); *v = (double)t->prof_launches; }

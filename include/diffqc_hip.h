@@ -289,7 +289,7 @@ int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigne
  *                    both tiles touch few 2 MB regions; 0: low qubits to one group, high qubits to the other),
  *   "fuse_overlaps" (1: the reverse-mode apply pass of a group also forms that group's control overlaps, in every kernel form;
  *                    0, default: only in the DMA form, where it costs no occupancy; -1: never).
- * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "two_level", "host_checkpoints", "pass_bytes", "prof_ms", "prof_bytes", "prof_launches", "dtype" */
+ * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "two_level", "host_checkpoints", "pass_bytes", "checkpoint_pool_bytes" (device bytes the checkpoint pools hold now), "prof_ms", "prof_bytes", "prof_launches", "dtype" */
 int dq_sctx_set_option(dq_sctx* ctx, const char* name, double value);
 int dq_sctx_get_info(dq_sctx* ctx, const char* name, double* value);
 int dq_sctx_propagate(dq_sctx* ctx, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out,

@@ -302,12 +302,20 @@ def test_two_level_checkpoints(dtype, B, tol):
         assert e.info("two_level") == 1 and e.info("checkpoint_stride") == s2
         p1 = e.info("passes")
         assert e.info("host_checkpoints") == 0
+        # the pools hold what this plan uses and nothing of the plan before it (S per-step checkpoints were released)
+        assert e.info("checkpoint_pool_bytes") <= sb * (need + 1)
         e.set_option("checkpoint_bytes", sb * (m * s2 + 2))          # room for one segment, not for the kept states: those go to the host
         l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
         assert e.info("two_level") == 1 and e.info("host_checkpoints") == 1 and e.info("checkpoint_stride") == s2 and e.info("passes") == p1
+        assert e.info("checkpoint_pool_bytes") <= sb * (m * s2 + 2)   # the device-side kept states are gone: segment + staging buffer only
         e.set_option("host_checkpoints", 0)
         l3, g3, f3, _ = e.energy_grad(u, dt, psi0)
         assert e.info("two_level") == 0 and e.info("checkpoint_stride") == -(-S // (m * s2 + 2))
+        assert e.info("checkpoint_pool_bytes") <= sb * (m * s2 + 2)   # one level: the segment pools and the staging buffer were released
+        e.set_option("checkpoint_bytes", 0)                          # default budget (70 % of free + held): every state fits again
+        ld, gd, fd, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("checkpoint_stride") == 1 and e.info("checkpoint_pool_bytes") == sb * S
+        assert abs(ld - la) <= tol * B and np.max(np.abs(gd - ga)) < tol * B
         e.set_option("checkpoint_bytes", sb * (need + 1))
         e.set_option("two_level", 0)
         l0, g0, f0, _ = e.energy_grad(u, dt, psi0)
