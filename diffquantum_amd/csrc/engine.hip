@@ -313,7 +313,10 @@ struct Ctx : dq_ctx {
   // adjoint sweep of the state-column form: -1 auto / 1 = the quadrature form (xs_backward_q_kernel) whenever a rule the kernels are
   // built for keeps its error bound below xs_quad_tol at this chain's theta, 0 = always the exact derivative of the polynomial
   int xs_adjoint = -1;
+  int xs_workgroups = 0;                       // > 0: at most that many workgroups per launch (tests of the several-columns-per-workgroup loop)
+  double xs_part_bytes = 268435456.0;          // scratch of the adjoint sweep's per-step partial sums: the chain is swept in segments that fit
   double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
+  double last_xs_segments = 0;                 // launches the last adjoint sweep was split into
   double last_xs_nodes = 0;                    // interior nodes of the rule the last adjoint sweep ran (0: the exact form)
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
@@ -1354,6 +1357,7 @@ struct XsLaunch {
   const dq::XrTab* tab;
   bool quad_ok;      // the adjoint sweep runs the quadrature form with the rule `quad`
   dq::XsQuad quad;
+  int seg_steps = 0; // steps per launch of the adjoint sweep (its partial-sum scratch is sized for that many)
 };
 
 // per-call set-up: weights of every step, buffers
@@ -1364,6 +1368,7 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   x.L = L;
   x.tab = xs_table(c);
   x.nblk = dq::xs_blocks(c->d, sizeof(T), B, c->n_cu, c->xs_variant);
+  if (c->xs_workgroups > 0) x.nblk = std::min(x.nblk, c->xs_workgroups);   // (tests: several columns per workgroup at any batch)
   x.lds_diag = dq::xs_lds_diagonals(c->d, *x.tab, c->xs_variant);
   const size_t sb = (size_t)c->d * B * sizeof(T2);
   c->xs_psi.ensure(sb);
@@ -1375,7 +1380,12 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
   if (backward) {
     if (!x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
-    c->xs_part.ensure(sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, S, x.nblk, *x.tab, c->xs_variant), 1));
+    // the per-step partial sums (workgroups x waves x slots doubles per step) are kept for a SEGMENT of the chain at a time: the sweep
+    // is restartable at any step (psi and lambda are in/out, gradient rows disjoint), so a long chain costs no more scratch than a
+    // segment of xs_part_bytes (default 256 MB; d = 4096: 262 KB per step, d = 512 at batch 4096: 327 KB per step)
+    const size_t per_step = sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, 1, x.nblk, *x.tab, c->xs_variant), 1);
+    x.seg_steps = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), (size_t)(c->xs_part_bytes / (double)per_step)));
+    c->xs_part.ensure(per_step * (size_t)x.seg_steps);
   }
   const dq::XrTab tb = *x.tab;
   long step = 0;
@@ -1761,11 +1771,17 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
     // sweeps per step: the exact form runs 3 L - 1 (L of them with the pairings), the quadrature form 2 L (L with the pairings)
     xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
     const dq::XrTab tb = *x.tab;
-    c->timed(DQ_PROF_STATECOL_BWD, fl, lb, [&] {
-      return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, L, x.nblk,
-                                    x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d(), 0, c->xs_variant,
-                                    x.quad_ok ? &x.quad : nullptr, c->st);
-    });
+    c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
+    for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {   // segments of the chain, last first (one launch when the whole chain fits)
+      const int s0 = std::max(0, s1 - x.seg_steps), ns = s1 - s0;
+      const double share = (double)ns / (double)S;
+      c->timed(DQ_PROF_STATECOL_BWD, fl * share, lb * share, [&] {
+        return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
+                                      c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, B, L, x.nblk,
+                                      x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
+                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, c->st);
+      });
+    }
   }
   if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
   HIPCK(hipStreamSynchronize(c->st));
@@ -2635,6 +2651,12 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_workgroups") {  // 0 = as many as fit the chip; > 0 caps the launch (tests: several columns per workgroup)
+    if (v < 0 || v > 65535) fail(DQ_ERR_INVALID, "state_columns_workgroups must be 0..65535");
+    c->xs_workgroups = (int)v;
+  } else if (s == "state_columns_part_bytes") {  // scratch budget of the adjoint sweep's partial sums (the chain is swept in segments that fit)
+    if (!(v >= 1)) fail(DQ_ERR_INVALID, "state_columns_part_bytes must be >= 1");
+    c->xs_part_bytes = v;
   } else if (s == "state_columns_quad_tol") {  // bound of the rule's error per step, relative to ||dA_k|| ||lambda|| ||psi||
     if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_quad_tol must be > 0");
     c->xs_quad_tol = v;
@@ -2673,6 +2695,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "xor_regular") return c->last_xr;
   if (s == "state_columns") return c->last_xs;
   if (s == "state_columns_quad_nodes") return c->last_xs_nodes;
+  if (s == "state_columns_segments") return c->last_xs_segments;
   if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;
   if (s == "real_hamiltonians") return c->real_h ? 1.0 : 0.0;

@@ -158,6 +158,10 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      step, no scratch; up to 16 XOR-diagonals, bound e (2 theta)^6 <= tol: theta <= 0.05 at the default);
  *                      0 = always the exact derivative of the step polynomial (3 L - 1 sweeps, forward terms parked in a scratch).
  *                      dq_get_info("state_columns_quad_nodes") = interior nodes of the rule the last adjoint sweep used (0: exact form)
+ *   state_columns_part_bytes  scratch of the adjoint sweep's per-step partial sums (default 256 MiB): a longer chain is swept in segments
+ *                      that fit (the sweep restarts at any step: psi and lambda are in/out); dq_get_info("state_columns_segments")
+ *   state_columns_workgroups  0 (default): as many workgroups as fit the chip; > 0 caps a launch (tests of the several-columns-per-
+ *                      workgroup loop at small batches)
  *   state_columns_quad_tol  bound of the rule's error per step relative to ||dA_k|| ||lambda|| ||psi|| (default 2^-40)
  *   force_tile, rgemm_cfg, rgemm_glds   kernel configurations (tests, tuning)
  * dq_get_info names: "degree", "squarings", "products", "theta", "time_chunk", "checkpoint_stride", "hermitian",

@@ -58,17 +58,20 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("workgroups", [0, 2], ids=["one_column_per_workgroup", "two_workgroups"])
 @pytest.mark.parametrize("case", list(CASES) + ["qaoa_ring_zz_controls"])
 @pytest.mark.parametrize("n", [8, 9])
-def test_state_columns_match_oracle(oracle, case, n):
-    """d = 256 (one wave per column, 4 rows per lane) and 512 (8 rows per lane): forward amplitudes, loss, dL/du vs the oracle."""
+def test_state_columns_match_oracle(oracle, case, n, workgroups):
+    """d = 256 (one wave per column, 4 rows per lane) and 512 (8 rows per lane): forward amplitudes, loss, dL/du vs the oracle.
+    `two_workgroups`: the 5 columns on 2 workgroups (3 + 2: the several-columns-per-workgroup loop of every kernel family -- sums
+    accumulated across a workgroup's columns, images reused, batch not a multiple of the workgroup count)."""
     H0, Hs, M = _qaoa(n) if case == "qaoa_ring_zz_controls" else CASES[case](n)
     K, d = len(Hs), 1 << n
     S, B, dt = 4, 5, 2e-3
     u = np.random.default_rng(n).uniform(-1, 1, (S, K))
     psi0 = problems.random_states(d, B, seed=2)
     rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
-    with _engine(H0, Hs, M, state_columns=1 if n == 8 else -1) as e:     # (auto takes the form from dim 512 up)
+    with _engine(H0, Hs, M, state_columns=1 if n == 8 else -1, state_columns_workgroups=workgroups) as e:     # (auto takes the form from dim 512 up)
         loss, grad, fin, en = e.energy_grad(u, dt, psi0)
         assert e.info("state_columns") == 1, "a Pauli-string generator did not take the state-column form"
         fwd = e.propagate(u, dt, psi0)
@@ -281,3 +284,28 @@ def test_full_2000_step_chain_matches_the_oracle_fixture(case, variant, adjoint)
     assert np.max(np.abs(en - a["energies"])) < TOL and abs(loss - a["loss"]) < TOL
     assert np.max(np.abs(grad - a["grad"])) < TOL, np.max(np.abs(grad - a["grad"]))
     assert np.max(np.abs(a["grad"])) > 1e-4
+
+
+@pytest.mark.parametrize("adjoint", [1, 0], ids=["quadrature", "exact_polynomial"])
+@pytest.mark.parametrize("dtype,variant,tol", [("c128", 0, 1e-12), ("c128", 1, 1e-12), ("c64", 0, 2e-5)])
+def test_several_columns_per_workgroup_and_segmented_sweep(dtype, variant, tol, adjoint):
+    """d = 1024 / 512: 7 columns on 3 workgroups (3 + 2 + 2) and the adjoint sweep split into segments of a few steps (scratch budget of
+    its partial sums) -- against the same engine with one column per workgroup and the chain in one launch: same arithmetic per column
+    and step, so the states are identical and the sums differ by their order only."""
+    n, S, B, dt = (10 if variant == 0 else 9), 23, 7, 2e-3
+    H0, Hs, M = problems.random_ising(n, seed=12)
+    u = np.random.default_rng(4).uniform(-1, 1, (S, n))
+    psi0 = problems.random_states(1 << n, B, seed=5)
+    if dtype == "c64":
+        psi0 = psi0.astype(np.complex64)
+    with _engine(H0, Hs, M, dtype=dtype, state_columns=1, state_columns_variant=variant, state_columns_adjoint=adjoint) as e:
+        l0, g0, f0, e0 = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1 and e.info("state_columns_segments") == 1
+        e.set_option("state_columns_workgroups", 3)
+        waves = (1 << n) // 8 // 64 if variant == 0 else 4
+        e.set_option("state_columns_part_bytes", 8 * 3 * max(1, waves) * 16 * 5)     # room for 5 steps of 3 workgroups' sums
+        l1, g1, f1, e1 = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns_segments") == 5
+    assert np.array_equal(f0, f1) and np.max(np.abs(e0 - e1)) <= tol
+    assert abs(l0 - l1) <= tol * B and np.max(np.abs(g0 - g1)) <= tol * B, np.max(np.abs(g0 - g1))
+    assert np.max(np.abs(g0)) > 1e-5
