@@ -2,6 +2,7 @@
 launch for the 3M complex product, the triangle's tiles only for the Hermitian-output form -- the algorithmic 8 M N K rate is
 kept beside it, classes are ranked by their share of the timed region, and the HBM class is bytes / time / 8 TB/s."""
 import importlib.util
+import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -118,3 +119,26 @@ def test_state_column_classes_are_priced_against_the_lds_array_with_the_scratch_
     assert bench.ranked(b)[0] is w and bench.ranked(b)[1] is f
     other = bench.roofline_blocks(prof, {"zgemm_alg": 2.0, "batch": 512, "chain_steps": K}, 1024)
     assert other["statecol_bwd"]["traffic"] is None                              # PMC constants hold for the headline shape only
+
+
+def test_the_eight_gpu_line_parses_and_fits():
+    """The N = 8 line (configs[3]: B = 32768 over 8 GPUs) as rank 0 would print it: built from the record of the 4-rank gloo rehearsal on
+    one GPU (profiles/r4_bench_gloo4_rehearsal.json -- more than 6 processes may not share the card of a gpurun box, so 8 ranks were never
+    started there) with the world size set to 8: one line < 4 KB that carries n_gpus, backend, the global batch and, beside the timed
+    form, the whole global batch on one GPU."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_gloo4_rehearsal.json")))
+    assert rec["n_gpus"] == 4 and rec["config"]["global_batch"] == 4 * 4096 and rec["backend"].startswith("gloo")
+    assert set(rec["beside"]) == {"sliced_form", "one_gpu_whole_global_batch"} and rec["config"]["parallelism"] == "dp4"
+    full = dict(rec)
+    full.update(n_gpus=8, backend="nccl (RCCL over xGMI)", value=8 * 20 / 0.0212)
+    full["config"] = dict(rec["config"], global_batch=8 * 4096, parallelism="dp8", parallelism_detail="dp8 (batch shards, one all-reduce of loss+dL/du)",
+                          workload=rec["config"]["workload"])
+    full["beside"] = {"sliced_form": [120.0, 66.0], "one_gpu_whole_global_batch": [8 * 20 / 0.1604, 8.02]}
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT
+    back = json.loads(text)
+    assert back["n_gpus"] == 8 and back["scaling"] == "weak" and back["config"]["global_batch"] == 32768
+    assert back["backend"].startswith("nccl") and back["beside"]["one_gpu_whole_global_batch"][1] == 8.02
+    for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert k in back, k
