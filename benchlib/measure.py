@@ -339,6 +339,12 @@ def measure_config5(dev, seed, S, B, dist, n=18, first=0, trials=1):
         el_g = float(np.median(times))
         ms_g, by_g, nl = e.info("prof_ms"), e.info("prof_bytes"), e.info("prof_launches")
         passes, dma_passes, stride = int(e.info("passes")), int(e.info("dma_passes")), int(e.info("checkpoint_stride"))
+        # what the checkpoint plan of the FULL chain costs in memory (the timed slice pins only its own share): kept states in pinned
+        # host memory when the plan puts them there, device pools otherwise
+        two_level, host_ck = bool(e.info("two_level")), bool(e.info("host_checkpoints"))
+        sbytes = float((1 << n) * B * 8)
+        pinned_full = sbytes * (-(-CONFIG5_CHAIN // max(stride, 1))) / 1e9 if host_ck else 0.0
+        pinned_now, pool_now = e.info("pinned_host_bytes") / 1e9, e.info("checkpoint_pool_bytes") / 1e9
         e.set_option("profile", 0)
         # beside it: the same slice with a checkpoint at every step (what a chain short enough for the HBM would cost; rounds 1-2 timed this)
         e.set_option("plan_steps", 0)
@@ -351,6 +357,8 @@ def measure_config5(dev, seed, S, B, dist, n=18, first=0, trials=1):
         gbf = by_f / ms_f * 1e-6 if ms_f > 0 else 0.0
         return {"steps_per_s": S / el_g, "seconds": el_g, "times": times, "fwd_steps_per_s": S / el_f, "degree": int(e.info("degree")),
                 "loss": loss, "grad_norm": float(np.linalg.norm(grad)), "checkpoint_stride": stride,
+                "two_level": two_level, "host_checkpoints": host_ck, "pinned_host_GB": pinned_full,
+                "pinned_host_GB_this_slice": pinned_now, "checkpoint_pool_GB_this_slice": pool_now,
                 "every_step_checkpointed": {"steps_per_s": S / el_ck, "checkpoint_stride": stride_ck},
                 "roofline": {"bound": "hbm",
                              "kernel": ("sapply_dma_kernel / schain_dma_kernel (matrix-free passes, LDS-DMA tiles)" if dma_passes
@@ -429,6 +437,8 @@ def run_config5(a, D):
                           "taylor_degree": m["degree"], "loss": m["loss"], "grad_norm": m["grad_norm"],
                           "forward_only_steps_per_s_rank0": m["fwd_steps_per_s"],
                           "checkpoint_stride": m["checkpoint_stride"], "every_step_checkpointed_steps_per_s_rank0": m["every_step_checkpointed"]["steps_per_s"],
+                          # the checkpoint plan of the full 4000-step chain per rank: two levels? kept states in pinned HOST memory (GB)?
+                          "two_level": m["two_level"], "host_checkpoints": m["host_checkpoints"], "pinned_host_GB": m["pinned_host_GB"],
                           "parallelism": "dp{}".format(D.world),
                           "parallelism_detail": "batch shards, one all-reduce of loss + dL/du"},
                "roofline": m["roofline"]}

@@ -1264,6 +1264,7 @@ struct SCtx : dq_sctx {
   double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0, last_dma_passes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
+  double host_checkpoint_bytes = 0;  // > 0: cap of the pinned host memory the kept states may take (0: 60 % of what the process may still use)
   int host_checkpoints = 1;  // 1: the kept states of the two-level plan may live in pinned host memory when the HBM holds one segment only
   double last_host_ck = 0;
   std::vector<SHostBuf> ckh;
@@ -1909,7 +1910,9 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       if ((int)c->ckh.size() < need) c->ckh.resize(need);
       double pinned = 0.0;
       for (const auto& b : c->ckh) pinned += (double)b.bytes;
-      bool ok = (double)need * (double)sb <= s_host_budget() + pinned;
+      // (no pinning beyond the budget: a plan the host cannot hold falls back to one level -- slower, never an out-of-memory kill)
+      const double hb = c->host_checkpoint_bytes > 0 ? c->host_checkpoint_bytes : s_host_budget() + pinned;
+      bool ok = (double)need * (double)sb <= hb;
       for (int i = 0; i < need && ok; ++i) ok = c->ckh[i].ensure(sb);
       if (ok) { two_level = true; host_ck = true; cstride = (int)s2; c->copy_stream_ready(); c->stage.ensure(sb); }
     }
@@ -2196,6 +2199,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
     else if (s == "two_level") t->two_level = v != 0 ? 1 : 0;
     else if (s == "host_checkpoints") t->host_checkpoints = v != 0 ? 1 : 0;
+    else if (s == "host_checkpoint_bytes") { if (v < 0) sfail(DQ_ERR_INVALID, "host_checkpoint_bytes must be >= 0"); t->host_checkpoint_bytes = v; }
     else if (s == "chain") t->chain = v != 0 ? 1 : 0;
     else if (s == "reverse_chain") t->reverse_chain = v != 0 ? 1 : 0;
     else if (s == "interleave_groups") t->interleave_groups = v > 0 ? (int)v : 0;
@@ -2221,6 +2225,11 @@ int dq_sctx_get_info(dq_sctx* c, const char* name, double* v) {
     else if (s == "two_level") *v = t->last_two_level;
     else if (s == "host_checkpoints") *v = t->last_host_ck;
     else if (s == "pass_bytes") *v = t->last_bytes;
+    else if (s == "pinned_host_bytes") {  // pinned host memory the kept states of the two-level plan hold now
+      double h = 0.0;
+      for (const auto& b : t->ckh) h += (double)b.bytes;
+      *v = h;
+    }
     else if (s == "checkpoint_pool_bytes") {  // device memory the checkpoint pools hold now (kept states, segment states + iterates, staging)
       double h = (double)t->stage.bytes;
       for (const auto& b : t->ck) h += (double)b.bytes;

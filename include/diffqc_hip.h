@@ -285,6 +285,8 @@ int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigne
  *                s-th state is kept and a segment at a time is recomputed with the Horner iterates of its steps stored; 0: one level),
  *   "host_checkpoints" (1, default: when the HBM holds one segment (m s states) but not the kept states as well, those live in pinned
  *                host memory -- one state down per s steps, one up per segment; 0: never),
+ *   "host_checkpoint_bytes" (0, default: those kept states may pin up to 60 % of the host memory the process may still use -- cgroup
+ *                limit or MemAvailable; > 0: that many bytes.  A chain whose kept states exceed it runs the one-level plan instead),
  *   "dma" (1, default: complex64 passes over 2^9-row tiles with batch % 16 == 0 run as persistent LDS-DMA kernels; 0: one tile per workgroup),
  *   "dma_workgroups" (persistent workgroups per pass; default = the device's CU count),
  *   "chain" (1, default: a Horner chain over two pure X-string groups finishes one application and starts the next in one pass),
@@ -293,7 +295,7 @@ int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigne
  *                    both tiles touch few 2 MB regions; 0: low qubits to one group, high qubits to the other),
  *   "fuse_overlaps" (1: the reverse-mode apply pass of a group also forms that group's control overlaps, in every kernel form;
  *                    0, default: only in the DMA form, where it costs no occupancy; -1: never).
- * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "two_level", "host_checkpoints", "pass_bytes", "checkpoint_pool_bytes" (device bytes the checkpoint pools hold now), "prof_ms", "prof_bytes", "prof_launches", "dtype" */
+ * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "two_level", "host_checkpoints", "pass_bytes", "checkpoint_pool_bytes" (device bytes the checkpoint pools hold now), "pinned_host_bytes" (pinned host memory of the kept states), "prof_ms", "prof_bytes", "prof_launches", "dtype" */
 int dq_sctx_set_option(dq_sctx* ctx, const char* name, double value);
 int dq_sctx_get_info(dq_sctx* ctx, const char* name, double* value);
 int dq_sctx_propagate(dq_sctx* ctx, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out,

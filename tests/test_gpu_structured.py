@@ -308,6 +308,12 @@ def test_two_level_checkpoints(dtype, B, tol):
         l2, g2, f2, _ = e.energy_grad(u, dt, psi0)
         assert e.info("two_level") == 1 and e.info("host_checkpoints") == 1 and e.info("checkpoint_stride") == s2 and e.info("passes") == p1
         assert e.info("checkpoint_pool_bytes") <= sb * (m * s2 + 2)   # the device-side kept states are gone: segment + staging buffer only
+        assert e.info("pinned_host_bytes") == sb * -(-S // s2)       # the kept states, in pinned host memory
+        e.set_option("host_checkpoint_bytes", sb * 2)                 # a host that will not pin that much: one level, no failure
+        l4, g4, f4, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("two_level") == 0 and e.info("host_checkpoints") == 0
+        assert abs(l4 - la) <= tol * B and np.max(np.abs(g4 - ga)) < tol * B
+        e.set_option("host_checkpoint_bytes", 0)
         e.set_option("host_checkpoints", 0)
         l3, g3, f3, _ = e.energy_grad(u, dt, psi0)
         assert e.info("two_level") == 0 and e.info("checkpoint_stride") == -(-S // (m * s2 + 2))
@@ -323,3 +329,31 @@ def test_two_level_checkpoints(dtype, B, tol):
     for l, g, f in ((l1, g1, f1), (l2, g2, f2), (l3, g3, f3), (l0, g0, f0)):
         assert abs(l - la) <= tol * B and np.max(np.abs(g - ga)) < tol * B and np.max(np.abs(f - fa)) < tol
     assert np.max(np.abs(ga)) > 1e-3
+
+
+@pytest.mark.parametrize("n", [10, 12])
+def test_fp32_gradient_over_the_full_4000_step_chain(n):
+    """configs[4]'s kernels over configs[4]'s chain length: 4000 steps, 32 states, complex64, the LDS-DMA forms with both checkpoint
+    levels in use -- against the complex128 dense engine on the same inputs (north_star's fp32 tolerance: 1e-4).  What this
+    separates: fp32 accumulation over 4000 steps (loss sums, overlaps, lambda) from the finite-difference noise of the n = 18
+    directional-derivative check (profiles/r3_config5_full_chain.txt: 1e-2 at B = 512)."""
+    K, S, B, dt = n, 4000, 32, 1e-3
+    terms = ising_x_terms(n, seed=21)
+    u = problems.pulse_table(K, S, S * dt, seed=22)
+    psi0 = problems.random_states(1 << n, B, seed=23).astype(np.complex64)
+    rl, rg, rf, _ = _dense_reference(terms, n, K, u, dt, psi0)
+    sb = (1 << n) * B * 8
+    with StructuredEngine(n, K, dtype="c64") as e:
+        e.set_terms(terms)
+        e.energy_grad(u[:4], dt, psi0)
+        m = int(e.info("degree"))
+        s2 = max(2, round((S / m) ** 0.5))
+        e.set_option("checkpoint_bytes", sb * (-(-S // s2) + m * s2 + 1))     # kept states + one segment with its iterates: two levels
+        l1, g1, f1, _ = e.energy_grad(u, dt, psi0)
+        assert e.info("two_level") == 1 and e.info("checkpoint_stride") == s2 and e.info("dma_passes") == e.info("passes") > 0
+    gmax = float(np.max(np.abs(rg)))
+    rel = float(np.max(np.abs(g1 - rg))) / gmax
+    assert gmax > 1e-4
+    assert np.max(np.abs(f1 - rf)) < 1e-4, np.max(np.abs(f1 - rf))
+    assert abs(l1 - rl) < 1e-4 * B, abs(l1 - rl)
+    assert rel < 1e-4, rel

@@ -16,6 +16,8 @@ from diffquantum_amd.structured import StructuredEngine, ising_x_terms  # noqa: 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 18
+EPS_RANDOM = [float(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0.25, 0.5, 1.0]
+EPS_GRAD = [float(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0.05, 0.1]
 dt = 1e-3
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
@@ -38,14 +40,20 @@ with StructuredEngine(n, n, device=0, dtype="c64") as e:
     print("n = {}  B = {}  S = {}  degree {}  checkpoint stride {}  passes {} ({:.2f} per step)".format(n, B, S, deg, stride, passes, passes / S))
     print("forward only : {:8.2f} s   {:8.2f} steps/s   max | |psi_b(T)| - 1 | = {:.2e}".format(t_f, S / t_f, drift))
     print("fwd + adjoint: {:8.2f} s   {:8.2f} steps/s   loss = {:.9f}   |grad| = {:.4e}".format(t_g, S / t_g, loss, float(np.linalg.norm(grad))))
-    v = rng.standard_normal(u.shape)
-    v /= np.linalg.norm(v)
-    eps = 0.5
+    print("two checkpoint levels: {}   kept states in pinned host memory: {:.1f} GB   device checkpoint pools: {:.1f} GB".format(
+        int(e.info("two_level")), e.info("pinned_host_bytes") / 1e9, e.info("checkpoint_pool_bytes") / 1e9))
 
     def L(uu):
         f = e.propagate(uu, dt, st)
         return float(torch.real(torch.sum(torch.conj(f).to(torch.complex128) * e.apply(f, observable=True).to(torch.complex128))))
 
-    fd = (L(u + eps * v) - L(u - eps * v)) / (2 * eps)
-    an = float(np.sum(grad * v))
-    print("directional derivative: adjoint {:.6e}   central difference (eps = {}) {:.6e}   relative difference {:.2e}".format(an, eps, fd, abs(an - fd) / max(abs(fd), 1e-30)))
+    # (1) a random pulse direction: the derivative along it is ~1e-3 of |grad| -- the loss difference it makes is of the size of the fp32
+    # noise of two 4000-step forward chains, whatever the step; (2) the direction of the gradient itself: a derivative of |grad|
+    dirs = [("random direction", rng.standard_normal(u.shape), EPS_RANDOM), ("gradient direction", np.array(grad, dtype=np.float64), EPS_GRAD)]
+    for name, v, steps in dirs:
+        v = v / np.linalg.norm(v)
+        an = float(np.sum(grad * v))
+        for eps in steps:
+            fd = (L(u + eps * v) - L(u - eps * v)) / (2 * eps)
+            print("directional derivative, {}: adjoint {:.6e}   central difference (eps = {}) {:.6e}   relative difference {:.2e}".format(
+                name, an, eps, fd, abs(an - fd) / max(abs(fd), 1e-30)), flush=True)
