@@ -313,6 +313,16 @@ struct Ctx : dq_ctx {
   // adjoint sweep of the state-column form: -1 auto / 1 = the quadrature form (xs_backward_q_kernel) whenever a rule the kernels are
   // built for keeps its error bound below xs_quad_tol at this chain's theta, 0 = always the exact derivative of the polynomial
   int xs_adjoint = -1;
+  // Matrix-free routing (structured.hip): a Pauli-sum generator whose dimension the state-column kernels do not take (complex128
+  // above dim 4096, complex64 above 8192) runs on the matrix-free passes INSIDE this context -- the strings are read off the
+  // XOR-regular table, the caller keeps the dense API (dq_set_hamiltonians accepts any dim: diffqc.cc:43-67).  mf_mode: -1 auto,
+  // 0 never, 1 whenever the table is a sum of Pauli strings (tests at small dim)
+  dq_sctx* mf = nullptr;
+  int mf_mode = -1;
+  bool mf_dirty = true, mf_possible = false, mf_has_obs = false;
+  double last_mf = 0, mf_checkpoint_bytes = 0;
+  std::vector<unsigned> tab_sgn_h;             // host copies of the table's sign words and offset-0 diagonals (find_*xor_regular)
+  std::vector<double> tab_dval_h;
   int xs_workgroups = 0;                       // > 0: at most that many workgroups per launch (tests of the several-columns-per-workgroup loop)
   double xs_part_bytes = 268435456.0;          // scratch of the adjoint sweep's per-step partial sums: the chain is swept in segments that fit
   double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
@@ -354,6 +364,7 @@ struct Ctx : dq_ctx {
     herm_tol = sizeof(T) == 8 ? 1e-12 : 1e-5;
   }
   ~Ctx() override {
+    if (mf) (void)dq_sctx_destroy(mf);
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : ev_free) (void)hipEventDestroy(e);
   }
@@ -375,7 +386,8 @@ struct Ctx : dq_ctx {
     return images + (size_t)d + 1024 <= max_lds;
   }
   bool zxr_on() const {
-    return sizeof(T) == 8 && zxr_ok && xor_mode != 0 && real_mode != 0 && force_degree <= 0 && force_s < 0 && column_lds_ok();
+    return sizeof(T) == 8 && zxr_ok && xor_mode != 0 && real_mode != 0 && force_degree <= 0 && force_s < 0 && column_lds_ok() &&
+           dq::zxr_supported(d, 1, zxr_tab.R, zxr_tab.nd);
   }
   bool xr_on(int q) const {
     return xr_ok && xor_mode != 0 && sparse_gen_on() && dq::xr_supported(d, q, xr_tab.R, xr_tab.nd, sizeof(T)) && column_lds_ok();
@@ -1434,6 +1446,134 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
     c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>(out_db, B, 0, (const T2*)c->xs_psi.p, d, 0, B, d, 0, 1, c->st); });
 }
 
+// ---- matrix-free routing (structured.hip behind the dense API) --------------------------------------------------------------------
+template <class T>
+const dq::XrTab* mf_table(Ctx<T>* c) {
+  if (c->xor_mode == 0) return nullptr;
+  if (c->real_h && c->xr_ok && c->sparse_mode != 0 && c->sparse_gen_mode != 0) return &c->xr_tab;
+  if (!c->real_h && c->zxr_ok) return &c->zxr_tab;
+  return nullptr;
+}
+
+// in-place Walsh-Hadamard transform: f[z] <- (1 / n) sum_i f[i] (-1)^popcount(i & z) -- the coefficients of the Z-strings of a diagonal
+inline void mf_wht(std::vector<double>& f) {
+  const size_t n = f.size();
+  for (size_t h = 1; h < n; h <<= 1)
+    for (size_t i = 0; i < n; i += h << 1)
+      for (size_t j = i; j < i + h; ++j) {
+        const double a = f[j], b = f[j + h];
+        f[j] = a + b;
+        f[j + h] = a - b;
+      }
+  const double inv = 1.0 / (double)n;
+  for (double& v : f) v *= inv;
+}
+
+// The table as Pauli strings (kron order of the reference, demo_maxcut.py:49-56: index bit b of a row <-> string position n-1-b;
+// masks are index-bit masks).  XOR-diagonal j: entries H[i, i ^ x] = (-1)^s_ij c i^ph.  It is ONE string a P, P = X on the bits of
+// x & ~z, Z on z & ~x, Y on x & z, iff s_ij = s_0j ^ parity(i & z) for a mask z; then P[i, i ^ x] = (-i)^ny (-1)^parity(i & z)
+// (ny = popcount(x & z)) and a = (-1)^s0 c i^(ph + ny), real for a Hermitian source.  Offset-0 diagonals: Z-strings by their
+// Walsh-Hadamard coefficients.  Returns false when a sign pattern is not a parity (a sum of strings of equal weight that the
+// table cannot tell apart): such inputs keep the explicit-propagator chain.
+template <class T>
+bool mf_build(Ctx<T>* c) {
+  if (!c->mf_dirty) return c->mf_possible;
+  c->mf_dirty = false;
+  c->mf_possible = false;
+  c->mf_has_obs = false;
+  if (c->mf) { (void)dq_sctx_destroy(c->mf); c->mf = nullptr; }
+  const dq::XrTab* tab = mf_table(c);
+  const int d = c->d;
+  int n = 0;
+  while ((1 << n) < d) ++n;
+  if (!tab || (1 << n) != d || n < 9 || n > 30) return false;
+  if (c->tab_sgn_h.size() != (size_t)d || c->tab_dval_h.size() < (size_t)tab->nd * d) return false;
+  std::vector<int> owner;
+  std::vector<unsigned> xm, zm;
+  std::vector<double> w;
+  auto parity = [](unsigned v) { return (unsigned)__builtin_popcount(v) & 1u; };
+  for (int j = 0; j < tab->R; ++j) {
+    const unsigned s0 = tab->sgn ? (c->tab_sgn_h[0] >> j) & 1u : 0u;
+    unsigned z = 0;
+    if (tab->sgn) {
+      for (int b = 0; b < n; ++b)
+        if (((c->tab_sgn_h[(size_t)1 << b] >> j) & 1u) != s0) z |= 1u << b;
+      for (int i = 0; i < d; ++i)
+        if (((c->tab_sgn_h[i] >> j) & 1u) != (s0 ^ parity((unsigned)i & z))) return false;
+    }
+    const unsigned x = (unsigned)tab->xoff[j];
+    const int ny = __builtin_popcount(x & z), e = tab->phase[j] + ny;
+    if (e & 1) return false;   // (an imaginary coefficient: not a Hermitian source -- cannot happen past the Hermiticity check)
+    double a = tab->cmag[j] * (s0 ? -1.0 : 1.0) * (((e >> 1) & 1) ? -1.0 : 1.0);
+    owner.push_back(tab->kid[j]);
+    xm.push_back(x);
+    zm.push_back(z);
+    w.push_back(a);
+  }
+  auto add_diagonal = [&](int own, const double* dg) {
+    std::vector<double> f(dg, dg + d);
+    double mx = 0.0;
+    for (double v : f) mx = std::max(mx, std::fabs(v));
+    mf_wht(f);
+    for (int z = 0; z < d; ++z)
+      if (std::fabs(f[z]) > 1e-15 * mx) {   // (dropped coefficients: below the rounding of the diagonal itself)
+        owner.push_back(own);
+        xm.push_back(0u);
+        zm.push_back((unsigned)z);
+        w.push_back(f[z]);
+      }
+  };
+  for (int jd = 0; jd < tab->nd; ++jd) add_diagonal(tab->dkid[jd], c->tab_dval_h.data() + (size_t)jd * d);
+  if (c->have_M && c->m_is_diag) {
+    std::vector<double> md((size_t)d);
+    HIPCK(hipMemcpyAsync(md.data(), c->m_diag.p, sizeof(double) * (size_t)d, hipMemcpyDeviceToHost, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+    add_diagonal(-2, md.data());
+    c->mf_has_obs = true;
+  }
+  auto ck = [&](int rc, const char* what) {
+    if (rc != DQ_OK) fail(rc, std::string("matrix-free routing: ") + what + ": " + dq_sctx_last_error());
+  };
+  ck(dq_sctx_create(&c->mf, n, c->K, c->dev, c->dtype), "dq_sctx_create");
+  ck(dq_sctx_set_stream(c->mf, (void*)c->st), "dq_sctx_set_stream");
+  ck(dq_sctx_set_terms(c->mf, (int)owner.size(), owner.data(), xm.data(), zm.data(), w.data()), "dq_sctx_set_terms");
+  c->mf_possible = true;
+  return true;
+}
+
+// does this call run on the matrix-free passes?
+template <class T>
+bool mf_route(Ctx<T>* c, int S, bool need_observable, bool targets) {
+  c->last_mf = 0;
+  if (c->mf_mode == 0 || S <= 0 || targets) return false;
+  const dq::XrTab* tab = mf_table(c);
+  if (!tab) return false;
+  // the options that pin another scheme keep it (as for the state-column form)
+  if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || c->compose_mode >= 0) return false;
+  // auto: only where the state-column kernels do not exist (their cost per step is far below a pass over HBM)
+  if (c->mf_mode < 0 && (c->d < 512 || dq::xs_supported(c->d, 1, tab->R, tab->nd, sizeof(T)))) return false;
+  if (need_observable && !(c->have_M && c->m_is_diag)) return false;   // (a general M is not a string table here)
+  if (!mf_build(c)) return false;
+  if (need_observable && !c->mf_has_obs) return false;
+  auto opt = [&](const char* name, double v) {
+    if (dq_sctx_set_option(c->mf, name, v) != DQ_OK) fail(DQ_ERR_INVALID, std::string("matrix-free routing: ") + dq_sctx_last_error());
+  };
+  opt("plan_steps", (double)c->plan_steps);
+  opt("checkpoint_bytes", c->mf_checkpoint_bytes);
+  if (dq_sctx_set_stream(c->mf, (void*)c->st) != DQ_OK) fail(DQ_ERR_HIP, dq_sctx_last_error());
+  return true;
+}
+
+template <class T>
+void mf_after(Ctx<T>* c) {
+  c->last_mf = 1;
+  double v = 0;
+  if (dq_sctx_get_info(c->mf, "degree", &v) == DQ_OK) c->last_degree = v;
+  if (dq_sctx_get_info(c->mf, "theta", &v) == DQ_OK) c->last_theta = v;
+  if (dq_sctx_get_info(c->mf, "checkpoint_stride", &v) == DQ_OK) c->last_cstride = v;
+  c->last_squarings = 0; c->last_products = 0; c->last_xs = 0; c->last_composed = 0; c->last_opback = 0;
+}
+
 template <class T>
 void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_in, void* psi_out, int B) {
   typedef TT T2;
@@ -1446,6 +1586,12 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d;
   const size_t sb = (size_t)d * B * sizeof(T2);
+  if (mf_route(c, S, false, false)) {
+    const int rc = dq_sctx_propagate(c->mf, u, S, dt, psi_in, psi_out, B);
+    if (rc != DQ_OK) fail(rc, std::string("matrix-free routing: ") + dq_sctx_last_error());
+    mf_after(c);
+    return;
+  }
   std::vector<double> uh = fetch_u(c, u, S);
   c->psi[0].ensure(sb);
   c->psi[1].ensure(sb);
@@ -1805,6 +1951,12 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d, K = c->K;
   const size_t sb = (size_t)d * B * sizeof(T2);
+  if (mf_route(c, S, true, targets != nullptr)) {   // a Pauli-sum generator beyond the state-column kernels' dimensions
+    const int rc = dq_sctx_energy_grad(c->mf, u, S, dt, psi0, B, loss, grad_u, psi_final, energies);
+    if (rc != DQ_OK) fail(rc, std::string("matrix-free routing: ") + dq_sctx_last_error());
+    mf_after(c);
+    return;
+  }
   // Operator-form backward sweep for batch >= dim. The cotangent of U_t is G_t = Lambda_{t+1} Psi_t^H; with
   // W_t = Lambda_t Psi_t^H (d x d) and Psi_t = U_t^H Psi_{t+1}, Lambda_t = U_t^H Lambda_{t+1}:
   //     G_t = W_{t+1} U_t,     W_t = U_t^H G_t,     W_S = Lambda_S Psi_S^H
@@ -2224,6 +2376,8 @@ void find_xor_regular(Ctx<T>* c, const std::vector<long>& rowptr, long nnz) {
   tab.dval = (const double*)c->xr_dval.p;
   c->xr_tab = tab;
   c->xr_ok = true;
+  c->tab_sgn_h = sgn;
+  c->tab_dval_h = dval;
 }
 
 // Complex Hermitian H0 / H_k that are sums of Pauli strings with X and Y factors (XOR-regular pattern, every XOR-diagonal of one
@@ -2235,7 +2389,7 @@ void find_zxor_regular(Ctx<T>* c) {
   typedef TT T2;
   if (!c->hermitian || c->real_h || c->K <= 0) return;   // (complex64 engines too: the state-column form takes the table)
   const int d = c->d, K = c->K, NS = K + 1;
-  if (!dq::zxr_supported(d, 1, 1, 0)) return;
+  if (d < 256 || (d & (d - 1)) != 0) return;   // (any power of two: dimensions beyond the column kernels' go to the matrix-free passes)
   DevBuf cnt_dev, base_dev, col_dev, re_dev, im_dev;
   cnt_dev.ensure(sizeof(int) * (size_t)NS * d);
   HIPCK(dq::zsp_count_launch((const T2*)c->H0.p, d, 1, (int*)cnt_dev.p, c->st));
@@ -2326,6 +2480,8 @@ void find_zxor_regular(Ctx<T>* c) {
   tab.dval = (const double*)c->xr_dval.p;
   c->zxr_tab = tab;
   c->zxr_ok = true;
+  c->tab_sgn_h = sgn;
+  c->tab_dval_h = dval;
 }
 
 // CSR of the Hamiltonians' nonzeros (real path), if they are sparse enough to pay: at most sparse_fill nonzeros per row
@@ -2443,6 +2599,7 @@ void do_set_hamiltonians(Ctx<T>* c, const void* H0, const void* Hs) {
   }
   build_sparse_controls(c);
   find_zxor_regular(c);
+  c->mf_dirty = true;
   c->have_H = true;
 }
 
@@ -2468,6 +2625,7 @@ void do_set_observable(Ctx<T>* c, const void* M) {
     HIPCK(hipStreamSynchronize(c->st));
     c->m_is_diag = off == 0.0;
   }
+  c->mf_dirty = true;
   c->have_M = true;
 }
 
@@ -2651,6 +2809,11 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "matrix_free") {  // -1 auto (Pauli-sum generators beyond the state-column kernels' dimensions), 0 never, 1 whenever the table is a string sum
+    c->mf_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "matrix_free_checkpoint_bytes") {  // checkpoint budget of the routed passes (0: 70 % of the free HBM)
+    if (v < 0) fail(DQ_ERR_INVALID, "matrix_free_checkpoint_bytes must be >= 0");
+    c->mf_checkpoint_bytes = v;
   } else if (s == "state_columns_workgroups") {  // 0 = as many as fit the chip; > 0 caps the launch (tests: several columns per workgroup)
     if (v < 0 || v > 65535) fail(DQ_ERR_INVALID, "state_columns_workgroups must be 0..65535");
     c->xs_workgroups = (int)v;
@@ -2694,6 +2857,12 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "sparse_generator") return c->last_spx;
   if (s == "xor_regular") return c->last_xr;
   if (s == "state_columns") return c->last_xs;
+  if (s == "matrix_free") return c->last_mf;
+  if (s.rfind("matrix_free_", 0) == 0 && c->mf) {   // "matrix_free_passes", "matrix_free_dma_passes", ...: the routed context's own info
+    double v = 0;
+    if (dq_sctx_get_info(c->mf, s.c_str() + 12, &v) == DQ_OK) return v;
+    fail(DQ_ERR_INVALID, std::string("matrix-free routing: ") + dq_sctx_last_error());
+  }
   if (s == "state_columns_quad_nodes") return c->last_xs_nodes;
   if (s == "state_columns_segments") return c->last_xs_segments;
   if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);

@@ -1497,6 +1497,9 @@ void set_terms(SCtx<T>* c, int nt, const int* owner, const unsigned* x, const un
     const double re[4] = {1, 0, -1, 0}, im[4] = {0, 1, 0, -1};
     wre[s] = t.w * re[ny]; wim[s] = t.w * im[ny];
     own[s] = t.owner;
+    // bound of the step's norm (Taylor degree): the off-diagonal strings by the sum of their weights; the Z-strings of a source
+    // by the largest entry of the diagonal they add up to (below) -- for an Ising drift far less than the sum of |J| and |h|
+    if (t.x == 0) continue;
     if (t.owner == -1) c->wsum0 += std::fabs(t.w);
     else if (t.owner >= 0) c->wsumk[t.owner] += std::fabs(t.w);
   }
@@ -1539,6 +1542,18 @@ void set_terms(SCtx<T>* c, int nt, const int* owner, const unsigned* x, const un
   }
   if (!c->diag_controls.empty())
     SHIP(hipMemcpy(c->Dkidx.p, c->diag_controls.data(), c->diag_controls.size() * sizeof(int), hipMemcpyHostToDevice));
+  {  // largest |entry| of the drift's diagonal and of every diagonal control's: their share of the norm bound
+    std::vector<T> h((size_t)c->d);
+    auto absmax = [&](const void* dev) {
+      SHIP(hipMemcpy(h.data(), dev, (size_t)c->d * sizeof(T), hipMemcpyDeviceToHost));
+      double m = 0.0;
+      for (T v : h) m = std::max(m, (double)std::fabs(v));
+      return m;
+    };
+    if (c->has_D0) c->wsum0 += absmax(c->D0.p);
+    for (size_t j = 0; j < c->diag_controls.size(); ++j)
+      c->wsumk[c->diag_controls[j]] += absmax((const char*)c->Dk.p + j * (size_t)c->d * sizeof(T));
+  }
   // observable coefficients are static: weight * i^{nY}
   if (c->n_slots) {
     hipLaunchKernelGGL(scoef_kernel<T>, dim3((c->n_slots + 63) / 64), dim3(64), 0, c->st,
