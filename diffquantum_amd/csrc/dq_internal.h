@@ -310,7 +310,7 @@ struct XsQuad {
 // the rule for a step of size theta (bound of ||A||): the fewest interior nodes whose error bound e (2 theta)^(2 ni + 2) stays below
 // tol (relative to ||dA_k|| ||lambda|| ||psi||); false when no rule the kernels are built for reaches it (ni_max <= XS_NIMAX)
 bool xs_quad_make(double theta, double tol, int ni_max, XsQuad* qd);
-bool xs_quad_supported(const XrTab& tab, int ni);  // the table / rule combinations xs_backward_q_kernel is instantiated for
+bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant);  // the table / rule / shape combinations xs_backward_q_kernel runs
 // variant: bit 0 = 1024 threads x 4 rows per workgroup at d = 4096 (default 512 x 8); bit 1 = prefetch of the next diagonal's partners
 int xs_blocks(int d, size_t elem, int B, int n_cu, int variant);   // workgroups of a launch over B columns
 int xs_waves(int d, int variant);

@@ -1388,7 +1388,7 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
   c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
   x.quad_ok = false;
-  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, &x.quad) && dq::xs_quad_supported(*x.tab, x.quad.ni);
+  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, &x.quad) && dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant);
   c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
   if (backward) {
     if (!x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));

@@ -370,7 +370,11 @@ bool xs_quad_make(double theta, double tol, int ni_max, XsQuad* qd) {
 #ifndef XS_QUAD_SIGNED
 #define XS_QUAD_SIGNED 0
 #endif
-bool xs_quad_supported(const XrTab& tab, int ni) { return ni == 2 && tab.R <= XR_RSMALL && (XS_QUAD_SIGNED || tab.sgn == nullptr); }
+// Shapes of 1024 threads per column (d = 4096 "wide", d = 8192 in complex64) keep the exact form: 16 waves leave a wave 128 registers,
+// the quadrature kernel's node values spill there (n = 13, complex64, 8192 states: 310 steps/s against 508, profiles/r4_perf_route_v0.txt).
+bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant) {
+  return ni == 2 && tab.R <= XR_RSMALL && (XS_QUAD_SIGNED || tab.sgn == nullptr) && xs_threads(d, variant) < 1024;
+}
 
 namespace {
 

@@ -241,7 +241,7 @@ template <class T, int NT, int RPT>
 hipError_t xs_backward_q_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
                             long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part, hipStream_t st) {
   typedef typename Cx<T>::type T2;
-  if (!xs_quad_supported(tab, qd.ni)) return hipErrorInvalidValue;
+  if (!xs_quad_supported(tab, qd.ni, NT * RPT, xs_threads(NT * RPT, 0) == NT ? 0 : 1)) return hipErrorInvalidValue;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr, dc = xs_has_diag_controls(tab);
   bool cplx = false;
@@ -263,12 +263,10 @@ template <class T>
 hipError_t xs_backward_q_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                               const double* dgs, long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part,
                               int variant, hipStream_t st) {
-  if constexpr (sizeof(T) == sizeof(float)) {
-    if (d == 8192) return xs_backward_q_go<T, 1024, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);
-  }
+  // (no 1024-thread shapes -- d = 8192 in complex64, the wide form of d = 4096: xs_quad_supported keeps them on the exact kernel)
   switch (d) {
     case 4096:
-      return (variant & 1) ? xs_backward_q_go<T, 1024, 4>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st)
+      return (variant & 1) ? hipErrorInvalidValue
                            : xs_backward_q_go<T, 512, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);
 #ifndef XS_PROBE_4096_ONLY
     case 2048: return xs_backward_q_go<T, 256, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);

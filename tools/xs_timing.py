@@ -13,14 +13,17 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 VARIANTS = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
 OTHER = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 XY = int(sys.argv[6]) if len(sys.argv) > 6 else 0     # 1: X drives on half of the qubits, Y drives on the other half (complex table)
-ADJ = [int(v) for v in sys.argv[7].split(",")] if len(sys.argv) > 7 else [-1]   # state_columns_adjoint: 1 / -1 quadrature form, 0 exact form
+ADJ = [int(v) for v in sys.argv[7].split(",")] if len(sys.argv) > 7 else [-1]
+DTYPE = sys.argv[8] if len(sys.argv) > 8 else "c128"   # state_columns_adjoint: 1 / -1 quadrature form, 0 exact form
 dev = torch.device("cuda:0")
 d = 1 << n
 H0, Hs, M = problems.xy_drives_torch(n, 0, dev, n_x=n // 2, n_y=n - n // 2) if XY else problems.random_ising_torch(n, 0, dev)
 u = torch.from_numpy(problems.pulse_table(n, S, 1e-3 * S, seed=0)).to(dev)
 psi0 = torch.from_numpy(problems.random_states(d, B, 0)).to(dev)
+if DTYPE == "c64":
+    H0, Hs, M, psi0 = H0.to(torch.complex64), Hs.to(torch.complex64), M.to(torch.complex64), psi0.to(torch.complex64)
 res = {}
-with Engine(d, n) as e:
+with Engine(d, n, dtype=DTYPE) as e:
     e.use_torch_stream()
     e.set_hamiltonians(H0, Hs)
     e.set_observable(M)
