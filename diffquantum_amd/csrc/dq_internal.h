@@ -254,7 +254,14 @@ struct XrTab {
   int dkid[XR_DMAX];     // source of an offset-0 diagonal: control index, or -1 for the drift
   const unsigned* sgn;   // [d] bit j set: entry (i, i ^ xoff[j]) is -cmag[j]; null when no entry is negative
   const double* dval;    // [nd][d] values of the offset-0 diagonals
+  // The signs as parities (every diagonal one Pauli string): bit j of sgn[i] = bit j of s0mask ^ parity(i & zmask[j]).  parity = 1 when
+  // that holds for every diagonal (xr_parity_signs); the state-column kernels take their signs from these two (no sign words).
+  unsigned zmask[XR_RMAX];
+  unsigned s0mask;
+  int parity;
 };
+// fills zmask / s0mask / parity from the host copy of the sign words (sgn_h may be null: no negative entry)
+void xr_parity_signs(XrTab& tab, const unsigned* sgn_h, int d);
 struct XrPoly {
   int q;
   double cc[XR_QMAX + 1], sc[XR_QMAX + 1];  // cos X = sum cc_j X^2j, sin X = sum sc_j X^(2j+1)
@@ -296,6 +303,8 @@ struct XsOrder {                   // the order in which the sweeps walk the tab
   int n0, n1;                      // LDS partners that keep / permute the thread's row list
   int nloc[8];                     // partners in the thread's own registers, by offset / threads
   int n0p1, n1p1, nlocp1[8];       // how many of each class have phase 1 (entries +-i c): every class is ordered phase 0 first
+  unsigned char rsn[20];           // per group (class 0 / 1 by phase: 0..3; register class xh by phase: 4 + 2 (xh - 1) + phase): how many of
+                                   // its diagonals, ordered LAST, carry a row factor of the sign (parity mask with bits at or above the thread count)
 };
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
 // Quadrature form of the adjoint sweep (xs_backward_q_kernel): a Gauss-Lobatto rule on [0, 1] with ni interior nodes.

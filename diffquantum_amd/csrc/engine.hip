@@ -1335,8 +1335,9 @@ int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
 template <class T>
 const dq::XrTab* xs_table(Ctx<T>* c) {
   if (c->xor_mode == 0 || c->xs_mode == 0) return nullptr;
-  if (c->real_h && c->xr_ok && c->sparse_mode != 0 && c->sparse_gen_mode != 0) return &c->xr_tab;
-  if (!c->real_h && c->zxr_ok) return &c->zxr_tab;
+  // (the state-column kernels take the signs as parities -- one Pauli string per diagonal; other sign patterns keep the column form)
+  if (c->real_h && c->xr_ok && c->sparse_mode != 0 && c->sparse_gen_mode != 0) return c->xr_tab.parity ? &c->xr_tab : nullptr;
+  if (!c->real_h && c->zxr_ok) return c->zxr_tab.parity ? &c->zxr_tab : nullptr;
   return nullptr;
 }
 
@@ -2374,6 +2375,7 @@ void find_xor_regular(Ctx<T>* c, const std::vector<long>& rowptr, long nnz) {
   HIPCK(hipStreamSynchronize(c->st));
   tab.sgn = neg ? (const unsigned*)c->xr_sgn.p : nullptr;
   tab.dval = (const double*)c->xr_dval.p;
+  dq::xr_parity_signs(tab, neg ? sgn.data() : nullptr, d);
   c->xr_tab = tab;
   c->xr_ok = true;
   c->tab_sgn_h = sgn;
@@ -2478,6 +2480,7 @@ void find_zxor_regular(Ctx<T>* c) {
   HIPCK(hipStreamSynchronize(c->st));
   tab.sgn = (const unsigned*)c->xr_sgn.p;
   tab.dval = (const double*)c->xr_dval.p;
+  dq::xr_parity_signs(tab, sgn.data(), d);
   c->zxr_tab = tab;
   c->zxr_ok = true;
   c->tab_sgn_h = sgn;

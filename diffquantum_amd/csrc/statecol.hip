@@ -60,11 +60,10 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
   T2* img = (T2*)xs_lds_raw;  // two images of D
   const int t = threadIdx.x;
-  unsigned sg[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+  const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
   XsCtl ctl;
   ctl.load_table(tab, ord, t & 63);
+  if (SIGN) ctl.load_row_signs(tab, t & 63, __builtin_ctz(NT));
   int p = 0;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     T2 cur[RPT];
@@ -222,6 +221,28 @@ hipError_t xs_diag_costate_launch(const float2* psi, const double* mdiag, float2
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 
+void xr_parity_signs(XrTab& tab, const unsigned* sgn_h, int d) {
+  memset(tab.zmask, 0, sizeof(tab.zmask));
+  tab.s0mask = 0;
+  tab.parity = 1;
+  if (!sgn_h) return;
+  int n = 0;
+  while ((1 << n) < d) ++n;
+  for (int j = 0; j < tab.R; ++j) {
+    const unsigned s0 = (sgn_h[0] >> j) & 1u;
+    unsigned z = 0;
+    for (int b = 0; b < n; ++b)
+      if (((sgn_h[(size_t)1 << b] >> j) & 1u) != s0) z |= 1u << b;
+    for (int i = 0; i < d; ++i)
+      if (((sgn_h[i] >> j) & 1u) != (s0 ^ ((unsigned)__builtin_popcount((unsigned)i & z) & 1u))) {
+        tab.parity = 0;   // (a sum of several strings of equal weight on one offset: the column kernels' sign words still take it)
+        return;
+      }
+    tab.zmask[j] = z;
+    tab.s0mask |= s0 << j;
+  }
+}
+
 bool xs_supported(int d, int L, int R, int nd, size_t elem) {
   if (elem != sizeof(double) && elem != sizeof(float)) return false;
   if (R < 1 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || L < 1 || L > 24) return false;
@@ -280,29 +301,40 @@ XsOrder xs_make_order(int d, const XrTab& tab, int variant, bool local) {
   XsOrder o;
   memset(&o, 0, sizeof(o));
   const int nt = xs_threads(d, variant);
+  int lnt = 0;
+  while ((1 << lnt) < nt) ++lnt;
+  // (row factor of the sign: the diagonal's parity mask reaches the row bits of the index)
+  auto rowsigned = [&](int j) { return tab.sgn != nullptr && tab.parity && (tab.zmask[j] >> lnt) != 0; };
   int at = 0;
+  // within every class: phase 0 first; within a phase: the diagonals without a row factor first
   for (int ph = 0; ph < 2; ++ph)
-    for (int j = 0; j < tab.R; ++j)
-      if ((tab.xoff[j] & (nt - 1)) != 0 && tab.xoff[j] < nt && (tab.phase[j] != 0) == (ph != 0)) {
-        o.perm[at++] = (unsigned char)j;
-        ++o.n0;
-        o.n0p1 += ph;
-      }
+    for (int rs = 0; rs < 2; ++rs)
+      for (int j = 0; j < tab.R; ++j)
+        if ((tab.xoff[j] & (nt - 1)) != 0 && tab.xoff[j] < nt && (tab.phase[j] != 0) == (ph != 0) && rowsigned(j) == (rs != 0)) {
+          o.perm[at++] = (unsigned char)j;
+          ++o.n0;
+          o.n0p1 += ph;
+          o.rsn[0 + ph] += rs;
+        }
   for (int ph = 0; ph < 2; ++ph)
-    for (int j = 0; j < tab.R; ++j)
-      if (((tab.xoff[j] & (nt - 1)) != 0 ? tab.xoff[j] >= nt : !local) && (tab.phase[j] != 0) == (ph != 0)) {
-        o.perm[at++] = (unsigned char)j;
-        ++o.n1;
-        o.n1p1 += ph;
-      }
+    for (int rs = 0; rs < 2; ++rs)
+      for (int j = 0; j < tab.R; ++j)
+        if (((tab.xoff[j] & (nt - 1)) != 0 ? tab.xoff[j] >= nt : !local) && (tab.phase[j] != 0) == (ph != 0) && rowsigned(j) == (rs != 0)) {
+          o.perm[at++] = (unsigned char)j;
+          ++o.n1;
+          o.n1p1 += ph;
+          o.rsn[2 + ph] += rs;
+        }
   for (int xh = 1; xh < 8 && local; ++xh)
     for (int ph = 0; ph < 2; ++ph)
-      for (int j = 0; j < tab.R; ++j)
-        if ((tab.xoff[j] & (nt - 1)) == 0 && tab.xoff[j] / nt == xh && (tab.phase[j] != 0) == (ph != 0)) {
-          o.perm[at++] = (unsigned char)j;
-          ++o.nloc[xh];
-          o.nlocp1[xh] += ph;
-        }
+      for (int rs = 0; rs < 2; ++rs)
+        for (int j = 0; j < tab.R; ++j)
+          if ((tab.xoff[j] & (nt - 1)) == 0 && tab.xoff[j] / nt == xh && (tab.phase[j] != 0) == (ph != 0) && rowsigned(j) == (rs != 0)) {
+            o.perm[at++] = (unsigned char)j;
+            ++o.nloc[xh];
+            o.nlocp1[xh] += ph;
+            o.rsn[4 + 2 * (xh - 1) + ph] += rs;
+          }
   return o;
 }
 size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)L * (size_t)d; }
@@ -364,16 +396,13 @@ bool xs_quad_make(double theta, double tol, int ni_max, XsQuad* qd) {
   }
   return false;
 }
-// (instantiated for tables of up to 16 XOR-diagonals -- one accumulator vector -- and the 4-point rule).  XS_QUAD_SIGNED: tables
-// with row signs run it too; off while their sign handling costs the quadrature kernel more registers than it has (measured at
-// d = B = 4096 on X / Y drives: 469 steps/s against 515 on the exact form, profiles/r4_xy_forms.txt)
-#ifndef XS_QUAD_SIGNED
-#define XS_QUAD_SIGNED 0
-#endif
-// Shapes of 1024 threads per column (d = 4096 "wide", d = 8192 in complex64) keep the exact form: 16 waves leave a wave 128 registers,
-// the quadrature kernel's node values spill there (n = 13, complex64, 8192 states: 310 steps/s against 508, profiles/r4_perf_route_v0.txt).
+// The quadrature kernel runs where it is the faster form (measured at d = B = 4096, tools/xs_timing.py, profiles/r4_xy_forms.txt):
+// unsigned tables without diagonal controls, up to 16 XOR-diagonals, the 4-point rule -- 1013 steps/s against 749 on the exact form.
+// Tables with row signs (X / Y drives: 588 against 633) or with diagonal controls (X / Z controls: 694 against 958) keep the exact
+// form: their extra state (sign handling, the row accumulators) costs the quadrature kernel more registers than it has; so do the
+// shapes of 1024 threads per column (d = 4096 "wide", d = 8192 in complex64: 128 registers per wave, 310 against 508 steps/s).
 bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant) {
-  return ni == 2 && tab.R <= XR_RSMALL && (XS_QUAD_SIGNED || tab.sgn == nullptr) && xs_threads(d, variant) < 1024;
+  return ni == 2 && tab.R <= XR_RSMALL && tab.sgn == nullptr && !xs_has_diag_controls(tab) && xs_threads(d, variant) < 1024;
 }
 
 namespace {

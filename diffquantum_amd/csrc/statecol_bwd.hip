@@ -29,12 +29,12 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   T2* W = (T2*)xs_lds_raw;
   T2* Lm = W + D;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  unsigned sg[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+  const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
   XsCtl ctl, ctlh;  // (ctlh: the order of the pairing sweeps -- every partner from LDS, phase 0 first)
   ctl.load_table(tab, ord, lane);
+  if (SIGN) ctl.load_row_signs(tab, lane, __builtin_ctz(NT));
   ctlh.load_table(tab, ordh, lane);
+  if (SIGN) ctlh.load_row_signs(tab, lane, __builtin_ctz(NT));
   T2* pk = park + (long)blockIdx.x * L * D;  // [l][r * NT + t] (uniform base, lane index t)
   // in-place update of the work image: every read of the sweep that just ran is done before any row is overwritten
   auto publish = [&](const T2* v) {

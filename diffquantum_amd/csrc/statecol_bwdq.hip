@@ -34,12 +34,12 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
   T2* W = (T2*)xs_lds_raw;
   T2* Lm = W + D;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  unsigned sg[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) sg[r] = SIGN ? tab.sgn[r * NT + t] : 0u;
+  const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
   XsCtl ctl, ctlh;
   ctl.load_table(tab, ord, lane);
+  if (SIGN) ctl.load_row_signs(tab, lane, __builtin_ctz(NT));
   ctlh.load_table(tab, ordh, lane);
+  if (SIGN) ctlh.load_row_signs(tab, lane, __builtin_ctz(NT));
   auto publish = [&](const T2* v) {
     __syncthreads();
     xs_put<T, NT, RPT>(W, t, v);
@@ -167,12 +167,12 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         // the partners at offsets without lane bits are the thread's own rows of r_m: those diagonals FIRST, while cur is still
         // live and the partner ring of the LDS classes is not yet (the two share registers in time), then the LDS classes
         xs_local_classes<T, RPT, 1, SIGN, true, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, (T)-1, o, q, (double*)&dacc[0]);
-        xs_lds_class<T, NT, RPT, SIGN, true, RM, false, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+        xs_lds_group<T, NT, RPT, SIGN, true, RM, false, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
         if constexpr (CPLX)
-          xs_lds_class<T, NT, RPT, SIGN, true, RM, false, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
-        xs_lds_class<T, NT, RPT, SIGN, true, RM, true, false, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+          xs_lds_group<T, NT, RPT, SIGN, true, RM, false, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+        xs_lds_group<T, NT, RPT, SIGN, true, RM, true, false, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
         if constexpr (CPLX)
-          xs_lds_class<T, NT, RPT, SIGN, true, RM, true, false, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+          xs_lds_group<T, NT, RPT, SIGN, true, RM, true, false, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
 #else
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, q, dacc);
 #endif
@@ -243,14 +243,9 @@ hipError_t xs_backward_q_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam
   typedef typename Cx<T>::type T2;
   if (!xs_quad_supported(tab, qd.ni, NT * RPT, xs_threads(NT * RPT, 0) == NT ? 0 : 1)) return hipErrorInvalidValue;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
-  const bool sgn = tab.sgn != nullptr, dc = xs_has_diag_controls(tab);
-  bool cplx = false;
-  for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
-  if (cplx && !sgn) return hipErrorInvalidValue;
+  // (xs_quad_supported: unsigned tables without diagonal controls only -- the one instantiation of the kernel's flag space that is built)
   void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, XsQuad, double*) =
-      cplx ? (dc ? xs_backward_q_kernel<T, NT, RPT, true, true, true, 2> : xs_backward_q_kernel<T, NT, RPT, true, false, true, 2>)
-           : (sgn ? (dc ? xs_backward_q_kernel<T, NT, RPT, true, true, false, 2> : xs_backward_q_kernel<T, NT, RPT, true, false, false, 2>)
-                  : (dc ? xs_backward_q_kernel<T, NT, RPT, false, true, false, 2> : xs_backward_q_kernel<T, NT, RPT, false, false, false, 2>));
+      xs_backward_q_kernel<T, NT, RPT, false, false, false, 2>;
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int var = xs_threads(NT * RPT, 0) == NT ? 0 : 1;

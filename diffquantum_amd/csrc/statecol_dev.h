@@ -49,15 +49,24 @@ __device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
 
 // One XOR-diagonal's contribution with the partner values in v[]:  o += a_ij v,  a_ij = -i w sigma_ij (PH = 0: entries +-c) or
 // w sigma_ij (PH = 1: entries +-i c).  The phase is a template parameter (the host orders every class phase 0 first, so each loop is
-// of one phase: a runtime branch cost 16 register copies per diagonal where its two updates merged).  SIGN: the row's sign
-// sigma_ij goes into the weight (one xor on its high word) instead of into both components of the partner value.
+// of one phase: a runtime branch cost 16 register copies per diagonal where its two updates merged).
+// SIGN: the signs along a diagonal of a Pauli string are a parity, sigma_ij = (-1)^(s0_j + parity(i & z_j)); with i = r NT + t that is a
+// factor per THREAD (bit j of tsg: s0_j ^ parity(t & z_j), folded into the weight once per diagonal) times a factor per ROW that is
+// the same for every thread (bit r of the diagonal's row mask: parity(r & (z_j / NT)), a scalar).  Most diagonals have no row
+// factor at all (z_j within the thread bits): their loop is the unsigned one with a per-thread weight.  (Round 3 kept a sign word per
+// row -- a shift, a mask and an xor per row and diagonal in every sweep, twice in the pairing sweeps.)
+// ej = table entry >> 20: the diagonal's index in the table (5 bits), row-sign bits of rows 1 .. 7 at bits 5 .. 11.
 // DOT: the level's gradient pairing of the partners with the thread's own rows xm, into lane `slot` of the accumulator vector.
-template <class T, int RPT, bool SIGN, bool DOT, int PH>
-__device__ __forceinline__ void xs_use(int j, int slot, T w, const unsigned* sg, const typename Cx<T>::type* v, typename Cx<T>::type* o,
+template <class T, int RPT, bool SIGN, bool DOT, int PH, bool RS = false>
+__device__ __forceinline__ void xs_use(int ej, int slot, T w, unsigned tsg, const typename Cx<T>::type* v, typename Cx<T>::type* o,
                                        const typename Cx<T>::type* xm, double* dacc) {
+  // RS: the diagonal has a row factor (the host orders those last within every class and phase: a loop of their own, no branch here)
+  const unsigned tb = SIGN ? (tsg >> (ej & 31)) & 1u : 0u;
+  const unsigned rm = (SIGN && RS) ? ((unsigned)ej >> 4) & 0xfeu : 0u;   // bit r: row r carries one more minus (the same in every thread)
+  const T wt = SIGN ? xs_flip(w, tb) : w;
   T wr[RPT];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) wr[r] = SIGN ? xs_flip(w, (sg[r] >> j) & 1u) : w;
+  for (int r = 0; r < RPT; ++r) wr[r] = (SIGN && RS) ? xs_flip(wt, (rm >> r) & 1u) : wt;
   if (PH) {
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -76,11 +85,13 @@ __device__ __forceinline__ void xs_use(int j, int slot, T w, const unsigned* sg,
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       T p = PH ? -xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y) : xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
-      if (SIGN) p = xs_flip(p, (sg[r] >> j) & 1u);
+      if (SIGN && RS) p = xs_flip(p, (rm >> r) & 1u);
       if (r & 1) sb += p;
       else sa += p;
     }
-    (*(xs_acc16*)dacc)[slot] += (double)sa + (double)sb;
+    double tot = (double)sa + (double)sb;
+    if (SIGN) tot = xs_flip(tot, tb);   // the thread's factor, once per diagonal
+    (*(xs_acc16*)dacc)[slot] += tot;
   }
 }
 
@@ -96,10 +107,13 @@ __device__ __forceinline__ double xs_readlane(double v, int j) {
 struct XsCtl {
   int R, n0, n1, n0p1, n1p1;  // (n0p1 / n1p1 / nlocp1: how many of a class's diagonals, its LAST ones, have phase 1)
   int nloc[8], nlocp1[8];
-  int ent;    // xoff | phase << 16 | (index in the table: sign bit, accumulator) << 20
+  int ent;    // xoff | phase << 16 | (index in the table: sign bit, accumulator) << 20 | row-sign bits << 25
   double w;   // dt u c_j of the current step
   int perm;   // this lane's index in the table
+  int rsn;    // lane g: how many diagonals of group g (its LAST ones) carry a row factor of the sign; groups: LDS class 0 / 1 by phase
+              // (0, 1 / 2, 3), then the register classes xh = 1 .. 7 by phase (4 + 2 (xh - 1) + phase)
   __device__ __forceinline__ void load_table(const XrTab& tab, const XsOrder& ord, int lane) {
+    rsn = lane < 18 ? ord.rsn[lane] : 0;
     R = tab.R;
     n0 = ord.n0;
     n1 = ord.n1;
@@ -112,6 +126,22 @@ struct XsCtl {
     }
     perm = lane < tab.R ? ord.perm[lane] : 0;
     ent = lane < tab.R ? (tab.xoff[perm] | (tab.phase[perm] << 16) | (perm << 20)) : 0;
+  }
+  // + the row-sign bits of a parity-signed table at bits 25 .. 31: bit 24 + r = parity(r & (z / NT)), r = 1 .. 7
+  __device__ __forceinline__ void load_row_signs(const XrTab& tab, int lane, int log_nt) {
+    if (lane < tab.R) {
+      const unsigned zh = tab.zmask[perm] >> log_nt;
+      unsigned rmask = 0;
+#pragma unroll
+      for (unsigned r = 1; r < 8; ++r) rmask |= (unsigned)(__popc(r & zh) & 1) << (24 + r);
+      ent |= (int)rmask;
+    }
+  }
+  // bit j of the result: the thread's factor of diagonal j, s0_j ^ parity(t & z_j) (t < NT: the thread bits of the row index)
+  static __device__ __forceinline__ unsigned thread_signs(const XrTab& tab, int t) {
+    unsigned w = tab.s0mask;
+    for (int j = 0; j < tab.R; ++j) w ^= (unsigned)(__popc((unsigned)t & tab.zmask[j]) & 1) << j;
+    return w;
   }
   __device__ __forceinline__ void load_step(const double* __restrict__ wrow, int lane) { w = lane < R ? wrow[perm] : 0.0; }
 };
@@ -182,6 +212,7 @@ __device__ __forceinline__ void xs_rows(F&& f) {
   }
 }
 // one row's share of a diagonal: o += a_ij v and, with DOT, the pairing sums in four chains s[0..3]
+// (sbit: the ROW's factor of the sign, a scalar; the thread's factor is in w and, for the pairing, applied to the diagonal's total)
 template <bool SIGN, bool DOT, int PH, int R>
 __device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, double2& o, const double2* xm, double* s) {
   if (SIGN && DOT) {  // the row's sign goes into the partner value (both uses take it from there)
@@ -210,8 +241,8 @@ __device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, do
 }
 // DEPTH = reads in flight (the read of element k + DEPTH of the class's (diagonal, row) sequence is issued right after element k
 // has been used; DEPTH = RPT: a slot is refilled with the same row of the next diagonal)
-template <int NT, int RPT, bool SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH>
-__device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, const unsigned* sg, const double2* __restrict__ src, int t,
+template <int NT, int RPT, bool SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH, bool RS>
+__device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, unsigned sg, const double2* __restrict__ src, int t,
                                             double sgn, double2* o, const double2* xm, double* dacc) {
   static_assert(DEPTH >= 1 && DEPTH <= RPT, "ring depth");
   if (n <= 0) return;
@@ -227,10 +258,10 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, con
   });
   xs_rows<DEPTH, RPT>([&](auto rc) { v[decltype(rc)::value] = 0.0; });  // (defined before their first in/out use)
   const int qe = q0 + n;
-  auto finish = [&](int q, const double* s) {
+  auto finish = [&](int q, const double* s, unsigned tb) {
     if (DOT) {
       const double tot = PH ? -((s[0] + s[1]) + (s[2] + s[3])) : (s[0] - s[1]) + (s[2] - s[3]);
-      (*(xs_acc16*)dacc)[q - SB] += tot;
+      (*(xs_acc16*)dacc)[q - SB] += xs_flip(tot, tb);   // (the pairing takes the thread's factor once per diagonal)
     }
   };
 #pragma clang loop unroll(disable)
@@ -238,13 +269,13 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, con
     const int en = __builtin_amdgcn_readlane(ctl.ent, q + 1);
     const unsigned an = base + (unsigned)((t ^ (en & (NT - 1))) << 4);
     const int xhn = (en & 0xffff) / NT;
-    const double w = sgn * xs_readlane(ctl.w, q);
-    const int j = e >> 20;
+    const unsigned tb = SIGN ? (sg >> ((e >> 20) & 31)) & 1u : 0u, rm = (SIGN && RS) ? ((unsigned)e >> 24) & 0xfeu : 0u;
+    const double w = xs_flip(sgn * xs_readlane(ctl.w, q), tb);   // (the thread's factor of the sign goes into the weight)
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     xs_rows<0, RPT>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       xs_ds_wait<DEPTH - 1>(v[r]);
-      xs_ring_use<SIGN, DOT, PH, r>(w, SIGN ? (sg[r] >> j) & 1u : 0u, v[r], o[r], xm, s);
+      xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r], o[r], xm, s);
       constexpr int k = r + DEPTH;  // the element whose read goes out now
       if constexpr (k < RPT) {
         if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
@@ -254,38 +285,38 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, con
         else xs_ds_read_next<(k - RPT) * NT * 16>(v[k - RPT], an);
       }
     });
-    finish(q, s);
+    finish(q, s, tb);
     e = en;
     a = an;
     xh = xhn;
   }
   {
-    const double w = sgn * xs_readlane(ctl.w, qe - 1);
-    const int j = e >> 20;
+    const unsigned tb = SIGN ? (sg >> ((e >> 20) & 31)) & 1u : 0u, rm = (SIGN && RS) ? ((unsigned)e >> 24) & 0xfeu : 0u;
+    const double w = xs_flip(sgn * xs_readlane(ctl.w, qe - 1), tb);
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     xs_rows<0, RPT>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       xs_ds_wait<(RPT - 1 - r < DEPTH - 1 ? RPT - 1 - r : DEPTH - 1)>(v[r]);
-      xs_ring_use<SIGN, DOT, PH, r>(w, SIGN ? (sg[r] >> j) & 1u : 0u, v[r], o[r], xm, s);
+      xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r], o[r], xm, s);
       constexpr int k = r + DEPTH;
       if constexpr (k < RPT) {
         if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
         else xs_ds_read_next<k * NT * 16>(v[k], a);
       }
     });
-    finish(qe - 1, s);
+    finish(qe - 1, s, tb);
   }
 }
 
 // the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0>
-__device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0, bool RS = false>
+__device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, unsigned sg,
                                              const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
                                              const typename Cx<T>::type* xm, double* dacc) {  // (SB: accumulator lane = position - SB)
   typedef typename Cx<T>::type T2;
   if (n <= 0) return;
   if constexpr (!PREF && RPT == 8 && sizeof(T) == sizeof(double) && ((DOT && XS_RING_PAIR) || (!DOT && XS_RING_PLAIN))) {
-    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
+    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN, RS>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
     return;
   }
   if (PREF) {
@@ -298,43 +329,60 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, co
     for (; q + 1 < qe; q += 2) {
       e1 = __builtin_amdgcn_readlane(ctl.ent, q + 1);
       xs_fetch<T, NT, RPT, PERM>(e1 & 0xffff, src, t, vb);
-      xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH, RS>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
       if (q + 2 < qe) {
         e0 = __builtin_amdgcn_readlane(ctl.ent, q + 2);
         xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
       }
-      xs_use<T, RPT, SIGN, DOT, PH>(e1 >> 20, q + 1 - SB, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH, RS>(e1 >> 20, q + 1 - SB, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
     }
-    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH, RS>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
   } else {
 #pragma clang loop unroll(disable)
     for (int q = q0; q < q0 + n; ++q) {
       const int e = __builtin_amdgcn_readlane(ctl.ent, q);
       T2 v[RPT];
       xs_fetch<T, NT, RPT, PERM>(e & 0xffff, src, t, v);
-      xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH, RS>(e >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
     }
+  }
+}
+
+// a group = one LDS class and phase: its diagonals without a row factor of the sign, then (signed tables) those with one
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0>
+__device__ __forceinline__ void xs_lds_group(const XsCtl& ctl, int q0, int n, unsigned sg, const typename Cx<T>::type* __restrict__ src,
+                                             int t, T sgn, typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+  if constexpr (SIGN) {
+    int nrs = __builtin_amdgcn_readlane(ctl.rsn, (PERM ? 2 : 0) + PH);
+    // (a caller may pass a part of the group -- the pairing sweeps split at accumulator 16: the row-signed ones are the group's last)
+    const int g_end = (PERM ? ctl.n0 + ctl.n1 : ctl.n0) - (PH ? 0 : (PERM ? ctl.n1p1 : ctl.n0p1));
+    const int rs0 = g_end - nrs;                         // first row-signed position of the group
+    const int qe = q0 + n, cut = rs0 < q0 ? q0 : (rs0 > qe ? qe : rs0);
+    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, false>(ctl, q0, cut - q0, sg, src, t, sgn, o, xm, dacc);
+    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, true>(ctl, cut, qe - cut, sg, src, t, sgn, o, xm, dacc);
+  } else {
+    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, false>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
   }
 }
 
 // a class of a pairing sweep with up to 32 diagonals: positions below 16 accumulate into the first accumulator vector, the others
 // into the second -- two instantiations of the loop, no per-diagonal choice of the vector
 template <class T, int NT, int RPT, bool SIGN, int RM, bool PERM, int PH>
-__device__ __forceinline__ void xs_pair_class(const XsCtl& ctl, int q0, int n, const unsigned* sg,
+__device__ __forceinline__ void xs_pair_class(const XsCtl& ctl, int q0, int n, unsigned sg,
                                               const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
                                               const typename Cx<T>::type* xm, xs_acc16* dacc) {
   const int qe = q0 + n;
   const int lo_end = qe < 16 ? qe : 16;
-  xs_lds_class<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 0>(ctl, q0, lo_end - q0, sg, src, t, sgn, o, xm, (double*)&dacc[0]);
+  xs_lds_group<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 0>(ctl, q0, lo_end - q0, sg, src, t, sgn, o, xm, (double*)&dacc[0]);
   if constexpr (RM > 16) {
     const int hi0 = q0 > 16 ? q0 : 16;
-    xs_lds_class<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 16>(ctl, hi0, qe - hi0, sg, src, t, sgn, o, xm, (double*)&dacc[1]);
+    xs_lds_group<T, NT, RPT, SIGN, true, RM, PERM, false, PH, 16>(ctl, hi0, qe - hi0, sg, src, t, sgn, o, xm, (double*)&dacc[1]);
   }
 }
 
 // the pairing sweep (Horner on lambda): o += sgn (A - diag) v with every partner from LDS, in the order of ctl (no register class)
 template <class T, int NT, int RPT, bool SIGN, int RM, bool CPLX>
-__device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
+__device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, unsigned sg, const typename Cx<T>::type* __restrict__ src,
                                                    int t, T sgn, typename Cx<T>::type* o, const typename Cx<T>::type* xm,
                                                    xs_acc16* dacc) {
   xs_pair_class<T, NT, RPT, SIGN, RM, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
@@ -344,8 +392,8 @@ __device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, const unsig
 }
 
 // the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class, phase 0 then phase 1
-template <class T, int RPT, int XH, bool SIGN, bool DOT, int PH>
-__device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
+template <class T, int RPT, int XH, bool SIGN, bool DOT, int PH, bool RS = false>
+__device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                             typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
 #pragma clang loop unroll(disable)
   for (int i = 0; i < n; ++i, ++q) {
@@ -353,16 +401,29 @@ __device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, cons
     typename Cx<T>::type v[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
-    xs_use<T, RPT, SIGN, DOT, PH>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+    xs_use<T, RPT, SIGN, DOT, PH, RS>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
   }
   return q;
 }
+// one register class and phase: the diagonals without a row factor of the sign, then those with one
+template <class T, int RPT, int XH, bool SIGN, bool DOT, int PH>
+__device__ __forceinline__ int xs_local_group(const XsCtl& ctl, int q, int n, unsigned sg, const typename Cx<T>::type* cur, T sgn,
+                                              typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
+  if constexpr (SIGN) {
+    int nrs = __builtin_amdgcn_readlane(ctl.rsn, 4 + 2 * (XH - 1) + PH);
+    nrs = nrs > n ? n : nrs;
+    q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, false>(ctl, q, n - nrs, sg, cur, sgn, o, xm, dacc);
+    return xs_local_run<T, RPT, XH, SIGN, DOT, PH, true>(ctl, q, nrs, sg, cur, sgn, o, xm, dacc);
+  } else {
+    return xs_local_run<T, RPT, XH, SIGN, DOT, PH, false>(ctl, q, n, sg, cur, sgn, o, xm, dacc);
+  }
+}
 template <class T, int RPT, int XH, bool SIGN, bool DOT, bool CPLX>
-__device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, const unsigned* sg, const typename Cx<T>::type* cur, T sgn,
+__device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                                  typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
   if constexpr (XH < RPT && XH < 8) {
-    q = xs_local_run<T, RPT, XH, SIGN, DOT, 0>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
-    if constexpr (CPLX) q = xs_local_run<T, RPT, XH, SIGN, DOT, 1>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    q = xs_local_group<T, RPT, XH, SIGN, DOT, 0>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    if constexpr (CPLX) q = xs_local_group<T, RPT, XH, SIGN, DOT, 1>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
     xs_local_classes<T, RPT, XH + 1, SIGN, DOT, CPLX>(ctl, q, sg, cur, sgn, o, xm, dacc);
   }
 }
@@ -373,13 +434,13 @@ __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, const 
 // position (xs_finish_kernel maps back).
 // CPLX = false (real tables: every phase 0): the phase-1 loops are not even instantiated (their code alone cost the real kernels 4 %).
 template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL, bool CPLX>
-__device__ __forceinline__ void xs_gather(const XsCtl& ctl, const unsigned* sg, const typename Cx<T>::type* __restrict__ src,
+__device__ __forceinline__ void xs_gather(const XsCtl& ctl, unsigned sg, const typename Cx<T>::type* __restrict__ src,
                                           const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
                                           const typename Cx<T>::type* xm, double* dacc) {
-  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
-  if constexpr (CPLX) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, false, PREF, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
-  xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
-  if constexpr (CPLX) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, true, PREF, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  xs_lds_group<T, NT, RPT, SIGN, DOT, RM, false, PREF, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_lds_group<T, NT, RPT, SIGN, DOT, RM, false, PREF, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
+  xs_lds_group<T, NT, RPT, SIGN, DOT, RM, true, PREF, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
+  if constexpr (CPLX) xs_lds_group<T, NT, RPT, SIGN, DOT, RM, true, PREF, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
   if (LOCAL) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
 }
 

@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(d_u, u.data(), sizeof(double) * u.size(), hipMemcpyHostToDevice));
   tab.dval = d_dval;
   tab.sgn = nullptr;
+  dq::xr_parity_signs(tab, nullptr, d);
   CK(hipMalloc(&d_dgs, sizeof(double) * dq::xs_dgs_doubles(d, S, tab)));
   CK(hipMalloc(&d_part, sizeof(double) * dq::xs_part_doubles(d, S, nblk, tab, variant)));
   CK(hipMalloc(&d_grad, sizeof(double) * S * K));

@@ -12,12 +12,17 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 VARIANTS = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
 OTHER = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-XY = int(sys.argv[6]) if len(sys.argv) > 6 else 0     # 1: X drives on half of the qubits, Y drives on the other half (complex table)
+XY = int(sys.argv[6]) if len(sys.argv) > 6 else 0     # 1: X drives on half of the qubits, Y drives on the other half (complex table); 2: X / Z controls
 ADJ = [int(v) for v in sys.argv[7].split(",")] if len(sys.argv) > 7 else [-1]
 DTYPE = sys.argv[8] if len(sys.argv) > 8 else "c128"   # state_columns_adjoint: 1 / -1 quadrature form, 0 exact form
 dev = torch.device("cuda:0")
 d = 1 << n
-H0, Hs, M = problems.xy_drives_torch(n, 0, dev, n_x=n // 2, n_y=n - n // 2) if XY else problems.random_ising_torch(n, 0, dev)
+H0, Hs, M = problems.xy_drives_torch(n, 0, dev, n_x=n // 2, n_y=n - n // 2) if XY == 1 else problems.random_ising_torch(n, 0, dev)
+if XY == 2:     # X_k on the even qubits, Z_k (diagonal controls: per-step diagonal weights, row accumulators in the adjoint sweep) on the odd ones
+    idx = torch.arange(d, device=dev)
+    for q in range(1, n, 2):
+        Hs[q].zero_()
+        Hs[q, idx, idx] = (1.0 - 2.0 * ((idx >> (n - 1 - q)) & 1)).to(torch.complex128)
 u = torch.from_numpy(problems.pulse_table(n, S, 1e-3 * S, seed=0)).to(dev)
 psi0 = torch.from_numpy(problems.random_states(d, B, 0)).to(dev)
 if DTYPE == "c64":
