@@ -1420,13 +1420,15 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   return x;
 }
 
-// flops / LDS bytes of `sweeps` sweeps over B columns, `dot_sweeps` of them carrying the gradient pairings (those read every
-// partner from LDS; the others take the partners at offsets without lane bits from registers)  (classes DQ_PROF_STATECOL_FWD / _BWD)
+// flops / LDS bytes of `sweeps` sweeps over B columns, `dot_sweeps` of them carrying the gradient pairings.  The plain sweeps take
+// the partners at offsets without lane bits from registers; so do the pairing sweeps of the quadrature form, those of the exact
+// form read every partner from LDS (dot_all_lds)  (classes DQ_PROF_STATECOL_FWD / _BWD)
 template <class T>
-void xs_book(Ctx<T>* c, const XsLaunch<T>& x, double sweeps, double dot_sweeps, int B, double* flops, double* lds_bytes) {
+void xs_book(Ctx<T>* c, const XsLaunch<T>& x, double sweeps, double dot_sweeps, bool dot_all_lds, int B, double* flops, double* lds_bytes) {
   const double rows = (double)c->d * B;
   *flops = rows * (sweeps * (4.0 * x.tab->R + 8.0) + dot_sweeps * 4.0 * x.tab->R);
-  *lds_bytes = rows * ((sweeps - dot_sweeps) * (double)x.lds_diag + dot_sweeps * (double)x.tab->R) * 2.0 * sizeof(T);
+  *lds_bytes = rows * ((sweeps - dot_sweeps) * (double)x.lds_diag + dot_sweeps * (dot_all_lds ? (double)x.tab->R : (double)x.lds_diag)) * 2.0 *
+               sizeof(T);
 }
 
 // psi (dev, [d][B]) -> U_{S-1} ... U_0 psi in c->xs_psi ([B][d]); the result's [d][B] image goes to `out_db` if given
@@ -1437,7 +1439,7 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
   const double by = 2.0 * sizeof(T2) * (double)d * B;
   c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, psi_db, B, 0, d, B, 0, 1, c->st); });
   double fl, lb;
-  xs_book(c, x, (double)x.L * S, 0.0, B, &fl, &lb);
+  xs_book(c, x, (double)x.L * S, 0.0, false, B, &fl, &lb);
   const dq::XrTab tb = *x.tab;
   c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
     return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, x.L,
@@ -1916,7 +1918,7 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
   if (S > 0) {
     double fl, lb;
     // sweeps per step: the exact form runs 3 L - 1 (L of them with the pairings), the quadrature form 2 L (L with the pairings)
-    xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, B, &fl, &lb);
+    xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, !x.quad_ok, B, &fl, &lb);
     const dq::XrTab tb = *x.tab;
     c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
     for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {   // segments of the chain, last first (one launch when the whole chain fits)
