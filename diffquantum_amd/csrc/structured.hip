@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_kernel(SApply<T> a) {
   }
 }
 
-// ---- LDS-DMA forms of the passes (round 3): complex64, 2^9-row tiles, batch a multiple of 16 ---------------------------------
+// ---- LDS-DMA forms of the passes (round 3: complex64, 2^9-row tiles; round 4: complex128 too, 2^8-row tiles), batch a multiple of 16 ----
 // The kernels above run ONE tile per workgroup: load -> barrier -> LDS work -> store, with whatever a second workgroup on the CU
 // overlaps (3.6-4.6 TB/s at B = 512; soverlap_kernel, at 80 VGPRs alone on its CU, 2.8 TB/s).  Here a workgroup is persistent and
 // walks its tiles with TWO tile buffers (128 KB of LDS): while it works on tile t, tile t + 1 streams into the other buffer by
@@ -392,28 +392,80 @@ typedef float sd_f4 __attribute__((ext_vector_type(4)));
 // -Rpass-analysis=kernel-resource-usage: ScratchSize 0 for every sapply_dma / schain / srchain instance that is launched).
 #define S_PIN(x_) asm volatile("" : "+v"(x_))
 // (-DSD_NT_STORES: nontemporal stores; measured on one box: B = 64 2.69 against 2.74 ms per step, B = 512 no difference -- left off)
+template <class V>
+__device__ __forceinline__ void s_store16(void* p, V v) {
 #ifdef SD_NT_STORES
-#define S_STORE16(p_, v_) __builtin_nontemporal_store((v_), (sd_f4*)(p_))
+  __builtin_nontemporal_store(v, (V*)p);
 #else
-#define S_STORE16(p_, v_) (*(sd_f4*)(p_) = (v_))
+  *(V*)p = v;
 #endif
+}
+#define S_STORE16(p_, v_) s_store16((p_), (v_))
 
 // SIMPLE: every string of the group is a pure X-string (no Z factor: no row-dependent sign, real coefficient) and there are at most
 // SD_SIMPLE_T of them -- offsets and coefficients sit in scalar registers, a gather is one v_xor + ds_read_b128 + two packed FMAs
 // (the general loop issues ~3x the instructions per tile, and at 16 waves per CU the passes were bound by instruction issue:
 // ~900 wave-instructions per tile and wave = 6 us of the 9.7 us a tile took).
+// Per-dtype shape of the DMA forms (round 4: complex128 too).  Both move 16 B per lane and hold 64 KB tiles: complex64 = 2^9 rows x 16
+// columns, a thread owns 2 columns of 4 rows (8 threads per row); complex128 = 2^8 rows x 16 columns, a thread owns 1 column of 4 rows
+// (16 threads per row).  One LDS-DMA wave instruction (64 lanes x 16 B) fills 8 rows of 128 B or 4 rows of 256 B.
+typedef double sd_d2 __attribute__((ext_vector_type(2)));
+template <class T> struct SDm;
+template <> struct SDm<float> { typedef sd_f4 V; static constexpr int P = 9, TPR = 8, CPT = 2, EB = 8; };
+template <> struct SDm<double> { typedef sd_d2 V; static constexpr int P = 8, TPR = 16, CPT = 1, EB = 16; };
+static_assert(SDm<float>::P == LocalBits<float>::P && SDm<double>::P == LocalBits<double>::P, "DMA tiles = the groups' tiles");
+#define S_GLOAD8(dst_, base_, off_) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(dst_) : "v"(off_), "s"(base_) : "memory")
+__device__ __forceinline__ void sd_gload_real(float& dst, const float* base, unsigned off) { S_GLOAD4(dst, base, off); }
+__device__ __forceinline__ void sd_gload_real(double& dst, const double* base, unsigned off) { S_GLOAD8(dst, base, off); }
+__device__ __forceinline__ float sd_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ double sd_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// (sr + i si) * w for the complex numbers a lane's 16 bytes hold
+__device__ __forceinline__ sd_f4 sd_rot(float sr, float si, sd_f4 w) {
+  sd_f4 o;
+  o.x = sr * w.x - si * w.y; o.y = sr * w.y + si * w.x;
+  o.z = sr * w.z - si * w.w; o.w = sr * w.w + si * w.z;
+  return o;
+}
+__device__ __forceinline__ sd_d2 sd_rot(double sr, double si, sd_d2 w) {
+  sd_d2 o;
+  o.x = sr * w.x - si * w.y; o.y = sr * w.y + si * w.x;
+  return o;
+}
+// Re / Im of conj(v) * z summed over the lane's complex numbers
+__device__ __forceinline__ float sd_cre(sd_f4 v, sd_f4 z) { return (v.x * z.x + v.y * z.y) + (v.z * z.z + v.w * z.w); }
+__device__ __forceinline__ float sd_cim(sd_f4 v, sd_f4 z) { return (v.x * z.y - v.y * z.x) + (v.z * z.w - v.w * z.z); }
+__device__ __forceinline__ double sd_cre(sd_d2 v, sd_d2 z) { return v.x * z.x + v.y * z.y; }
+__device__ __forceinline__ double sd_cim(sd_d2 v, sd_d2 z) { return v.x * z.y - v.y * z.x; }
+// s += cf * v (complex coefficient)
+__device__ __forceinline__ void sd_cfma(float2 cf, sd_f4 v, sd_f4& s) {
+  s.x = fmaf(cf.x, v.x, s.x); s.x = fmaf(-cf.y, v.y, s.x);
+  s.y = fmaf(cf.x, v.y, s.y); s.y = fmaf(cf.y, v.x, s.y);
+  s.z = fmaf(cf.x, v.z, s.z); s.z = fmaf(-cf.y, v.w, s.z);
+  s.w = fmaf(cf.x, v.w, s.w); s.w = fmaf(cf.y, v.z, s.w);
+}
+__device__ __forceinline__ void sd_cfma(double2 cf, sd_d2 v, sd_d2& s) {
+  s.x = fma(cf.x, v.x, s.x); s.x = fma(-cf.y, v.y, s.x);
+  s.y = fma(cf.x, v.y, s.y); s.y = fma(cf.y, v.x, s.y);
+}
+
 constexpr int SD_SIMPLE_T = 10;
 
 // OVL (SIMPLE only, at most SD_OVL_T strings): the pass also forms the overlaps <y, P_m zo> of the group's control strings -- they are
 // among the applied strings, so the partner rows of y are gathered once for both; zo is one more register operand per row.
 constexpr int SD_OVL_T = 10;
 
-template <int FLAGS, bool SIMPLE, bool OVL = false>
-__global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, SDmaWalk wk) {
+template <class T, int FLAGS, bool SIMPLE, bool OVL = false>
+__global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<T> a, SDmaWalk wk) {
   static_assert(!OVL || SIMPLE, "fused overlaps exist for the pure X-string form only");
   constexpr bool HAS_PREV = FLAGS & 1, HAS_ADD = FLAGS & 2, HAS_ACC = FLAGS & 4, HAS_DIAG = FLAGS & 8;
   constexpr int NSTORE = SD_RPT * (1 + (HAS_ACC ? 1 : 0));  // vector-memory stores a thread issues per tile
-  typedef float2 T2;
+  typedef typename dq::Cx<T>::type T2;
+  typedef SDm<T> SD;
+  typedef typename SD::V V;
+  constexpr int ROWS = 1 << SD::P, RSTEP = STHREADS / SD::TPR, EB = SD::EB;
+  static_assert(ROWS / RSTEP == SD_RPT, "4 rows per thread in both forms");
   extern __shared__ __align__(16) unsigned char sd_raw[];
   T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
   __shared__ DTerm tt[SMAXT];
@@ -422,13 +474,13 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
   if (!SIMPLE)
     for (int m = threadIdx.x; m < a.nterms; m += STHREADS) { tt[m] = a.terms[m]; tc[m] = a.coef[a.terms[m].slot]; }
   unsigned xl[SIMPLE ? SD_SIMPLE_T : 1];  // byte offset of the partner row (XOR on the row's LDS address), per string: uniform
-  float cr[SIMPLE ? SD_SIMPLE_T : 1];
+  T cr[SIMPLE ? SD_SIMPLE_T : 1];
   unsigned omask = 0;  // applied strings whose overlap is wanted
-  float px[OVL ? SD_OVL_T : 1], py[OVL ? SD_OVL_T : 1];
+  T px[OVL ? SD_OVL_T : 1], py[OVL ? SD_OVL_T : 1];
   if (OVL) {
 #pragma unroll
     for (int m = 0; m < SD_OVL_T; ++m) {
-      px[m] = 0.f; py[m] = 0.f;
+      px[m] = (T)0; py[m] = (T)0;
       if (m < a.nterms && a.omap[m] >= 0) omask |= 1u << m;
     }
     omask = __builtin_amdgcn_readfirstlane(omask);
@@ -436,28 +488,28 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
   if (SIMPLE) {
 #pragma unroll
     for (int m = 0; m < SD_SIMPLE_T; ++m) {
-      xl[m] = 0; cr[m] = 0.f;
+      xl[m] = 0; cr[m] = (T)0;
       if (m < a.nterms) {  // uniform (a group may have no strings at all: its table is then unset)
         const DTerm t = a.terms[m];
-        xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * 8));
-        cr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.coef[t.slot].x)));
+        xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * EB));
+        cr[m] = sd_uniform(a.coef[t.slot].x);
       }
     }
   }
-  const int c = (threadIdx.x % 8) * 2;
-  const int rbase = threadIdx.x / 8;
+  const int c = (threadIdx.x % SD::TPR) * SD::CPT;
+  const int rbase = threadIdx.x / SD::TPR;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned dep[SD_RPT];
 #pragma unroll
-  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * RSTEP), a.lmask);
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
   auto issue = [&](unsigned u, int buf) {  // tile unit u -> buffer buf (this wave's 4 pieces of 1 KiB)
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
+      const unsigned ld = lds0 + (unsigned)buf * (ROWS * SBC * EB) + (unsigned)(wave * (64 / SD::TPR) + q * RSTEP) * (SBC * EB);
       S_DMA16(a.y, off, ld);
     }
   };
@@ -470,24 +522,24 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
-    sd_f4 pv[SD_RPT], ad[SD_RPT], ac[SD_RPT], zo[OVL ? SD_RPT : 1];
-    float dg[SD_RPT];
+    V pv[SD_RPT], ad[SD_RPT], ac[SD_RPT], zo[OVL ? SD_RPT : 1];
+    T dg[SD_RPT];
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned i = base | dep[q];
-      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;   // byte offset: the same for every operand
+      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;   // byte offset: the same for every operand
       if (OVL) S_GLOAD16(zo[q], a.zo, off);
       if (HAS_PREV) S_GLOAD16(pv[q], a.prev, off);
       if (HAS_ADD) S_GLOAD16(ad[q], a.add, off);
       if (HAS_ACC) S_GLOAD16(ac[q], a.acc_in, off);
-      if (HAS_DIAG) S_GLOAD4(dg[q], a.diag, i * 4u);
+      if (HAS_DIAG) sd_gload_real(dg[q], a.diag, (i) * (unsigned)sizeof(T));
     }
     const bool more = u + gridDim.x < wk.nunits;  // uniform
     if (more) issue(u + gridDim.x, buf ^ 1);
-    const T2* tile = tiles + (size_t)buf * (SD_ROWS * SBC);
-    sd_f4 s[SD_RPT];   // (re, im) of the thread's two columns, per row
+    const T2* tile = tiles + (size_t)buf * (ROWS * SBC);
+    V s[SD_RPT];   // (re, im) of the thread's two columns, per row
 #pragma unroll
-    for (int q = 0; q < SD_RPT; ++q) s[q] = (sd_f4)(0.f);
+    for (int q = 0; q < SD_RPT; ++q) s[q] = (V)((T)0);
     if (OVL) {  // zo is needed inside the gathers: the operands are waited for here (the next tile's DMA stays in flight)
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,7 +551,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
     }
     if (SIMPLE) {
       const unsigned char* tb = (const unsigned char*)tile;
-      const unsigned ra = (unsigned)(rbase * SBC + c) * 8u;  // own row and columns; the rows q * 128 above it are bits 14-15
+      const unsigned ra = (unsigned)(rbase * SBC + c) * (unsigned)EB;  // own row and columns; the rows q * 128 above it are bits 14-15
 #pragma unroll
       for (int m = 0; m < SD_SIMPLE_T; ++m)
         if (m < a.nterms) {  // uniform
@@ -507,11 +559,11 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
           asm volatile("" : "+s"(xl[m]));
 #pragma unroll
           for (int q = 0; q < SD_RPT; ++q) {
-            const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+            const V v = *(const V*)(tb + ((ra | (unsigned)(q * RSTEP * SBC * EB)) ^ xl[m]));
             s[q] += cr[m] * v;
             if (OVL && m < SD_OVL_T && (omask >> m & 1u)) {  // uniform; conj(y[i ^ x]) * zo[i]
-              px[m < SD_OVL_T ? m : 0] += (v.x * zo[q].x + v.y * zo[q].y) + (v.z * zo[q].z + v.w * zo[q].w);
-              py[m < SD_OVL_T ? m : 0] += (v.x * zo[q].y - v.y * zo[q].x) + (v.z * zo[q].w - v.w * zo[q].z);
+              px[m < SD_OVL_T ? m : 0] += sd_cre(v, zo[q]);
+              py[m < SD_OVL_T ? m : 0] += sd_cim(v, zo[q]);
             }
           }
         }
@@ -521,14 +573,11 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
         const T2 cf0 = tc[m];
 #pragma unroll
         for (int q = 0; q < SD_RPT; ++q) {
-          const int r = rbase + q * SD_RSTEP;
-          const sd_f4 v = *(const sd_f4*)(tile + (r ^ t.xloc) * SBC + c);
+          const int r = rbase + q * RSTEP;
+          const V v = *(const V*)(tile + (r ^ t.xloc) * SBC + c);
           T2 cf = cf0;
           if (t.zmask != 0 && (__popc(((base | dep[q]) ^ t.xmask) & t.zmask) & 1)) { cf.x = -cf.x; cf.y = -cf.y; }
-          s[q].x = fmaf(cf.x, v.x, s[q].x); s[q].x = fmaf(-cf.y, v.y, s[q].x);
-          s[q].y = fmaf(cf.x, v.y, s[q].y); s[q].y = fmaf(cf.y, v.x, s[q].y);
-          s[q].z = fmaf(cf.x, v.z, s[q].z); s[q].z = fmaf(-cf.y, v.w, s[q].z);
-          s[q].w = fmaf(cf.x, v.w, s[q].w); s[q].w = fmaf(cf.y, v.z, s[q].w);
+          sd_cfma(cf, v, s[q]);
         }
       }
     }
@@ -546,17 +595,15 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
     }
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const int r = rbase + q * SD_RSTEP;
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      sd_f4 w = s[q];
+      const int r = rbase + q * RSTEP;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
+      V w = s[q];
       if (HAS_DIAG) {
-        const sd_f4 v = *(const sd_f4*)(tile + r * SBC + c);
-        w.x = fmaf(dg[q], v.x, w.x); w.y = fmaf(dg[q], v.y, w.y); w.z = fmaf(dg[q], v.z, w.z); w.w = fmaf(dg[q], v.w, w.w);
+        const V v = *(const V*)(tile + r * SBC + c);
+        w += dg[q] * v;
       }
       if (HAS_PREV && !OVL) w += pv[q];
-      sd_f4 o;
-      o.x = a.sr * w.x - a.si * w.y; o.y = a.sr * w.y + a.si * w.x;
-      o.z = a.sr * w.z - a.si * w.w; o.w = a.sr * w.w + a.si * w.z;
+      V o = sd_rot(a.sr, a.si, w);
       if (HAS_ADD) o += ad[q];
       S_STORE16((unsigned char*)a.out + off, o);
       if (HAS_ACC) S_STORE16((unsigned char*)a.acc + off, ac[q] + o);
@@ -568,7 +615,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
 #pragma unroll
     for (int m = 0; m < SD_OVL_T; ++m)
       if (omask >> m & 1u) {
-        const double tx = s_wave_sum<float>(px[m]), ty = s_wave_sum<float>(py[m]);
+        const double tx = s_wave_sum<T>(px[m]), ty = s_wave_sum<T>(py[m]);
         if (lane == 0) {
           const int mm = a.omap[m];
           a.part[(blk * a.n_ovl + mm) * 2 + 0] = tx;
@@ -584,42 +631,47 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<float> a, S
 // next application may start on the same group g with the tile it has: after a barrier the tile's rows are overwritten in place
 // with z', and out2 = D z' + H_g z' goes out as the next pass's `prev`.  Per application 5 state-units (y, prev, add in; z', out2
 // out) instead of 2 + 4, and m + 1 tile walks for m applications instead of 2 m.  Pure X-string groups only (scalar tables).
-__global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, SDmaWalk wk) {
+template <class T>
+__global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaWalk wk) {
   constexpr int NSTORE = 2 * SD_RPT;
-  typedef float2 T2;
+  typedef typename dq::Cx<T>::type T2;
+  typedef SDm<T> SD;
+  typedef typename SD::V V;
+  constexpr int ROWS = 1 << SD::P, RSTEP = STHREADS / SD::TPR, EB = SD::EB;
+  static_assert(ROWS / RSTEP == SD_RPT, "4 rows per thread in both forms");
   extern __shared__ __align__(16) unsigned char sd_raw[];
   T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
   const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
   unsigned xl[SD_SIMPLE_T];
-  float cr[SD_SIMPLE_T];
+  T cr[SD_SIMPLE_T];
 #pragma unroll
   for (int m = 0; m < SD_SIMPLE_T; ++m) {
-    xl[m] = 0; cr[m] = 0.f;
+    xl[m] = 0; cr[m] = (T)0;
     if (m < a.nterms) {
       const DTerm t = a.terms[m];
-      xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * 8));
-      cr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.coef[t.slot].x)));
+      xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * EB));
+      cr[m] = sd_uniform(a.coef[t.slot].x);
     }
   }
   const bool has_diag = a.diag != nullptr;  // uniform
-  const int c = (threadIdx.x % 8) * 2;
-  const int rbase = threadIdx.x / 8;
+  const int c = (threadIdx.x % SD::TPR) * SD::CPT;
+  const int rbase = threadIdx.x / SD::TPR;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned dep[SD_RPT];
 #pragma unroll
-  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * RSTEP), a.lmask);
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
   auto issue = [&](unsigned u, int buf) {
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
+      const unsigned ld = lds0 + (unsigned)buf * (ROWS * SBC * EB) + (unsigned)(wave * (64 / SD::TPR) + q * RSTEP) * (SBC * EB);
       S_DMA16(a.y, off, ld);
     }
   };
-  const unsigned ra = (unsigned)(rbase * SBC + c) * 8u;
+  const unsigned ra = (unsigned)(rbase * SBC + c) * (unsigned)EB;
   unsigned u = blockIdx.x;
   if (u < wk.nunits) issue(u, 0);
   int buf = 0;
@@ -629,31 +681,31 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
-    sd_f4 pv[SD_RPT], ad[SD_RPT];
-    float dg[SD_RPT];
+    V pv[SD_RPT], ad[SD_RPT];
+    T dg[SD_RPT];
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned i = base | dep[q];
-      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;   // byte offset: the same for every operand
+      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;   // byte offset: the same for every operand
       S_GLOAD16(pv[q], a.prev, off);
       S_GLOAD16(ad[q], a.add, off);
-      dg[q] = 0.f;
-      if (has_diag) S_GLOAD4(dg[q], a.diag, i * 4u);
+      dg[q] = (T)0;
+      if (has_diag) sd_gload_real(dg[q], a.diag, (i) * (unsigned)sizeof(T));
     }
     const bool more = u + gridDim.x < wk.nunits;  // uniform
     if (more) issue(u + gridDim.x, buf ^ 1);
-    unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (SD_ROWS * SBC));
-    sd_f4 s[SD_RPT];
+    unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (ROWS * SBC));
+    V s[SD_RPT];
     auto gather = [&]() {
 #pragma unroll
-      for (int q = 0; q < SD_RPT; ++q) s[q] = (sd_f4)(0.f);
+      for (int q = 0; q < SD_RPT; ++q) s[q] = (V)((T)0);
 #pragma unroll
       for (int m = 0; m < SD_SIMPLE_T; ++m)
         if (m < a.nterms) {  // uniform
           asm volatile("" : "+s"(xl[m]));
 #pragma unroll
           for (int q = 0; q < SD_RPT; ++q) {
-            const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+            const V v = *(const V*)(tb + ((ra | (unsigned)(q * RSTEP * SBC * EB)) ^ xl[m]));
             s[q] += cr[m] * v;
           }
         }
@@ -661,37 +713,36 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<float> a, S
     gather();  // H_g y
     if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    sd_f4 z[SD_RPT];
+    V z[SD_RPT];
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       S_PIN(pv[q]); S_PIN(ad[q]);
       if (has_diag) S_PIN(dg[q]);
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      const sd_f4 w = s[q] + pv[q];
-      z[q].x = a.sr * w.x - a.si * w.y + ad[q].x; z[q].y = a.sr * w.y + a.si * w.x + ad[q].y;
-      z[q].z = a.sr * w.z - a.si * w.w + ad[q].z; z[q].w = a.sr * w.w + a.si * w.z + ad[q].w;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
+      const V w = s[q] + pv[q];
+      z[q] = sd_rot(a.sr, a.si, w) + ad[q];
       S_STORE16((unsigned char*)a.out + off, z[q]);
     }
     // every wave is done with the rows of y: the tile becomes z' in place (LDS-only waits: the DMA and the stores stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < SD_RPT; ++q) *(sd_f4*)(tb + (ra | (unsigned)(q * SD_RSTEP * SBC * 8))) = z[q];
+    for (int q = 0; q < SD_RPT; ++q) *(V*)(tb + (ra | (unsigned)(q * RSTEP * SBC * EB))) = z[q];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     gather();  // H_g z'
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
       S_STORE16((unsigned char*)a.out2 + off, s[q] + dg[q] * z[q]);
     }
   }
 }
 
-inline void schain_dma_launch(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st) {
-  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
-  (void)hipFuncSetAttribute((const void*)schain_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(schain_dma_kernel, dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+constexpr size_t SD_LDS = (size_t)2 * 65536;   // two 64 KB tile buffers (2^9 rows x 16 complex64 columns = 2^8 rows x 16 complex128 columns)
+template <class T>
+void schain_dma_launch(const SApply<T>& a, SDmaWalk wk, int nblk, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)schain_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SD_LDS);
+  hipLaunchKernelGGL(schain_dma_kernel<T>, dim3((unsigned)nblk), dim3(STHREADS), SD_LDS, st, a, wk);
 }
-inline void schain_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t) {}
 
 // ---- chain form of the reverse sweep ----------------------------------------------------------------------------------------------
 // zbar_j = s_j H zbar_{j-1} (s_j = i dt / j), lambda_t = lambda_{t+1} + sum_j zbar_j, overlaps <zbar_{j-1}, P_m z_j> per stage j and
@@ -699,46 +750,51 @@ inline void schain_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t)
 // out, stage-j overlaps of g's strings against zo = z_j) rewrites its tile with zbar_j and starts stage j + 1 there (out2 = D zbar_j
 // + H_g zbar_j; stage-(j+1) overlaps of g's strings against zo2 = z_{j+1}, weighted ovl2_scale = j / (j+1) into the SAME sums, which
 // soverlap_finish_kernel then scales by dt / j).  8 state-units per stage instead of 3 + 6, m + 1 walks instead of 2 m.
-__global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, SDmaWalk wk) {
+template <class T>
+__global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<T> a, SDmaWalk wk) {
   constexpr int NSTORE = 3 * SD_RPT;
-  typedef float2 T2;
+  typedef typename dq::Cx<T>::type T2;
+  typedef SDm<T> SD;
+  typedef typename SD::V V;
+  constexpr int ROWS = 1 << SD::P, RSTEP = STHREADS / SD::TPR, EB = SD::EB;
+  static_assert(ROWS / RSTEP == SD_RPT, "4 rows per thread in both forms");
   extern __shared__ __align__(16) unsigned char sd_raw[];
   T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
   const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
   unsigned xl[SD_OVL_T];
-  float cr[SD_OVL_T];
+  T cr[SD_OVL_T];
   unsigned omask = 0;
-  float px[SD_OVL_T], py[SD_OVL_T];
+  T px[SD_OVL_T], py[SD_OVL_T];
 #pragma unroll
   for (int m = 0; m < SD_OVL_T; ++m) {
-    xl[m] = 0; cr[m] = 0.f; px[m] = 0.f; py[m] = 0.f;
+    xl[m] = 0; cr[m] = (T)0; px[m] = (T)0; py[m] = (T)0;
     if (m < a.nterms) {
       const DTerm t = a.terms[m];
-      xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * 8));
-      cr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.coef[t.slot].x)));
+      xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * EB));
+      cr[m] = sd_uniform(a.coef[t.slot].x);
       if (a.omap[m] >= 0) omask |= 1u << m;
     }
   }
   omask = __builtin_amdgcn_readfirstlane(omask);
   const bool has_diag = a.diag != nullptr;  // uniform
-  const int c = (threadIdx.x % 8) * 2;
-  const int rbase = threadIdx.x / 8;
+  const int c = (threadIdx.x % SD::TPR) * SD::CPT;
+  const int rbase = threadIdx.x / SD::TPR;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned dep[SD_RPT];
 #pragma unroll
-  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * RSTEP), a.lmask);
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
   auto issue = [&](unsigned u, int buf) {
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
+      const unsigned ld = lds0 + (unsigned)buf * (ROWS * SBC * EB) + (unsigned)(wave * (64 / SD::TPR) + q * RSTEP) * (SBC * EB);
       S_DMA16(a.y, off, ld);
     }
   };
-  const unsigned ra = (unsigned)(rbase * SBC + c) * 8u;
+  const unsigned ra = (unsigned)(rbase * SBC + c) * (unsigned)EB;
   unsigned u = blockIdx.x;
   if (u < wk.nunits) issue(u, 0);
   int buf = 0;
@@ -748,18 +804,18 @@ __global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, 
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
-    sd_f4 s[SD_RPT], ac[SD_RPT], zo[SD_RPT];
+    V s[SD_RPT], ac[SD_RPT], zo[SD_RPT];
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned i = base | dep[q];
-      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;   // byte offset: the same for every operand
+      const unsigned off = (i * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;   // byte offset: the same for every operand
       S_GLOAD16(zo[q], a.zo, off);
       S_GLOAD16(s[q], a.prev, off);
       S_GLOAD16(ac[q], a.acc_in, off);
     }
     const bool more = u + gridDim.x < wk.nunits;  // uniform
     if (more) issue(u + gridDim.x, buf ^ 1);
-    unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (SD_ROWS * SBC));
+    unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (ROWS * SBC));
     if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -773,36 +829,35 @@ __global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, 
         asm volatile("" : "+s"(xl[m]));
 #pragma unroll
         for (int q = 0; q < SD_RPT; ++q) {
-          const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+          const V v = *(const V*)(tb + ((ra | (unsigned)(q * RSTEP * SBC * EB)) ^ xl[m]));
           s[q] += cr[m] * v;
           if (omask >> m & 1u) {
-            px[m] += (v.x * zo[q].x + v.y * zo[q].y) + (v.z * zo[q].z + v.w * zo[q].w);
-            py[m] += (v.x * zo[q].y - v.y * zo[q].x) + (v.z * zo[q].w - v.w * zo[q].z);
+            px[m] += sd_cre(v, zo[q]);
+            py[m] += sd_cim(v, zo[q]);
           }
         }
       }
     // the next stage's cotangent rows take the registers of this stage's (requested now, needed after the tile is rewritten; the
     // eight stores below are younger, the next tile's DMA older: by then it has had the whole first stage to arrive)
-    sd_f4 zn[SD_RPT];
-    float dg[SD_RPT];
+    V zn[SD_RPT];
+    T dg[SD_RPT];
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      S_GLOAD16(zn[q], a.zo2, ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u);
-      dg[q] = 0.f;
-      if (has_diag) S_GLOAD4(dg[q], a.diag, (base | dep[q]) * 4u);
+      S_GLOAD16(zn[q], a.zo2, ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB);
+      dg[q] = (T)0;
+      if (has_diag) sd_gload_real(dg[q], a.diag, ((base | dep[q])) * (unsigned)sizeof(T));
     }
-    sd_f4 z[SD_RPT];
+    V z[SD_RPT];
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      z[q].x = a.sr * s[q].x - a.si * s[q].y; z[q].y = a.sr * s[q].y + a.si * s[q].x;
-      z[q].z = a.sr * s[q].z - a.si * s[q].w; z[q].w = a.sr * s[q].w + a.si * s[q].z;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
+      z[q] = sd_rot(a.sr, a.si, s[q]);
       S_STORE16((unsigned char*)a.out + off, z[q]);
       S_STORE16((unsigned char*)a.acc + off, ac[q] + z[q]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < SD_RPT; ++q) *(sd_f4*)(tb + (ra | (unsigned)(q * SD_RSTEP * SBC * 8))) = z[q];
+    for (int q = 0; q < SD_RPT; ++q) *(V*)(tb + (ra | (unsigned)(q * RSTEP * SBC * EB))) = z[q];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // stage j + 1 starts on the same tile, now zbar_j
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SD_RPT) : "memory");
@@ -818,17 +873,17 @@ __global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, 
         asm volatile("" : "+s"(xl[m]));
 #pragma unroll
         for (int q = 0; q < SD_RPT; ++q) {
-          const sd_f4 v = *(const sd_f4*)(tb + ((ra | (unsigned)(q * SD_RSTEP * SBC * 8)) ^ xl[m]));
+          const V v = *(const V*)(tb + ((ra | (unsigned)(q * RSTEP * SBC * EB)) ^ xl[m]));
           s[q] += cr[m] * v;
           if (omask >> m & 1u) {
-            px[m] += (v.x * zn[q].x + v.y * zn[q].y) + (v.z * zn[q].z + v.w * zn[q].w);
-            py[m] += (v.x * zn[q].y - v.y * zn[q].x) + (v.z * zn[q].w - v.w * zn[q].z);
+            px[m] += sd_cre(v, zn[q]);
+            py[m] += sd_cim(v, zn[q]);
           }
         }
       }
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
       S_STORE16((unsigned char*)a.out2 + off, s[q]);
     }
   }
@@ -837,7 +892,7 @@ __global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, 
 #pragma unroll
   for (int m = 0; m < SD_OVL_T; ++m)
     if (omask >> m & 1u) {
-      const double tx = s_wave_sum<float>(px[m]), ty = s_wave_sum<float>(py[m]);
+      const double tx = s_wave_sum<T>(px[m]), ty = s_wave_sum<T>(py[m]);
       if (lane == 0) {
         const int mm = a.omap[m];
         a.part[(blk * a.n_ovl + mm) * 2 + 0] = tx;
@@ -846,18 +901,17 @@ __global__ void __launch_bounds__(STHREADS) srchain_dma_kernel(SApply<float> a, 
     }
 }
 
-inline void srchain_dma_launch(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st) {
-  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
-  (void)hipFuncSetAttribute((const void*)srchain_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(srchain_dma_kernel, dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+template <class T>
+void srchain_dma_launch(const SApply<T>& a, SDmaWalk wk, int nblk, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)srchain_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SD_LDS);
+  hipLaunchKernelGGL(srchain_dma_kernel<T>, dim3((unsigned)nblk), dim3(STHREADS), SD_LDS, st, a, wk);
 }
-inline void srchain_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t) {}
 
-// can this pass take the DMA form?  (complex64 only: the template below exists for float)
+// can this pass take the DMA form?  (whole tiles of the dtype's size, batch a multiple of 16, states below 4 GB: 32-bit byte offsets)
 template <class T>
 bool sdma_ok(int p, int B, int nterms, int mode, int n) {
-  return mode != 0 && sizeof(T) == sizeof(float) && p == SD_P && (B % SBC) == 0 && nterms <= SMAXT &&
-         ((double)B * 8.0 * (double)(1ull << n) < 4294967296.0);   // 32-bit byte offsets
+  return mode != 0 && p == SDm<T>::P && (B % SBC) == 0 && nterms <= SMAXT &&
+         ((double)B * (double)SDm<T>::EB * (double)(1ull << n) < 4294967296.0);
 }
 inline int sdma_blocks(unsigned nunits, int n_cu) {  // one persistent workgroup per CU (128 KB of LDS), equal rounds
   unsigned nb = (unsigned)n_cu < nunits ? (unsigned)n_cu : nunits;
@@ -865,58 +919,57 @@ inline int sdma_blocks(unsigned nunits, int n_cu) {  // one persistent workgroup
   nb = (nunits + rounds - 1) / rounds;
   return (int)(nb < 1 ? 1 : nb);
 }
-template <int F>
-void sapply_dma_launch_f(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st, bool simple) {
-  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
+template <class T, int F>
+void sapply_dma_launch_f(const SApply<T>& a, SDmaWalk wk, int nblk, hipStream_t st, bool simple) {
+  const size_t lds = SD_LDS;
   if (simple) {
-    (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((sapply_dma_kernel<F, true>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
-  } else {
-    (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((sapply_dma_kernel<F, false>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+    (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<T, F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((sapply_dma_kernel<T, F, true>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+  } else if constexpr (!(sizeof(T) == sizeof(double) && F == 15)) {  // (that one form is not built: see apply_groups)
+    (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<T, F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((sapply_dma_kernel<T, F, false>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
   }
 }
-template <int F>
-void sapply_dma_launch_ovl(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st) {
-  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
-  (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<F, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((sapply_dma_kernel<F, true, true>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
+template <class T, int F>
+void sapply_dma_launch_ovl(const SApply<T>& a, SDmaWalk wk, int nblk, hipStream_t st) {
+  const size_t lds = SD_LDS;
+  (void)hipFuncSetAttribute((const void*)sapply_dma_kernel<T, F, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((sapply_dma_kernel<T, F, true, true>), dim3((unsigned)nblk), dim3(STHREADS), lds, st, a, wk);
 }
 inline bool sapply_ovl_flags_ok(int f);
-inline void sapply_dma_launch(const SApply<float>& a, SDmaWalk wk, int nblk, hipStream_t st, bool simple) {
+template <class T>
+void sapply_dma_launch(const SApply<T>& a, SDmaWalk wk, int nblk, hipStream_t st, bool simple) {
   const int f = (a.prev ? 1 : 0) | (a.add ? 2 : 0) | (a.acc ? 4 : 0) | (a.diag ? 8 : 0);
   if (a.zo) {  // fused overlaps: the caller has checked simple && sapply_ovl_flags_ok(f)
     switch (f) {
-      case 0: sapply_dma_launch_ovl<0>(a, wk, nblk, st); break;
-      case 1: sapply_dma_launch_ovl<1>(a, wk, nblk, st); break;
-      case 4: sapply_dma_launch_ovl<4>(a, wk, nblk, st); break;
-      case 5: sapply_dma_launch_ovl<5>(a, wk, nblk, st); break;
-      case 8: sapply_dma_launch_ovl<8>(a, wk, nblk, st); break;
-      default: sapply_dma_launch_ovl<12>(a, wk, nblk, st); break;
+      case 0: sapply_dma_launch_ovl<T, 0>(a, wk, nblk, st); break;
+      case 1: sapply_dma_launch_ovl<T, 1>(a, wk, nblk, st); break;
+      case 4: sapply_dma_launch_ovl<T, 4>(a, wk, nblk, st); break;
+      case 5: sapply_dma_launch_ovl<T, 5>(a, wk, nblk, st); break;
+      case 8: sapply_dma_launch_ovl<T, 8>(a, wk, nblk, st); break;
+      default: sapply_dma_launch_ovl<T, 12>(a, wk, nblk, st); break;
     }
     return;
   }
   switch (f) {
-    case 0: sapply_dma_launch_f<0>(a, wk, nblk, st, simple); break;
-    case 1: sapply_dma_launch_f<1>(a, wk, nblk, st, simple); break;
-    case 2: sapply_dma_launch_f<2>(a, wk, nblk, st, simple); break;
-    case 3: sapply_dma_launch_f<3>(a, wk, nblk, st, simple); break;
-    case 4: sapply_dma_launch_f<4>(a, wk, nblk, st, simple); break;
-    case 5: sapply_dma_launch_f<5>(a, wk, nblk, st, simple); break;
-    case 6: sapply_dma_launch_f<6>(a, wk, nblk, st, simple); break;
-    case 7: sapply_dma_launch_f<7>(a, wk, nblk, st, simple); break;
-    case 8: sapply_dma_launch_f<8>(a, wk, nblk, st, simple); break;
-    case 9: sapply_dma_launch_f<9>(a, wk, nblk, st, simple); break;
-    case 10: sapply_dma_launch_f<10>(a, wk, nblk, st, simple); break;
-    case 11: sapply_dma_launch_f<11>(a, wk, nblk, st, simple); break;
-    case 12: sapply_dma_launch_f<12>(a, wk, nblk, st, simple); break;
-    case 13: sapply_dma_launch_f<13>(a, wk, nblk, st, simple); break;
-    case 14: sapply_dma_launch_f<14>(a, wk, nblk, st, simple); break;
-    default: sapply_dma_launch_f<15>(a, wk, nblk, st, simple); break;
+    case 0: sapply_dma_launch_f<T, 0>(a, wk, nblk, st, simple); break;
+    case 1: sapply_dma_launch_f<T, 1>(a, wk, nblk, st, simple); break;
+    case 2: sapply_dma_launch_f<T, 2>(a, wk, nblk, st, simple); break;
+    case 3: sapply_dma_launch_f<T, 3>(a, wk, nblk, st, simple); break;
+    case 4: sapply_dma_launch_f<T, 4>(a, wk, nblk, st, simple); break;
+    case 5: sapply_dma_launch_f<T, 5>(a, wk, nblk, st, simple); break;
+    case 6: sapply_dma_launch_f<T, 6>(a, wk, nblk, st, simple); break;
+    case 7: sapply_dma_launch_f<T, 7>(a, wk, nblk, st, simple); break;
+    case 8: sapply_dma_launch_f<T, 8>(a, wk, nblk, st, simple); break;
+    case 9: sapply_dma_launch_f<T, 9>(a, wk, nblk, st, simple); break;
+    case 10: sapply_dma_launch_f<T, 10>(a, wk, nblk, st, simple); break;
+    case 11: sapply_dma_launch_f<T, 11>(a, wk, nblk, st, simple); break;
+    case 12: sapply_dma_launch_f<T, 12>(a, wk, nblk, st, simple); break;
+    case 13: sapply_dma_launch_f<T, 13>(a, wk, nblk, st, simple); break;
+    case 14: sapply_dma_launch_f<T, 14>(a, wk, nblk, st, simple); break;
+    default: sapply_dma_launch_f<T, 15>(a, wk, nblk, st, simple); break;
   }
 }
-// (the double-typed engine never takes these paths: sdma_ok is false for it)
-inline void sapply_dma_launch(const SApply<double>&, SDmaWalk, int, hipStream_t, bool) {}
 template <class T, int F>
 void sapply_launch_f(const SApply<T>& a, dim3 grid, hipStream_t st) {
   if ((a.B & 1) == 0) hipLaunchKernelGGL((sapply_kernel<T, F, 2>), grid, dim3(STHREADS), 0, st, a);
@@ -1159,7 +1212,7 @@ __global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<float> 
 }
 
 inline void soverlap_dma_launch(const SOverlap<float>& o, SDmaWalk wk, int nblk, hipStream_t st) {
-  const size_t lds = (size_t)2 * SD_ROWS * SBC * sizeof(float2);
+  const size_t lds = SD_LDS;
   (void)hipFuncSetAttribute((const void*)soverlap_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(soverlap_dma_kernel, dim3((unsigned)nblk), dim3(STHREADS), lds, st, o, wk);
 }
@@ -1597,7 +1650,10 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
     T2* dst = last ? out : (T2*)c->tmp[g & 1].p;
     a.out = dst;
     dim3 grid(c->d >> a.p, (B + SBC - 1) / SBC);
-    const bool dma = sdma_ok<T>(a.p, B, a.nterms, c->dma, c->n);
+    // (complex128: the general -- not pure X-string -- form with all four register operands keeps the one-tile kernel: its DMA form
+    // needs more than the 128 registers a wave of a 1024-thread workgroup has, and the asm loads allow no spill)
+    const bool dma = sdma_ok<T>(a.p, B, a.nterms, c->dma, c->n) &&
+                     !(sizeof(T) == sizeof(double) && !groups[g].simple && prev && a.add && a.acc && a.diag);
     a.omap = nullptr;
     if (zo && !groups[g].ovl.empty()) {
       a.zo = zo;
@@ -2016,7 +2072,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         const unsigned ychunks = (B + SBC - 1) / SBC;
         o.tpw = (int)std::max(1u, std::min(8u, (o.ntiles * ychunks) / 512u));  // keep >= ~512 workgroups (2 per CU)
         dim3 grid((o.ntiles + o.tpw - 1) / o.tpw, ychunks);
-        const bool use_dma = sdma_ok<T>(o.p, B, o.nterms, c->dma, c->n) && o.nterms <= SOVL_TCH;
+        const bool use_dma = sizeof(T) == sizeof(float) && sdma_ok<T>(o.p, B, o.nterms, c->dma, c->n) && o.nterms <= SOVL_TCH;   // (the separate overlap pass has a DMA form in complex64 only)
         SDmaWalk wk = sdma_walk(o.ntiles, ychunks, o.lmask);
         const int nblk = use_dma ? sdma_blocks(wk.nunits, c->n_cu) : (int)(grid.x * grid.y);
         c->part.ensure((size_t)nblk * o.nterms * 16);

@@ -26,7 +26,7 @@ with Engine(d, n, dtype=dtype) as e:
     e.set_option("plan_steps", 2000)
     for name, mf in [("matrix-free route", -1)] + ([] if skip_dense else [("explicit-propagator chain", 0)]):
         e.set_option("matrix_free", mf)
-        e.energy_grad(u[:1].contiguous(), 1e-3, psi0, want_final=False, want_energies=False)
+        e.energy_grad(u, 1e-3, psi0, want_final=False, want_energies=False)     # warm-up over the same chain: checkpoint pools allocated here
         torch.cuda.synchronize(); t0 = time.perf_counter()
         loss, g, _, _ = e.energy_grad(u, 1e-3, psi0, want_final=False, want_energies=False)
         torch.cuda.synchronize(); el = time.perf_counter() - t0
