@@ -15,6 +15,7 @@ Backward step t (lam = lambda_{t+1}, psi1 = psi_{t+1}):
     lam_t = lam - A y_0                                               (= U^H lam)
     dL/du_k[t] = Re sum_l <y_l, dA_k x_l>,   dA_k = -1j dt H_k
 with <y, dA_k x> evaluated diagonal by diagonal from the partner values y[i ^ xoff] that the sweep A y fetches anyway.
+Round 4 added the quadrature form of the backward step (backward_step_quad: 2 L sweeps, the headline's kernel).
 """
 import numpy as np
 
@@ -119,6 +120,58 @@ def backward_step(tab, u_row, dt, psi1, lam, L, K):
     return psi, lam_t, g
 
 
+def lobatto(npts):
+    """Nodes and weights of the npts-point Gauss-Lobatto rule on [0, 1] (end points included; exact to degree 2 npts - 3)."""
+    from numpy.polynomial import legendre as Lg
+    c = np.zeros(npts)
+    c[-1] = 1.0                                   # P_{npts-1}
+    xi = np.sort(np.real(Lg.legroots(Lg.legder(c))))
+    x = np.concatenate([[-1.0], xi, [1.0]])
+    w = 2.0 / (npts * (npts - 1) * Lg.legval(x, c) ** 2)
+    return (x + 1.0) / 2.0, w / 2.0
+
+
+def backward_step_quad(tab, u_row, dt, psi1, lam, L, K, npts=4):
+    """The QUADRATURE form of the backward step (csrc/statecol_bwdq.hip): (psi_t, lam_t, grad_row[K]) from (psi_{t+1}, lam_{t+1}).
+
+    Both vectors run backward under the same operator, phi(s) = exp(-s A) phi_{t+1}, and dexp(A)[E] = int_0^1 exp((1-s)A) E exp(sA) ds
+    gives dL/du_k[t] = Re int_0^1 <lam(s), dA_k psi(s)> ds -- evaluated by a Gauss-Lobatto rule whose node values are sums of the
+    Taylor terms the propagation produces anyway:
+        phase 1:  z_m = (-A)^m lam / m!,  lam_t = sum_m z_m,  node values lam(s_i) = sum_m s_i^m z_m
+        phase 2:  r_m = (-A)^m psi1 / m!, psi_t = sum_m r_m;  the sweep that forms r_{m+1} pairs the partner values r_m[i ^ x] it fetches
+                  with the own rows of q_m = sum_i w_i s_i^m lam(s_i):  sum_i w_i <lam(s_i), dA psi(s_i)> = sum_m <q_m, dA r_m>
+                  = -sum_m <r_m, dA q_m>  (dA anti-Hermitian), which is the form the pairing code of apply_A takes."""
+    w, dg = _weights(tab, u_row, dt)
+    R = len(tab["xoff"])
+    s, wq = lobatto(npts)
+    cur = lam
+    nodes = [lam.copy() for _ in range(npts)]           # node 0 (s = 0) stays lam_{t+1}; the last (s = 1) becomes lam_t
+    for m in range(1, L + 1):
+        cur = apply_A(tab, w, dg, cur, sign=-1.0) / m
+        for i in range(1, npts):
+            nodes[i] = nodes[i] + (s[i] ** m) * cur
+    lam_t = nodes[-1]
+    dots = [0.0] * R
+    rowacc = np.zeros(tab["d"])
+    cur, psi = psi1, psi1.copy()
+    for m in range(L):
+        q = sum(wq[i] * (s[i] ** m) * nodes[i] for i in range(1, npts))
+        if m == 0:
+            q = q + wq[0] * nodes[0]
+        q = -q                                            # (the sign of <q, dA r> = -<r, dA q>)
+        rowacc += cur.real * q.imag - cur.imag * q.real
+        cur = apply_A(tab, w, dg, cur, sign=-1.0, dots=dots, xm=q) / (m + 1)
+        psi = psi + cur
+    g = np.zeros(K)
+    for j in range(R):
+        if tab["kid"][j] >= 0:
+            g[tab["kid"][j]] += dt * tab["cmag"][j] * dots[j]
+    for jd, k in enumerate(tab["dkid"]):
+        if k >= 0:
+            g[k] += dt * np.sum(tab["dval"][jd] * rowacc)
+    return psi, lam_t, g
+
+
 def taylor_degree(theta, tol=1.1102230246251565e-16):
     for L in range(1, 17):
         v = 1.0
@@ -129,8 +182,9 @@ def taylor_degree(theta, tol=1.1102230246251565e-16):
     raise ValueError("step too large for the polynomial alone")
 
 
-def energy_grad(H0, Hs, M, u, dt, psi0, L=None):
-    """(loss, grad[S][K], psi_S) of L = sum_b <psi_b|M|psi_b> through the state-column recurrences."""
+def energy_grad(H0, Hs, M, u, dt, psi0, L=None, quad_points=0):
+    """(loss, grad[S][K], psi_S) of L = sum_b <psi_b|M|psi_b> through the state-column recurrences (quad_points > 0: the backward
+    steps in the quadrature form with that many Gauss-Lobatto points)."""
     tab = table_from_dense(H0, Hs)
     assert tab is not None, "not an XOR-regular generator"
     u = np.asarray(u, dtype=np.float64)
@@ -153,6 +207,9 @@ def energy_grad(H0, Hs, M, u, dt, psi0, L=None):
         loss += float(np.real(np.vdot(psi, mp)))
         lam = 2.0 * mp
         for t in range(S - 1, -1, -1):
-            psi, lam, g = backward_step(tab, u[t], dt, psi, lam, L, K)
+            if quad_points:
+                psi, lam, g = backward_step_quad(tab, u[t], dt, psi, lam, L, K, quad_points)
+            else:
+                psi, lam, g = backward_step(tab, u[t], dt, psi, lam, L, K)
             grad[t] += g
     return loss, grad, fin

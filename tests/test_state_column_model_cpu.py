@@ -55,3 +55,26 @@ def test_state_column_model_matches_oracle(oracle, name, prob):
 def test_table_rejects_what_is_not_a_pauli_sum():
     H0, Hs, _ = problems.random_hermitian_problem(3, 2, seed=0)
     assert nsc.table_from_dense(H0, Hs) is None
+
+
+@pytest.mark.parametrize("name,prob", list(_cases()))
+def test_quadrature_form_of_the_backward_step_matches_oracle(oracle, name, prob):
+    """The quadrature form (4-point Gauss-Lobatto rule on the step integral of dexp: csrc/statecol_bwdq.hip) against the oracle's exact
+    Frechet derivative: at the step size the engine takes it for (theta <= 0.05) to rounding; the 5-point rule at theta ~ 0.2; and the
+    error of the 4-point rule grows as the bound says ((2 theta)^6) when the step is pushed beyond that."""
+    H0, Hs, M = prob
+    K, d = len(Hs), H0.shape[0]
+    S, B = 4, 2
+    u = np.random.default_rng(8).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=3)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    scale = n1(H0) + sum(n1(h) for h in Hs)
+    errs = {}
+    for theta, pts in ((0.04, 4), (0.2, 5), (0.2, 4)):
+        dt = theta / scale
+        rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+        loss, grad, fin = nsc.energy_grad(H0, Hs, M, u, dt, psi0, quad_points=pts)
+        assert np.max(np.abs(fin - rf)) < 1e-12 and abs(loss - rl) < 1e-11
+        errs[(theta, pts)] = np.max(np.abs(grad - rg)) / np.max(np.abs(rg))
+    assert errs[(0.04, 4)] < 1e-13 and errs[(0.2, 5)] < 1e-12, errs
+    assert errs[(0.2, 4)] < 6.6e-7 * 0.4 ** 6 * 50, errs           # (the bound of the rule, with room for the norms it is relative to)
