@@ -110,6 +110,12 @@ def test_bench_line_fits_the_driver_window_as_the_driver_runs_it():
         _check_line(d)
         assert d["steps"] == 20 and d["cpu_baseline"]["value"] > 0 and d["roofline"]["frac"] > 0
         assert d["extras"] == "bench_extras.json" and os.path.exists(os.path.join(ROOT, d["extras"]))
+        # round 4: the north-star kernel and the full chain are in the driver-parsed line
+        m = d["roofline_mfma"]
+        assert m["kernel"].startswith("zgemm_lin_kernel") and m["peak"] == 78.6 and 0.5 < m["frac"] < 1.0 and m["launches"] > 0
+        assert abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-6
+        fc = d["full_chain"]
+        assert fc[0] == 2000 and fc[1] > 0 and fc[2] is not None and fc[2] < 1e-10      # max |dL/du - the checkpointed GEMM chain's|
 
 
 def test_bench_general_path_only():
@@ -189,4 +195,4 @@ def test_graft_entry_smoke():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.count("smoke ok") == 7
+    assert out.stdout.count("smoke ok") == 8 and "quadrature adjoint" in out.stdout and "routed to the matrix-free passes" in out.stdout
