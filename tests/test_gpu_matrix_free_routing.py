@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from diffquantum_amd import problems
-from test_gpu_state_columns import CASES, _engine, _qaoa
+from test_gpu_state_columns import CASES, _engine, _qaoa, oracle_answer
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -27,7 +27,7 @@ def test_forced_route_matches_oracle_at_dimension_512(oracle, case):
     u = np.random.default_rng(n).uniform(-1, 1, (S, K))
     psi0 = problems.random_states(d, B, seed=2)
     diag_m = not np.any(M - np.diag(np.diag(M)))
-    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    rl, rg, rf = oracle_answer(oracle, (case, n, S, B, dt), H0, Hs, M, u, dt, psi0)      # (the inputs of test_state_columns_match_oracle at n = 9)
     with _engine(H0, Hs, M, matrix_free=1) as e:
         fwd = e.propagate(u, dt, psi0)
         assert e.info("matrix_free") == 1, "a Pauli-string generator was not routed to the matrix-free passes"
