@@ -64,8 +64,11 @@ def test_headline_dimension_matches_oracle(ising12, scheme, compose):
         for k, v in opts.items():
             e.set_option(k, v)
         if scheme == "state_columns":
-            if compose:
-                pytest.skip("one form only")
+            # ("state_form" id: the 32 columns on 5 workgroups -- 7, 7, 6, 6, 6 columns each: the several-columns-per-workgroup loop of
+            # the headline's kernels (sums accumulated over a workgroup's columns, images reused) against the ORACLE at this dimension;
+            # "operator_form" id: one column per workgroup)
+            if not compose:
+                e.set_option("state_columns_workgroups", 5)
         else:
             e.set_option("compose", compose)
             e.set_option("state_columns", 0)
