@@ -114,6 +114,7 @@ def test_headline_dimension_complex_pauli_sum_matches_oracle(xyz12, form):
         assert e.info("real_hamiltonians") == 0 and e.info("xor_regular_found") == 11
         if form == "state_columns":
             e.set_option("state_columns", 1)
+            e.set_option("state_columns_workgroups", 3)      # 16 columns on 3 workgroups (6 + 5 + 5): the several-columns loop, signed kernels
         else:
             e.set_option("state_columns", 0)
             e.set_option("compose", 1 if form == "column_form_operator" else 0)
