@@ -307,18 +307,35 @@ struct XsOrder {                   // the order in which the sweeps walk the tab
                                    // its diagonals, ordered LAST, carry a row factor of the sign (parity mask with bits at or above the thread count)
 };
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
-// Quadrature form of the adjoint sweep (xs_backward_q_kernel): a Gauss-Lobatto rule on [0, 1] with ni interior nodes.
-// c1[m][i] = s_i^m, c2[m][i] = -w_i s_i^m, w0 / w1 = minus the weights of the end points.
-constexpr int XS_LMAX = 24;   // largest Taylor degree of the state-column kernels
+// The step polynomial p(A) = sum_{m <= L} g[m] A^m / m! of the state-column kernels.  g = 1 is the Taylor polynomial; the economized
+// form is the Chebyshev expansion of exp on the spectral interval i [-theta, theta] of the anti-Hermitian A,
+//     exp(i theta x) = J_0(theta) + 2 sum_k i^k J_k(theta) T_k(x),       |x| <= 1,
+// cut at degree L (error at most 2 sum_{k > L} |J_k(theta)|, against theta^(L+1) / (L+1)! for Taylor: a factor 2^L smaller, so one
+// to four degrees fewer for the same tolerance) and rewritten in powers of A: the kernels keep their recurrence v_m = A v_{m-1} / m and
+// accumulate g[m] v_m.
+constexpr int XS_LMAX = 24;   // largest degree of the state-column kernels
+struct XsPoly {
+  double g[XS_LMAX + 1];
+};
+// the lowest degree whose error bound stays below tol for steps of size <= theta (0: none up to XS_LMAX) and its level factors;
+// economize = 0: Taylor (g = 1).  Steps of theta > 2 keep Taylor (the power form of a Chebyshev sum loses digits as theta grows).
+int xs_poly_make(double theta, double tol, int economize, XsPoly* p);
+// Quadrature form of the adjoint sweep (xs_backward_q_kernel): a Gauss-Lobatto rule on [0, 1] with ni interior nodes s_i.  The node
+// values exp(-s_i A) lambda are polynomials of the same degree on the shorter interval s_i theta, with their own level factors g_i[m]:
+// c1[m][i] = g_i[m] s_i^m, c2[m][i] = -w_i g_i[m] s_i^m, w0 = minus the weight of the end point 0, w1[m] = -g[m] x the weight of the
+// end point 1 (g: the factors of the whole step).
 constexpr int XS_NIMAX = 3;
 struct XsQuad {
   int ni;
-  double w0, w1;
+  double w0;
+  double g[XS_LMAX + 1];    // the level factors of the whole step (XsPoly)
+  double w1[XS_LMAX + 1];
   double c1[XS_LMAX + 1][XS_NIMAX], c2[XS_LMAX + 1][XS_NIMAX];
 };
 // the rule for a step of size theta (bound of ||A||): the fewest interior nodes whose error bound e (2 theta)^(2 ni + 2) stays below
-// tol (relative to ||dA_k|| ||lambda|| ||psi||); false when no rule the kernels are built for reaches it (ni_max <= XS_NIMAX)
-bool xs_quad_make(double theta, double tol, int ni_max, XsQuad* qd);
+// tol (relative to ||dA_k|| ||lambda|| ||psi||); false when no rule the kernels are built for reaches it (ni_max <= XS_NIMAX).
+// L, economize, poly: the step polynomial the node tables are built for (xs_poly_make).
+bool xs_quad_make(double theta, double tol, int ni_max, int L, int economize, const XsPoly& poly, XsQuad* qd);
 bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant);  // the table / rule / shape combinations xs_backward_q_kernel runs
 // variant: bit 0 = 1024 threads x 4 rows per workgroup at d = 4096 (default 512 x 8); bit 1 = prefetch of the next diagonal's partners
 int xs_blocks(int d, size_t elem, int B, int n_cu, int variant);   // workgroups of a launch over B columns
@@ -337,15 +354,15 @@ size_t xs_dgs_doubles(int d, int S, const XrTab& tab);       // doubles of the d
 hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
                              hipStream_t st);
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, hipStream_t st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st);
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, hipStream_t st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st);
 // psi: psi_S in, psi_0 out;  lam: lambda_S in, lambda_0 out;  grad[s][k] (+)= dL/du_k[s]
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
-                              int accumulate, int variant, const XsQuad* quad, hipStream_t st);  // quad != null: the quadrature form (park unused)
+                              int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st);  // quad != null: the quadrature form (park unused); poly = null: Taylor
 hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
-                              int variant, const XsQuad* quad, hipStream_t st);
+                              int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st);
 
 }  // namespace dq

@@ -326,6 +326,9 @@ struct Ctx : dq_ctx {
   int xs_workgroups = 0;                       // > 0: at most that many workgroups per launch (tests of the several-columns-per-workgroup loop)
   double xs_part_bytes = 268435456.0;          // scratch of the adjoint sweep's per-step partial sums: the chain is swept in segments that fit
   double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
+  int xs_economize = 1;                        // step polynomial of the state-column kernels: 1 = Chebyshev-economized (default), 0 = Taylor
+  dq::XsPoly xs_poly;                          // its level factors (set by xs_degree for the chain at hand)
+  double last_xs_taylor_degree = 0;            // the Taylor degree the same tolerance would have needed
   double last_xs_segments = 0;                 // launches the last adjoint sweep was split into
   double last_xs_nodes = 0;                    // interior nodes of the rule the last adjoint sweep ran (0: the exact form)
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
@@ -1354,13 +1357,16 @@ int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B)
   double th = 0.0;
   for (int t = 0; t < S; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
   if ((size_t)4 * sizeof(T) * (size_t)c->d > c->max_lds) return 0;  // two images of a column must fit the device's LDS
-  for (int L = 1; L <= 24; ++L)
-    if (taylor_remainder(th, L) <= c->expm_tol) {
-      if (!dq::xs_supported(c->d, L, tab->R, tab->nd, sizeof(T))) return 0;
-      c->last_theta = th;
-      return L;
-    }
-  return 0;
+  // the step polynomial: Chebyshev-economized on the spectral interval i [-theta, theta] (dq_internal.h, XsPoly), same error bound as
+  // the Taylor polynomial it replaces with one to four degrees fewer -- every sweep of the kernels is one degree
+  dq::XsPoly pol;
+  const int L = dq::xs_poly_make(th, c->expm_tol, c->xs_economize, &pol);
+  if (L <= 0 || !dq::xs_supported(c->d, L, tab->R, tab->nd, sizeof(T))) return 0;
+  c->xs_poly = pol;
+  c->last_theta = th;
+  dq::XsPoly tay;
+  c->last_xs_taylor_degree = dq::xs_poly_make(th, c->expm_tol, 0, &tay);
+  return L;
 }
 
 template <class T>
@@ -1389,7 +1395,7 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
   c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
   x.quad_ok = false;
-  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, &x.quad) && dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant);
+  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, L, c->xs_economize, c->xs_poly, &x.quad) && dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant);
   c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
   if (backward) {
     if (!x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
@@ -1443,7 +1449,7 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
   const dq::XrTab tb = *x.tab;
   c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
     return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, x.L,
-                                 x.nblk, c->xs_variant, c->st);
+                                 x.nblk, c->xs_variant, &c->xs_poly, c->st);
   });
   if (out_db)
     c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>(out_db, B, 0, (const T2*)c->xs_psi.p, d, 0, B, d, 0, 1, c->st); });
@@ -1928,7 +1934,7 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
         return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
                                       c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, B, L, x.nblk,
                                       x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
-                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, c->st);
+                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, c->st);
       });
     }
   }
@@ -2814,6 +2820,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_polynomial") {  // 1 (default): Chebyshev-economized step polynomial; 0: Taylor
+    c->xs_economize = v != 0 ? 1 : 0;
   } else if (s == "matrix_free") {  // -1 auto (Pauli-sum generators beyond the state-column kernels' dimensions), 0 never, 1 whenever the table is a string sum
     c->mf_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "matrix_free_checkpoint_bytes") {  // checkpoint budget of the routed passes (0: 70 % of the free HBM)
@@ -2869,6 +2877,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
     fail(DQ_ERR_INVALID, std::string("matrix-free routing: ") + dq_sctx_last_error());
   }
   if (s == "state_columns_quad_nodes") return c->last_xs_nodes;
+  if (s == "state_columns_taylor_degree") return c->last_xs_taylor_degree;
   if (s == "state_columns_segments") return c->last_xs_segments;
   if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;
@@ -2913,6 +2922,16 @@ extern "C" {
 
 const char* dq_version(void) { return "diffqc_hip 0.4 (gfx950; complex128 + complex64; real-symmetric fast path; time-sliced operator form)"; }
 const char* dq_last_error(void) { return g_err.c_str(); }
+
+int dq_step_polynomial(double theta, double tol, int economize, int* degree, double* factors) {
+  return guarded([&] {
+    if (!degree || !factors) fail(DQ_ERR_INVALID, "null output");
+    if (!(theta >= 0.0) || !(tol > 0.0)) fail(DQ_ERR_INVALID, "theta must be >= 0 and tol > 0");
+    dq::XsPoly p;
+    *degree = dq::xs_poly_make(theta, tol, economize, &p);
+    for (int m = 0; m <= dq::XS_LMAX; ++m) factors[m] = p.g[m];
+  });
+}
 
 int dq_device_count(int* n) {
   return guarded([&] {

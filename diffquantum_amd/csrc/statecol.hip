@@ -54,7 +54,7 @@ template <class T, int NT, int RPT, bool SIGN, bool PREF, bool CPLX>
 __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
                                                         typename Cx<T>::type* __restrict__ psi_out, XrTab tab, XsOrder ord,
                                                         const double* __restrict__ wt, const double* __restrict__ dgs, long dgs_step,
-                                                        int S, int B, int L) {
+                                                        int S, int B, int L, XsPoly pol) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
@@ -78,9 +78,11 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
       const double* dgr = dgs + (long)s * dgs_step;
       T2 acc[RPT];
       T dg[RPT];  // the rows' diagonal weights of this step (registers: a load per sweep would sit in the vmcnt queue of every wait)
+      const T g0 = (T)pol.g[0];
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        acc[r] = cur[r];
+        acc[r].x = g0 * cur[r].x;
+        acc[r].y = g0 * cur[r].y;
         dg[r] = (T)dgr[r * NT + t];
       }
       for (int m = 1; m <= L; ++m) {
@@ -91,15 +93,15 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
           o[r].y = 0;
         }
         xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
-        const T inv = (T)1 / (T)m;
+        const T inv = (T)1 / (T)m, gm = (T)pol.g[m];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {  // + the diagonal: -i dg v
           const T ox = xs_fma(dg[r], cur[r].y, o[r].x) * inv;
           const T oy = xs_fma(-dg[r], cur[r].x, o[r].y) * inv;
           cur[r].x = ox;
           cur[r].y = oy;
-          acc[r].x += ox;
-          acc[r].y += oy;
+          acc[r].x = xs_fma(gm, ox, acc[r].x);
+          acc[r].y = xs_fma(gm, oy, acc[r].y);
         }
         if (m < L) {
           p ^= 1;
@@ -356,11 +358,84 @@ hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, in
   return hipGetLastError();
 }
 
+namespace {
+XsPoly xs_poly_taylor() {
+  XsPoly p;
+  for (int m = 0; m <= XS_LMAX; ++m) p.g[m] = 1.0;
+  return p;
+}
+// J_k(x), 0 <= x <= 2: the power series (alternating, terms falling from the first on)
+long double xs_bessel(int k, long double x) {
+  long double term = 1.0L;
+  for (int j = 1; j <= k; ++j) term *= 0.5L * x / (long double)j;
+  long double sum = term;
+  for (int j = 1; j < 60; ++j) {
+    term *= -0.25L * x * x / ((long double)j * (long double)(k + j));
+    sum += term;
+    if (fabsl(term) < 1e-24L * fabsl(sum)) break;
+  }
+  return sum;
+}
+// level factors g[m] = m! x (coefficient of z^m, z = i theta x) of the Chebyshev sum of exp(i theta x) cut at degree L, in extended
+// precision: g[m] = 1 - O(theta^2) and the sum below is led by its first term, 2 J_m(theta) 2^(m-1) / theta^m = 1 / m! (1 + O(theta^2))
+void xs_poly_factors(double theta, int L, double* g) {
+  if (!(theta > 0.0)) {
+    for (int m = 0; m <= L; ++m) g[m] = 1.0;
+    return;
+  }
+  static long double tc[XS_LMAX + 1][XS_LMAX + 1];  // T_k's coefficients (integers below 2^23: exact)
+  static bool have = false;
+  if (!have) {
+    memset(tc, 0, sizeof(tc));
+    tc[0][0] = 1.0L;
+    tc[1][1] = 1.0L;
+    for (int k = 2; k <= XS_LMAX; ++k)
+      for (int m = 0; m <= k; ++m) tc[k][m] = (m > 0 ? 2.0L * tc[k - 1][m - 1] : 0.0L) - tc[k - 2][m];
+    have = true;
+  }
+  long double jk[XS_LMAX + 1];
+  for (int k = 0; k <= L; ++k) jk[k] = xs_bessel(k, (long double)theta);
+  long double pw = 1.0L, fact = 1.0L;  // theta^m, m!
+  for (int m = 0; m <= L; ++m) {
+    if (m > 0) {
+      pw *= (long double)theta;
+      fact *= (long double)m;
+    }
+    long double acc = 0.0L;
+    for (int k = m; k <= L; k += 2)  // i^k T_k(x) = sum_m tc[k][m] i^(k-m) (i x)^m, i^(k-m) = (-1)^((k-m)/2)
+      acc += (k == 0 ? 1.0L : 2.0L) * jk[k] * tc[k][m] * (((k - m) / 2) & 1 ? -1.0L : 1.0L);
+    g[m] = (double)(acc / pw * fact);
+  }
+}
+}  // namespace
+
+int xs_poly_make(double theta, double tol, int economize, XsPoly* p) {
+  *p = xs_poly_taylor();
+  if (!(theta >= 0.0)) return 0;
+  if (economize && theta <= 2.0) {
+    long double tail[XS_LMAX + 42];
+    for (int k = 0; k < XS_LMAX + 42; ++k) tail[k] = fabsl(xs_bessel(k, (long double)theta));
+    for (int k = XS_LMAX + 40; k >= 0; --k) tail[k] += tail[k + 1];  // tail[k] = sum_{j >= k} |J_j|
+    for (int L = 1; L <= XS_LMAX; ++L)
+      if ((double)(2.0L * tail[L + 1]) <= tol) {
+        xs_poly_factors(theta, L, p->g);
+        return L;
+      }
+    return 0;
+  }
+  for (int L = 1; L <= XS_LMAX; ++L) {
+    double v = 1.0;
+    for (int j = 1; j <= L + 1; ++j) v *= theta / j;
+    if (v <= tol) return L;
+  }
+  return 0;
+}
+
 // Gauss-Lobatto rules on [0, 1] with 2 and 3 interior nodes (4 / 5 points: exact to degree 5 / 7).  The rule's error for an
 // integrand with |f^(p)| <= F, p = 2 ni + 2, is e F with e = |int s^p - Q[s^p]| / p! (its Peano kernel keeps one sign).
-bool xs_quad_make(double theta, double tol, int ni_max, XsQuad* qd) {
+bool xs_quad_make(double theta, double tol, int ni_max, int L, int economize, const XsPoly& poly, XsQuad* qd) {
   memset(qd, 0, sizeof(*qd));
-  if (!(theta >= 0.0)) return false;
+  if (!(theta >= 0.0) || L < 1 || L > XS_LMAX) return false;
   for (int ni = 2; ni <= ni_max && ni <= XS_NIMAX; ++ni) {
     double s[XS_NIMAX], w[XS_NIMAX], we;
     if (ni == 2) {
@@ -386,12 +461,19 @@ bool xs_quad_make(double theta, double tol, int ni_max, XsQuad* qd) {
     if (e * std::pow(2.0 * theta, p) > tol) continue;
     qd->ni = ni;
     qd->w0 = -we;
-    qd->w1 = -we;
-    for (int m = 0; m <= XS_LMAX; ++m)
-      for (int i = 0; i < ni; ++i) {
-        qd->c1[m][i] = std::pow(s[i], m);
+    for (int m = 0; m <= XS_LMAX; ++m) {
+      qd->g[m] = poly.g[m];
+      qd->w1[m] = -we * poly.g[m];
+    }
+    for (int i = 0; i < ni; ++i) {
+      double gi[XS_LMAX + 1];
+      for (int m = 0; m <= XS_LMAX; ++m) gi[m] = 1.0;
+      if (economize && theta <= 2.0) xs_poly_factors(theta * s[i], L, gi);  // the same degree on the shorter interval s_i theta
+      for (int m = 0; m <= XS_LMAX; ++m) {
+        qd->c1[m][i] = gi[m] * std::pow(s[i], m);
         qd->c2[m][i] = -w[i] * qd->c1[m][i];
       }
+    }
     return true;
   }
   return false;
@@ -409,49 +491,50 @@ namespace {
 
 template <class T, int NT, int RPT>
 hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* out, const XrTab& tab, const double* wt, const double* dgs,
-                         long dgs_step, int S, int B, int L, int nblk, bool pref, hipStream_t st) {
+                         long dgs_step, int S, int B, int L, int nblk, bool pref, const XsPoly& pol, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr;
   bool cplx = false;
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
   if (cplx && !sgn) return hipErrorInvalidValue;  // (complex tables always carry sign words)
-  void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int) =
+  void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, XsPoly) =
       cplx ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, true> : xs_forward_kernel<T, NT, RPT, true, false, true>)
            : (sgn ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, false> : xs_forward_kernel<T, NT, RPT, true, false, false>)
                   : (pref ? xs_forward_kernel<T, NT, RPT, false, true, false> : xs_forward_kernel<T, NT, RPT, false, false, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true), wt, dgs,
-                     dgs_step, S, B, L);
+                     dgs_step, S, B, L, pol);
   return hipGetLastError();
 }
 
 // variant: bit 0 = 1024 threads x 4 rows at d = 4096; bit 1 = prefetch of the next diagonal's partners in the sweeps without pairings
 template <class T>
 hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* out, int d, const XrTab& tab, const double* wt,
-                        const double* dgs, long dgs_step, int S, int B, int L, int nblk, int variant, hipStream_t st) {
+                        const double* dgs, long dgs_step, int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
   if (B <= 0) return hipSuccess;
+  const XsPoly pol = poly ? *poly : xs_poly_taylor();
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T))) return hipErrorInvalidValue;
   const bool pf = (variant & 2) != 0;
   if constexpr (sizeof(T) == sizeof(float)) {
-    if (d == 8192) return xs_forward_go<T, 1024, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    if (d == 8192) return xs_forward_go<T, 1024, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
   }
   switch (d) {
     case 4096:
-      return (variant & 1) ? xs_forward_go<T, 1024, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
-                           : xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+      return (variant & 1) ? xs_forward_go<T, 1024, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
+                           : xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
 #ifndef XS_PROBE_4096_ONLY
-    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
     case 1024:
-      return (variant & 1) ? xs_forward_go<T, 256, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
-                           : xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+      return (variant & 1) ? xs_forward_go<T, 256, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
+                           : xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
     case 512:
-      return (variant & 1) ? xs_forward_go<T, 256, 2>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
-                           : xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+      return (variant & 1) ? xs_forward_go<T, 256, 2>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
+                           : xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
     default:
-      return (variant & 1) ? xs_forward_go<T, 256, 1>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st)
-                           : xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, st);
+      return (variant & 1) ? xs_forward_go<T, 256, 1>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
+                           : xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
 #else
     default: return hipErrorInvalidValue;
 #endif
@@ -461,11 +544,12 @@ hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* ou
 template <class T>
 hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                          const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
-                         int K, double dt, double* grad, int accumulate, int variant, const XsQuad* quad, hipStream_t st) {
+                         int K, double dt, double* grad, int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
+  const XsPoly pol = poly ? *poly : xs_poly_taylor();
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T)) || (!park && !quad) || !part) return hipErrorInvalidValue;
   const hipError_t e = quad ? xs_backward_quad_launch<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, *quad, part, variant, st)
-                            : xs_backward_exact_launch<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
+                            : xs_backward_exact_launch<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, variant, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d, variant), xs_slots(tab),
                      xs_rm(tab), S, tab, xs_make_order(d, tab, variant, quad && XS_PAIR_LOCAL), K, dt, grad, accumulate);
@@ -475,22 +559,22 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
 }  // namespace
 
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, hipStream_t st) {
-  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
+  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, st);
 }
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, hipStream_t st) {
-  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
+  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, st);
 }
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
-                              int accumulate, int variant, const XsQuad* quad, hipStream_t st) {
-  return xs_backward_t<double>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, st);
+                              int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st) {
+  return xs_backward_t<double>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, poly, st);
 }
 hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
-                              int variant, const XsQuad* quad, hipStream_t st) {
-  return xs_backward_t<float>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, st);
+                              int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st) {
+  return xs_backward_t<float>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, poly, st);
 }
 
 }  // namespace dq

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
                                                          XrTab tab, XsOrder ord, XsOrder ordh, const double* __restrict__ wt,
                                                          const double* __restrict__ dgs, long dgs_step, int S, int B, int L,
                                                          typename Cx<T>::type* __restrict__ park,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ part, XsPoly pol) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
   constexpr int NW = NT / 64;
@@ -70,8 +70,12 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       publish(cur);
       {
         T2 acc[RPT];
+        const T g0 = (T)pol.g[0];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
+        for (int r = 0; r < RPT; ++r) {
+          acc[r].x = g0 * cur[r].x;
+          acc[r].y = g0 * cur[r].y;
+        }
         for (int m = 1; m <= L; ++m) {
           T2 o[RPT];
 #pragma unroll
@@ -80,15 +84,15 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
             o[r].y = 0;
           }
           xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, W, cur, t, (T)-1, o, nullptr, nullptr);
-          const T inv = (T)1 / (T)m;
+          const T inv = (T)1 / (T)m, gm = (T)pol.g[m];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {  // + i dg v
             const T ox = xs_fma(-dg[r], cur[r].y, o[r].x) * inv;
             const T oy = xs_fma(dg[r], cur[r].x, o[r].y) * inv;
             cur[r].x = ox;
             cur[r].y = oy;
-            acc[r].x += ox;
-            acc[r].y += oy;
+            acc[r].x = xs_fma(gm, ox, acc[r].x);
+            acc[r].y = xs_fma(gm, oy, acc[r].y);
           }
           if (m < L) publish(cur);
         }
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       T2 xm[RPT];
       {
         // x_{L-1} is still in the registers (cur): it is this sweep's pairing partner
-        const T inv = (T)1 / (T)L;
+        const T inv = (T)pol.g[L] / (T)L;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           xm[r] = cur[r];
@@ -158,12 +162,13 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           (void)pl;
 #endif
         }
+        const T gl = (T)pol.g[l];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           const T dgv = (T)dgr[r * NT + t];  // (L2-resident table; not kept in registers across the sweep)
           const T2 g = Lm[r * NT + t];
-          o[r].x = xs_fma(-dgv, cur[r].y, g.x);  // lam - (-i dg y)
-          o[r].y = xs_fma(dgv, cur[r].x, g.y);
+          o[r].x = xs_fma(-dgv, cur[r].y, gl * g.x);  // g_l lam - (-i dg y)
+          o[r].y = xs_fma(dgv, cur[r].x, gl * g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, xm, dacc);
@@ -234,14 +239,14 @@ namespace {
 
 template <class T, int NT, int RPT, bool PREF, int RM>
 hipError_t xs_backward_rm(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
-                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
+                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, const XsPoly& pol, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr, dc = xs_has_diag_controls(tab);
   bool cplx = false;
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
   if (cplx && !sgn) return hipErrorInvalidValue;
-  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, T2*, double*) =
+  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, T2*, double*, XsPoly) =
       cplx ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, RM, PREF, true> : xs_backward_kernel<T, NT, RPT, true, false, RM, PREF, true>)
            : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, RM, PREF, false>
                         : xs_backward_kernel<T, NT, RPT, true, false, RM, PREF, false>)
@@ -250,40 +255,40 @@ hipError_t xs_backward_rm(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true),
-                     xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, false), wt, dgs, dgs_step, S, B, L, park, part);
+                     xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, false), wt, dgs, dgs_step, S, B, L, park, part, pol);
   return hipGetLastError();
 }
 
 template <class T, int NT, int RPT, bool PREF>
 hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
-                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, hipStream_t st) {
+                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, const XsPoly& pol, hipStream_t st) {
   return xs_rm(tab) > XR_RSMALL
-             ? xs_backward_rm<T, NT, RPT, PREF, 2 * XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
-             : xs_backward_rm<T, NT, RPT, PREF, XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+             ? xs_backward_rm<T, NT, RPT, PREF, 2 * XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
+             : xs_backward_rm<T, NT, RPT, PREF, XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
 }
 
 template <class T, bool PREF>
 hipError_t xs_backward_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                             const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
-                            int variant, hipStream_t st) {
+                            const XsPoly& pol, int variant, hipStream_t st) {
   if constexpr (sizeof(T) == sizeof(float)) {
-    if (d == 8192) return xs_backward_go<T, 1024, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    if (d == 8192) return xs_backward_go<T, 1024, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
   }
   switch (d) {
     case 4096:
-      return (variant & 1) ? xs_backward_go<T, 1024, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
-                           : xs_backward_go<T, 512, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+      return (variant & 1) ? xs_backward_go<T, 1024, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
+                           : xs_backward_go<T, 512, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
 #ifndef XS_PROBE_4096_ONLY
-    case 2048: return xs_backward_go<T, 256, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+    case 2048: return xs_backward_go<T, 256, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
     case 1024:
-      return (variant & 1) ? xs_backward_go<T, 256, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
-                           : xs_backward_go<T, 128, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+      return (variant & 1) ? xs_backward_go<T, 256, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
+                           : xs_backward_go<T, 128, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
     case 512:
-      return (variant & 1) ? xs_backward_go<T, 256, 2, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
-                           : xs_backward_go<T, 64, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+      return (variant & 1) ? xs_backward_go<T, 256, 2, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
+                           : xs_backward_go<T, 64, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
     default:
-      return (variant & 1) ? xs_backward_go<T, 256, 1, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st)
-                           : xs_backward_go<T, 64, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, st);
+      return (variant & 1) ? xs_backward_go<T, 256, 1, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
+                           : xs_backward_go<T, 64, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
 #else
     default: return hipErrorInvalidValue;
 #endif
@@ -295,14 +300,14 @@ hipError_t xs_backward_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam
 template <class T>
 hipError_t xs_backward_exact_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                                     const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park,
-                                    double* part, int variant, hipStream_t st) {
+                                    double* part, const XsPoly& pol, int variant, hipStream_t st) {
   // (no prefetch in the backward kernel: its sweeps carry more live registers, and the second partner buffer costs more in spills
   // than it hides in latency -- measured 24.5 against 26.7 ms per 20 steps at d = B = 4096)
-  return xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, variant, st);
+  return xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, variant, st);
 }
 template hipError_t xs_backward_exact_launch<double>(double2*, double2*, int, const XrTab&, const double*, const double*, long, int, int, int,
-                                                     int, double2*, double*, int, hipStream_t);
+                                                     int, double2*, double*, const XsPoly&, int, hipStream_t);
 template hipError_t xs_backward_exact_launch<float>(float2*, float2*, int, const XrTab&, const double*, const double*, long, int, int, int,
-                                                    int, float2*, double*, int, hipStream_t);
+                                                    int, float2*, double*, const XsPoly&, int, hipStream_t);
 
 }  // namespace dq

@@ -19,7 +19,10 @@ namespace dq {
 //             q_0 = w_0 lambda_{t+1} + sum_i w_i lambda(s_i) + w_1 lambda_t (the end points 0 and 1 are nodes of the rule)
 //     phase 2 (psi, register-resident between steps): L pairing sweeps; accumulates psi_t; q_m = sum_i w_i s_i^m lambda(s_i) + w_1 lambda_t.
 // The numpy twin is tests/np_state_column.py::backward_step_quad.  qd.c1[m][i] = s_i^m, qd.c2[m][i] = -w_i s_i^m (the sign:
-// <q, dA r> = -<r, dA q>, and the pairing code takes the fetched partners as its first factor), qd.w0 = -w_0, qd.w1 = -w_1.
+// <q, dA r> = -<r, dA q>, and the pairing code takes the fetched partners as its first factor), qd.w0 = -w_0, qd.w1[m] = -w_1.
+// With an economized step polynomial (XsPoly, dq_internal.h) exp(-s A) ~ sum_m g^(s)[m] (-s A)^m / m! with level factors of the
+// interval s theta: every s_i^m above carries its g_i[m] (folded into c1 / c2 by the host), lambda_t and psi_t accumulate
+// qd.g[m] z_m / qd.g[m] r_m, and the end point 1 pairs r_m with g[m] lambda_t (qd.w1[m] = -w_1 g[m]).
 template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, bool CPLX, int NI>
 __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
                                                            XrTab tab, XsOrder ord, XsOrder ordh, const double* __restrict__ wt,
@@ -70,12 +73,20 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       // ---- phase 1: lambda_s = sum_m z_m, node values ---------------------------------------------------------------------
       {
         T2 zc[RPT], acc[RPT];
+        const T g0 = (T)qd.g[0];
+        T cf0[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cf0[i] = (T)qd.c1[0][i];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           zc[r] = Lm[r * NT + t];
-          acc[r] = zc[r];
+          acc[r].x = g0 * zc[r].x;
+          acc[r].y = g0 * zc[r].y;
 #pragma unroll
-          for (int i = 0; i < NI; ++i) nd[i][r] = zc[r];
+          for (int i = 0; i < NI; ++i) {
+            nd[i][r].x = cf0[i] * zc[r].x;
+            nd[i][r].y = cf0[i] * zc[r].y;
+          }
         }
         publish(zc);
         for (int m = 1; m <= L; ++m) {
@@ -86,7 +97,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             o[r].y = 0;
           }
           xs_gather<T, NT, RPT, SIGN, false, 1, false, true, CPLX>(ctl, sg, W, zc, t, (T)-1, o, nullptr, nullptr);
-          const T inv = (T)1 / (T)m;
+          const T inv = (T)1 / (T)m, gm = (T)qd.g[m];
           T cf[NI];
 #pragma unroll
           for (int i = 0; i < NI; ++i) cf[i] = (T)qd.c1[m][i];
@@ -97,8 +108,8 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             const T oy = xs_fma(dgv, zc[r].x, o[r].y) * inv;
             zc[r].x = ox;
             zc[r].y = oy;
-            acc[r].x += ox;
-            acc[r].y += oy;
+            acc[r].x = xs_fma(gm, ox, acc[r].x);
+            acc[r].y = xs_fma(gm, oy, acc[r].y);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
               nd[i][r].x = xs_fma(cf[i], ox, nd[i][r].x);
@@ -110,7 +121,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         T cw[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) cw[i] = (T)qd.c2[0][i];
-        const T w0 = (T)qd.w0, w1 = (T)qd.w1;
+        const T w0 = (T)qd.w0, w1 = (T)qd.w1[0];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           const T2 g = Lm[r * NT + t];
@@ -133,15 +144,21 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
 #pragma unroll
       for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
       T2 acc[RPT];
+      {
+        const T g0 = (T)qd.g[0];
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) acc[r] = cur[r];
+        for (int r = 0; r < RPT; ++r) {
+          acc[r].x = g0 * cur[r].x;
+          acc[r].y = g0 * cur[r].y;
+        }
+      }
       publish(cur);
       for (int m = 0; m < L; ++m) {
         if (m > 0) {
           T cw[NI];
 #pragma unroll
           for (int i = 0; i < NI; ++i) cw[i] = (T)qd.c2[m][i];
-          const T w1 = (T)qd.w1;
+          const T w1 = (T)qd.w1[m];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {
             const T2 g = Lm[r * NT + t];
@@ -176,13 +193,13 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
 #else
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, q, dacc);
 #endif
-        const T inv = (T)1 / (T)(m + 1);
+        const T inv = (T)1 / (T)(m + 1), gm = (T)qd.g[m + 1];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           cur[r].x = o[r].x * inv;
           cur[r].y = o[r].y * inv;
-          acc[r].x += cur[r].x;
-          acc[r].y += cur[r].y;
+          acc[r].x = xs_fma(gm, cur[r].x, acc[r].x);
+          acc[r].y = xs_fma(gm, cur[r].y, acc[r].y);
         }
         if (m + 1 < L) publish(cur);
       }

@@ -70,6 +70,12 @@ typedef struct dq_profile {
 const char* dq_version(void);
 const char* dq_last_error(void);
 int dq_device_count(int* n);
+/* Host-only (no GPU call): the step polynomial p(A) = sum_{m <= degree} factors[m] A^m / m! the state-column kernels use for
+ * exp(A), A anti-Hermitian with ||A|| <= theta, at sup-norm error <= tol on the spectrum -- the Chebyshev-economized form
+ * (economize = 1; one to four degrees below Taylor's) or the Taylor polynomial (0: factors = 1).  factors: 25 doubles;
+ * degree = 0 when no degree up to 24 reaches tol.  (The reference's step is torch.matrix_exp, diffqc.cc:83-88, through
+ * scipy.linalg.expm's Pade form on the CPU: any polynomial within tol of exp is the same step to that tolerance.) */
+int dq_step_polynomial(double theta, double tol, int economize, int* degree, double* factors);
 
 /* Context = one Hilbert-space dimension + one set of Hamiltonians on one GPU.
  * Replaces the process-global store g_H0/g_Hs of diffqc.cc:21-25 with an explicit handle. */
@@ -158,6 +164,9 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      step, no scratch; up to 16 XOR-diagonals, bound e (2 theta)^6 <= tol: theta <= 0.05 at the default);
  *                      0 = always the exact derivative of the step polynomial (3 L - 1 sweeps, forward terms parked in a scratch).
  *                      dq_get_info("state_columns_quad_nodes") = interior nodes of the rule the last adjoint sweep used (0: exact form)
+ *   state_columns_polynomial   1 (default) = Chebyshev-economized step polynomial (dq_step_polynomial: one to four sweeps fewer per
+ *                      step at the same tolerance), 0 = Taylor.  dq_get_info("degree") = the degree in use,
+ *                      ("state_columns_taylor_degree") = the degree Taylor needs at the same tolerance
  *   state_columns_part_bytes  scratch of the adjoint sweep's per-step partial sums (default 256 MiB): a longer chain is swept in segments
  *                      that fit (the sweep restarts at any step: psi and lambda are in/out); dq_get_info("state_columns_segments")
  *   state_columns_workgroups  0 (default): as many workgroups as fit the chip; > 0 caps a launch (tests of the several-columns-per-

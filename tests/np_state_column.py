@@ -15,9 +15,49 @@ Backward step t (lam = lambda_{t+1}, psi1 = psi_{t+1}):
     lam_t = lam - A y_0                                               (= U^H lam)
     dL/du_k[t] = Re sum_l <y_l, dA_k x_l>,   dA_k = -1j dt H_k
 with <y, dA_k x> evaluated diagonal by diagonal from the partner values y[i ^ xoff] that the sweep A y fetches anyway.
-Round 4 added the quadrature form of the backward step (backward_step_quad: 2 L sweeps, the headline's kernel).
+Round 4 added the quadrature form of the backward step (backward_step_quad: 2 L sweeps, the headline's kernel) and the
+Chebyshev-economized step polynomial (poly_factors / economized_degree: p(A) = sum_m g[m] A^m / m!, one to four degrees below Taylor's
+at the same sup-norm error on the spectrum i [-theta, theta]): every step function takes the level factors `g` (None = Taylor).
 """
+from math import factorial
+
 import numpy as np
+
+_LD = np.longdouble
+
+
+def _bessel(k, x):
+    x = _LD(x)
+    return sum((_LD(-1) ** j) * (x / 2) ** (k + 2 * j) / (_LD(factorial(j)) * _LD(factorial(k + j))) for j in range(40))
+
+
+def poly_factors(theta, L):
+    """g[m] = m! x the coefficient of z^m (z = i theta x) in J_0(theta) + 2 sum_{k <= L} i^k J_k(theta) T_k(x)  (csrc/statecol.hip
+    xs_poly_factors; extended precision: g[m] = 1 - O(theta^2))."""
+    if theta == 0:
+        return np.ones(L + 1)
+    T = [np.zeros(L + 1, dtype=_LD) for _ in range(L + 1)]
+    T[0][0] = 1
+    if L >= 1:
+        T[1][1] = 1
+    for k in range(2, L + 1):
+        T[k][1:] = 2 * T[k - 1][:-1]
+        T[k] -= T[k - 2]
+    g = np.zeros(L + 1)
+    for m in range(L + 1):
+        acc = _LD(0)
+        for k in range(m, L + 1, 2):
+            acc += (1 if k == 0 else 2) * _bessel(k, theta) * T[k][m] * (_LD(-1) ** ((k - m) // 2))
+        g[m] = float(acc / _LD(theta) ** m * _LD(factorial(m)))
+    return g
+
+
+def economized_degree(theta, tol=1.1102230246251565e-16):
+    """The lowest L with 2 sum_{k > L} |J_k(theta)| <= tol (csrc/statecol.hip xs_poly_make)."""
+    for L in range(1, 25):
+        if float(2 * sum(abs(_bessel(k, theta)) for k in range(L + 1, L + 40))) <= tol:
+            return L
+    raise ValueError("step too large for the polynomial alone")
 
 
 def table_from_dense(H0, Hs, tol=0.0):
@@ -82,34 +122,38 @@ def apply_A(tab, w, dg, v, sign=1.0, dots=None, xm=None):
     return o
 
 
-def forward_step(tab, u_row, dt, psi, L):
+def forward_step(tab, u_row, dt, psi, L, g=None):
+    g = np.ones(L + 1) if g is None else g
     w, dg = _weights(tab, u_row, dt)
-    cur, acc = psi, psi.copy()
+    cur, acc = psi, g[0] * psi
     for m in range(1, L + 1):
         cur = apply_A(tab, w, dg, cur) / m
-        acc = acc + cur
+        acc = acc + g[m] * cur
     return acc
 
 
-def backward_step(tab, u_row, dt, psi1, lam, L, K):
-    """(psi_t, lam_t, grad_row[K]) from (psi_{t+1}, lam_{t+1})."""
+def backward_step(tab, u_row, dt, psi1, lam, L, K, g=None):
+    """(psi_t, lam_t, grad_row[K]) from (psi_{t+1}, lam_{t+1}).  With level factors g the step is p(A) = sum g[m] A^m / m!:
+    the Horner levels become y_{L-1} = g[L] lam / L, y_{l-1} = (g[l] lam - A y_l) / l, lam_t = g[0] lam - A y_0 (so that
+    y_l = sum_{m > l} g[m] (l! / m!) (-A)^(m-1-l) lam, and dp(A)[E] pairs y_l with E x_l exactly as before)."""
+    g = np.ones(L + 1) if g is None else g
     w, dg = _weights(tab, u_row, dt)
     R = len(tab["xoff"])
-    cur, psi = psi1, psi1.copy()
+    cur, psi = psi1, g[0] * psi1
     for m in range(1, L + 1):                       # reversal
         cur = apply_A(tab, w, dg, cur, sign=-1.0) / m
-        psi = psi + cur
+        psi = psi + g[m] * cur
     xs = [psi]
     for l in range(1, L):                           # the forward terms of psi_t
         xs.append(apply_A(tab, w, dg, xs[-1]) / l)
     dots = [0.0] * R
     rowacc = np.zeros(tab["d"])
-    y = lam / L
+    y = g[L] * lam / L
     for l in range(L - 1, 0, -1):                   # sweep forming y_{l-1} from y_l pairs y_l with x_l
         rowacc += y.real * xs[l].imag - y.imag * xs[l].real
-        y = (lam - apply_A(tab, w, dg, y, dots=dots, xm=xs[l])) / l
+        y = (g[l] * lam - apply_A(tab, w, dg, y, dots=dots, xm=xs[l])) / l
     rowacc += y.real * xs[0].imag - y.imag * xs[0].real
-    lam_t = lam - apply_A(tab, w, dg, y, dots=dots, xm=xs[0])
+    lam_t = g[0] * lam - apply_A(tab, w, dg, y, dots=dots, xm=xs[0])
     g = np.zeros(K)
     for j in range(R):
         if tab["kid"][j] >= 0:
@@ -131,7 +175,7 @@ def lobatto(npts):
     return (x + 1.0) / 2.0, w / 2.0
 
 
-def backward_step_quad(tab, u_row, dt, psi1, lam, L, K, npts=4):
+def backward_step_quad(tab, u_row, dt, psi1, lam, L, K, npts=4, g=None, theta=None):
     """The QUADRATURE form of the backward step (csrc/statecol_bwdq.hip): (psi_t, lam_t, grad_row[K]) from (psi_{t+1}, lam_{t+1}).
 
     Both vectors run backward under the same operator, phi(s) = exp(-s A) phi_{t+1}, and dexp(A)[E] = int_0^1 exp((1-s)A) E exp(sA) ds
@@ -140,28 +184,32 @@ def backward_step_quad(tab, u_row, dt, psi1, lam, L, K, npts=4):
         phase 1:  z_m = (-A)^m lam / m!,  lam_t = sum_m z_m,  node values lam(s_i) = sum_m s_i^m z_m
         phase 2:  r_m = (-A)^m psi1 / m!, psi_t = sum_m r_m;  the sweep that forms r_{m+1} pairs the partner values r_m[i ^ x] it fetches
                   with the own rows of q_m = sum_i w_i s_i^m lam(s_i):  sum_i w_i <lam(s_i), dA psi(s_i)> = sum_m <q_m, dA r_m>
-                  = -sum_m <r_m, dA q_m>  (dA anti-Hermitian), which is the form the pairing code of apply_A takes."""
+                  = -sum_m <r_m, dA q_m>  (dA anti-Hermitian), which is the form the pairing code of apply_A takes.
+    With an economized polynomial (g, theta given) exp(-s_i A) is the degree-L polynomial of the interval s_i theta, with its own
+    level factors g_i: every s_i^m carries g_i[m], the end point 1 carries g[m]."""
     w, dg = _weights(tab, u_row, dt)
     R = len(tab["xoff"])
     s, wq = lobatto(npts)
+    g = np.ones(L + 1) if g is None else g
+    gi = [None] + [np.ones(L + 1) if theta is None else poly_factors(theta * s[i], L) for i in range(1, npts - 1)] + [g]
     cur = lam
-    nodes = [lam.copy() for _ in range(npts)]           # node 0 (s = 0) stays lam_{t+1}; the last (s = 1) becomes lam_t
+    nodes = [lam.copy()] + [gi[i][0] * lam for i in range(1, npts)]   # node 0 (s = 0) stays lam_{t+1}; the last (s = 1) becomes lam_t
     for m in range(1, L + 1):
         cur = apply_A(tab, w, dg, cur, sign=-1.0) / m
         for i in range(1, npts):
-            nodes[i] = nodes[i] + (s[i] ** m) * cur
+            nodes[i] = nodes[i] + gi[i][m] * (s[i] ** m) * cur
     lam_t = nodes[-1]
     dots = [0.0] * R
     rowacc = np.zeros(tab["d"])
-    cur, psi = psi1, psi1.copy()
+    cur, psi = psi1, g[0] * psi1
     for m in range(L):
-        q = sum(wq[i] * (s[i] ** m) * nodes[i] for i in range(1, npts))
+        q = sum(wq[i] * gi[i][m] * (s[i] ** m) * nodes[i] for i in range(1, npts))
         if m == 0:
             q = q + wq[0] * nodes[0]
         q = -q                                            # (the sign of <q, dA r> = -<r, dA q>)
         rowacc += cur.real * q.imag - cur.imag * q.real
         cur = apply_A(tab, w, dg, cur, sign=-1.0, dots=dots, xm=q) / (m + 1)
-        psi = psi + cur
+        psi = psi + g[m + 1] * cur
     g = np.zeros(K)
     for j in range(R):
         if tab["kid"][j] >= 0:
@@ -173,7 +221,7 @@ def backward_step_quad(tab, u_row, dt, psi1, lam, L, K, npts=4):
 
 
 def taylor_degree(theta, tol=1.1102230246251565e-16):
-    for L in range(1, 17):
+    for L in range(1, 25):
         v = 1.0
         for j in range(1, L + 2):
             v *= theta / j
@@ -182,17 +230,19 @@ def taylor_degree(theta, tol=1.1102230246251565e-16):
     raise ValueError("step too large for the polynomial alone")
 
 
-def energy_grad(H0, Hs, M, u, dt, psi0, L=None, quad_points=0):
+def energy_grad(H0, Hs, M, u, dt, psi0, L=None, quad_points=0, economized=False):
     """(loss, grad[S][K], psi_S) of L = sum_b <psi_b|M|psi_b> through the state-column recurrences (quad_points > 0: the backward
-    steps in the quadrature form with that many Gauss-Lobatto points)."""
+    steps in the quadrature form with that many Gauss-Lobatto points; economized: the Chebyshev-economized step polynomial)."""
     tab = table_from_dense(H0, Hs)
     assert tab is not None, "not an XOR-regular generator"
     u = np.asarray(u, dtype=np.float64)
     S, K = u.shape
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    th = max(abs(dt) * (n1(H0) + sum(abs(row[k]) * n1(Hs[k]) for k in range(K))) for row in u) if S else 0.0
     if L is None:
-        n1 = lambda A: np.abs(A).sum(axis=0).max()
-        th = max(abs(dt) * (n1(H0) + sum(abs(row[k]) * n1(Hs[k]) for k in range(K))) for row in u) if S else 0.0
-        L = taylor_degree(th)
+        L = economized_degree(th) if economized else taylor_degree(th)
+    g = poly_factors(th, L) if economized else None
+    tq = th if economized else None
     psi0 = np.asarray(psi0, dtype=np.complex128)
     B = psi0.shape[1]
     grad = np.zeros((S, K))
@@ -201,15 +251,15 @@ def energy_grad(H0, Hs, M, u, dt, psi0, L=None, quad_points=0):
     for b in range(B):
         psi = psi0[:, b]
         for t in range(S):
-            psi = forward_step(tab, u[t], dt, psi, L)
+            psi = forward_step(tab, u[t], dt, psi, L, g)
         fin[:, b] = psi
         mp = M @ psi
         loss += float(np.real(np.vdot(psi, mp)))
         lam = 2.0 * mp
         for t in range(S - 1, -1, -1):
             if quad_points:
-                psi, lam, g = backward_step_quad(tab, u[t], dt, psi, lam, L, K, quad_points)
+                psi, lam, gr = backward_step_quad(tab, u[t], dt, psi, lam, L, K, quad_points, g, tq)
             else:
-                psi, lam, g = backward_step(tab, u[t], dt, psi, lam, L, K)
-            grad[t] += g
+                psi, lam, gr = backward_step(tab, u[t], dt, psi, lam, L, K, g)
+            grad[t] += gr
     return loss, grad, fin

@@ -320,3 +320,51 @@ def test_several_columns_per_workgroup_and_segmented_sweep(dtype, variant, tol, 
     assert np.array_equal(f0, f1) and np.max(np.abs(e0 - e1)) <= tol
     assert abs(l0 - l1) <= tol * B and np.max(np.abs(g0 - g1)) <= tol * B, np.max(np.abs(g0 - g1))
     assert np.max(np.abs(g0)) > 1e-5
+
+
+@pytest.mark.parametrize("adjoint", [1, 0], ids=["quadrature", "exact_polynomial"])
+@pytest.mark.parametrize("case,n,dt", [("ising_x", 9, 2e-3), ("ising_x", 9, 2e-2), ("xy_drives", 9, 3e-3), ("mixed_two_body", 8, 4e-3),
+                                       ("qaoa_ring_zz_controls", 8, 2e-2)])
+def test_economized_step_polynomial_against_taylor_and_the_oracle(oracle, case, n, dt, adjoint):
+    """The default step polynomial is the Chebyshev-economized one (dq_step_polynomial; csrc/statecol.hip xs_poly_make): at these step
+    sizes one to three sweeps fewer per step than the Taylor polynomial of the same tolerance (option state_columns_polynomial = 0),
+    and both chains and both adjoint forms -- the exact form's Horner levels and the quadrature form's node sums carry the level
+    factors -- match the oracle (scipy expm / expm_frechet) to the same 1e-10."""
+    H0, Hs, M = _qaoa(n) if case == "qaoa_ring_zz_controls" else CASES[case](n)
+    K, d = len(Hs), 1 << n
+    S, B = 5, 6
+    u = np.random.default_rng(40 + n).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=41)
+    rl, rg, rf = oracle_answer(oracle, ("econ", case, n, dt), H0, Hs, M, u, dt, psi0)
+    out = {}
+    with _engine(H0, Hs, M, state_columns=1, state_columns_adjoint=adjoint) as e:
+        for poly in (1, 0):
+            e.set_option("state_columns_polynomial", poly)
+            loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+            assert e.info("state_columns") == 1
+            out[poly] = (loss, grad, fin, e.info("degree"), e.info("state_columns_taylor_degree"), e.propagate(u, dt, psi0), e.info("degree"))
+    assert out[0][3] == out[0][4] == out[1][4], "Taylor: the degree of the remainder bound"
+    assert out[1][3] <= out[0][3] and out[1][6] == out[1][3], (out[1][3], out[0][3])
+    if dt >= 1e-2:
+        assert out[1][3] <= out[0][3] - 1 and e is not None, (out[1][3], out[0][3])     # (theta ~ 0.2 .. 0.4: two degrees fewer)
+    for poly in (1, 0):
+        loss, grad, fin, _, _, fwd, _ = out[poly]
+        assert np.max(np.abs(fin - rf)) < TOL and np.max(np.abs(fwd - rf)) < TOL and abs(loss - rl) < TOL
+        assert np.max(np.abs(grad - rg)) < TOL, (poly, np.max(np.abs(grad - rg)))
+    assert np.max(np.abs(out[1][1] - out[0][1])) < 1e-12 * max(1.0, np.max(np.abs(rg))) and np.max(np.abs(out[1][2] - out[0][2])) < 1e-13
+    assert np.max(np.abs(rg)) > 1e-5
+
+
+def test_economized_step_polynomial_in_complex64():
+    """fp32 tolerance (6e-8): degree 3 where Taylor takes 4; against the complex128 state-column chain."""
+    n, S, B, dt = 10, 40, 9, 4e-3
+    H0, Hs, M = problems.random_ising(n, seed=44)
+    u = problems.pulse_table(n, S, S * dt, seed=45)
+    psi0 = problems.random_states(1 << n, B, seed=46)
+    with _engine(H0, Hs, M) as e:
+        rl, rg, rf, _ = e.energy_grad(u, dt, psi0)
+    with _engine(H0, Hs, M, dtype="c64") as e:
+        loss, grad, fin, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("state_columns") == 1 and e.info("degree") < e.info("state_columns_taylor_degree")
+    assert np.max(np.abs(fin - rf)) < 1e-4 and abs(loss - rl) < 1e-4 * B
+    assert np.max(np.abs(grad - rg)) < 1e-4 * max(1.0, np.max(np.abs(rg))) and np.max(np.abs(rg)) > 1e-4

@@ -78,3 +78,56 @@ def test_quadrature_form_of_the_backward_step_matches_oracle(oracle, name, prob)
         errs[(theta, pts)] = np.max(np.abs(grad - rg)) / np.max(np.abs(rg))
     assert errs[(0.04, 4)] < 1e-13 and errs[(0.2, 5)] < 1e-12, errs
     assert errs[(0.2, 4)] < 6.6e-7 * 0.4 ** 6 * 50, errs           # (the bound of the rule, with room for the norms it is relative to)
+
+
+@pytest.mark.parametrize("name,prob", list(_cases()))
+def test_economized_step_polynomial_matches_oracle(oracle, name, prob):
+    """The Chebyshev-economized step polynomial (csrc/statecol.hip xs_poly_make; the kernels' default): its degree is below Taylor's
+    at the same tolerance, and the chain + both forms of the adjoint through it match the oracle (scipy expm / expm_frechet) as the
+    Taylor form does -- the Horner levels of the exact form and the node sums of the quadrature form carry the level factors."""
+    H0, Hs, M = prob
+    K, d = len(Hs), H0.shape[0]
+    S, B = 4, 2
+    u = np.random.default_rng(9).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=4)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    scale = n1(H0) + sum(n1(h) for h in Hs)
+    for theta, pts in ((0.03, 0), (0.03, 4), (0.25, 0), (0.25, 5)):
+        dt = theta / scale
+        th = max(abs(dt) * (n1(H0) + sum(abs(row[k]) * n1(Hs[k]) for k in range(K))) for row in u)
+        assert nsc.economized_degree(th) <= nsc.taylor_degree(th) - (1 if theta > 0.1 else 0)
+        rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+        loss, grad, fin = nsc.energy_grad(H0, Hs, M, u, dt, psi0, quad_points=pts, economized=True)
+        assert np.max(np.abs(fin - rf)) < 1e-12 and abs(loss - rl) < 1e-11
+        assert np.max(np.abs(grad - rg)) < 1e-12 * max(1.0, np.max(np.abs(rg))), (theta, pts)
+
+
+def test_library_step_polynomial_matches_the_model():
+    """dq_step_polynomial (host-only entry of the C-ABI, include/diffqc_hip.h): degree and level factors against the numpy
+    construction, the sup-norm error on the spectral interval against the tolerance, one to four degrees below Taylor."""
+    import ctypes as C
+    from math import factorial
+    from diffquantum_amd import _lib
+    lib = _lib.load()
+    for theta in (0.0, 1e-9, 0.0177, 0.0295, 0.05, 0.2, 1.0, 2.0):
+        for tol in (2.0 ** -53, 6e-8):
+            L, g = C.c_int(), (C.c_double * 25)()
+            Lt, gt = C.c_int(), (C.c_double * 25)()
+            assert lib.dq_step_polynomial(theta, tol, 1, C.byref(L), g) == 0
+            assert lib.dq_step_polynomial(theta, tol, 0, C.byref(Lt), gt) == 0
+            assert 1 <= L.value <= Lt.value and all(v == 1.0 for v in gt)
+            assert Lt.value == nsc.taylor_degree(theta, tol) if theta > 0 else Lt.value == 1
+            if theta == 0:
+                continue
+            assert L.value == nsc.economized_degree(theta, tol)
+            gg = np.array(g[:L.value + 1])
+            assert np.max(np.abs(gg - nsc.poly_factors(theta, L.value))) < 4e-16
+            z = 1j * np.longdouble(theta) * np.linspace(-1, 1, 2001).astype(np.longdouble)
+            p = sum(np.longdouble(gg[m]) * z ** m / factorial(m) for m in range(L.value + 1))
+            # (+ the factors' rounding to double: at most 2^-53 sum_m theta^m / m!)
+            assert float(np.max(np.abs(p - np.exp(z)))) <= tol * 1.01 + 2.0 ** -53 * np.exp(theta) * 0.5
+    L, g = C.c_int(), (C.c_double * 25)()
+    assert lib.dq_step_polynomial(0.0295, 2.0 ** -53, 1, C.byref(L), g) == 0 and L.value == 6      # the headline's step: Taylor needs 7
+    assert lib.dq_step_polynomial(1.0, 2.0 ** -53, 1, C.byref(L), g) == 0 and L.value == 14        # Taylor: 18
+    assert lib.dq_step_polynomial(2.5, 2.0 ** -53, 1, C.byref(L), g) == 0 and L.value == 0         # beyond the kernels' degrees
+    assert lib.dq_step_polynomial(-1.0, 1e-9, 1, C.byref(L), g) != 0 and b"theta" in lib.dq_last_error()

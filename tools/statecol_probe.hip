@@ -2,7 +2,8 @@
 // drift + X_k controls) at n qubits, B columns, S steps; times the forward and the backward launch with HIP events and, built
 // with -DXS_STAMPS, prints the backward kernel's shader cycles per phase.  Not part of the library.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DXS_STAMPS -DXS_PROBE_4096_ONLY -Idiffquantum_amd/csrc tools/statecol_probe.hip -o tools/_build/statecol_probe
-//   tools/_build/statecol_probe [n=12] [B=4096] [S=20] [L=7] [variant=2]
+//   tools/_build/statecol_probe [n=12] [B=4096] [S=20] [L=7] [variant=2] [forms=3] [economized=1]
+// economized = 1: the Chebyshev-economized step polynomial for theta = 0.03 at 2^-53 (degree 6; L is ignored), 0: Taylor of degree L
 #include "../diffquantum_amd/csrc/statecol.hip"
 #include "../diffquantum_amd/csrc/statecol_bwd.hip"
 #include "../diffquantum_amd/csrc/statecol_bwdq.hip"
@@ -15,8 +16,15 @@
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 12, B = argc > 2 ? atoi(argv[2]) : 4096, S = argc > 3 ? atoi(argv[3]) : 20;
-  const int L = argc > 4 ? atoi(argv[4]) : 7, variant = argc > 5 ? atoi(argv[5]) : 2;
+  int L = argc > 4 ? atoi(argv[4]) : 7;
+  const int variant = argc > 5 ? atoi(argv[5]) : 2;
   const int forms = argc > 6 ? atoi(argv[6]) : 3;   // bit 0: the exact adjoint form, bit 1: the quadrature form
+  const int econ = argc > 7 ? atoi(argv[7]) : 1;
+  dq::XsPoly pol;
+  {
+    const int Le = dq::xs_poly_make(0.03, 1.1102230246251565e-16, econ, &pol);
+    if (econ) L = Le;
+  }
   const int d = 1 << n, K = n;
   dq::XrTab tab;
   memset(&tab, 0, sizeof(tab));
@@ -56,14 +64,14 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   dq::XsQuad quad;
-  if (!dq::xs_quad_make(0.04, 9.1e-13, 2, &quad)) { printf("no quadrature rule\n"); return 1; }
+  if (!dq::xs_quad_make(0.03, 9.1e-13, 2, L, econ, pol, &quad)) { printf("no quadrature rule\n"); return 1; }
   std::vector<double> g_exact((size_t)S * K), g_quad((size_t)S * K);
   for (int form = 0; form < 2; ++form) {
   if (!((forms >> form) & 1)) continue;
   for (int rep = 0; rep < 3; ++rep) {
     float msf = 0, msb = 0;
     CK(hipEventRecord(e0));
-    CK(dq::xs_forward_launch(d_in, d_psi, d, tab, d_wt, d_dgs, step, S, B, L, nblk, variant, nullptr));
+    CK(dq::xs_forward_launch(d_in, d_psi, d, tab, d_wt, d_dgs, step, S, B, L, nblk, variant, &pol, nullptr));
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&msf, e0, e1));
@@ -74,7 +82,7 @@ int main(int argc, char** argv) {
 #endif
     CK(hipEventRecord(e0));
     CK(dq::xs_backward_launch(d_psi, d_lam, d, tab, d_wt, d_dgs, step, S, B, L, nblk, d_park, d_part, K, 1e-3, d_grad, 0, variant,
-                              form ? &quad : nullptr, nullptr));
+                              form ? &quad : nullptr, &pol, nullptr));
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&msb, e0, e1));
