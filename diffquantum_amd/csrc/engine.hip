@@ -327,6 +327,9 @@ struct Ctx : dq_ctx {
   double xs_part_bytes = 268435456.0;          // scratch of the adjoint sweep's per-step partial sums: the chain is swept in segments that fit
   double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
   int xs_economize = 1;                        // step polynomial of the state-column kernels: 1 = Chebyshev-economized (default), 0 = Taylor
+  // the polynomial's error is the same function of the spectrum at every step, so over a chain it can add up coherently: its per-step
+  // bound is min(expm_tol, xs_chain_tol / steps) -- no effect in fp64 below 90000 steps, one degree more in fp32 beyond ~330 steps
+  double xs_chain_tol = sizeof(T) == sizeof(double) ? 1e-11 : 2e-5;
   dq::XsPoly xs_poly;                          // its level factors (set by xs_degree for the chain at hand)
   double last_xs_taylor_degree = 0;            // the Taylor degree the same tolerance would have needed
   double last_xs_segments = 0;                 // launches the last adjoint sweep was split into
@@ -1360,12 +1363,13 @@ int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B)
   // the step polynomial: Chebyshev-economized on the spectral interval i [-theta, theta] (dq_internal.h, XsPoly), same error bound as
   // the Taylor polynomial it replaces with one to four degrees fewer -- every sweep of the kernels is one degree
   dq::XsPoly pol;
-  const int L = dq::xs_poly_make(th, c->expm_tol, c->xs_economize, &pol);
+  const double tol = std::min(c->expm_tol, c->xs_chain_tol / std::max(S, 1));
+  const int L = dq::xs_poly_make(th, tol, c->xs_economize, &pol);
   if (L <= 0 || !dq::xs_supported(c->d, L, tab->R, tab->nd, sizeof(T))) return 0;
   c->xs_poly = pol;
   c->last_theta = th;
   dq::XsPoly tay;
-  c->last_xs_taylor_degree = dq::xs_poly_make(th, c->expm_tol, 0, &tay);
+  c->last_xs_taylor_degree = dq::xs_poly_make(th, tol, 0, &tay);
   return L;
 }
 
@@ -2820,6 +2824,9 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_chain_tol") {  // bound of the step polynomial's error summed over the chain (per step: min(expm_tol, this / steps))
+    if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_chain_tol must be > 0");
+    c->xs_chain_tol = v;
   } else if (s == "state_columns_polynomial") {  // 1 (default): Chebyshev-economized step polynomial; 0: Taylor
     c->xs_economize = v != 0 ? 1 : 0;
   } else if (s == "matrix_free") {  // -1 auto (Pauli-sum generators beyond the state-column kernels' dimensions), 0 never, 1 whenever the table is a string sum

@@ -167,6 +167,9 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *   state_columns_polynomial   1 (default) = Chebyshev-economized step polynomial (dq_step_polynomial: one to four sweeps fewer per
  *                      step at the same tolerance), 0 = Taylor.  dq_get_info("degree") = the degree in use,
  *                      ("state_columns_taylor_degree") = the degree Taylor needs at the same tolerance
+ *   state_columns_chain_tol   bound of the step polynomial's error summed over the chain (default 1e-11 in complex128, 2e-5 in
+ *                      complex64): the per-step bound is min(expm_tol, state_columns_chain_tol / n_steps) -- the polynomial's error is
+ *                      the same function of the spectrum at every step and may add up coherently
  *   state_columns_part_bytes  scratch of the adjoint sweep's per-step partial sums (default 256 MiB): a longer chain is swept in segments
  *                      that fit (the sweep restarts at any step: psi and lambda are in/out); dq_get_info("state_columns_segments")
  *   state_columns_workgroups  0 (default): as many workgroups as fit the chip; > 0 caps a launch (tests of the several-columns-per-

@@ -356,15 +356,22 @@ def test_economized_step_polynomial_against_taylor_and_the_oracle(oracle, case, 
 
 
 def test_economized_step_polynomial_in_complex64():
-    """fp32 tolerance (6e-8): degree 3 where Taylor takes 4; against the complex128 state-column chain."""
-    n, S, B, dt = 10, 40, 9, 4e-3
+    """fp32 tolerance (6e-8 per step): the step size is set from the engine's own bound so that theta = 0.12 -- Taylor takes degree 5
+    there (theta^6 / 720), the economized polynomial 4 (2 J_5(theta)); against the complex128 state-column chain.  A long chain
+    tightens the per-step bound (state_columns_chain_tol / steps): the same step over 2000 steps takes one degree more (and Taylor's degree 5 already meets it)."""
+    n, S, B = 10, 40, 9
     H0, Hs, M = problems.random_ising(n, seed=44)
-    u = problems.pulse_table(n, S, S * dt, seed=45)
+    u = problems.pulse_table(n, S, 1.0, seed=45)
     psi0 = problems.random_states(1 << n, B, seed=46)
     with _engine(H0, Hs, M) as e:
+        e.propagate(u, 1e-3, psi0)
+        dt = 1e-3 * 0.12 / e.info("theta")
         rl, rg, rf, _ = e.energy_grad(u, dt, psi0)
     with _engine(H0, Hs, M, dtype="c64") as e:
         loss, grad, fin, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
-        assert e.info("state_columns") == 1 and e.info("degree") < e.info("state_columns_taylor_degree")
+        assert e.info("state_columns") == 1 and abs(e.info("theta") - 0.12) < 1e-6
+        assert (e.info("degree"), e.info("state_columns_taylor_degree")) == (4, 5)
+        e.propagate(np.tile(u, (50, 1)), dt, psi0.astype(np.complex64))
+        assert (e.info("degree"), e.info("state_columns_taylor_degree")) == (5, 5)     # (1e-8 per step: 2 J_5 = 2.6e-8 is too much, theta^6 / 720 = 4e-9 is not)
     assert np.max(np.abs(fin - rf)) < 1e-4 and abs(loss - rl) < 1e-4 * B
     assert np.max(np.abs(grad - rg)) < 1e-4 * max(1.0, np.max(np.abs(rg))) and np.max(np.abs(rg)) > 1e-4
