@@ -27,9 +27,9 @@ TRAFFIC = {
     "statecol_fwd": (5.376e8, "profiles/r3_bench_headline_summary.txt"),
     "statecol_bwd_per_step": (3.60e9, "profiles/r3_bench_headline_summary.txt"),     # exact form (xs_backward_kernel)
     # quadrature form (xs_backward_q_kernel, round 4): no forward-term scratch; what is left per step is register spill traffic
-    # (profiles/r4_bench_headline_summary.txt: 749 MB read + 662 MB written per average launch of 11 steps = the states and costates in
-    # and out, 1074 MB, + 30.6 MB per step)
-    "statecol_bwdq_per_step": (3.06e7, "profiles/r4_bench_headline_summary.txt"),
+    # (profiles/r4_bench_headline_summary.txt: 700 MB read + 644 MB written per average launch of 11 steps = the states and costates in
+    # and out, 1074 MB, + 24.6 MB per step -- at degree 6, the economized step polynomial; 30.6 MB per step at Taylor's degree 7)
+    "statecol_bwdq_per_step": (2.455e7, "profiles/r4_bench_headline_summary.txt"),
     "xr": (6.60e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 1441 MB xr_reverse [Ubar
                                                                      # read + its power scratch written back and re-read]) / 3
 }
@@ -256,7 +256,7 @@ def roofline_blocks(prof, info, d):
              "per step and column: reversal psi_t = U_t^H psi_{t+1} (L sweeps), the forward terms x_l (L - 1 sweeps, parked in an L2 / "
              "Infinity-Cache resident scratch), Horner on lambda with the gradient pairings (L sweeps): 3L - 1 sweeps of R partner reads per row"),
             ("statecol_fwd", "xs_forward_kernel (whole Trotter chains on state columns in LDS)",
-             "per step and column: L sweeps of R partner reads per row (Taylor polynomial of exp(-i dt H(t)) applied to the column)")):
+             "per step and column: L sweeps of R partner reads per row (economized polynomial of exp(-i dt H(t)) applied to the column)")):
         sc = prof.get(name)
         if not sc:
             continue
