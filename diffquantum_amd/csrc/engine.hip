@@ -1363,7 +1363,7 @@ int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B)
   // the step polynomial: Chebyshev-economized on the spectral interval i [-theta, theta] (dq_internal.h, XsPoly), same error bound as
   // the Taylor polynomial it replaces with one to four degrees fewer -- every sweep of the kernels is one degree
   dq::XsPoly pol;
-  const double tol = std::min(c->expm_tol, c->xs_chain_tol / std::max(S, 1));
+  const double tol = std::min(c->expm_tol, c->xs_chain_tol / (double)std::max<long>(std::max<long>(S, c->plan_steps), 1));
   const int L = dq::xs_poly_make(th, tol, c->xs_economize, &pol);
   if (L <= 0 || !dq::xs_supported(c->d, L, tab->R, tab->nd, sizeof(T))) return 0;
   c->xs_poly = pol;
@@ -1573,6 +1573,8 @@ bool mf_route(Ctx<T>* c, int S, bool need_observable, bool targets) {
   };
   opt("plan_steps", (double)c->plan_steps);
   opt("checkpoint_bytes", c->mf_checkpoint_bytes);
+  opt("polynomial", (double)c->xs_economize);   // (the step polynomial's options name the same thing on both engines)
+  opt("chain_tol", c->xs_chain_tol);
   if (dq_sctx_set_stream(c->mf, (void*)c->st) != DQ_OK) fail(DQ_ERR_HIP, dq_sctx_last_error());
   return true;
 }

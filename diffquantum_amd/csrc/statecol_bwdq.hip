@@ -44,9 +44,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
   ctlh.load_table(tab, ordh, lane);
   if (SIGN) ctlh.load_row_signs(tab, lane, __builtin_ctz(NT));
   auto publish = [&](const T2* v) {
-#ifndef XS_EXPERIMENT_ONE_BARRIER   // (timing experiment only: results are wrong without the first barrier)
     __syncthreads();
-#endif
     xs_put<T, NT, RPT>(W, t, v);
     __syncthreads();
   };

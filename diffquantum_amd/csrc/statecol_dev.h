@@ -82,12 +82,22 @@ __device__ __forceinline__ void xs_use(int ej, int slot, T w, unsigned tsg, cons
   }
   if (DOT) {  // (dacc: an xs_acc16; slot = the diagonal's sorted position, wave-uniform)
     T sa = 0, sb = 0;  // two chains: the sums over the rows are latency-bound otherwise
+    if constexpr (SIGN && RS) {
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      T p = PH ? -xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y) : xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
-      if (SIGN && RS) p = xs_flip(p, (rm >> r) & 1u);
-      if (r & 1) sb += p;
-      else sa += p;
+      for (int r = 0; r < RPT; ++r) {
+        T p = PH ? -xs_fma(v[r].x, xm[r].x, v[r].y * xm[r].y) : xs_fma(v[r].x, xm[r].y, -v[r].y * xm[r].x);
+        p = xs_flip(p, (rm >> r) & 1u);
+        if (r & 1) sb += p;
+        else sa += p;
+      }
+    } else {  // no row factor: the two products of a row are the two chains (2 FMAs per row; a product, an FMA and an add before)
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        sa = xs_fma(v[r].x, PH ? xm[r].x : xm[r].y, sa);
+        sb = xs_fma(v[r].y, PH ? xm[r].y : xm[r].x, sb);
+      }
+      if (PH) sa = -sa;   // PH: -(sa + sb);  else sa - sb
+      sb = -sb;
     }
     double tot = (double)sa + (double)sb;
     if (SIGN) tot = xs_flip(tot, tb);   // the thread's factor, once per diagonal

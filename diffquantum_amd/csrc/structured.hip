@@ -1314,6 +1314,17 @@ struct SCtx : dq_sctx {
   std::vector<double> wsumk;        // per control
   double tol = 0, checkpoint_bytes = 0;
   int force_degree = 0;
+  // The step polynomial in Horner form z_m = psi, z_{j-1} = psi + rho[j] A z_j: rho[j] = 1 / j is Taylor's; the Chebyshev-economized
+  // one (dq_internal.h XsPoly: sum g[j] A^j / j!, one to four degrees fewer at the same sup-norm error on the spectrum i [-theta,
+  // theta]), normalised to constant term 1 (p / g[0]: |1 - g[0]| is below the truncation bound, and the bound asked of the cut is
+  // HALF the tolerance so that both together stay inside it), has rho[j] = g[j] / (j g[j-1]).  The reverse mode of the recursion carries
+  // the same factors (zbar_j = conj(rho[j]) A^H zbar_{j-1}; overlaps weighted dt rho[j]).
+  int economize = 1;
+  // the polynomial's error is the same function of the spectrum at every step and may add up coherently over a chain: the per-step
+  // bound is min(tol, chain_tol / steps) (steps: of the call, or plan_steps when that is larger)
+  double chain_tol = sizeof(T) == 8 ? 1e-11 : 2e-5;
+  double last_taylor_degree = 0;
+  std::vector<double> rho;
   double last_degree = 0, last_theta = 0, last_groups = 0, last_cstride = 0, last_passes = 0, last_bytes = 0, last_dma_passes = 0;
   SBuf u_dev, grad_dev, e_dev, part, tmp[2], lam[2], psi[2], zbar[2];
   std::vector<SBuf> zs, ck, oparts;  // oparts: per-group partial sums of the fused overlap passes
@@ -1732,7 +1743,20 @@ int plan_degree(SCtx<T>* c, const std::vector<double>& uh, int S, double dt) {
     th = std::max(th, std::fabs(dt) * h);
   }
   c->last_theta = th;
-  const int m = taylor_degree(th, c->tol, c->force_degree);
+  const double tol = std::min(c->tol, c->chain_tol / (double)std::max(std::max(S, c->plan_steps), 1));
+  int m = taylor_degree(th, tol, c->force_degree);
+  c->last_taylor_degree = m;
+  c->rho.assign((size_t)m + 2, 0.0);
+  for (int j = 1; j <= m + 1; ++j) c->rho[j] = 1.0 / j;
+  if (c->force_degree <= 0 && c->economize && th <= 2.0) {
+    dq::XsPoly pol;
+    const int L = dq::xs_poly_make(th, 0.5 * tol, 1, &pol);
+    if (L > 0 && L < m) {
+      m = L;
+      c->rho.assign((size_t)m + 2, 0.0);
+      for (int j = 1; j <= m; ++j) c->rho[j] = pol.g[j] / ((double)j * pol.g[j - 1]);
+    }
+  }
   c->last_degree = m;
   return m;
 }
@@ -1793,10 +1817,10 @@ void taylor_chain(SCtx<T>* c, int jhi, int jlo, double dt, double sign, const ty
     g ^= 1;  // the application is finished on the other group ...
     T2* znew = dst(j - 1);
     if (j > jlo || to) {  // ... which also starts the next one (of this chain, or of the chain that follows)
-      chain_pass<T>(c, g, 1, zj, (const T2*)c->tmp[pb].p, in, znew, (T2*)c->tmp[pb ^ 1].p, 0.0, -sign * dt / j, B);
+      chain_pass<T>(c, g, 1, zj, (const T2*)c->tmp[pb].p, in, znew, (T2*)c->tmp[pb ^ 1].p, 0.0, -sign * dt * c->rho[j], B);
       pb ^= 1;
     } else {
-      chain_pass<T>(c, g, 2, zj, (const T2*)c->tmp[pb].p, in, znew, nullptr, 0.0, -sign * dt / j, B);
+      chain_pass<T>(c, g, 2, zj, (const T2*)c->tmp[pb].p, in, znew, nullptr, 0.0, -sign * dt * c->rho[j], B);
     }
     zj = znew;
   }
@@ -1846,7 +1870,7 @@ void reverse_chain(SCtx<T>* c, int m, double dt, int B, const std::vector<const 
   };
   int g = 0, pb = 0;
   pass(g, 0, lam_old, nullptr, nullptr, z[1], nullptr, (T2*)c->tmp[pb].p, nullptr, 0.0, 0.0);   // stage 1 starts on group 0
-  finish(g, dt);
+  finish(g, dt * c->rho[1]);
   const T2* zprev = lam_old;
   for (int j = 1; j <= m; ++j) {
     g ^= 1;
@@ -1854,12 +1878,12 @@ void reverse_chain(SCtx<T>* c, int m, double dt, int B, const std::vector<const 
     T2* zb_new = (T2*)c->zbar[j & 1].p;
     const T2* acc_in = j == 1 ? lam_old : (const T2*)lam_new;
     if (j < m) {
-      pass(g, 1, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], z[j + 1], zb_new, (T2*)c->tmp[pb ^ 1].p, dt / j, (double)j / (j + 1));
+      pass(g, 1, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], z[j + 1], zb_new, (T2*)c->tmp[pb ^ 1].p, dt * c->rho[j], c->rho[j + 1] / c->rho[j]);
       pb ^= 1;
     } else {
-      pass(g, 2, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], nullptr, zb_new, nullptr, dt / j, 0.0);
+      pass(g, 2, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], nullptr, zb_new, nullptr, dt * c->rho[j], 0.0);
     }
-    finish(g, dt / j);
+    finish(g, dt * c->rho[j]);
     zprev = zb_new;
   }
 }
@@ -1886,7 +1910,7 @@ void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx
     if (j == 1) dst = out;
     else if (store) { (*store)[j - 1].ensure(sb); dst = (T2*)(*store)[j - 1].p; }
     else { c->zbar[j & 1].ensure(sb); dst = (T2*)c->zbar[j & 1].p; }
-    apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, in, dst, (T2*)nullptr, 0.0, -sign * dt / j, B);
+    apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, in, dst, (T2*)nullptr, 0.0, -sign * dt * c->rho[j], B);
     zj = dst;
   }
   if (m == 0) SHIP(hipMemcpyAsync(out, in, sb, hipMemcpyDeviceToDevice, c->st));
@@ -2085,14 +2109,14 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         c->last_passes += 1; c->last_bytes += 2.0 * sb;
         hipLaunchKernelGGL(soverlap_finish_kernel, dim3(o.nterms), dim3(256), 0, c->st, (const double*)c->part.p, nblk, o.nterms,
                            (const int*)g.d_ovl_slots.p, (const int*)c->d_owner.p, (const double*)c->d_wre.p,
-                           (const double*)c->d_wim.p, dt / j, (double*)c->grad_dev.p + (size_t)t * K);
+                           (const double*)c->d_wim.p, dt * c->rho[j], (double*)c->grad_dev.p + (size_t)t * K);
         SHIP(hipGetLastError());
       }
       // zbar_j = (A^H zbar_{j-1})/j = (+i dt/j) H zbar_{j-1}; accumulated into lambda_t
       c->zbar[j & 1].ensure(sb);
       T2* zb_new = (T2*)c->zbar[j & 1].p;
       apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zb_prev, (const T2*)nullptr, zb_new, lam_new, 0.0,
-                   dt / j, B, fuse ? z[j] : (const T2*)nullptr, &c->oparts, j == 1 ? (const T2*)c->lam[lcur].p : (const T2*)nullptr);
+                   dt * c->rho[j], B, fuse ? z[j] : (const T2*)nullptr, &c->oparts, j == 1 ? (const T2*)c->lam[lcur].p : (const T2*)nullptr);
       if (fuse)
         for (size_t gi = 0; gi < c->hgroups.size(); ++gi) {
           auto& g = c->hgroups[gi];
@@ -2100,7 +2124,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
           const int nblk = g.last_nblk;
           hipLaunchKernelGGL(soverlap_finish_kernel, dim3((unsigned)g.ovl.size()), dim3(256), 0, c->st,
                              (const double*)c->oparts[gi].p, nblk, (int)g.ovl.size(), (const int*)g.d_ovl_slots.p,
-                             (const int*)c->d_owner.p, (const double*)c->d_wre.p, (const double*)c->d_wim.p, dt / j,
+                             (const int*)c->d_owner.p, (const double*)c->d_wre.p, (const double*)c->d_wim.p, dt * c->rho[j],
                              (double*)c->grad_dev.p + (size_t)t * K);
           SHIP(hipGetLastError());
         }
@@ -2146,7 +2170,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
           for (int j = m; j >= 2; --j) {
             zs[j - 1].ensure(sb);
             apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, (const T2*)psi_of(t), (T2*)zs[j - 1].p, (T2*)nullptr, 0.0,
-                         -dt / j, B);
+                         -dt * c->rho[j], B);
             zj = (const T2*)zs[j - 1].p;
           }
         }
@@ -2186,7 +2210,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
       for (int j = m; j >= 2; --j) {
         c->zs[j - 1].ensure(sb);
         T2* dst = (T2*)c->zs[j - 1].p;
-        apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, psi_t, dst, (T2*)nullptr, 0.0, -dt / j, B);
+        apply_groups(c, c->hgroups, (const T2*)c->d_coef.p, step_diag(c), zj, psi_t, dst, (T2*)nullptr, 0.0, -dt * c->rho[j], B);
         z[j - 1] = dst;
         zj = dst;
       }
@@ -2267,6 +2291,8 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     const std::string s(name);
     if (s == "tol") { if (!(v > 0)) sfail(DQ_ERR_INVALID, "tol must be > 0"); t->tol = v; }
     else if (s == "force_degree") t->force_degree = (int)v;
+    else if (s == "polynomial") t->economize = v != 0 ? 1 : 0;   // 1 (default): Chebyshev-economized step polynomial, 0: Taylor
+    else if (s == "chain_tol") { if (!(v > 0)) sfail(DQ_ERR_INVALID, "chain_tol must be > 0"); t->chain_tol = v; }
     else if (s == "checkpoint_bytes") t->checkpoint_bytes = v;
     else if (s == "two_level") t->two_level = v != 0 ? 1 : 0;
     else if (s == "host_checkpoints") t->host_checkpoints = v != 0 ? 1 : 0;
@@ -2288,6 +2314,7 @@ int dq_sctx_get_info(dq_sctx* c, const char* name, double* v) {
     if (!name || !v) sfail(DQ_ERR_INVALID, "null argument");
     const std::string s(name);
     if (s == "degree") *v = t->last_degree;
+    else if (s == "taylor_degree") *v = t->last_taylor_degree;
     else if (s == "theta") *v = t->last_theta;
     else if (s == "groups") *v = (double)t->hgroups.size();
     else if (s == "checkpoint_stride") *v = t->last_cstride;

@@ -291,7 +291,11 @@ int dq_sctx_destroy(dq_sctx* ctx);
 int dq_sctx_set_stream(dq_sctx* ctx, void* hip_stream);
 int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigned* xmask, const unsigned* zmask,
                       const double* weight);
-/* options: "tol" (Taylor remainder bound), "force_degree", "checkpoint_bytes", "profile" (1 on, 0 off, -1 reset);
+/* options: "tol" (bound of the step polynomial's error per step), "force_degree" (Taylor of that degree), "checkpoint_bytes",
+ *   "profile" (1 on, 0 off, -1 reset);
+ *   "polynomial" (1, default: the Chebyshev-economized step polynomial of dq_step_polynomial in Horner form, normalised to constant
+ *                term 1, taken when its degree is below Taylor's; 0: Taylor), "chain_tol" (bound of the polynomial's error summed
+ *                over the chain: per step min(tol, chain_tol / max(n_steps, plan_steps)); 1e-11 in complex128, 2e-5 in complex64),
  *   "plan_steps" (checkpoint stride as for a chain of this many steps: a timed slice of a long chain pays the long chain's reversals),
  *   "two_level" (1, default: when not every state fits but steps / s + m s states do (m = Taylor degree, s = sqrt(steps / m)), every
  *                s-th state is kept and a segment at a time is recomputed with the Horner iterates of its steps stored; 0: one level),
@@ -307,7 +311,7 @@ int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigne
  *                    both tiles touch few 2 MB regions; 0: low qubits to one group, high qubits to the other),
  *   "fuse_overlaps" (1: the reverse-mode apply pass of a group also forms that group's control overlaps, in every kernel form;
  *                    0, default: only in the DMA form, where it costs no occupancy; -1: never).
- * info: "degree", "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "two_level", "host_checkpoints", "pass_bytes", "checkpoint_pool_bytes" (device bytes the checkpoint pools hold now), "pinned_host_bytes" (pinned host memory of the kept states), "prof_ms", "prof_bytes", "prof_launches", "dtype" */
+ * info: "degree", "taylor_degree" (Taylor's at the same bound), "theta", "groups", "checkpoint_stride", "passes", "dma_passes", "two_level", "host_checkpoints", "pass_bytes", "checkpoint_pool_bytes" (device bytes the checkpoint pools hold now), "pinned_host_bytes" (pinned host memory of the kept states), "prof_ms", "prof_bytes", "prof_launches", "dtype" */
 int dq_sctx_set_option(dq_sctx* ctx, const char* name, double value);
 int dq_sctx_get_info(dq_sctx* ctx, const char* name, double* value);
 int dq_sctx_propagate(dq_sctx* ctx, const double* u, int n_steps, double dt, const void* psi_in, void* psi_out,

@@ -348,7 +348,7 @@ def test_fp32_gradient_over_the_full_4000_step_chain(n):
     sb = (1 << n) * B * 8
     with StructuredEngine(n, K, dtype="c64") as e:
         e.set_terms(terms)
-        e.energy_grad(u[:4], dt, psi0)
+        e.propagate(u, dt, psi0)           # (the degree of the 4000-step chain: the polynomial's per-step bound is chain_tol / steps there)
         m = int(e.info("degree"))
         s2 = max(2, round((S / m) ** 0.5))
         e.set_option("checkpoint_bytes", sb * (-(-S // s2) + m * s2 + 1))     # kept states + one segment with its iterates: two levels
@@ -360,3 +360,32 @@ def test_fp32_gradient_over_the_full_4000_step_chain(n):
     assert np.max(np.abs(f1 - rf)) < 1e-4, np.max(np.abs(f1 - rf))
     assert abs(l1 - rl) < 1e-4 * B, abs(l1 - rl)
     assert rel < 1e-4, rel
+
+
+@pytest.mark.parametrize("dtype,n,B,tol", [("c128", 10, 6, 1e-10), ("c128", 11, 16, 1e-10), ("c64", 11, 32, 1e-4)])
+def test_economized_step_polynomial_matches_taylor_and_the_dense_engine(dtype, n, B, tol):
+    """The matrix-free step in Horner form with the economized polynomial's ratios (option polynomial = 1, the default; csrc/structured.hip
+    plan_degree): fewer stages than Taylor at the same bound, the chain, its reversals (checkpoint stride 3) and the reverse mode of the
+    recursion against the dense engine's result, and against the Taylor form of the same engine."""
+    K, S, dt = n, 12, 0.01
+    terms = ising_x_terms(n, seed=31)
+    u = problems.pulse_table(K, S, S * dt, seed=32)
+    psi0 = problems.random_states(1 << n, B, seed=33)
+    if dtype == "c64":
+        psi0 = psi0.astype(np.complex64)
+    rl, rg, rf, _ = _dense_reference(terms, n, K, u, dt, psi0)
+    out = {}
+    with StructuredEngine(n, K, dtype=dtype) as e:
+        e.set_terms(terms)
+        e.set_option("checkpoint_bytes", (1 << n) * B * (16 if dtype == "c128" else 8) * 4)      # 4 states: stride 3, reversals in between
+        for poly in (1, 0):
+            e.set_option("polynomial", poly)
+            loss, grad, fin, _ = e.energy_grad(u, dt, psi0)
+            assert e.info("checkpoint_stride") >= 2
+            out[poly] = (loss, grad, fin, e.info("degree"), e.info("taylor_degree"), e.propagate(u, dt, psi0))
+    assert out[0][3] == out[0][4] == out[1][4] and out[1][3] < out[0][3], (out[1][3], out[0][3])
+    for poly in (1, 0):
+        loss, grad, fin, _, _, fwd = out[poly]
+        assert np.max(np.abs(fin - rf)) < tol and np.max(np.abs(fwd - rf)) < tol
+        assert abs(loss - rl) < tol * B and np.max(np.abs(grad - rg)) < tol * max(1.0, float(np.max(np.abs(rg)))) * 4
+    assert np.max(np.abs(rg)) > 1e-4
