@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             o[r].x = 0;
             o[r].y = 0;
           }
-          xs_gather<T, NT, RPT, SIGN, false, 1, false, true, CPLX>(ctl, sg, W, zc, t, (T)-1, o, nullptr, nullptr);
+          xs_gather<T, NT, RPT, SIGN, false, 1, false, true, CPLX, true>(ctl, sg, W, zc, t, (T)-1, o, nullptr, nullptr);
           const T inv = (T)1 / (T)m, gm = (T)qd.g[m];
           T cf[NI];
 #pragma unroll

@@ -443,15 +443,20 @@ __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, unsign
 // partner is read from LDS and the caller's copy of v need not stay in registers.  DOT: the sweep carries the gradient pairings; dacc is then an xs_acc16 indexed by the diagonal's SORTED
 // position (xs_finish_kernel maps back).
 // CPLX = false (real tables: every phase 0): the phase-1 loops are not even instantiated (their code alone cost the real kernels 4 %).
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL, bool CPLX>
+template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL, bool CPLX, bool STAGGER = false>
 __device__ __forceinline__ void xs_gather(const XsCtl& ctl, unsigned sg, const typename Cx<T>::type* __restrict__ src,
                                           const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
                                           const typename Cx<T>::type* xm, double* dacc) {
+  // STAGGER: the two waves that share a SIMD (w and w + 4 of a 512-thread workgroup) walk a plain sweep in opposite order of its two
+  // kinds of work -- one starts with the register partners (vector work only) while the other issues its LDS reads.  Measured at
+  // d = B = 4096 (tools/statecol_probe.hip): phase 1 of the quadrature adjoint -2.4 % per launch, the forward kernel +1.5 % (not used there)
+  const bool local_first = STAGGER && LOCAL && !DOT && NT >= 512 && ((t >> 8) & 1);
+  if (local_first) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
   xs_lds_group<T, NT, RPT, SIGN, DOT, RM, false, PREF, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
   if constexpr (CPLX) xs_lds_group<T, NT, RPT, SIGN, DOT, RM, false, PREF, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
   xs_lds_group<T, NT, RPT, SIGN, DOT, RM, true, PREF, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
   if constexpr (CPLX) xs_lds_group<T, NT, RPT, SIGN, DOT, RM, true, PREF, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, xm, dacc);
-  if (LOCAL) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
+  if (LOCAL && !local_first) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
 }
 
 template <class T, int NT, int RPT>
