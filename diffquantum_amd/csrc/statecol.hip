@@ -383,16 +383,18 @@ void xs_poly_factors(double theta, int L, double* g) {
     for (int m = 0; m <= L; ++m) g[m] = 1.0;
     return;
   }
-  static long double tc[XS_LMAX + 1][XS_LMAX + 1];  // T_k's coefficients (integers below 2^23: exact)
-  static bool have = false;
-  if (!have) {
-    memset(tc, 0, sizeof(tc));
-    tc[0][0] = 1.0L;
-    tc[1][1] = 1.0L;
-    for (int k = 2; k <= XS_LMAX; ++k)
-      for (int m = 0; m <= k; ++m) tc[k][m] = (m > 0 ? 2.0L * tc[k - 1][m - 1] : 0.0L) - tc[k - 2][m];
-    have = true;
-  }
+  struct ChebTable {   // T_k's coefficients (integers below 2^23: exact); built once (thread-safe static initialisation)
+    long double c[XS_LMAX + 1][XS_LMAX + 1];
+    ChebTable() {
+      memset(c, 0, sizeof(c));
+      c[0][0] = 1.0L;
+      c[1][1] = 1.0L;
+      for (int k = 2; k <= XS_LMAX; ++k)
+        for (int m = 0; m <= k; ++m) c[k][m] = (m > 0 ? 2.0L * c[k - 1][m - 1] : 0.0L) - c[k - 2][m];
+    }
+  };
+  static const ChebTable cheb;
+  const auto& tc = cheb.c;
   long double jk[XS_LMAX + 1];
   for (int k = 0; k <= L; ++k) jk[k] = xs_bessel(k, (long double)theta);
   long double pw = 1.0L, fact = 1.0L;  // theta^m, m!
