@@ -27,9 +27,9 @@ TRAFFIC = {
     "statecol_fwd": (5.376e8, "profiles/r3_bench_headline_summary.txt"),
     "statecol_bwd_per_step": (3.60e9, "profiles/r3_bench_headline_summary.txt"),     # exact form (xs_backward_kernel)
     # quadrature form (xs_backward_q_kernel, round 4): no forward-term scratch; what is left per step is register spill traffic
-    # (profiles/r4_bench_headline_summary.txt: 700 MB read + 644 MB written per average launch of 11 steps = the states and costates in
-    # and out, 1074 MB, + 24.6 MB per step -- at degree 6, the economized step polynomial; 30.6 MB per step at Taylor's degree 7)
-    "statecol_bwdq_per_step": (2.455e7, "profiles/r4_bench_headline_summary.txt"),
+    # (profiles/r4_bench_headline_summary.txt: 752 MB read + 640 MB written per average launch of 11 steps = the states and costates in
+    # and out, 1074 MB, + 29 MB per step -- at degree 6, the economized step polynomial: 25-29 MB by run; 30.6 MB at Taylor's degree 7)
+    "statecol_bwdq_per_step": (2.9e7, "profiles/r4_bench_headline_summary.txt"),
     "xr": (6.60e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 1441 MB xr_reverse [Ubar
                                                                      # read + its power scratch written back and re-read]) / 3
 }
