@@ -668,6 +668,7 @@ def run_config3(a, D):
             "path": ("state-column form (Pauli-string H)" if info.get("state_columns", 0) > 0 else
                      "real-symmetric fast path (H real)" if info["real_path"] > 0 else "general complex path"),
             "state_columns": bool(info.get("state_columns", 0) > 0),
+            "polynomial_degree": int(info["degree"]), "taylor_degree_at_same_bound": int(info.get("state_columns_taylor_degree", 0)) or None,
             "checkpoint_stride": int(info["checkpoint_stride"]), "operator_backward": opback,
             "trajectory_steps_per_s": steps_per_s * B,
             "loss": loss, "grad_norm": float(torch.linalg.norm(grad).item()) if hasattr(grad, "norm") else float(np.linalg.norm(grad)),

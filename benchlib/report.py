@@ -304,15 +304,15 @@ def executed_tflops(blocks, seconds):
 
 INFO_KEYS = ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk", "zgemm_alg", "real_path",
              "real_hamiltonians", "sparse_controls", "sparse_generator", "control_nonzeros", "xor_regular", "xor_regular_found", "state_columns",
-             "state_columns_quad_nodes")
+             "state_columns_quad_nodes", "state_columns_taylor_degree")
 
 
 def describe_expm(info):
     if info.get("state_columns", 0) > 0:
         return ("state-column form: H is a sum of Pauli strings ({} XOR-diagonals), so NO propagator is built -- every state column "
-                "stays in LDS for the whole chain and each step applies the Taylor polynomial of degree {} of exp(-i dt H(t)) as sweeps "
-                "of partner reads; adjoint sweep the same way (statecol.hip), theta<={:.3g}".format(
-                    int(info["xor_regular_found"]), int(info["degree"]), info["theta"]))
+                "stays in LDS for the whole chain and each step applies the Chebyshev-economized polynomial of degree {} (Taylor would "
+                "need {}) of exp(-i dt H(t)) as sweeps of partner reads; adjoint sweep the same way (statecol.hip), theta<={:.3g}".format(
+                    int(info["xor_regular_found"]), int(info["degree"]), int(info.get("state_columns_taylor_degree", 0)), info["theta"]))
     if info.get("xor_regular", 0) > 1:
         return ("Taylor degree {0}: H complex Hermitian and a sum of Pauli strings ({1} XOR-diagonals with entries +-c or +-i c, a real "
                 "diagonal): every row of U = exp(-i dt H) is a chain of {0} complex sparse matrix-vector products held in LDS (xorexp.hip, "
