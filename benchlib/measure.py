@@ -248,7 +248,7 @@ def other_configs(dev, seed, headline=None):
     out["config2_qaoa_n8_S1000_B1024_fwd"] = measure_config2(dev, seed, 1000, 1024, reps=1)
     c5 = measure_config5(dev, seed, 20, 64, None)
     out["config5_pergpu_n18_B64_c64_structured"] = {
-        "fwd_steps_per_s": c5["fwd_steps_per_s"], "fwd_adjoint_steps_per_s": c5["steps_per_s"], "taylor_degree": c5["degree"],
+        "fwd_steps_per_s": c5["fwd_steps_per_s"], "fwd_adjoint_steps_per_s": c5["steps_per_s"], "polynomial_degree": c5["degree"],
         "roofline": c5["roofline"]}
     # the headline problem itself, given as Pauli strings to the matrix-free engine (complex128): what the same chain
     # costs when the Hamiltonian is never densified (HBM-bound state passes instead of d x d MFMA products)
@@ -262,7 +262,7 @@ def other_configs(dev, seed, headline=None):
             ls, gs, _, _ = e.energy_grad(u, dt, psi0, want_final=False)
             torch.cuda.synchronize(); el = time.perf_counter() - t0
             out["headline_problem_matrix_free_c128"] = {
-                "fwd_adjoint_steps_per_s": len(u) / el, "taylor_degree": int(e.info("degree")),
+                "fwd_adjoint_steps_per_s": len(u) / el, "polynomial_degree": int(e.info("degree")),
                 "abs_loss_diff_vs_dense_engine": abs(ls - loss_dense),
                 "note": "same H0 / H_k / M as Pauli strings on the structured engine (dq_sctx_*), same states and pulse "
                         "table: an extra, not the headline -- the dense engine takes ANY dense Hermitian H"}
@@ -434,7 +434,7 @@ def run_config5(a, D):
                "config": {"workload": "BASELINE configs[4]: {}-qubit Ising + X_k as Pauli strings (d={}), batch {} = {} per "
                                       "GPU, complex64, fwd+adjoint, dt=1e-3; {} of {} Trotter steps timed at the full chain's checkpoint stride".format(n, 1 << n, total, B, S, CONFIG5_CHAIN),
                           "n_qubits": n, "dim": 1 << n, "n_controls": n, "batch_per_gpu": B, "global_batch": total, "chain_steps": S,
-                          "taylor_degree": m["degree"], "loss": m["loss"], "grad_norm": m["grad_norm"],
+                          "polynomial_degree": m["degree"], "loss": m["loss"], "grad_norm": m["grad_norm"],
                           "forward_only_steps_per_s_rank0": m["fwd_steps_per_s"],
                           "checkpoint_stride": m["checkpoint_stride"], "every_step_checkpointed_steps_per_s_rank0": m["every_step_checkpointed"]["steps_per_s"],
                           # the checkpoint plan of the full 4000-step chain per rank: two levels? kept states in pinned HOST memory (GB)?
