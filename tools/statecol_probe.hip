@@ -105,6 +105,97 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int r = 0; r < RPT; ++r) out[r * NT + t] = cur[r];
   }
 }
+template <int XH>
+__device__ __forceinline__ void xp_local8(double w, const double2* cur, double2* o) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    o[r].x = __builtin_fma(w, cur[r ^ XH].y, o[r].x);
+    o[r].y = __builtin_fma(-w, cur[r ^ XH].x, o[r].y);
+  }
+}
+// the same idea with the library's shape: 512 threads x 8 rows, one image in place, capped at 128 registers so that two workgroups
+// (4 waves per SIMD) share a CU; partner bursts of 4 rows
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) xp_forward_2wg512_kernel(
+    const double2* __restrict__ psi_in, double2* __restrict__ psi_out, const double* __restrict__ wt, const double* __restrict__ dgs,
+    int S, int B, int L, XsPoly pol) {
+  constexpr int NT = 512, RPT = 8, D = NT * RPT;
+  extern __shared__ __align__(16) unsigned char xs_lds_raw[];
+  double2* img = (double2*)xs_lds_raw;
+  const int t = threadIdx.x, lane = t & 63;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    double2 cur[RPT];
+    const double2* in = psi_in + (long)b * D;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) cur[r] = in[r * NT + t];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) img[r * NT + t] = cur[r];
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+      const double wl = lane < 12 ? wt[(long)s * 12 + lane] : 0.0;
+      double2 acc[RPT];
+      const double g0 = pol.g[0];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        acc[r].x = g0 * cur[r].x;
+        acc[r].y = g0 * cur[r].y;
+      }
+      for (int m = 1; m <= L; ++m) {
+        double2 o[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          o[r].x = 0;
+          o[r].y = 0;
+        }
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < 9; ++k) {   // LDS partners: offsets 1 << k, table index 11 - k
+          const double w = xs_readlane(wl, 11 - k);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double2 v[4];
+            xs_fetch<double, NT, 4, false>(1 << k, img + h * 4 * NT, t, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              o[h * 4 + r].x = __builtin_fma(w, v[r].y, o[h * 4 + r].x);
+              o[h * 4 + r].y = __builtin_fma(-w, v[r].x, o[h * 4 + r].y);
+            }
+          }
+        }
+        xp_local8<1>(xs_readlane(wl, 2), cur, o);   // offsets 512, 1024, 2048
+        xp_local8<2>(xs_readlane(wl, 1), cur, o);
+        xp_local8<4>(xs_readlane(wl, 0), cur, o);
+        const double inv = 1.0 / m, gm = pol.g[m];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const double dgv = dgs[r * NT + t];
+          const double ox = __builtin_fma(dgv, cur[r].y, o[r].x) * inv;
+          const double oy = __builtin_fma(-dgv, cur[r].x, o[r].y) * inv;
+          cur[r].x = ox;
+          cur[r].y = oy;
+          acc[r].x = __builtin_fma(gm, ox, acc[r].x);
+          acc[r].y = __builtin_fma(gm, oy, acc[r].y);
+        }
+        if (m < L) {
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) img[r * NT + t] = cur[r];
+          __syncthreads();
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
+      if (s + 1 < S) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) img[r * NT + t] = cur[r];
+        __syncthreads();
+      }
+    }
+    double2* out = psi_out + (long)b * D;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) out[r * NT + t] = cur[r];
+  }
+}
 }  // namespace dq
 
 #include <cstdio>
@@ -203,8 +294,9 @@ int main(int argc, char** argv) {
     printf("max |grad (quadrature) - grad (exact form)| = %.3e  (max |grad| %.3e)\n", gd, gm);
   }
   if (n == 12 && econ) {   // the two-workgroups-per-CU forward experiment against the library's forward kernel
-    double2* d_alt;
+    double2 *d_alt, *d_alt2;
     CK(hipMalloc(&d_alt, sizeof(double2) * psi.size()));
+    CK(hipMalloc(&d_alt2, sizeof(double2) * psi.size()));
     CK(hipFuncSetAttribute((const void*)dq::xp_forward_2wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     for (int rep = 0; rep < 3; ++rep) {
       float ms = 0, ms0 = 0;
@@ -218,15 +310,25 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&ms0, e0, e1));
-      printf("forward, two workgroups of 256 x 16 per CU (in place): %.3f ms   library kernel (512 x 8, two images): %.3f ms\n", ms, ms0);
+      float ms2 = 0;
+      CK(hipFuncSetAttribute((const void*)dq::xp_forward_2wg512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(dq::xp_forward_2wg512_kernel, dim3(512), dim3(512), 65536, nullptr, d_in, d_alt2, d_wt, d_dgs, S, B, L, pol);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms2, e0, e1));
+      printf("forward, two workgroups per CU in place: 256 x 16 %.3f ms, 512 x 8 at 128 registers %.3f ms   library kernel (512 x 8, two images): %.3f ms\n", ms, ms2, ms0);
     }
     std::vector<double2> a(psi.size()), c(psi.size());
     CK(hipMemcpy(a.data(), d_alt, sizeof(double2) * a.size(), hipMemcpyDeviceToHost));
     CK(hipMemcpy(c.data(), d_lam, sizeof(double2) * c.size(), hipMemcpyDeviceToHost));
-    double df = 0;
+    double df = 0, df2 = 0;
     for (size_t i = 0; i < a.size(); ++i) df = fmax(df, fmax(fabs(a[i].x - c[i].x), fabs(a[i].y - c[i].y)));
-    printf("max |final states (experiment) - final states (library)| = %.3e\n", df);
+    CK(hipMemcpy(a.data(), d_alt2, sizeof(double2) * a.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < a.size(); ++i) df2 = fmax(df2, fmax(fabs(a[i].x - c[i].x), fabs(a[i].y - c[i].y)));
+    printf("max |final states (experiment) - final states (library)| = %.3e (256 x 16), %.3e (512 x 8)\n", df, df2);
     CK(hipFree(d_alt));
+    CK(hipFree(d_alt2));
   }
   // reversal check: the backward kernel leaves psi_0 in d_psi
   std::vector<double2> back(psi.size());
