@@ -344,6 +344,15 @@ def test_economized_step_polynomial_against_taylor_and_the_oracle(oracle, case, 
             assert e.info("state_columns") == 1
             out[poly] = (loss, grad, fin, e.info("degree"), e.info("state_columns_taylor_degree"), e.propagate(u, dt, psi0), e.info("degree"))
     assert out[0][3] == out[0][4] == out[1][4], "Taylor: the degree of the remainder bound"
+    # the host-only entry of the C-ABI names the same polynomials for the step bound the engine reports
+    import ctypes as C
+    from diffquantum_amd import _lib
+    with _engine(H0, Hs, M, state_columns=1) as e2:
+        e2.propagate(u, dt, psi0)
+        theta = e2.info("theta")
+    L1, L0, g = C.c_int(), C.c_int(), (C.c_double * 25)()
+    assert _lib.load().dq_step_polynomial(theta, 2.0 ** -53, 1, C.byref(L1), g) == 0 and L1.value == out[1][3]
+    assert _lib.load().dq_step_polynomial(theta, 2.0 ** -53, 0, C.byref(L0), g) == 0 and L0.value == out[0][3]
     assert out[1][3] <= out[0][3] and out[1][6] == out[1][3], (out[1][3], out[0][3])
     if dt >= 1e-2:
         assert out[1][3] <= out[0][3] - 1 and e is not None, (out[1][3], out[0][3])     # (theta ~ 0.2 .. 0.4: two degrees fewer)
