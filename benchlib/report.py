@@ -164,7 +164,11 @@ def emit(full):
 
 def roofline_blocks(prof, info, d):
     """One block per kernel class of a dense-engine profile (`dq_profile_get`), each with its share of the timed region."""
-    three_m = bool(info["zgemm_alg"]) and d >= 1024          # 3M runs on the 128 tile (fp64); smaller tiles are 4M
+    # 3M runs on the 128 x 128 tile (fp64), which a launch takes when M, N >= 128 and it has at least 64 tiles (zgemm_pick_tile):
+    # every d x d product from d = 1024 up, and below that the BATCHED launches, which carry nearly all of the class's flops
+    # (configs[1]: zgemm_kernel<double,128,128,8,2,4,0,0,1,...> in the kernel trace).  Launches that fall to the 64 tile run 4M and
+    # execute more than is counted here: `frac` may understate, never overstate.  Below d = 128 everything is 4M.
+    three_m = bool(info["zgemm_alg"]) and d >= 128
     f3 = 0.75 if three_m else 1.0
     nt = (d + 127) // 128
     tri = (nt * (nt + 1) / 2) / float(nt * nt) if d >= 1024 else 1.0   # Hermitian-output form: tiles on/above the diagonal

@@ -317,6 +317,10 @@ constexpr int XS_LMAX = 24;   // largest degree of the state-column kernels
 struct XsPoly {
   double g[XS_LMAX + 1];
 };
+// time segments of a forward launch (xs_forward_segments_launch): cols = columns per segment (0: none), total = steps of the table
+struct XsSeg {
+  int cols, total;
+};
 // the lowest degree whose error bound stays below tol for steps of size <= theta (0: none up to XS_LMAX) and its level factors;
 // economize = 0: Taylor (g = 1).  Steps of theta > 2 keep Taylor (the power form of a Chebyshev sum loses digits as theta grows).
 int xs_poly_make(double theta, double tol, int economize, XsPoly* p);
@@ -357,6 +361,14 @@ hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab
                              int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st);
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                              int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st);
+// the propagators of n_seg consecutive time segments (columns of the identity through the forward kernel): out[(g d + i) d ..] =
+// column i of segment g's propagator, i.e. block g is the propagator's transpose
+hipError_t xs_forward_segments_launch(double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                                      int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
+                                      hipStream_t st);
+hipError_t xs_forward_segments_launch(float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                                      int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
+                                      hipStream_t st);
 // psi: psi_S in, psi_0 out;  lam: lambda_S in, lambda_0 out;  grad[s][k] (+)= dL/du_k[s]
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,

@@ -326,6 +326,8 @@ struct Ctx : dq_ctx {
   int xs_workgroups = 0;                       // > 0: at most that many workgroups per launch (tests of the several-columns-per-workgroup loop)
   double xs_part_bytes = 268435456.0;          // scratch of the adjoint sweep's per-step partial sums: the chain is swept in segments that fit
   double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
+  int xs_compose_mode = -1;                    // products of a chain's propagators (composed forward, time slices) from state columns: -1 auto, 0 off
+  double last_xs_segments_fwd = 0;             // time segments of the last such product (0: built from explicit propagators)
   int xs_economize = 1;                        // step polynomial of the state-column kernels: 1 = Chebyshev-economized (default), 0 = Taylor
   // the polynomial's error is the same function of the spectrum at every step, so over a chain it can add up coherently: its per-step
   // bound is min(expm_tol, xs_chain_tol / steps) -- no effect in fp64 below 90000 steps, one degree more in fp32 beyond ~330 steps
@@ -1269,28 +1271,53 @@ void require_H(Ctx<T>* c) {
 // log-depth tree of batched products per time chunk (8 d^3 flop per step, O(log n) launches instead of n) and a running
 // product across chunks. Returns the d x d product (a pool slot), or null for S = 0.
 template <class T>
-TT* compose_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int tc) {
+TT* xs_compose_segments(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int* n_out);
+
+// X = m stacked d x d matrices (time order) -> their product X[m-1] ... X[0] by a tree of batched products; returns where it is
+template <class T>
+TT* tree_product(Ctx<T>* c, TT* X, int m, bool first_level_symmetric) {
+  typedef TT T2;
+  const int d = c->d;
+  int lvl = 0;
+  while (m > 1) {
+    const int pairs = m / 2;
+    T2* Y = c->mat(SLOT_TREE + (lvl & 1), (size_t)(pairs + (m & 1)));
+    const long s2 = 2 * (long)c->nn();
+    // (level 0 multiplies the propagators themselves: complex symmetric on the real path, U = cos X + i sin X)
+    c->zgemm(lvl == 0 && first_level_symmetric ? 2 : 0, 0, d, d, d, 1.0, X + c->nn(), d, s2, X, d, s2, 0.0, Y, d, (long)c->nn(), pairs);
+    if (m & 1)
+      HIPCK(hipMemcpyAsync(Y + (size_t)pairs * c->nn(), X + (size_t)(m - 1) * c->nn(), c->mat_bytes(),
+                           hipMemcpyDeviceToDevice, c->st));
+    X = Y;
+    m = pairs + (m & 1);
+    ++lvl;
+  }
+  return X;
+}
+
+template <class T>
+TT* compose_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int tc, bool allow_state_columns = false) {
   typedef TT T2;
   const int d = c->d;
   T2* running = nullptr;
+  c->last_xs_segments_fwd = 0;
+  if (allow_state_columns) {   // (not for the time slices of dq_slice_forward: their explicit propagators fill the cache the backward call reads)
+    // Pauli-sum generators: no step exponential at all -- the product of the chain's propagators is what the state-column forward
+    // kernel makes of the identity's columns (d columns x S steps: the cost of a forward pass over d states), cut into time segments
+    // when d columns alone do not fill the chip; the segments' propagators are then multiplied as the steps' would be
+    int nseg = 0;
+    if (T2* X = xs_compose_segments(c, uh, S, dt, &nseg)) {
+      T2* P = tree_product(c, X, nseg, false);
+      running = c->mat(SLOT_TREE + 2, 1);
+      HIPCK(hipMemcpyAsync(running, P, c->mat_bytes(), hipMemcpyDeviceToDevice, c->st));
+      return running;
+    }
+  }
   for (int c0 = 0; c0 < S; c0 += tc) {
     const int n = std::min(tc, S - c0);
     const ExpmPlan p = chunk_plan(c, uh, c0, n, dt);
     T2* X = build_propagators(c, p, c0, n, dt);
-    int m = n, lvl = 0;
-    while (m > 1) {
-      const int pairs = m / 2;
-      T2* Y = c->mat(SLOT_TREE + (lvl & 1), (size_t)(pairs + (m & 1)));
-      const long s2 = 2 * (long)c->nn();
-      // (level 0 multiplies the propagators themselves: complex symmetric on the real path, U = cos X + i sin X)
-      c->zgemm(lvl == 0 && p.rq > 0 ? 2 : 0, 0, d, d, d, 1.0, X + c->nn(), d, s2, X, d, s2, 0.0, Y, d, (long)c->nn(), pairs);
-      if (m & 1)
-        HIPCK(hipMemcpyAsync(Y + (size_t)pairs * c->nn(), X + (size_t)(m - 1) * c->nn(), c->mat_bytes(),
-                             hipMemcpyDeviceToDevice, c->st));
-      X = Y;
-      m = pairs + (m & 1);
-      ++lvl;
-    }
+    X = tree_product(c, X, n, p.rq > 0);
     if (!running) {
       running = c->mat(SLOT_TREE + 2, 1);
       HIPCK(hipMemcpyAsync(running, X, c->mat_bytes(), hipMemcpyDeviceToDevice, c->st));
@@ -1307,13 +1334,13 @@ TT* compose_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
 // holding the result. compose: multiply the propagators together (compose_chain) and apply the product ONCE -- cheaper
 // as soon as the batch is wider than the dimension.
 template <class T>
-int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B, int cur, bool compose) {
+int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B, int cur, bool compose, bool allow_state_columns = true) {
   typedef TT T2;
   const int d = c->d;
   const int tc = time_chunk(c, std::max(S, 1));
   c->last_chunk = tc;
   if (compose) {
-    T2* running = compose_chain(c, uh, S, dt, tc);
+    T2* running = compose_chain(c, uh, S, dt, tc, allow_state_columns);
     if (running) {
       c->zgemm(0, 0, d, B, d, 1.0, running, d, 0, (const T2*)c->psi[cur].p, B, 0, 0.0, (T2*)c->psi[cur ^ 1].p, B, 0, 1);
       cur ^= 1;
@@ -1349,14 +1376,15 @@ const dq::XrTab* xs_table(Ctx<T>* c) {
 
 // Taylor degree of the whole chain's polynomial (the largest step decides), or 0 when the state-column form is not to be used
 template <class T>
-int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B) {
+int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B, bool for_compose = false) {
   const dq::XrTab* tab = xs_table(c);
   if (!tab) return 0;
   // the options that pin another scheme keep it
-  if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || c->compose_mode >= 0) return 0;
+  if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || (c->compose_mode >= 0 && !for_compose)) return 0;
   // auto: from dim 512 up (at 256 a column is one wave and the tree-composed operator form is faster: 0.34 M against 0.11 M forward
   // steps/s on BASELINE configs[1]) and while the batch is at most xs_batch_ratio x dim
-  if (c->xs_mode < 0 && (c->d < c->xs_min_dim || (double)B > c->xs_batch_ratio * (double)c->d)) return 0;
+  // (for_compose: the columns are the identity's, d of them per time segment -- neither bound concerns it)
+  if (!for_compose && c->xs_mode < 0 && (c->d < c->xs_min_dim || (double)B > c->xs_batch_ratio * (double)c->d)) return 0;
   double th = 0.0;
   for (int t = 0; t < S; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
   if ((size_t)4 * sizeof(T) * (size_t)c->d > c->max_lds) return 0;  // two images of a column must fit the device's LDS
@@ -1457,6 +1485,43 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
   });
   if (out_db)
     c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>(out_db, B, 0, (const T2*)c->xs_psi.p, d, 0, B, d, 0, 1, c->st); });
+}
+
+// The propagators of the chain's time segments from the state-column forward kernel (see compose_chain): n stacked d x d matrices
+// in time order (pool slot SLOT_TP_L), or null when the generator / the options do not allow the state-column form.
+template <class T>
+TT* xs_compose_segments(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int* n_out) {
+  typedef TT T2;
+  *n_out = 0;
+  if (S <= 0 || c->xs_compose_mode == 0) return nullptr;
+  const int d = c->d;
+  const int L = xs_degree(c, uh, S, dt, d, true);
+  if (!L) return nullptr;
+  // segments: as many as it takes for d columns each to fill the chip's workgroup slots once (d = 256: 20, d = 4096: 1); each costs
+  // a d^3 product in the tree afterwards
+  const int cap = dq::xs_blocks(d, sizeof(T), 1 << 30, c->n_cu, c->xs_variant);
+  int G = std::max(1, std::min(S, (cap + d - 1) / d));
+  const int seg = (S + G - 1) / G;
+  G = (S + seg - 1) / seg;
+  const int B = G * d;
+  XsLaunch<T> x = xs_prepare(c, S, dt, B, L, false);
+  x.nblk = dq::xs_blocks(d, sizeof(T), B, c->n_cu, c->xs_variant);
+  double fl, lb;
+  xs_book(c, x, (double)x.L * seg, 0.0, false, B, &fl, &lb);
+  const dq::XrTab tb = *x.tab;
+  c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
+    return dq::xs_forward_segments_launch((T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, seg, G, x.L, x.nblk,
+                                          c->xs_variant, &c->xs_poly, c->st);
+  });
+  // block g of the launch's output is the transpose of segment g's propagator
+  T2* X = c->mat(SLOT_TP_L, (size_t)G);
+  const long nn = (long)c->nn();
+  c->timed(DQ_PROF_OTHER, 0.0, 2.0 * sizeof(T2) * (double)nn * G,
+           [&] { return dq::ztranspose_launch<T>(X, d, nn, (const T2*)c->xs_psi.p, d, nn, d, d, 0, G, c->st); });
+  c->last_xs_segments_fwd = G;
+  c->last_xs = 0;   // ("state_columns" reports the STATES' path; this product is reported by state_columns_compose_segments)
+  *n_out = G;
+  return X;
 }
 
 // ---- matrix-free routing (structured.hip behind the dense API) --------------------------------------------------------------------
@@ -1611,7 +1676,16 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
   c->psi[0].ensure(sb);
   c->psi[1].ensure(sb);
   c->last_xs = 0;
-  if (const int Lx = S > 0 ? xs_degree(c, uh, S, dt, B) : 0) {
+  c->last_xs_segments_fwd = 0;
+  // A batch wider than the dimension: sweeping the B states costs ~ S B d L row-sweeps, the product of the chain's propagators from
+  // the identity's columns (compose_chain) S d d L plus the products that combine its segments and apply it (8 d^2 (B + G d) flop).
+  // Rates at d = 256 .. 4096: 2.3 ps per row and sweep, 60 TF/s on the products; the composed form has to win by 30 %.
+  bool prefer_compose = false;
+  if (S > 0 && B > d && c->compose_mode != 0 && c->xs_compose_mode != 0 && c->xs_mode != 0) {
+    const double Lest = 6.0, segs = std::max(1.0, 5120.0 / d);
+    prefer_compose = (double)S * (B - d) * Lest > 0.0754 * d * ((double)B + segs * d);
+  }
+  if (const int Lx = (S > 0 && !prefer_compose) ? xs_degree(c, uh, S, dt, B) : 0) {
     const XsLaunch<T> x = xs_prepare(c, S, dt, B, Lx, false);
     const T2* p0 = in_dev(c, psi_in, sb, c->psi[1]);
     xs_forward(c, x, p0, S, B, (T2*)c->psi[0].p);
@@ -1993,6 +2067,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   c->last_opback = opback ? 1.0 : 0.0;
   std::vector<double> uh = fetch_u(c, u, S);
   c->last_xs = 0;
+  c->last_xs_segments_fwd = 0;
   if (const int Lx = S > 0 ? xs_degree(c, uh, S, dt, B) : 0) {
     do_energy_grad_xs(c, S, dt, psi0, B, loss, grad_u, psi_final, energies, targets, Lx);
     return;
@@ -2011,7 +2086,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   if (opback) {
     c->last_cstride = 0;  // no state checkpoints
     setup_pcache(c, uh, S, dt, tc, opback);
-    cur = forward_chain(c, uh, S, dt, B, 0, compose);
+    cur = forward_chain(c, uh, S, dt, B, 0, compose, false);   // (explicit propagators: they fill the cache the operator-form sweep reads)
   } else {
     // checkpoint stride from the memory budget
     double budget = c->checkpoint_bytes;
@@ -2826,6 +2901,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_compose") {  // products of a chain's propagators (composed forward pass, time slices) from the state-column kernel: -1 auto, 0 off
+    c->xs_compose_mode = v != 0 ? -1 : 0;
   } else if (s == "state_columns_chain_tol") {  // bound of the step polynomial's error summed over the chain (per step: min(expm_tol, this / steps))
     if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_chain_tol must be > 0");
     c->xs_chain_tol = v;
@@ -2887,6 +2964,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   }
   if (s == "state_columns_quad_nodes") return c->last_xs_nodes;
   if (s == "state_columns_taylor_degree") return c->last_xs_taylor_degree;
+  if (s == "state_columns_compose_segments") return c->last_xs_segments_fwd;
   if (s == "state_columns_segments") return c->last_xs_segments;
   if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;

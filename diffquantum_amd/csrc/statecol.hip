@@ -54,7 +54,7 @@ template <class T, int NT, int RPT, bool SIGN, bool PREF, bool CPLX>
 __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
                                                         typename Cx<T>::type* __restrict__ psi_out, XrTab tab, XsOrder ord,
                                                         const double* __restrict__ wt, const double* __restrict__ dgs, long dgs_step,
-                                                        int S, int B, int L, XsPoly pol) {
+                                                        int S, int B, int L, XsPoly pol, XsSeg seg) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
@@ -67,15 +67,28 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
   int p = 0;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     T2 cur[RPT];
-    const T2* in = psi_in + (long)b * D;
+    // segments (seg.cols > 0): column b belongs to time segment b / seg.cols and runs the steps [s0, s0 + ns) of the table only;
+    // without an input the columns are those of the identity (column b % D): the launch then leaves the segments' propagators
+    const int s0 = seg.cols > 0 ? (b / seg.cols) * S : 0;
+    const int ns = seg.cols > 0 ? (seg.total - s0 < S ? seg.total - s0 : S) : S;
+    if (psi_in) {
+      const T2* in = psi_in + (long)b * D;
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) cur[r] = in[r * NT + t];
+      for (int r = 0; r < RPT; ++r) cur[r] = in[r * NT + t];
+    } else {
+      const int one = b % D;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        cur[r].x = (r * NT + t == one) ? (T)1 : (T)0;
+        cur[r].y = (T)0;
+      }
+    }
     p ^= 1;
     xs_put<T, NT, RPT>(img + p * D, t, cur);
     __syncthreads();
-    for (int s = 0; s < S; ++s) {
-      ctl.load_step(wt + (long)s * tab.R, t & 63);
-      const double* dgr = dgs + (long)s * dgs_step;
+    for (int s = 0; s < ns; ++s) {
+      ctl.load_step(wt + (long)(s0 + s) * tab.R, t & 63);
+      const double* dgr = dgs + (long)(s0 + s) * dgs_step;
       T2 acc[RPT];
       T dg[RPT];  // the rows' diagonal weights of this step (registers: a load per sweep would sit in the vmcnt queue of every wait)
       const T g0 = (T)pol.g[0];
@@ -111,7 +124,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
       }
 #pragma unroll
       for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
-      if (s + 1 < S) {
+      if (s + 1 < ns) {
         p ^= 1;
         xs_put<T, NT, RPT>(img + p * D, t, cur);
         __syncthreads();
@@ -493,50 +506,52 @@ namespace {
 
 template <class T, int NT, int RPT>
 hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* out, const XrTab& tab, const double* wt, const double* dgs,
-                         long dgs_step, int S, int B, int L, int nblk, bool pref, const XsPoly& pol, hipStream_t st) {
+                         long dgs_step, int S, int B, int L, int nblk, bool pref, const XsPoly& pol, const XsSeg& seg, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr;
   bool cplx = false;
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
   if (cplx && !sgn) return hipErrorInvalidValue;  // (complex tables always carry sign words)
-  void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, XsPoly) =
+  void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, XsPoly, XsSeg) =
       cplx ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, true> : xs_forward_kernel<T, NT, RPT, true, false, true>)
            : (sgn ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, false> : xs_forward_kernel<T, NT, RPT, true, false, false>)
                   : (pref ? xs_forward_kernel<T, NT, RPT, false, true, false> : xs_forward_kernel<T, NT, RPT, false, false, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true), wt, dgs,
-                     dgs_step, S, B, L, pol);
+                     dgs_step, S, B, L, pol, seg);
   return hipGetLastError();
 }
 
 // variant: bit 0 = 1024 threads x 4 rows at d = 4096; bit 1 = prefetch of the next diagonal's partners in the sweeps without pairings
 template <class T>
 hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* out, int d, const XrTab& tab, const double* wt,
-                        const double* dgs, long dgs_step, int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
+                        const double* dgs, long dgs_step, int S, int B, int L, int nblk, int variant, const XsPoly* poly, const XsSeg& seg,
+                        hipStream_t st) {
   if (B <= 0) return hipSuccess;
+  if (!in && seg.cols <= 0) return hipErrorInvalidValue;
   const XsPoly pol = poly ? *poly : xs_poly_taylor();
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T))) return hipErrorInvalidValue;
   const bool pf = (variant & 2) != 0;
   if constexpr (sizeof(T) == sizeof(float)) {
-    if (d == 8192) return xs_forward_go<T, 1024, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
+    if (d == 8192) return xs_forward_go<T, 1024, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st);
   }
   switch (d) {
     case 4096:
-      return (variant & 1) ? xs_forward_go<T, 1024, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
-                           : xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
+      return (variant & 1) ? xs_forward_go<T, 1024, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st)
+                           : xs_forward_go<T, 512, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st);
 #ifndef XS_PROBE_4096_ONLY
-    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
+    case 2048: return xs_forward_go<T, 256, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st);
     case 1024:
-      return (variant & 1) ? xs_forward_go<T, 256, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
-                           : xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
+      return (variant & 1) ? xs_forward_go<T, 256, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st)
+                           : xs_forward_go<T, 128, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st);
     case 512:
-      return (variant & 1) ? xs_forward_go<T, 256, 2>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
-                           : xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
+      return (variant & 1) ? xs_forward_go<T, 256, 2>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st)
+                           : xs_forward_go<T, 64, 8>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st);
     default:
-      return (variant & 1) ? xs_forward_go<T, 256, 1>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st)
-                           : xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, st);
+      return (variant & 1) ? xs_forward_go<T, 256, 1>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st)
+                           : xs_forward_go<T, 64, 4>(in, out, tab, wt, dgs, dgs_step, S, B, L, nblk, pf, pol, seg, st);
 #else
     default: return hipErrorInvalidValue;
 #endif
@@ -562,11 +577,24 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
 
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                              int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
-  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, st);
+  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0}, st);
 }
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                              int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
-  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, st);
+  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0}, st);
+}
+// The propagators of n_seg consecutive time segments of seg_steps steps each (the last one what is left of S_total): column i of
+// segment g -- exp(A_{s0+ns-1}) ... exp(A_{s0}) e_i, s0 = g seg_steps -- goes to out[(g d + i) d ..]: the d x d block of segment g
+// holds the TRANSPOSE of its propagator.  wt / dgs: the weight tables of all S_total steps.
+hipError_t xs_forward_segments_launch(double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                                      int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
+                                      hipStream_t st) {
+  return xs_forward_t<double>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly, XsSeg{d, S_total}, st);
+}
+hipError_t xs_forward_segments_launch(float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
+                                      int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
+                                      hipStream_t st) {
+  return xs_forward_t<float>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly, XsSeg{d, S_total}, st);
 }
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,

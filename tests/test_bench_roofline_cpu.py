@@ -45,13 +45,16 @@ def test_fractions_at_the_headline_shape():
         assert 0.0 <= blk["frac"] <= 1.0
 
 
-def test_small_dimension_uses_the_4m_count_and_no_traffic_constant():
-    d = 256
-    W = 8.0 * d ** 3
-    b = bench.roofline_blocks(_prof(zgemm={"launches": 10, "ms": 1.0, "flops": 10 * W, "bytes": 1.0}), {"zgemm_alg": 2.0}, d)
-    z = b["zgemm"]
-    assert z["executed_over_algorithmic_flops"] == 1.0 and z["traffic"] is None and z["traffic_source"] is None
-    assert bench.ranked(b) == [z]
+def test_small_dimensions_the_3m_count_from_the_128_tile_up_and_no_traffic_constant():
+    """d = 256 (configs[1]): the batched products run the 3M form on the 128 tile -- executed = 0.75 of the algorithmic count, so the
+    fraction never counts flops that were not executed; below d = 128 everything is 4M.  PMC traffic constants hold at d = 4096 only."""
+    for d, factor in ((256, 0.75), (64, 1.0)):
+        W = 8.0 * d ** 3
+        b = bench.roofline_blocks(_prof(zgemm={"launches": 10, "ms": 1.0, "flops": 10 * W, "bytes": 1.0}), {"zgemm_alg": 2.0}, d)
+        z = b["zgemm"]
+        assert z["executed_over_algorithmic_flops"] == factor and z["traffic"] is None and z["traffic_source"] is None
+        assert abs(z["achieved"] - factor * z["achieved_algorithmic"]) < 1e-12
+        assert bench.ranked(b) == [z]
 
 
 def test_column_form_class_is_priced_against_the_lds_array():

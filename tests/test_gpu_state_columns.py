@@ -384,3 +384,50 @@ def test_economized_step_polynomial_in_complex64():
         assert (e.info("degree"), e.info("state_columns_taylor_degree")) == (5, 5)     # (1e-8 per step: 2 J_5 = 2.6e-8 is too much, theta^6 / 720 = 4e-9 is not)
     assert np.max(np.abs(fin - rf)) < 1e-4 and abs(loss - rl) < 1e-4 * B
     assert np.max(np.abs(grad - rg)) < 1e-4 * max(1.0, np.max(np.abs(rg))) and np.max(np.abs(rg)) > 1e-4
+
+
+@pytest.mark.parametrize("case,n,S,B", [("qaoa_ring_zz_controls", 8, 203, 600), ("ising_x", 9, 41, 1100), ("xy_drives", 9, 7, 700),
+                                        ("mixed_two_body", 8, 1, 300)])
+def test_composed_forward_pass_from_state_column_segments(oracle, case, n, S, B):
+    """Batch wider than the dimension: the forward pass applies the PRODUCT of the chain's propagators once (sim_plain.py:135-150 /
+    diffqc.cc:190-200 chained).  For a Pauli-sum generator that product comes from the state-column forward kernel run on the
+    identity's columns, cut into time segments that are multiplied afterwards (engine.hip xs_compose_segments; BASELINE configs[1]'s
+    shape) -- against the explicit-propagator tree of the same engine and, for four columns, against the oracle's chain."""
+    H0, Hs, M = _qaoa(n) if case == "qaoa_ring_zz_controls" else CASES[case](n)
+    K, d = len(Hs), 1 << n
+    dt = 1.5e-3
+    u = np.random.default_rng(50 + S).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=51)
+    with _engine(H0, Hs, M) as e:
+        if d > 256:
+            e.set_option("compose", 1)       # (d = 256 composes by itself; above that the engine weighs it against sweeping the B states)
+        f1 = e.propagate(u, dt, psi0)
+        segs = e.info("state_columns_compose_segments")
+        assert e.info("composed") == 1 and segs >= 1 and segs <= S, "the composed forward pass did not take the state-column product"
+        assert e.info("state_columns") == 0                  # (the STATES are applied by one product, not swept)
+        e.set_option("state_columns_compose", 0)
+        f0 = e.propagate(u, dt, psi0)
+        assert e.info("state_columns_compose_segments") == 0 and e.info("composed") == 1
+    assert np.max(np.abs(f1 - f0)) < 1e-11, np.max(np.abs(f1 - f0))
+    ref = oracle.propagate(H0, list(Hs), u, dt, psi0[:, :4])
+    assert np.max(np.abs(f1[:, :4] - ref)) < TOL
+    assert np.max(np.abs(np.linalg.norm(f1, axis=0) - 1.0)) < 1e-12
+
+
+def test_wide_batches_take_the_composed_form_when_it_is_cheaper():
+    """d = 512: 1100 states over 300 steps cost more swept one by one than the product of the chain from the identity's 512 columns + one
+    application; over 10 steps they do not.  Same numbers either way."""
+    n, B, dt = 9, 1100, 1.5e-3
+    H0, Hs, M = problems.random_ising(n, 4)
+    psi0 = problems.random_states(1 << n, B, seed=61)
+    with _engine(H0, Hs, M) as e:
+        for S, composed in ((300, 1), (10, 0)):
+            u = np.random.default_rng(S).uniform(-1, 1, (S, n))
+            f1 = e.propagate(u, dt, psi0)
+            assert e.info("composed") == composed and (e.info("state_columns_compose_segments") > 0) == bool(composed)
+            assert e.info("state_columns") == 1 - composed
+            e.set_option("state_columns_compose", 0)
+            f0 = e.propagate(u, dt, psi0)
+            assert e.info("state_columns") == 1 and e.info("composed") == 0        # (without the composed form: the states are swept)
+            e.set_option("state_columns_compose", -1)
+            assert np.max(np.abs(f1 - f0)) < 1e-11
