@@ -308,10 +308,17 @@ def executed_tflops(blocks, seconds):
 
 INFO_KEYS = ("degree", "squarings", "products", "theta", "checkpoint_stride", "time_chunk", "zgemm_alg", "real_path",
              "real_hamiltonians", "sparse_controls", "sparse_generator", "control_nonzeros", "xor_regular", "xor_regular_found", "state_columns",
-             "state_columns_quad_nodes", "state_columns_taylor_degree")
+             "state_columns_quad_nodes", "state_columns_taylor_degree", "state_columns_compose_segments")
 
 
 def describe_expm(info):
+    if info.get("state_columns_compose_segments", 0) > 0:
+        return ("composed form from state columns: H is a sum of Pauli strings ({} XOR-diagonals), so the product of the chain's propagators "
+                "is what the state-column forward kernel makes of the identity's columns -- {} time segments of dim columns each, "
+                "economized polynomial of degree {} (Taylor would need {}), their propagators multiplied by a tree of batched products and "
+                "applied to the batch once (no step exponential, no product per step), theta<={:.3g}".format(
+                    int(info["xor_regular_found"]), int(info["state_columns_compose_segments"]), int(info["degree"]),
+                    int(info.get("state_columns_taylor_degree", 0)), info["theta"]))
     if info.get("state_columns", 0) > 0:
         return ("state-column form: H is a sum of Pauli strings ({} XOR-diagonals), so NO propagator is built -- every state column "
                 "stays in LDS for the whole chain and each step applies the Chebyshev-economized polynomial of degree {} (Taylor would "

@@ -1681,7 +1681,7 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
   // the identity's columns (compose_chain) S d d L plus the products that combine its segments and apply it (8 d^2 (B + G d) flop).
   // Rates at d = 256 .. 4096: 2.3 ps per row and sweep, 60 TF/s on the products; the composed form has to win by 30 %.
   bool prefer_compose = false;
-  if (S > 0 && B > d && c->compose_mode != 0 && c->xs_compose_mode != 0 && c->xs_mode != 0) {
+  if (S > 0 && B > d && c->compose_mode != 0 && c->xs_compose_mode != 0 && c->xs_mode < 0) {   // (state_columns = 1 asks for the swept states)
     const double Lest = 6.0, segs = std::max(1.0, 5120.0 / d);
     prefer_compose = (double)S * (B - d) * Lest > 0.0754 * d * ((double)B + segs * d);
   }
