@@ -1500,7 +1500,10 @@ TT* xs_compose_segments(Ctx<T>* c, const std::vector<double>& uh, int S, double 
   // segments: as many as it takes for d columns each to fill the chip's workgroup slots once (d = 256: 20, d = 4096: 1); each costs
   // a d^3 product in the tree afterwards
   const int cap = dq::xs_blocks(d, sizeof(T), 1 << 30, c->n_cu, c->xs_variant);
-  int G = std::max(1, std::min(S, (cap + d - 1) / d));
+  int G0 = std::max(1, (cap + d - 1) / d), G2 = 1;
+  while (2 * G2 <= G0) G2 *= 2;   // a power of two: full levels in the tree of products, the same count of columns on every SIMD
+                                  // (configs[1], d = 256: 16 segments 0.92 ms, 20 segments 1.04 - 1.11 ms, 8 segments 1.03 ms)
+  int G = std::max(1, std::min(S, c->xs_compose_mode > 0 ? c->xs_compose_mode : G2));   // (option value > 0: that many)
   const int seg = (S + G - 1) / G;
   G = (S + seg - 1) / seg;
   const int B = G * d;
@@ -2902,7 +2905,7 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "state_columns_compose") {  // products of a chain's propagators (composed forward pass, time slices) from the state-column kernel: -1 auto, 0 off
-    c->xs_compose_mode = v != 0 ? -1 : 0;
+    c->xs_compose_mode = v < 0 ? -1 : (v > 4096 ? 4096 : (int)v);   // (> 0: that many segments)
   } else if (s == "state_columns_chain_tol") {  // bound of the step polynomial's error summed over the chain (per step: min(expm_tol, this / steps))
     if (!(v > 0)) fail(DQ_ERR_INVALID, "state_columns_chain_tol must be > 0");
     c->xs_chain_tol = v;

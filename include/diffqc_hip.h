@@ -172,7 +172,7 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      state-column forward kernel run on the identity's columns -- dim columns x n_steps steps, cut into time segments
  *                      (as many as fill the chip) whose propagators are multiplied afterwards -- instead of one step exponential and
  *                      one dim^3 product per step; dq_propagate also prefers this form over sweeping the states when its cost model
- *                      says so (batch > dim and enough steps).  0: explicit propagators.
+ *                      says so (batch > dim and enough steps).  0: explicit propagators; v > 0: that many segments.
  *                      dq_get_info("state_columns_compose_segments") = segments of the last call (0: not used)
  *   state_columns_chain_tol   bound of the step polynomial's error summed over the chain (default 1e-11 in complex128, 2e-5 in
  *                      complex64): the per-step bound is min(expm_tol, state_columns_chain_tol / n_steps) -- the polynomial's error is
