@@ -1301,7 +1301,7 @@ TT* compose_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
   const int d = c->d;
   T2* running = nullptr;
   c->last_xs_segments_fwd = 0;
-  if (allow_state_columns) {   // (not for the time slices of dq_slice_forward: their explicit propagators fill the cache the backward call reads)
+  if (allow_state_columns) {   // (not where the explicit propagators are read again: the operator-form sweep of dq_energy_grad)
     // Pauli-sum generators: no step exponential at all -- the product of the chain's propagators is what the state-column forward
     // kernel makes of the identity's columns (d columns x S steps: the cost of a forward pass over d states), cut into time segments
     // when d columns alone do not fill the chip; the segments' propagators are then multiplied as the steps' would be
@@ -2205,7 +2205,9 @@ void do_slice_forward(Ctx<T>* c, const double* u, int n, double dt, void* P_out)
   c->last_chunk = tc;
   PcOff<T> pc_off{c};
   setup_pcache(c, uh, n, dt, tc, true);
-  T2* P = compose_chain(c, uh, n, dt, tc);
+  // (Pauli-sum generators: the slice's product from state-column segments; the backward call then finds no cached propagators and
+  // builds its own -- 0.2 ms per step on the column kernels against the 5.8 ms product per step this saves at d = 4096)
+  T2* P = compose_chain(c, uh, n, dt, tc, true);
   if (!P) {
     P = c->mat(SLOT_TREE + 2, 1);
     c->lincomb(P, 0, nullptr, nullptr, 1.0, 1, false);  // empty slice: the identity
