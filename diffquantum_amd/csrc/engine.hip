@@ -326,6 +326,8 @@ struct Ctx : dq_ctx {
   int xs_workgroups = 0;                       // > 0: at most that many workgroups per launch (tests of the several-columns-per-workgroup loop)
   double xs_part_bytes = 268435456.0;          // scratch of the adjoint sweep's per-step partial sums: the chain is swept in segments that fit
   double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
+  int xs_wide_mode = -1;                       // energy gradients of batches wider than the dimension on dim columns (do_energy_grad_xs_wide): -1 by cost (default), 0 off, 1 on
+  double last_xs_wide = 0;
   int xs_compose_mode = -1;                    // products of a chain's propagators (composed forward, time slices) from state columns: -1 auto, 0 off
   double last_xs_segments_fwd = 0;             // time segments of the last such product (0: built from explicit propagators)
   int xs_economize = 1;                        // step polynomial of the state-column kernels: 1 = Chebyshev-economized (default), 0 = Taylor
@@ -2025,6 +2027,73 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
   HIPCK(hipStreamSynchronize(c->st));
 }
 
+// Energy objective, batch wider than the dimension, Pauli-sum generator: the gradient of L = sum_b <psi_b|M|psi_b> = tr(M P R P^H)
+// (R = Psi0 Psi0^H, P = the chain's product) needs no sweep over the B states:
+//     dL/du_k[t] = 2 Re tr(M Q_{t+1} dU_t P_t R P^H) = Re sum_i <lambda_i(t+1)| dU_t |y_i(t)>,   y_i = P_t R e_i,  lambda_i = Q_{t+1}^H 2 M P e_i
+// -- the state-column adjoint sweep as it stands on the d columns of (psi_S, lambda_S) = (P R, 2 M P), with P from the state-column
+// segments of compose_chain; three d^3 products and the Gram product per call.  Final states / per-state energies, when asked for,
+// cost one more d x d x B product.
+template <class T>
+void do_energy_grad_xs_wide(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, const void* psi0, int B, double* loss,
+                            double* grad_u, void* psi_final, double* energies, int L) {
+  typedef TT T2;
+  const int d = c->d, K = c->K;
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  c->psi[0].ensure(sb);
+  c->psi[1].ensure(sb);
+  c->lam[0].ensure(sb);
+  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
+  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
+  const int tc = time_chunk(c, std::max(S, 1));
+  T2* P = compose_chain(c, uh, S, dt, tc, true);
+  if (!P || c->last_xs_segments_fwd <= 0) fail(DQ_ERR_STATE, "wide-batch adjoint: the product of the chain did not come from state columns");
+  T2* Rm = c->mat(SLOT_TP_Q, 1);
+  T2* Ym = c->mat(SLOT_TP_Z, 1);
+  T2* Lm = c->mat(SLOT_TP_R, 1);
+  c->zgemm(0, 1, d, d, B, 1.0, p0, B, 0, p0, B, 0, 0.0, Rm, d, 0, 1);                 // R = Psi0 Psi0^H
+  c->zgemm(0, 0, d, d, d, 1.0, P, d, 0, Rm, d, 0, 0.0, Ym, d, 0, 1);                  // Y = P R
+  c->zgemm(3, 0, d, d, d, 2.0, (const T2*)c->M.p, d, 0, P, d, 0, 0.0, Lm, d, 0, 1);   // Lambda = 2 M P   (M Hermitian)
+  // L = sum_i <p_i| M |y_i> = 1/2 Re sum_i <lambda_i, y_i>
+  c->e_dev.ensure(sizeof(double) * ((size_t)std::max(B, d) + 1));
+  c->part.ensure(sizeof(double) * (size_t)dq::coldot_chunks(d) * std::max(B, d));
+  c->timed(DQ_PROF_OTHER, 4.0 * d * d, 4.0 * sizeof(T) * d * d,
+           [&] { return dq::coldot_launch<T>(Ym, d, Lm, d, d, d, 0.5, c->e_dev.d(), c->part.d(), c->st); });
+  c->timed(DQ_PROF_OTHER, d, 8.0 * d, [&] { return dq::sum_launch(c->e_dev.d(), d, c->e_dev.d() + d, c->st); });
+  if (loss) out_copy(c, loss, c->e_dev.d() + d, sizeof(double));
+  // the adjoint sweep over the d columns
+  const XsLaunch<T> x = xs_prepare(c, S, dt, d, L, true);
+  const double by = 2.0 * sizeof(T2) * (double)d * d;
+  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_psi.p, d, 0, Ym, d, 0, d, d, 0, 1, c->st); });
+  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, Lm, d, 0, d, d, 0, 1, c->st); });
+  {
+    double fl, lb;
+    xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, !x.quad_ok, d, &fl, &lb);
+    const dq::XrTab tb = *x.tab;
+    c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
+    for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {
+      const int s0 = std::max(0, s1 - x.seg_steps), ns = s1 - s0;
+      const double share = (double)ns / (double)S;
+      c->timed(DQ_PROF_STATECOL_BWD, fl * share, lb * share, [&] {
+        return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
+                                      c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, d, L, x.nblk,
+                                      x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
+                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, c->st);
+      });
+    }
+  }
+  if (grad_u && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
+  if (psi_final || energies) {   // Psi_S = P Psi0 (the pool slot of P is untouched by the sweep)
+    c->zgemm(0, 0, d, B, d, 1.0, P, d, 0, p0, B, 0, 0.0, (T2*)c->psi[0].p, B, 0, 1);
+    if (psi_final) out_copy(c, psi_final, c->psi[0].p, sb);
+    if (energies) do_energy(c, (const T2*)c->psi[0].p, B, (T2*)c->lam[0].p, energies, nullptr);
+  }
+  c->last_xs = 0;
+  c->last_xs_wide = 1;
+  c->last_composed = 1;
+  c->last_opback = 0;
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
 template <class T>
 void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* psi0, int B, double* loss,
                     double* grad_u, void* psi_final, double* energies, const void* targets = nullptr) {
@@ -2071,6 +2140,18 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   std::vector<double> uh = fetch_u(c, u, S);
   c->last_xs = 0;
   c->last_xs_segments_fwd = 0;
+  c->last_xs_wide = 0;
+  if (S > 0 && B > d && !targets && c->xs_compose_mode != 0 && (c->xs_wide_mode > 0 || (c->xs_wide_mode < 0 && c->xs_mode < 0))) {   // (state_columns = 1 asks for the swept states)
+    // (-1: by cost -- fwd + adjoint sweeps over B - d columns saved against the Gram product, three d^3 products and the final
+    // application; rates as in do_propagate)
+    bool take = c->xs_wide_mode > 0;
+    if (!take) take = (double)S * (B - d) * 18.0 > 0.0754 * d * (2.0 * B + 8.0 * d);
+    if (take)
+      if (const int Lw = xs_degree(c, uh, S, dt, d, true)) {
+        do_energy_grad_xs_wide(c, uh, S, dt, psi0, B, loss, grad_u, psi_final, energies, Lw);
+        return;
+      }
+  }
   if (const int Lx = S > 0 ? xs_degree(c, uh, S, dt, B) : 0) {
     do_energy_grad_xs(c, S, dt, psi0, B, loss, grad_u, psi_final, energies, targets, Lx);
     return;
@@ -2906,6 +2987,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_variant = (int)v & 3;
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
+  } else if (s == "state_columns_wide_adjoint") {  // energy gradients of batches wider than dim on dim columns: -1 by cost (default), 0 off, 1 on
+    c->xs_wide_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "state_columns_compose") {  // products of a chain's propagators (composed forward pass, time slices) from the state-column kernel: -1 auto, 0 off
     c->xs_compose_mode = v < 0 ? -1 : (v > 4096 ? 4096 : (int)v);   // (> 0: that many segments)
   } else if (s == "state_columns_chain_tol") {  // bound of the step polynomial's error summed over the chain (per step: min(expm_tol, this / steps))
@@ -2970,6 +3053,7 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
   if (s == "state_columns_quad_nodes") return c->last_xs_nodes;
   if (s == "state_columns_taylor_degree") return c->last_xs_taylor_degree;
   if (s == "state_columns_compose_segments") return c->last_xs_segments_fwd;
+  if (s == "state_columns_wide_adjoint") return c->last_xs_wide;
   if (s == "state_columns_segments") return c->last_xs_segments;
   if (s == "xor_regular_found") return c->xr_ok ? (double)c->xr_tab.R : (c->zxr_ok ? (double)c->zxr_tab.R : -1.0);
   if (s == "sparse_drift") return c->sparse_h && c->sparse_x ? 1.0 : 0.0;

@@ -431,3 +431,34 @@ def test_wide_batches_take_the_composed_form_when_it_is_cheaper():
             assert e.info("state_columns") == 1 and e.info("composed") == 0        # (without the composed form: the states are swept)
             e.set_option("state_columns_compose", -1)
             assert np.max(np.abs(f1 - f0)) < 1e-11
+
+
+@pytest.mark.parametrize("case,n,S,B,dtype,tol", [("ising_x", 9, 40, 1100, "c128", 1e-10), ("qaoa_ring_zz_controls", 8, 25, 700, "c128", 1e-10),
+                                                   ("xy_drives", 9, 12, 600, "c128", 1e-10), ("mixed_two_body", 8, 6, 300, "c128", 1e-10),
+                                                   ("ising_x", 9, 40, 1100, "c64", 2e-4)])
+def test_wide_batch_energy_gradient_on_dim_columns(oracle, case, n, S, B, dtype, tol):
+    """Batch wider than the dimension, energy objective (option state_columns_wide_adjoint): L = tr(M P R P^H) with R = Psi0 Psi0^H and P
+    the chain's product, so the adjoint sweep runs on the dim columns of (P R, 2 M P) instead of the B states (engine.hip
+    do_energy_grad_xs_wide) -- loss, dL/du, per-state energies and final states against the sweep over the states themselves, and
+    dL/du against the oracle on a slice of the batch where the batch is additive."""
+    H0, Hs, M = _qaoa(n) if case == "qaoa_ring_zz_controls" else CASES[case](n)
+    K, d = len(Hs), 1 << n
+    dt = 2e-3
+    u = np.random.default_rng(70 + S).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=71)
+    if dtype == "c64":
+        psi0 = psi0.astype(np.complex64)
+    with _engine(H0, Hs, M, dtype=dtype, state_columns=1, state_columns_wide_adjoint=0) as e:
+        l0, g0, f0, e0 = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1 and e.info("state_columns_wide_adjoint") == 0
+        e.set_option("state_columns", -1)
+        e.set_option("state_columns_wide_adjoint", 1)
+        l1, g1, f1, e1 = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns_wide_adjoint") == 1 and e.info("state_columns_compose_segments") >= 1
+        l2, g2, _, _ = e.energy_grad(u, dt, psi0, want_final=False, want_energies=False)     # (no application of P to the batch)
+        assert e.info("state_columns_wide_adjoint") == 1
+    scale = max(1.0, float(np.max(np.abs(g0))))
+    assert abs(l1 - l0) < tol * B and abs(l2 - l0) < tol * B
+    assert np.max(np.abs(g1 - g0)) < tol * scale and np.max(np.abs(g2 - g0)) < tol * scale, np.max(np.abs(g1 - g0))
+    assert np.max(np.abs(f1 - f0)) < tol * 10 and np.max(np.abs(e1 - e0)) < tol * 100
+    assert np.max(np.abs(g0)) > 1e-5
