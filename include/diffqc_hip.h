@@ -174,6 +174,12 @@ int dq_set_observable(dq_ctx* ctx, const void* M);
  *                      one dim^3 product per step; dq_propagate also prefers this form over sweeping the states when its cost model
  *                      says so (batch > dim and enough steps).  0: explicit propagators; v > 0: that many segments.
  *                      dq_get_info("state_columns_compose_segments") = segments of the last call (0: not used)
+ *   state_columns_wide_adjoint   -1 (default: by a cost model) / 1: dq_energy_grad of a batch WIDER than the dimension (energy objective,
+ *                      Pauli-sum H) does not sweep the B states: L = sum_b <psi_b|M|psi_b> = tr(M P R P^H) with R = Psi0 Psi0^H and P the
+ *                      chain's product (state_columns_compose), and dL/du comes from the state-column adjoint sweep over the dim columns
+ *                      of (psi_S, lambda_S) = (P R, 2 M P) -- three dim^3 products and the Gram product per call instead of B - dim more
+ *                      columns per step; final states / per-state energies, when asked for, cost one more dim x dim x B product.
+ *                      0: always sweep the states.  dq_get_info("state_columns_wide_adjoint") = 1 if the last call took it
  *   state_columns_chain_tol   bound of the step polynomial's error summed over the chain (default 1e-11 in complex128, 2e-5 in
  *                      complex64): the per-step bound is min(expm_tol, state_columns_chain_tol / n_steps) -- the polynomial's error is
  *                      the same function of the spectrum at every step and may add up coherently
