@@ -2144,8 +2144,11 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   if (S > 0 && B > d && !targets && c->xs_compose_mode != 0 && (c->xs_wide_mode > 0 || (c->xs_wide_mode < 0 && c->xs_mode < 0))) {   // (state_columns = 1 asks for the swept states)
     // (-1: by cost -- fwd + adjoint sweeps over B - d columns saved against the Gram product, three d^3 products and the final
     // application; rates as in do_propagate)
+    // (measured at d = 4096, B = 32768, S = 20, tools/wide_adjoint_timing.py: 77 ms against 137 ms without the final application,
+    // about equal with it: a pairing sweep counts 1.4 plain ones, the products run at 90 TF/s algorithmic, 15 % margin)
     bool take = c->xs_wide_mode > 0;
-    if (!take) take = (double)S * (B - d) * 18.0 > 0.0754 * d * (2.0 * B + 8.0 * d);
+    const bool need_apply = psi_final != nullptr || energies != nullptr;
+    if (!take) take = (double)S * (B - d) * 22.8 > 0.0444 * d * ((need_apply ? 2.0 : 1.0) * B + 8.0 * d);
     if (take)
       if (const int Lw = xs_degree(c, uh, S, dt, d, true)) {
         do_energy_grad_xs_wide(c, uh, S, dt, psi0, B, loss, grad_u, psi_final, energies, Lw);
