@@ -131,3 +131,36 @@ def test_library_step_polynomial_matches_the_model():
     assert lib.dq_step_polynomial(1.0, 2.0 ** -53, 1, C.byref(L), g) == 0 and L.value == 14        # Taylor: 18
     assert lib.dq_step_polynomial(2.5, 2.0 ** -53, 1, C.byref(L), g) == 0 and L.value == 0         # beyond the kernels' degrees
     assert lib.dq_step_polynomial(-1.0, 1e-9, 1, C.byref(L), g) != 0 and b"theta" in lib.dq_last_error()
+
+
+@pytest.mark.parametrize("name,prob", list(_cases())[:3])
+def test_wide_batch_gradient_on_dim_columns_model(oracle, name, prob):
+    """The identity behind engine.hip do_energy_grad_xs_wide (batches wider than the dimension): L = sum_b <psi_b|M|psi_b> =
+    tr(M P R P^H), R = Psi0 Psi0^H, and dL/du from the SAME backward steps run on the d columns of (psi_S, lambda_S) = (P R, 2 M P) --
+    against the oracle's gradient over the B states (scipy expm / expm_frechet)."""
+    H0, Hs, M = prob
+    K, d = len(Hs), H0.shape[0]
+    S, B, dt = 4, 3 * d + 1, 0.02
+    u = np.random.default_rng(11).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=5)
+    rl, rg, _ = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    tab = nsc.table_from_dense(H0, Hs)
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    th = max(abs(dt) * (n1(H0) + sum(abs(row[k]) * n1(Hs[k]) for k in range(K))) for row in u)
+    L = nsc.economized_degree(th)
+    g = nsc.poly_factors(th, L)
+    P = np.eye(d, dtype=np.complex128)
+    for t in range(S):                                                   # the chain's product, column by column
+        P = np.stack([nsc.forward_step(tab, u[t], dt, P[:, i], L, g) for i in range(d)], axis=1)
+    R = psi0 @ psi0.conj().T
+    Y, Lam = P @ R, 2.0 * (M @ P)
+    loss = 0.5 * float(np.real(np.sum(Lam.conj() * Y)))
+    grad = np.zeros((S, K))
+    for i in range(d):
+        psi, lam = Y[:, i], Lam[:, i]
+        for t in range(S - 1, -1, -1):
+            psi, lam, gr = nsc.backward_step(tab, u[t], dt, psi, lam, L, K, g)
+            grad[t] += gr
+    assert abs(loss - rl) < 1e-10 * B
+    assert np.max(np.abs(grad - rg)) < 1e-11 * B, np.max(np.abs(grad - rg))
+    assert np.max(np.abs(rg)) > 1e-6
