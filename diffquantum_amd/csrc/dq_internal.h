@@ -259,9 +259,17 @@ struct XrTab {
   unsigned zmask[XR_RMAX];
   unsigned s0mask;
   int parity;
+  // The offset-0 diagonals of CONTROLS as Z-strings: dstring = 1 when every source jd with dkid[jd] >= 0 is one Pauli-Z string,
+  // dval[jd][i] = dmag[jd] (-1)^parity(i & dzmask[jd]) (the reference's ZZ-edge controls, demo_maxcut.py:71-74): the adjoint kernels
+  // then contract their per-row sums with signs made from the masks instead of reading nd x d table values per step (xr_diag_strings)
+  unsigned dzmask[XR_DMAX];
+  double dmag[XR_DMAX];
+  int dstring;
 };
 // fills zmask / s0mask / parity from the host copy of the sign words (sgn_h may be null: no negative entry)
 void xr_parity_signs(XrTab& tab, const unsigned* sgn_h, int d);
+// fills dzmask / dmag / dstring from the host copy of the offset-0 diagonals ([nd][d])
+void xr_diag_strings(XrTab& tab, const double* dval_h, int d);
 struct XrPoly {
   int q;
   double cc[XR_QMAX + 1], sc[XR_QMAX + 1];  // cos X = sum cc_j X^2j, sin X = sum sc_j X^(2j+1)
@@ -305,6 +313,10 @@ struct XsOrder {                   // the order in which the sweeps walk the tab
   int n0p1, n1p1, nlocp1[8];       // how many of each class have phase 1 (entries +-i c): every class is ordered phase 0 first
   unsigned char rsn[20];           // per group (class 0 / 1 by phase: 0..3; register class xh by phase: 4 + 2 (xh - 1) + phase): how many of
                                    // its diagonals, ordered LAST, carry a row factor of the sign (parity mask with bits at or above the thread count)
+  unsigned long long gmask;        // bit g: loop g of the walk has at least one diagonal.  g = perm 4 + phase 2 + rs for the LDS classes,
+                                   // 8 + (xh - 1) 4 + phase 2 + rs for the register classes: a signed complex table has 36 loops of which
+                                   // a handful run, and an empty one is a bit test instead of its count arithmetic (round 5: the
+                                   // headers of empty loops were a fifth of the X / Y-drive sweeps)
 };
 bool xs_supported(int d, int L, int R, int nd, size_t elem);  // elem = sizeof(real type)
 // The step polynomial p(A) = sum_{m <= L} g[m] A^m / m! of the state-column kernels.  g = 1 is the Taylor polynomial; the economized
@@ -328,9 +340,15 @@ int xs_poly_make(double theta, double tol, int economize, XsPoly* p);
 // values exp(-s_i A) lambda are polynomials of the same degree on the shorter interval s_i theta, with their own level factors g_i[m]:
 // c1[m][i] = g_i[m] s_i^m, c2[m][i] = -w_i g_i[m] s_i^m, w0 = minus the weight of the end point 0, w1[m] = -g[m] x the weight of the
 // end point 1 (g: the factors of the whole step).
+// basis = 1 (difference basis, ni = 2; the kernels that keep the rule's second vector in LDS as fp32): the SAME rule with its two node
+// values replaced by u_1 = lambda(s_near) - a_1 lambda_t and u_2 = lambda(s_far) - a_0 lambda_t - beta u_1, a_i = g_i[0] / g[0] and
+// beta such that u_2 has no first-order term: |u_1| ~ 0.28 theta |lambda|, |u_2| ~ 0.16 theta^2 |lambda|.  The tables keep their
+// places and shapes -- phase 1 accumulates vector i with c1[m][i] (now: u_1, u_2; both rows m = 0 are 0 and c1[1][1] = 0),
+// q_m = w1[m] lambda_t + c2[m][0] u_1 + c2[m][1] u_2 (+ w0 lambda_{t+1} at m = 0) -- so the kernel's arithmetic is the node form's.
 constexpr int XS_NIMAX = 3;
 struct XsQuad {
   int ni;
+  int basis;
   double w0;
   double g[XS_LMAX + 1];    // the level factors of the whole step (XsPoly)
   double w1[XS_LMAX + 1];
@@ -339,8 +357,9 @@ struct XsQuad {
 // the rule for a step of size theta (bound of ||A||): the fewest interior nodes whose error bound e (2 theta)^(2 ni + 2) stays below
 // tol (relative to ||dA_k|| ||lambda|| ||psi||); false when no rule the kernels are built for reaches it (ni_max <= XS_NIMAX).
 // L, economize, poly: the step polynomial the node tables are built for (xs_poly_make).
-bool xs_quad_make(double theta, double tol, int ni_max, int L, int economize, const XsPoly& poly, XsQuad* qd);
-bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant);  // the table / rule / shape combinations xs_backward_q_kernel runs
+bool xs_quad_make(double theta, double tol, int ni_max, int L, int economize, const XsPoly& poly, XsQuad* qd, int basis = 0);
+bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant, size_t elem = sizeof(double));  // the table / rule / shape combinations xs_backward_q_kernel runs
+bool xs_quad_basis(const XrTab& tab, int d, int variant, size_t elem);   // the basis the kernel of this table class / shape takes (true: the difference basis, XsQuad::basis = 1)
 // variant: bit 0 = 1024 threads x 4 rows per workgroup at d = 4096 (default 512 x 8); bit 1 = prefetch of the next diagonal's partners
 int xs_blocks(int d, size_t elem, int B, int n_cu, int variant);   // workgroups of a launch over B columns
 int xs_waves(int d, int variant);

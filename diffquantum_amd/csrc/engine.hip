@@ -1429,7 +1429,8 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
   c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
   x.quad_ok = false;
-  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, L, c->xs_economize, c->xs_poly, &x.quad) && dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant);
+  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, L, c->xs_economize, c->xs_poly, &x.quad, dq::xs_quad_basis(*x.tab, c->d, c->xs_variant, sizeof(T)) ? 1 : 0) &&
+                                              dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant, sizeof(T));
   c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
   if (backward) {
     if (!x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
@@ -2554,6 +2555,7 @@ void find_xor_regular(Ctx<T>* c, const std::vector<long>& rowptr, long nnz) {
   tab.sgn = neg ? (const unsigned*)c->xr_sgn.p : nullptr;
   tab.dval = (const double*)c->xr_dval.p;
   dq::xr_parity_signs(tab, neg ? sgn.data() : nullptr, d);
+  dq::xr_diag_strings(tab, dval.empty() ? nullptr : dval.data(), d);
   c->xr_tab = tab;
   c->xr_ok = true;
   c->tab_sgn_h = sgn;
@@ -2659,6 +2661,7 @@ void find_zxor_regular(Ctx<T>* c) {
   tab.sgn = (const unsigned*)c->xr_sgn.p;
   tab.dval = (const double*)c->xr_dval.p;
   dq::xr_parity_signs(tab, sgn.data(), d);
+  dq::xr_diag_strings(tab, dval.empty() ? nullptr : dval.data(), d);
   c->zxr_tab = tab;
   c->zxr_ok = true;
   c->tab_sgn_h = sgn;

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double
 
 // psi_out[b][:] = U_{S-1} ... U_0 psi_in[b][:] for the columns b = blockIdx.x, + gridDim.x, ...  (states stored column by
 // column: [B][D]).  dgs + s * dgs_step: the rows' diagonal weights of step s.
-template <class T, int NT, int RPT, bool SIGN, bool PREF, bool CPLX>
+template <class T, int NT, int RPT, int SIGN, bool PREF, bool CPLX>
 __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::type* __restrict__ psi_in,
                                                         typename Cx<T>::type* __restrict__ psi_out, XrTab tab, XsOrder ord,
                                                         const double* __restrict__ wt, const double* __restrict__ dgs, long dgs_step,
@@ -258,6 +258,31 @@ void xr_parity_signs(XrTab& tab, const unsigned* sgn_h, int d) {
   }
 }
 
+void xr_diag_strings(XrTab& tab, const double* dval_h, int d) {
+  memset(tab.dzmask, 0, sizeof(tab.dzmask));
+  memset(tab.dmag, 0, sizeof(tab.dmag));
+  tab.dstring = 0;
+  if (!dval_h) return;
+  int n = 0;
+  while ((1 << n) < d) ++n;
+  bool any = false;
+  for (int jd = 0; jd < tab.nd; ++jd) {
+    if (tab.dkid[jd] < 0) continue;
+    const double* v = dval_h + (size_t)jd * d;
+    const double c = v[0];
+    if (c == 0.0) return;
+    unsigned z = 0;
+    for (int b = 0; b < n; ++b)
+      if (v[(size_t)1 << b] != c) z |= 1u << b;
+    for (int i = 0; i < d; ++i)
+      if (v[i] != ((__builtin_popcount((unsigned)i & z) & 1) ? -c : c)) return;   // (not a single Z-string: the table values stay in use)
+    tab.dzmask[jd] = z;
+    tab.dmag[jd] = c;
+    any = true;
+  }
+  tab.dstring = any ? 1 : 0;
+}
+
 bool xs_supported(int d, int L, int R, int nd, size_t elem) {
   if (elem != sizeof(double) && elem != sizeof(float)) return false;
   if (R < 1 || R > XR_RMAX || nd < 0 || nd > XR_DMAX || L < 1 || L > 24) return false;
@@ -330,6 +355,7 @@ XsOrder xs_make_order(int d, const XrTab& tab, int variant, bool local) {
           ++o.n0;
           o.n0p1 += ph;
           o.rsn[0 + ph] += rs;
+          o.gmask |= 1ull << (0 + ph * 2 + rs);
         }
   for (int ph = 0; ph < 2; ++ph)
     for (int rs = 0; rs < 2; ++rs)
@@ -339,6 +365,7 @@ XsOrder xs_make_order(int d, const XrTab& tab, int variant, bool local) {
           ++o.n1;
           o.n1p1 += ph;
           o.rsn[2 + ph] += rs;
+          o.gmask |= 1ull << (4 + ph * 2 + rs);
         }
   for (int xh = 1; xh < 8 && local; ++xh)
     for (int ph = 0; ph < 2; ++ph)
@@ -349,9 +376,12 @@ XsOrder xs_make_order(int d, const XrTab& tab, int variant, bool local) {
             ++o.nloc[xh];
             o.nlocp1[xh] += ph;
             o.rsn[4 + 2 * (xh - 1) + ph] += rs;
+            o.gmask |= 1ull << (8 + (xh - 1) * 4 + ph * 2 + rs);
           }
   return o;
 }
+// any diagonal of the order with a row factor of its sign (the odd bits of gmask)
+bool xs_order_row_signs(const XsOrder& o) { return (o.gmask & 0xAAAAAAAAAull) != 0; }
 size_t xs_park_elems(int d, int L, int nblk) { return (size_t)nblk * (size_t)L * (size_t)d; }
 size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant) {
   return (size_t)nblk * (size_t)S * (size_t)xs_waves(d, variant) * (size_t)xs_slots(tab);
@@ -448,7 +478,7 @@ int xs_poly_make(double theta, double tol, int economize, XsPoly* p) {
 
 // Gauss-Lobatto rules on [0, 1] with 2 and 3 interior nodes (4 / 5 points: exact to degree 5 / 7).  The rule's error for an
 // integrand with |f^(p)| <= F, p = 2 ni + 2, is e F with e = |int s^p - Q[s^p]| / p! (its Peano kernel keeps one sign).
-bool xs_quad_make(double theta, double tol, int ni_max, int L, int economize, const XsPoly& poly, XsQuad* qd) {
+bool xs_quad_make(double theta, double tol, int ni_max, int L, int economize, const XsPoly& poly, XsQuad* qd, int basis) {
   memset(qd, 0, sizeof(*qd));
   if (!(theta >= 0.0) || L < 1 || L > XS_LMAX) return false;
   for (int ni = 2; ni <= ni_max && ni <= XS_NIMAX; ++ni) {
@@ -489,17 +519,48 @@ bool xs_quad_make(double theta, double tol, int ni_max, int L, int economize, co
         qd->c2[m][i] = -w[i] * qd->c1[m][i];
       }
     }
+    if (basis != 0) {
+      if (ni != 2) return false;
+      // the difference basis (dq_internal.h): node 1 (s = 0.72) is the near one to the end point 1, node 0 (s = 0.28) the far one
+      const double a0 = qd->c1[0][0] / qd->g[0], a1 = qd->c1[0][1] / qd->g[0];
+      double e0[XS_LMAX + 1], e1[XS_LMAX + 1];
+      e0[0] = e1[0] = 0.0;
+      for (int m = 1; m <= XS_LMAX; ++m) {
+        e0[m] = qd->c1[m][0] - a0 * qd->g[m];
+        e1[m] = qd->c1[m][1] - a1 * qd->g[m];
+      }
+      const double beta = e0[1] / e1[1];
+      for (int m = 0; m <= XS_LMAX; ++m) {
+        const double c20 = qd->c2[m][0], c21 = qd->c2[m][1];   // the weights of q_m on the far / near node value
+        qd->w1[m] += c20 * a0 + c21 * a1;
+        qd->c2[m][0] = c20 * beta + c21;
+        qd->c2[m][1] = c20;
+        qd->c1[m][0] = e1[m];
+        qd->c1[m][1] = m <= 1 ? 0.0 : e0[m] - beta * e1[m];
+      }
+      qd->basis = 1;
+    }
     return true;
   }
   return false;
 }
-// The quadrature kernel runs where it is the faster form (measured at d = B = 4096, tools/xs_timing.py, profiles/r4_xy_forms.txt):
-// unsigned tables without diagonal controls, up to 16 XOR-diagonals, the 4-point rule -- 1013 steps/s against 749 on the exact form.
-// Tables with row signs (X / Y drives: 588 against 633) or with diagonal controls (X / Z controls: 694 against 958) keep the exact
-// form: their extra state (sign handling, the row accumulators) costs the quadrature kernel more registers than it has; so do the
-// shapes of 1024 threads per column (d = 4096 "wide", d = 8192 in complex64: 128 registers per wave, 310 against 508 steps/s).
-bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant) {
-  return ni == 2 && tab.R <= XR_RSMALL && tab.sgn == nullptr && !xs_has_diag_controls(tab) && xs_threads(d, variant) < 1024;
+// The quadrature kernel (statecol_bwdq.hip): tables of up to 16 XOR-diagonals, the 4-point rule, shapes of up to 512 threads per
+// column.  Unsigned real tables without diagonal controls (BASELINE's Ising + X_k) keep the node basis, both node vectors in
+// registers; tables with parity signs / complex phases (I/Q drives) or diagonal controls (ZZ-edge + X-vertex QAOA) take the difference
+// basis with u_2 in LDS (round 5): in complex128 their sign state and row accumulators did not fit beside two node vectors (129 - 175
+// spilled registers, slower than the exact form in round 4).  The shapes of 1024 threads per column (d = 4096 "wide", d = 8192 in
+// complex64: 128 registers per wave) keep the exact form.
+#ifndef XS_FORCE_BASIS
+#define XS_FORCE_BASIS 0   // probe builds: 1 = every table takes the difference-basis kernel
+#endif
+bool xs_quad_basis(const XrTab& tab, int d, int variant, size_t elem) {
+  if (elem != sizeof(double) || d / xs_threads(d, variant) != 8) return false;   // (built for complex128 at 8 rows per thread)
+  return XS_FORCE_BASIS || tab.sgn != nullptr || xs_has_diag_controls(tab);
+}
+bool xs_quad_supported(const XrTab& tab, int ni, int d, int variant, size_t elem) {
+  if (ni != 2 || tab.R > XR_RSMALL || xs_threads(d, variant) >= 1024) return false;
+  if (xs_quad_basis(tab, d, variant, elem) && xs_lds_bytes(d, elem) + sizeof(float2) * (size_t)d > (size_t)160 * 1024) return false;
+  return true;
 }
 
 namespace {
@@ -513,13 +574,17 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
   bool cplx = false;
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
   if (cplx && !sgn) return hipErrorInvalidValue;  // (complex tables always carry sign words)
+  const XsOrder ord = xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true);
+  const bool rs = xs_order_row_signs(ord);   // (SIGN = 2: the loops of row-signed diagonals exist; 1: parity signs within the thread bits)
   void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, XsPoly, XsSeg) =
-      cplx ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, true> : xs_forward_kernel<T, NT, RPT, true, false, true>)
-           : (sgn ? (pref ? xs_forward_kernel<T, NT, RPT, true, true, false> : xs_forward_kernel<T, NT, RPT, true, false, false>)
-                  : (pref ? xs_forward_kernel<T, NT, RPT, false, true, false> : xs_forward_kernel<T, NT, RPT, false, false, false>));
+      cplx ? (rs ? (pref ? xs_forward_kernel<T, NT, RPT, 2, true, true> : xs_forward_kernel<T, NT, RPT, 2, false, true>)
+                 : (pref ? xs_forward_kernel<T, NT, RPT, 1, true, true> : xs_forward_kernel<T, NT, RPT, 1, false, true>))
+           : (sgn ? (rs ? (pref ? xs_forward_kernel<T, NT, RPT, 2, true, false> : xs_forward_kernel<T, NT, RPT, 2, false, false>)
+                        : (pref ? xs_forward_kernel<T, NT, RPT, 1, true, false> : xs_forward_kernel<T, NT, RPT, 1, false, false>))
+                  : (pref ? xs_forward_kernel<T, NT, RPT, 0, true, false> : xs_forward_kernel<T, NT, RPT, 0, false, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true), wt, dgs,
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, ord, wt, dgs,
                      dgs_step, S, B, L, pol, seg);
   return hipGetLastError();
 }

@@ -15,7 +15,7 @@ namespace dq {
 // part[((blockIdx.x * S + s) * NW + wave) * NS + slot]: this workgroup's share, over its columns, of
 //   slot < RM: sum_i of the level pairings of the XOR-diagonal at SORTED position `slot` (before the factors cmag and dt);
 //   slot = RM + jd (DIAGCTL): sum_i dval_jd[i] rowacc[i] of the diagonal control jd.
-template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, int RM, bool PREF, bool CPLX>
+template <class T, int NT, int RPT, int SIGN, bool DIAGCTL, int RM, bool PREF, bool CPLX>
 __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
                                                          XrTab tab, XsOrder ord, XsOrder ordh, const double* __restrict__ wt,
                                                          const double* __restrict__ dgs, long dgs_step, int S, int B, int L,
@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   T2* Lm = W + D;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
+  const unsigned dsg = (DIAGCTL && tab.dstring) ? xs_diag_thread_signs(tab, t) : 0u;
   XsCtl ctl, ctlh;  // (ctlh: the order of the pairing sweeps -- every partner from LDS, phase 0 first)
   ctl.load_table(tab, ord, lane);
   if (SIGN) ctl.load_row_signs(tab, lane, __builtin_ctz(NT));
@@ -198,16 +199,20 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       }
       if (DIAGCTL) {
         double dv[XR_DMAX];
+        if (tab.dstring) {   // Z-string controls: signs from the masks (statecol_dev.h), no table reads
+          xs_diag_string_sums<RPT>(tab, rowacc, dsg, __builtin_ctz(NT), dv);
+        } else {
 #pragma unroll
-        for (int jd = 0; jd < XR_DMAX; ++jd) dv[jd] = 0.0;
+          for (int jd = 0; jd < XR_DMAX; ++jd) dv[jd] = 0.0;
 #pragma clang loop unroll(disable)
-        for (int jd = 0; jd < tab.nd; ++jd) {  // (runtime loop + tree select: unrolled, the 16 x RPT loads are hoisted and spill)
-          if (tab.dkid[jd] < 0) continue;
-          const double* dvr = tab.dval + (long)jd * D;
-          double v = 0.0;
+          for (int jd = 0; jd < tab.nd; ++jd) {  // (runtime loop + tree select: unrolled, the 16 x RPT loads are hoisted and spill)
+            if (tab.dkid[jd] < 0) continue;
+            const double* dvr = tab.dval + (long)jd * D;
+            double v = 0.0;
 #pragma unroll
-          for (int r = 0; r < RPT; ++r) v = __builtin_fma(dvr[r * NT + t], rowacc[r], v);
-          xs_acc<0, XR_DMAX>(dv, jd, v);
+            for (int r = 0; r < RPT; ++r) v = __builtin_fma(dvr[r * NT + t], rowacc[r], v);
+            xs_acc<0, XR_DMAX>(dv, jd, v);
+          }
         }
         const double v = xs_wave_sums16(dv, lane);
         if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
@@ -246,12 +251,13 @@ hipError_t xs_backward_rm(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   bool cplx = false;
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
   if (cplx && !sgn) return hipErrorInvalidValue;
+  // (SIGN = 2 for every signed table: the exact form is the fallback of the quadrature kernels, one instantiation per class)
   void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, T2*, double*, XsPoly) =
-      cplx ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, RM, PREF, true> : xs_backward_kernel<T, NT, RPT, true, false, RM, PREF, true>)
-           : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, true, true, RM, PREF, false>
-                        : xs_backward_kernel<T, NT, RPT, true, false, RM, PREF, false>)
-                  : (dc ? xs_backward_kernel<T, NT, RPT, false, true, RM, PREF, false>
-                        : xs_backward_kernel<T, NT, RPT, false, false, RM, PREF, false>));
+      cplx ? (dc ? xs_backward_kernel<T, NT, RPT, 2, true, RM, PREF, true> : xs_backward_kernel<T, NT, RPT, 2, false, RM, PREF, true>)
+           : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, 2, true, RM, PREF, false>
+                        : xs_backward_kernel<T, NT, RPT, 2, false, RM, PREF, false>)
+                  : (dc ? xs_backward_kernel<T, NT, RPT, 0, true, RM, PREF, false>
+                        : xs_backward_kernel<T, NT, RPT, 0, false, RM, PREF, false>));
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true),

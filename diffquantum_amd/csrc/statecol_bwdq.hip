@@ -23,7 +23,7 @@ namespace dq {
 // With an economized step polynomial (XsPoly, dq_internal.h) exp(-s A) ~ sum_m g^(s)[m] (-s A)^m / m! with level factors of the
 // interval s theta: every s_i^m above carries its g_i[m] (folded into c1 / c2 by the host), lambda_t and psi_t accumulate
 // qd.g[m] z_m / qd.g[m] r_m, and the end point 1 pairs r_m with g[m] lambda_t (qd.w1[m] = -w_1 g[m]).
-template <class T, int NT, int RPT, bool SIGN, bool DIAGCTL, bool CPLX, int NI>
+template <class T, int NT, int RPT, int SIGN, bool DIAGCTL, bool CPLX, int NI, bool U2L>
 __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
                                                            XrTab tab, XsOrder ord, XsOrder ordh, const double* __restrict__ wt,
                                                            const double* __restrict__ dgs, long dgs_step, int S, int B, int L, XsQuad qd,
@@ -36,8 +36,22 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
   T2* W = (T2*)xs_lds_raw;
   T2* Lm = W + D;
+  // U2L (difference basis, XsQuad::basis = 1; complex128, 8 rows per thread): the rule's second vector u_2 = O(theta^2) |lambda|
+  // spends phase 2 in the LDS a column's two images leave free, rounded to fp32 (8 B per row: 32 of the 160 KB at d = 4096), two rows
+  // to a 16-byte slot [k NT + t].  Relative to |lambda| that rounding is 6e-8 x 0.16 theta^2 (2e-11 at theta = 0.05), and it enters q_m
+  // with the weight w s^m <= 0.12 from m = 1 on, where the pairing partner r_m is O(theta^m) itself: 1e-13 of the gradient's scale
+  // (q_0, whose partner is psi itself, is formed while u_2 is still in its fp64 registers: accumulating u_2 in fp32 as well measured
+  // 1e-12 instead of 1e-14 against the exact form).  During phase 1 the same slots hold rows 0 .. 3 of psi_{s+1}, which has nothing to
+  // do there: phase 1 then holds 4 rows of psi, zc, acc, u_1, u_2, o and the partner buffer = 208 registers, phase 2 o, q, acc, u_1,
+  // 16 accumulators, the partner ring (+ 8 row accumulators with diagonal controls) = 176 - 208.  Every slot is written and read by
+  // its own thread only: no barrier concerns them.
+  static_assert(!U2L || (sizeof(T) == sizeof(double) && RPT == 8 && NI == 2), "difference-basis kernel: complex128, 8 rows per thread");
+  typedef float xs_f4 __attribute__((ext_vector_type(4)));
+  T2* Pk = Lm + D;              // [k NT + t], k < RPT / 2: psi rows during phase 1 ...
+  xs_f4* U2v = (xs_f4*)(Lm + D);   // ... and (u_2[2k], u_2[2k + 1]) during phase 2
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
+  const unsigned dsg = (DIAGCTL && tab.dstring) ? xs_diag_thread_signs(tab, t) : 0u;
   XsCtl ctl, ctlh;
   ctl.load_table(tab, ord, lane);
   if (SIGN) ctl.load_row_signs(tab, lane, __builtin_ctz(NT));
@@ -70,6 +84,11 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       const double* dgr = dgs + (long)s * dgs_step;
       T2 nd[NI][RPT];  // the interior node values lambda(s_i)
       T2 q[RPT];
+      T2 u2f[U2L ? RPT : 1];   // u_2 in the difference-basis kernels (nd[1] is not used there): fp64 while phase 1 accumulates it and forms q_0
+      if constexpr (U2L) {
+#pragma unroll
+        for (int k = 0; k < RPT / 2; ++k) Pk[k * NT + t] = cur[k];
+      }
       // ---- phase 1: lambda_s = sum_m z_m, node values ---------------------------------------------------------------------
       {
         T2 zc[RPT], acc[RPT];
@@ -83,9 +102,13 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           acc[r].x = g0 * zc[r].x;
           acc[r].y = g0 * zc[r].y;
 #pragma unroll
-          for (int i = 0; i < NI; ++i) {
+          for (int i = 0; i < (U2L ? NI - 1 : NI); ++i) {
             nd[i][r].x = cf0[i] * zc[r].x;
             nd[i][r].y = cf0[i] * zc[r].y;
+          }
+          if constexpr (U2L) {   // (c1[0][1] = c1[1][1] = 0: u_2 starts at the second-order term)
+            u2f[r].x = 0;
+            u2f[r].y = 0;
           }
         }
         publish(zc);
@@ -111,9 +134,13 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             acc[r].x = xs_fma(gm, ox, acc[r].x);
             acc[r].y = xs_fma(gm, oy, acc[r].y);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < (U2L ? NI - 1 : NI); ++i) {
               nd[i][r].x = xs_fma(cf[i], ox, nd[i][r].x);
               nd[i][r].y = xs_fma(cf[i], oy, nd[i][r].y);
+            }
+            if constexpr (U2L) {
+              u2f[r].x = xs_fma(cf[NI - 1], ox, u2f[r].x);
+              u2f[r].y = xs_fma(cf[NI - 1], oy, u2f[r].y);
             }
           }
           if (m < L) publish(zc);
@@ -127,13 +154,29 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           const T2 g = Lm[r * NT + t];
           T qx = xs_fma(w0, g.x, w1 * acc[r].x), qy = xs_fma(w0, g.y, w1 * acc[r].y);
 #pragma unroll
-          for (int i = 0; i < NI; ++i) {
+          for (int i = 0; i < (U2L ? NI - 1 : NI); ++i) {
             qx = xs_fma(cw[i], nd[i][r].x, qx);
             qy = xs_fma(cw[i], nd[i][r].y, qy);
+          }
+          if constexpr (U2L) {
+            qx = xs_fma(cw[NI - 1], u2f[r].x, qx);
+            qy = xs_fma(cw[NI - 1], u2f[r].y, qy);
           }
           q[r].x = qx;
           q[r].y = qy;
           Lm[r * NT + t] = acc[r];  // lambda_s (own rows only: no barrier concerns it)
+        }
+        if constexpr (U2L) {   // rows 0 .. 3 of psi_{s+1} come back, their slots take u_2
+#pragma unroll
+          for (int k = 0; k < RPT / 2; ++k) {
+            cur[k] = Pk[k * NT + t];
+            xs_f4 f;
+            f.x = (float)u2f[2 * k].x;
+            f.y = (float)u2f[2 * k].y;
+            f.z = (float)u2f[2 * k + 1].x;
+            f.w = (float)u2f[2 * k + 1].y;
+            U2v[k * NT + t] = f;
+          }
         }
       }
       XS_STAMP(1);
@@ -164,12 +207,22 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             const T2 g = Lm[r * NT + t];
             T qx = w1 * g.x, qy = w1 * g.y;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < (U2L ? NI - 1 : NI); ++i) {
               qx = xs_fma(cw[i], nd[i][r].x, qx);
               qy = xs_fma(cw[i], nd[i][r].y, qy);
             }
             q[r].x = qx;
             q[r].y = qy;
+          }
+          if constexpr (U2L) {
+#pragma unroll
+            for (int k = 0; k < RPT / 2; ++k) {
+              const xs_f4 f = U2v[k * NT + t];
+              q[2 * k].x = xs_fma(cw[NI - 1], (T)f.x, q[2 * k].x);
+              q[2 * k].y = xs_fma(cw[NI - 1], (T)f.y, q[2 * k].y);
+              q[2 * k + 1].x = xs_fma(cw[NI - 1], (T)f.z, q[2 * k + 1].x);
+              q[2 * k + 1].y = xs_fma(cw[NI - 1], (T)f.w, q[2 * k + 1].y);
+            }
           }
         }
         T2 o[RPT];
@@ -217,16 +270,20 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       }
       if (DIAGCTL) {
         double dv[XR_DMAX];
+        if (tab.dstring) {
+          xs_diag_string_sums<RPT>(tab, rowacc, dsg, __builtin_ctz(NT), dv);
+        } else {
 #pragma unroll
-        for (int jd = 0; jd < XR_DMAX; ++jd) dv[jd] = 0.0;
+          for (int jd = 0; jd < XR_DMAX; ++jd) dv[jd] = 0.0;
 #pragma clang loop unroll(disable)
-        for (int jd = 0; jd < tab.nd; ++jd) {
-          if (tab.dkid[jd] < 0) continue;
-          const double* dvr = tab.dval + (long)jd * D;
-          double v = 0.0;
+          for (int jd = 0; jd < tab.nd; ++jd) {
+            if (tab.dkid[jd] < 0) continue;
+            const double* dvr = tab.dval + (long)jd * D;
+            double v = 0.0;
 #pragma unroll
-          for (int r = 0; r < RPT; ++r) v = __builtin_fma(dvr[r * NT + t], rowacc[r], v);
-          xs_acc<0, XR_DMAX>(dv, jd, v);
+            for (int r = 0; r < RPT; ++r) v = __builtin_fma(dvr[r * NT + t], rowacc[r], v);
+            xs_acc<0, XR_DMAX>(dv, jd, v);
+          }
         }
         const double v = xs_wave_sums16(dv, lane);
         if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
@@ -253,22 +310,50 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
 
 namespace {
 
-// the quadrature form (tables of up to 16 XOR-diagonals, 4-point rule)
+// the quadrature form (tables of up to 16 XOR-diagonals, 4-point rule).  The headline's table class (real, unsigned, no diagonal
+// controls) keeps the node basis with both vectors in registers; every other class (parity signs, complex phases, diagonal controls:
+// the reference's own control sets -- ZZ-edge + X-vertex QAOA, demo_maxcut.py:71-79, and I/Q drives) runs the difference basis with
+// u_2 in LDS (qd.basis = 1, made by xs_quad_make for those tables): its 32 registers are what the sign state / the row accumulators need
+template <class T, int NT, int RPT, int SIGN, bool DIAGCTL, bool CPLX, bool U2L>
+hipError_t xs_backward_q_start(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const XsOrder& ord, const XsOrder& ordh,
+                               const double* wt, const double* dgs, long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd,
+                               double* part, hipStream_t st) {
+  typedef typename Cx<T>::type T2;
+  const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T)) + (U2L ? sizeof(float2) * (size_t)(NT * RPT) : 0);   // + the u_2 slots
+  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, XsQuad, double*) =
+      xs_backward_q_kernel<T, NT, RPT, SIGN, DIAGCTL, CPLX, 2, U2L>;
+  hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, qd, part);
+  return hipGetLastError();
+}
 template <class T, int NT, int RPT>
 hipError_t xs_backward_q_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
                             long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part, hipStream_t st) {
-  typedef typename Cx<T>::type T2;
-  if (!xs_quad_supported(tab, qd.ni, NT * RPT, xs_threads(NT * RPT, 0) == NT ? 0 : 1)) return hipErrorInvalidValue;
-  const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
-  // (xs_quad_supported: unsigned tables without diagonal controls only -- the one instantiation of the kernel's flag space that is built)
-  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, XsQuad, double*) =
-      xs_backward_q_kernel<T, NT, RPT, false, false, false, 2>;
-  hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
   const int var = xs_threads(NT * RPT, 0) == NT ? 0 : 1;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, var, true),
-                     xs_make_order(NT * RPT, tab, var, false), wt, dgs, dgs_step, S, B, L, qd, part);
-  return hipGetLastError();
+  if (!xs_quad_supported(tab, qd.ni, NT * RPT, var, sizeof(T))) return hipErrorInvalidValue;
+  const bool sgn = tab.sgn != nullptr, dc = xs_has_diag_controls(tab), cplx = xs_table_is_complex(tab);
+  if (cplx && !sgn) return hipErrorInvalidValue;  // (complex tables always carry sign words)
+  constexpr bool UL = sizeof(T) == sizeof(double) && RPT == 8;   // the shapes the difference-basis kernels are built for
+  if ((qd.basis != 0) != xs_quad_basis(tab, NT * RPT, var, sizeof(T))) return hipErrorInvalidValue;   // (the rule's tables are made for the kernel's basis)
+  if (qd.basis != 0 && !UL) return hipErrorInvalidValue;
+  const XsOrder ord = xs_make_order(NT * RPT, tab, var, true), ordh = xs_make_order(NT * RPT, tab, var, false);
+  const bool rs = xs_order_row_signs(ord) || xs_order_row_signs(ordh);   // SIGN = 2: some diagonal's sign has a row factor
+#define XS_QGO(SG, DC, CX, U) xs_backward_q_start<T, NT, RPT, SG, DC, CX, U>(psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st)
+#define XS_QSG(DC, CX, U) (rs ? XS_QGO(2, DC, CX, U) : XS_QGO(1, DC, CX, U))
+  if (!sgn && !dc && !qd.basis) return XS_QGO(0, false, false, false);
+  if constexpr (UL) {   // (signed tables / diagonal controls always take the difference basis on these shapes: xs_quad_basis)
+    if (!qd.basis) return hipErrorInvalidValue;
+    if (!sgn) return dc ? XS_QGO(0, true, false, true) : XS_QGO(0, false, false, true);
+    if (cplx) return dc ? XS_QSG(true, true, true) : XS_QSG(false, true, true);
+    return dc ? XS_QSG(true, false, true) : XS_QSG(false, false, true);
+  } else {
+    if (!sgn) return XS_QGO(0, true, false, false);
+    if (cplx) return dc ? XS_QSG(true, true, false) : XS_QSG(false, true, false);
+    return dc ? XS_QSG(true, false, false) : XS_QSG(false, false, false);
+  }
+#undef XS_QSG
+#undef XS_QGO
 }
 
 template <class T>

@@ -50,14 +50,16 @@ __device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
 // One XOR-diagonal's contribution with the partner values in v[]:  o += a_ij v,  a_ij = -i w sigma_ij (PH = 0: entries +-c) or
 // w sigma_ij (PH = 1: entries +-i c).  The phase is a template parameter (the host orders every class phase 0 first, so each loop is
 // of one phase: a runtime branch cost 16 register copies per diagonal where its two updates merged).
-// SIGN: the signs along a diagonal of a Pauli string are a parity, sigma_ij = (-1)^(s0_j + parity(i & z_j)); with i = r NT + t that is a
+// SIGN (0 / 1 / 2: unsigned table / parity signs whose masks stay within the thread bits / parity signs with row factors -- the loops
+// of row-signed diagonals are instantiated for 2 only: their code alone, never run, cost an X / Y-drive table 17 % of its adjoint sweep):
+// the signs along a diagonal of a Pauli string are a parity, sigma_ij = (-1)^(s0_j + parity(i & z_j)); with i = r NT + t that is a
 // factor per THREAD (bit j of tsg: s0_j ^ parity(t & z_j), folded into the weight once per diagonal) times a factor per ROW that is
 // the same for every thread (bit r of the diagonal's row mask: parity(r & (z_j / NT)), a scalar).  Most diagonals have no row
 // factor at all (z_j within the thread bits): their loop is the unsigned one with a per-thread weight.  (Round 3 kept a sign word per
 // row -- a shift, a mask and an xor per row and diagonal in every sweep, twice in the pairing sweeps.)
 // ej = table entry >> 20: the diagonal's index in the table (5 bits), row-sign bits of rows 1 .. 7 at bits 5 .. 11.
 // DOT: the level's gradient pairing of the partners with the thread's own rows xm, into lane `slot` of the accumulator vector.
-template <class T, int RPT, bool SIGN, bool DOT, int PH, bool RS = false>
+template <class T, int RPT, int SIGN, bool DOT, int PH, bool RS = false>
 __device__ __forceinline__ void xs_use(int ej, int slot, T w, unsigned tsg, const typename Cx<T>::type* v, typename Cx<T>::type* o,
                                        const typename Cx<T>::type* xm, double* dacc) {
   // RS: the diagonal has a row factor (the host orders those last within every class and phase: a loop of their own, no branch here)
@@ -120,10 +122,12 @@ struct XsCtl {
   int ent;    // xoff | phase << 16 | (index in the table: sign bit, accumulator) << 20 | row-sign bits << 25
   double w;   // dt u c_j of the current step
   int perm;   // this lane's index in the table
+  unsigned long long gmask;   // XsOrder::gmask: which loops of the walk have diagonals
   int rsn;    // lane g: how many diagonals of group g (its LAST ones) carry a row factor of the sign; groups: LDS class 0 / 1 by phase
               // (0, 1 / 2, 3), then the register classes xh = 1 .. 7 by phase (4 + 2 (xh - 1) + phase)
   __device__ __forceinline__ void load_table(const XrTab& tab, const XsOrder& ord, int lane) {
     rsn = lane < 18 ? ord.rsn[lane] : 0;
+    gmask = ord.gmask;
     R = tab.R;
     n0 = ord.n0;
     n1 = ord.n1;
@@ -192,6 +196,12 @@ __device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __r
 #ifndef XS_PAIR_LOCAL
 #define XS_PAIR_LOCAL 1   // quadrature form: the pairing sweeps take the partners at offsets without lane bits from registers
 #endif
+#ifndef XS_NO_RS
+#define XS_NO_RS 0        // probe builds: 1 = the loops of diagonals with a row factor of the sign are not instantiated
+#endif
+#ifndef XS_RING_SLOTS_DEPTH
+#define XS_RING_SLOTS_DEPTH 1   // 1: the ring has DEPTH slots instead of one per row (see xs_lds_ring); 0: a slot per row (round 4)
+#endif
 #ifndef XS_RING_DEPTH_PLAIN
 #define XS_RING_DEPTH_PLAIN 8
 #endif
@@ -223,7 +233,7 @@ __device__ __forceinline__ void xs_rows(F&& f) {
 }
 // one row's share of a diagonal: o += a_ij v and, with DOT, the pairing sums in four chains s[0..3]
 // (sbit: the ROW's factor of the sign, a scalar; the thread's factor is in w and, for the pairing, applied to the diagonal's total)
-template <bool SIGN, bool DOT, int PH, int R>
+template <int SIGN, bool DOT, int PH, int R>
 __device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, double2& o, const double2* xm, double* s) {
   if (SIGN && DOT) {  // the row's sign goes into the partner value (both uses take it from there)
     v.x = xs_flip(v.x, sbit);
@@ -251,12 +261,16 @@ __device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, do
 }
 // DEPTH = reads in flight (the read of element k + DEPTH of the class's (diagonal, row) sequence is issued right after element k
 // has been used; DEPTH = RPT: a slot is refilled with the same row of the next diagonal)
-template <int NT, int RPT, bool SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH, bool RS>
+// NSLOT: registers of the ring in complex numbers -- RPT (a slot per row) or DEPTH (RPT a multiple of DEPTH: element k of the class's
+// (diagonal, row) sequence lives in slot k % DEPTH and its slot takes the read of element k + DEPTH as soon as it has been used: the
+// same schedule in half the registers at DEPTH = 4, for the kernels that have none to spare)
+template <int NT, int RPT, int SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH, bool RS, int NSLOT = RPT>
 __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, unsigned sg, const double2* __restrict__ src, int t,
                                             double sgn, double2* o, const double2* xm, double* dacc) {
   static_assert(DEPTH >= 1 && DEPTH <= RPT, "ring depth");
+  static_assert(NSLOT == RPT || (NSLOT == DEPTH && RPT % DEPTH == 0), "ring slots");
   if (n <= 0) return;
-  xs_d2 v[RPT];
+  xs_d2 v[NSLOT];
   const unsigned base = xs_lds_addr(src);
   int e = __builtin_amdgcn_readlane(ctl.ent, q0);
   unsigned a = base + (unsigned)((t ^ (e & (NT - 1))) << 4);
@@ -266,7 +280,7 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
     if constexpr (PERM) xs_ds_read_first<0>(v[r], a + (unsigned)(((r ^ xh) * NT) << 4));
     else xs_ds_read_first<r * NT * 16>(v[r], a);
   });
-  xs_rows<DEPTH, RPT>([&](auto rc) { v[decltype(rc)::value] = 0.0; });  // (defined before their first in/out use)
+  xs_rows<DEPTH, NSLOT>([&](auto rc) { v[decltype(rc)::value] = 0.0; });  // (defined before their first in/out use)
   const int qe = q0 + n;
   auto finish = [&](int q, const double* s, unsigned tb) {
     if (DOT) {
@@ -284,15 +298,15 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     xs_rows<0, RPT>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      xs_ds_wait<DEPTH - 1>(v[r]);
-      xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r], o[r], xm, s);
+      xs_ds_wait<DEPTH - 1>(v[r % NSLOT]);
+      xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r % NSLOT], o[r], xm, s);
       constexpr int k = r + DEPTH;  // the element whose read goes out now
       if constexpr (k < RPT) {
-        if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
-        else xs_ds_read_next<k * NT * 16>(v[k], a);
+        if constexpr (PERM) xs_ds_read_next<0>(v[k % NSLOT], a + (unsigned)(((k ^ xh) * NT) << 4));
+        else xs_ds_read_next<k * NT * 16>(v[k % NSLOT], a);
       } else {
-        if constexpr (PERM) xs_ds_read_next<0>(v[k - RPT], an + (unsigned)((((k - RPT) ^ xhn) * NT) << 4));
-        else xs_ds_read_next<(k - RPT) * NT * 16>(v[k - RPT], an);
+        if constexpr (PERM) xs_ds_read_next<0>(v[(k - RPT) % NSLOT], an + (unsigned)((((k - RPT) ^ xhn) * NT) << 4));
+        else xs_ds_read_next<(k - RPT) * NT * 16>(v[(k - RPT) % NSLOT], an);
       }
     });
     finish(q, s, tb);
@@ -306,12 +320,12 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     xs_rows<0, RPT>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      xs_ds_wait<(RPT - 1 - r < DEPTH - 1 ? RPT - 1 - r : DEPTH - 1)>(v[r]);
-      xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r], o[r], xm, s);
+      xs_ds_wait<(RPT - 1 - r < DEPTH - 1 ? RPT - 1 - r : DEPTH - 1)>(v[r % NSLOT]);
+      xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r % NSLOT], o[r], xm, s);
       constexpr int k = r + DEPTH;
       if constexpr (k < RPT) {
-        if constexpr (PERM) xs_ds_read_next<0>(v[k], a + (unsigned)(((k ^ xh) * NT) << 4));
-        else xs_ds_read_next<k * NT * 16>(v[k], a);
+        if constexpr (PERM) xs_ds_read_next<0>(v[k % NSLOT], a + (unsigned)(((k ^ xh) * NT) << 4));
+        else xs_ds_read_next<k * NT * 16>(v[k % NSLOT], a);
       }
     });
     finish(qe - 1, s, tb);
@@ -319,14 +333,15 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
 }
 
 // the n diagonals q0 .. q0 + n - 1 of one LDS class; PREF: the next diagonal's partners are fetched while this one's are used
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0, bool RS = false>
+template <class T, int NT, int RPT, int SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0, bool RS = false>
 __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, unsigned sg,
                                              const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
                                              const typename Cx<T>::type* xm, double* dacc) {  // (SB: accumulator lane = position - SB)
   typedef typename Cx<T>::type T2;
   if (n <= 0) return;
   if constexpr (!PREF && RPT == 8 && sizeof(T) == sizeof(double) && ((DOT && XS_RING_PAIR) || (!DOT && XS_RING_PLAIN))) {
-    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN, RS>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
+    constexpr int DEPTH = DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN;
+    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DEPTH, RS, (XS_RING_SLOTS_DEPTH && RPT % DEPTH == 0) ? DEPTH : RPT>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
     return;
   }
   if (PREF) {
@@ -359,17 +374,19 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, un
 }
 
 // a group = one LDS class and phase: its diagonals without a row factor of the sign, then (signed tables) those with one
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0>
+template <class T, int NT, int RPT, int SIGN, bool DOT, int RM, bool PERM, bool PREF, int PH, int SB = 0>
 __device__ __forceinline__ void xs_lds_group(const XsCtl& ctl, int q0, int n, unsigned sg, const typename Cx<T>::type* __restrict__ src,
                                              int t, T sgn, typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
-  if constexpr (SIGN) {
+  constexpr int G = (PERM ? 4 : 0) + PH * 2;   // the group's two loops in XsOrder::gmask
+  if (((unsigned)(ctl.gmask >> G) & 3u) == 0u) return;
+  if constexpr (SIGN == 2 && !XS_NO_RS) {
     int nrs = __builtin_amdgcn_readlane(ctl.rsn, (PERM ? 2 : 0) + PH);
     // (a caller may pass a part of the group -- the pairing sweeps split at accumulator 16: the row-signed ones are the group's last)
     const int g_end = (PERM ? ctl.n0 + ctl.n1 : ctl.n0) - (PH ? 0 : (PERM ? ctl.n1p1 : ctl.n0p1));
     const int rs0 = g_end - nrs;                         // first row-signed position of the group
     const int qe = q0 + n, cut = rs0 < q0 ? q0 : (rs0 > qe ? qe : rs0);
-    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, false>(ctl, q0, cut - q0, sg, src, t, sgn, o, xm, dacc);
-    xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, true>(ctl, cut, qe - cut, sg, src, t, sgn, o, xm, dacc);
+    if ((unsigned)(ctl.gmask >> G) & 1u) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, false>(ctl, q0, cut - q0, sg, src, t, sgn, o, xm, dacc);
+    if ((unsigned)(ctl.gmask >> G) & 2u) xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, true>(ctl, cut, qe - cut, sg, src, t, sgn, o, xm, dacc);
   } else {
     xs_lds_class<T, NT, RPT, SIGN, DOT, RM, PERM, PREF, PH, SB, false>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
   }
@@ -377,7 +394,7 @@ __device__ __forceinline__ void xs_lds_group(const XsCtl& ctl, int q0, int n, un
 
 // a class of a pairing sweep with up to 32 diagonals: positions below 16 accumulate into the first accumulator vector, the others
 // into the second -- two instantiations of the loop, no per-diagonal choice of the vector
-template <class T, int NT, int RPT, bool SIGN, int RM, bool PERM, int PH>
+template <class T, int NT, int RPT, int SIGN, int RM, bool PERM, int PH>
 __device__ __forceinline__ void xs_pair_class(const XsCtl& ctl, int q0, int n, unsigned sg,
                                               const typename Cx<T>::type* __restrict__ src, int t, T sgn, typename Cx<T>::type* o,
                                               const typename Cx<T>::type* xm, xs_acc16* dacc) {
@@ -391,7 +408,7 @@ __device__ __forceinline__ void xs_pair_class(const XsCtl& ctl, int q0, int n, u
 }
 
 // the pairing sweep (Horner on lambda): o += sgn (A - diag) v with every partner from LDS, in the order of ctl (no register class)
-template <class T, int NT, int RPT, bool SIGN, int RM, bool CPLX>
+template <class T, int NT, int RPT, int SIGN, int RM, bool CPLX>
 __device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, unsigned sg, const typename Cx<T>::type* __restrict__ src,
                                                    int t, T sgn, typename Cx<T>::type* o, const typename Cx<T>::type* xm,
                                                    xs_acc16* dacc) {
@@ -402,7 +419,7 @@ __device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, unsigned sg
 }
 
 // the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class, phase 0 then phase 1
-template <class T, int RPT, int XH, bool SIGN, bool DOT, int PH, bool RS = false>
+template <class T, int RPT, int XH, int SIGN, bool DOT, int PH, bool RS = false>
 __device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                             typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
 #pragma clang loop unroll(disable)
@@ -416,24 +433,29 @@ __device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, unsi
   return q;
 }
 // one register class and phase: the diagonals without a row factor of the sign, then those with one
-template <class T, int RPT, int XH, bool SIGN, bool DOT, int PH>
+template <class T, int RPT, int XH, int SIGN, bool DOT, int PH>
 __device__ __forceinline__ int xs_local_group(const XsCtl& ctl, int q, int n, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                               typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
-  if constexpr (SIGN) {
+  constexpr int G = 8 + (XH - 1) * 4 + PH * 2;
+  if constexpr (SIGN == 2 && !XS_NO_RS) {
+    if (((unsigned)(ctl.gmask >> G) & 3u) == 0u) return q;
     int nrs = __builtin_amdgcn_readlane(ctl.rsn, 4 + 2 * (XH - 1) + PH);
     nrs = nrs > n ? n : nrs;
-    q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, false>(ctl, q, n - nrs, sg, cur, sgn, o, xm, dacc);
-    return xs_local_run<T, RPT, XH, SIGN, DOT, PH, true>(ctl, q, nrs, sg, cur, sgn, o, xm, dacc);
+    if ((unsigned)(ctl.gmask >> G) & 1u) q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, false>(ctl, q, n - nrs, sg, cur, sgn, o, xm, dacc);
+    if ((unsigned)(ctl.gmask >> G) & 2u) q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, true>(ctl, q, nrs, sg, cur, sgn, o, xm, dacc);
+    return q;
   } else {
     return xs_local_run<T, RPT, XH, SIGN, DOT, PH, false>(ctl, q, n, sg, cur, sgn, o, xm, dacc);
   }
 }
-template <class T, int RPT, int XH, bool SIGN, bool DOT, bool CPLX>
+template <class T, int RPT, int XH, int SIGN, bool DOT, bool CPLX>
 __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                                  typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
   if constexpr (XH < RPT && XH < 8) {
-    q = xs_local_group<T, RPT, XH, SIGN, DOT, 0>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
-    if constexpr (CPLX) q = xs_local_group<T, RPT, XH, SIGN, DOT, 1>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    if (((unsigned)(ctl.gmask >> (8 + (XH - 1) * 4)) & 15u) != 0u) {   // (an empty class: one test)
+      q = xs_local_group<T, RPT, XH, SIGN, DOT, 0>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+      if constexpr (CPLX) q = xs_local_group<T, RPT, XH, SIGN, DOT, 1>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+    }
     xs_local_classes<T, RPT, XH + 1, SIGN, DOT, CPLX>(ctl, q, sg, cur, sgn, o, xm, dacc);
   }
 }
@@ -443,14 +465,14 @@ __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, unsign
 // partner is read from LDS and the caller's copy of v need not stay in registers.  DOT: the sweep carries the gradient pairings; dacc is then an xs_acc16 indexed by the diagonal's SORTED
 // position (xs_finish_kernel maps back).
 // CPLX = false (real tables: every phase 0): the phase-1 loops are not even instantiated (their code alone cost the real kernels 4 %).
-template <class T, int NT, int RPT, bool SIGN, bool DOT, int RM, bool PREF, bool LOCAL, bool CPLX, bool STAGGER = false>
+template <class T, int NT, int RPT, int SIGN, bool DOT, int RM, bool PREF, bool LOCAL, bool CPLX, bool STAGGER = false>
 __device__ __forceinline__ void xs_gather(const XsCtl& ctl, unsigned sg, const typename Cx<T>::type* __restrict__ src,
                                           const typename Cx<T>::type* cur, int t, T sgn, typename Cx<T>::type* o,
                                           const typename Cx<T>::type* xm, double* dacc) {
   // STAGGER: the two waves that share a SIMD (w and w + 4 of a 512-thread workgroup) walk a plain sweep in opposite order of its two
   // kinds of work -- one starts with the register partners (vector work only) while the other issues its LDS reads.  Measured at
   // d = B = 4096 (tools/statecol_probe.hip): phase 1 of the quadrature adjoint -2.4 % per launch, the forward kernel +1.5 % (not used there)
-  const bool local_first = STAGGER && LOCAL && !DOT && NT >= 512 && ((t >> 8) & 1);
+  const bool local_first = STAGGER && SIGN == 0 && LOCAL && !DOT && NT >= 512 && ((t >> 8) & 1);   // (unsigned tables only: the second copy of the register classes is code the signed kernels have enough of)
   if (local_first) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
   xs_lds_group<T, NT, RPT, SIGN, DOT, RM, false, PREF, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
   if constexpr (CPLX) xs_lds_group<T, NT, RPT, SIGN, DOT, RM, false, PREF, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, xm, dacc);
@@ -495,6 +517,47 @@ __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
   return v;  // lane l: the total of value (l & 15)
 }
 
+// Diagonal controls that are Z-strings (XrTab::dstring): the step's sums sum_i D_jd[i] rho[i] over the thread's rows, rho = rowacc.
+// D_jd[i] = dmag (-1)^parity(i & z), i = r NT + t: the rows' factor parity(r & (z / NT)) makes the sum over r a Walsh-Hadamard
+// coefficient of rowacc (all RPT of them: RPT log2 RPT additions), the thread's factor parity(t & z) is one sign flip per source
+// (bit jd of dsg).  dv[jd] = this thread's share of source jd.  Replaces nd x RPT table reads per thread and step (they were 19 k of
+// the 22 k cycles a ring-QAOA step spent after its sweeps).
+template <int RPT>
+__device__ __forceinline__ void xs_diag_string_sums(const XrTab& tab, const double* rowacc, unsigned dsg, int log_nt, double* dv) {
+  typedef double wvec __attribute__((ext_vector_type(8)));
+  static_assert(RPT <= 8, "rows per thread");
+  wvec w = 0.0;
+  {
+    double a[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = r < RPT ? rowacc[r] : 0.0;
+#pragma unroll
+    for (int h = 1; h < 8; h <<= 1) {
+      double b[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) b[r] = (r & h) ? a[r ^ h] - a[r] : a[r] + a[r ^ h];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) a[r] = b[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r] = a[r];   // w[zh] = sum_r (-1)^parity(r & zh) rowacc[r]
+  }
+#pragma unroll
+  for (int jd = 0; jd < XR_DMAX; ++jd) {
+    dv[jd] = 0.0;
+    if (jd < tab.nd && tab.dkid[jd] >= 0) {
+      const int zh = (int)(tab.dzmask[jd] >> log_nt) & 7;
+      dv[jd] = xs_flip(tab.dmag[jd] * w[zh], (dsg >> jd) & 1u);
+    }
+  }
+}
+// bit jd: this thread's factor of Z-string source jd, parity(t & dzmask[jd])
+__device__ __forceinline__ unsigned xs_diag_thread_signs(const XrTab& tab, int t) {
+  unsigned w = 0;
+  for (int jd = 0; jd < tab.nd; ++jd) w |= (unsigned)(__popc((unsigned)t & tab.dzmask[jd]) & 1) << jd;
+  return w;
+}
+
 #ifdef XS_STAMPS
 // development builds (tools/statecol_probe.hip): shader cycles per phase of the backward kernel, summed over workgroups
 __device__ unsigned long long xs_stamps[8];
@@ -522,6 +585,7 @@ size_t xs_lds_bytes(int d, size_t elem);
 int xs_threads(int d, int variant);
 bool xs_has_diag_controls(const XrTab& tab);
 XsOrder xs_make_order(int d, const XrTab& tab, int variant, bool local);
+bool xs_order_row_signs(const XsOrder& o);
 // the adjoint kernels by form (statecol_bwd.hip / statecol_bwdq.hip); `variant` as in xs_backward_launch
 template <class T>
 hipError_t xs_backward_exact_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):
@@ -36,9 +38,16 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def oracle():
-    """The CPU restatement of the reference path (test infrastructure, see oracle/trotter_oracle.py)."""
+    """The CPU restatement of the reference path (test infrastructure, see oracle/trotter_oracle.py), behind the memo of its slow
+    evaluations (tests/oracle_memo.py: answers of byte-identical earlier calls come from tests/golden/oracle_memo.npz)."""
     from oracle import trotter_oracle
-    return trotter_oracle
+    from oracle_memo import OracleMemo
+    memo = OracleMemo(trotter_oracle)
+    yield memo
+    memo.flush()
+    if memo.hits or memo.misses:
+        print("\noracle memo: {} calls answered from the fixture ({:.0f} s of oracle time), {} computed".format(
+            memo.hits, memo.seconds_saved, memo.misses))
 
 
 @pytest.fixture(scope="session")

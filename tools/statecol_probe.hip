@@ -210,21 +210,60 @@ int main(int argc, char** argv) {
   const int variant = argc > 5 ? atoi(argv[5]) : 2;
   const int forms = argc > 6 ? atoi(argv[6]) : 3;   // bit 0: the exact adjoint form, bit 1: the quadrature form
   const int econ = argc > 7 ? atoi(argv[7]) : 1;
+  // table: 0 = Ising drift + X_k (BASELINE's generator: real, unsigned), 1 = X_k on half of the qubits and Y_k on the others (I/Q drives:
+  // complex, parity-signed), 2 = ring QAOA (drift + ZZ-edge controls on the diagonal, X-vertex controls; demo_maxcut.py:71-79),
+  // 3 = X_k on half of the qubits, Z_k on the others
+  const int kind = argc > 8 ? atoi(argv[8]) : 0;
   dq::XsPoly pol;
   {
     const int Le = dq::xs_poly_make(0.03, 1.1102230246251565e-16, econ, &pol);
     if (econ) L = Le;
   }
-  const int d = 1 << n, K = n;
+  const int d = 1 << n, K = kind == 2 ? 2 * n : n;
   dq::XrTab tab;
   memset(&tab, 0, sizeof(tab));
-  tab.R = n;
   tab.nd = 1;
-  for (int j = 0; j < n; ++j) { tab.xoff[j] = 1 << (n - 1 - j); tab.kid[j] = j; tab.cmag[j] = 1.0; tab.phase[j] = 0; }
   tab.dkid[0] = -1;
-  std::vector<double> dval(d), u((size_t)S * K);
+  std::vector<unsigned> sgn;
   srand(1);
+  std::vector<double> dval(d);
   for (auto& v : dval) v = 20.0 * (rand() / (double)RAND_MAX - 0.5);
+  if (kind == 0) {
+    tab.R = n;
+    for (int j = 0; j < n; ++j) { tab.xoff[j] = 1 << (n - 1 - j); tab.kid[j] = j; tab.cmag[j] = 1.0; tab.phase[j] = 0; }
+  } else if (kind == 1) {
+    tab.R = n;
+    sgn.assign(d, 0u);
+    for (int j = 0; j < n; ++j) {
+      tab.xoff[j] = 1 << (n - 1 - j); tab.kid[j] = j; tab.cmag[j] = 1.0;
+      tab.phase[j] = j < n / 2 ? 0 : 1;   // Y[0][1] = -i, Y[1][0] = +i: row i carries -i where its bit is clear
+      if (tab.phase[j]) for (int i = 0; i < d; ++i) if (!(i & tab.xoff[j])) sgn[i] |= 1u << j;
+    }
+  } else if (kind == 2) {
+    tab.R = n;
+    for (int j = 0; j < n; ++j) { tab.xoff[j] = 1 << (n - 1 - j); tab.kid[j] = n + j; tab.cmag[j] = 1.0; tab.phase[j] = 0; }
+    tab.nd = 1 + n;
+    dval.assign((size_t)(1 + n) * d, 0.0);
+    for (int e = 0; e < n; ++e) {
+      tab.dkid[1 + e] = e;
+      const int a = 1 << (n - 1 - e), b = 1 << (n - 1 - (e + 1) % n);
+      for (int i = 0; i < d; ++i) {
+        const double zz = ((i & a) ? -1.0 : 1.0) * ((i & b) ? -1.0 : 1.0);
+        dval[(size_t)(1 + e) * d + i] = zz;
+        dval[i] += 1.0 - zz;
+      }
+    }
+  } else {
+    tab.R = n / 2;
+    for (int j = 0; j < n / 2; ++j) { tab.xoff[j] = 1 << (n - 1 - j); tab.kid[j] = j; tab.cmag[j] = 1.0; tab.phase[j] = 0; }
+    tab.nd = 1 + (n - n / 2);
+    dval.resize((size_t)tab.nd * d);
+    for (int j = n / 2; j < n; ++j) {
+      tab.dkid[1 + j - n / 2] = j;
+      for (int i = 0; i < d; ++i) dval[(size_t)(1 + j - n / 2) * d + i] = (i & (1 << (n - 1 - j))) ? -1.0 : 1.0;
+    }
+  }
+  std::vector<double> u((size_t)S * K);
   for (auto& v : u) v = 2.0 * (rand() / (double)RAND_MAX - 0.5);
   std::vector<double2> psi((size_t)B * d), lam((size_t)B * d);
   for (auto& v : psi) { v.x = rand() / (double)RAND_MAX - 0.5; v.y = rand() / (double)RAND_MAX - 0.5; }
@@ -232,14 +271,20 @@ int main(int argc, char** argv) {
   double *d_dval, *d_u, *d_wt, *d_dgs, *d_part, *d_grad;
   double2 *d_in, *d_psi, *d_lam, *d_park;
   const int nblk = dq::xs_blocks(d, 8, B, 256, variant);
-  CK(hipMalloc(&d_dval, sizeof(double) * d));
+  CK(hipMalloc(&d_dval, sizeof(double) * dval.size()));
+  unsigned* d_sgn = nullptr;
+  if (!sgn.empty()) {
+    CK(hipMalloc(&d_sgn, sizeof(unsigned) * d));
+    CK(hipMemcpy(d_sgn, sgn.data(), sizeof(unsigned) * d, hipMemcpyHostToDevice));
+  }
   CK(hipMalloc(&d_u, sizeof(double) * u.size()));
-  CK(hipMalloc(&d_wt, sizeof(double) * S * n));
-  CK(hipMemcpy(d_dval, dval.data(), sizeof(double) * d, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_wt, sizeof(double) * S * tab.R));
+  CK(hipMemcpy(d_dval, dval.data(), sizeof(double) * dval.size(), hipMemcpyHostToDevice));
   CK(hipMemcpy(d_u, u.data(), sizeof(double) * u.size(), hipMemcpyHostToDevice));
   tab.dval = d_dval;
-  tab.sgn = nullptr;
-  dq::xr_parity_signs(tab, nullptr, d);
+  tab.sgn = d_sgn;
+  dq::xr_parity_signs(tab, sgn.empty() ? nullptr : sgn.data(), d);
+  dq::xr_diag_strings(tab, getenv("XS_NO_DSTRING") ? nullptr : dval.data(), d);
   CK(hipMalloc(&d_dgs, sizeof(double) * dq::xs_dgs_doubles(d, S, tab)));
   CK(hipMalloc(&d_part, sizeof(double) * dq::xs_part_doubles(d, S, nblk, tab, variant)));
   CK(hipMalloc(&d_grad, sizeof(double) * S * K));
@@ -254,7 +299,8 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   dq::XsQuad quad;
-  if (!dq::xs_quad_make(0.03, 9.1e-13, 2, L, econ, pol, &quad)) { printf("no quadrature rule\n"); return 1; }
+  if (!dq::xs_quad_make(0.03, 9.1e-13, 2, L, econ, pol, &quad, dq::xs_quad_basis(tab, d, variant, sizeof(double)) ? 1 : 0)) { printf("no quadrature rule\n"); return 1; }
+  printf("table kind %d: R = %d, diagonal sources %d, signed %d, complex %d, quadrature basis %d\n", kind, tab.R, tab.nd, (int)(tab.sgn != nullptr), (int)dq::xs_table_is_complex(tab), quad.basis);
   std::vector<double> g_exact((size_t)S * K), g_quad((size_t)S * K);
   for (int form = 0; form < 2; ++form) {
   if (!((forms >> form) & 1)) continue;
@@ -293,7 +339,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < g_exact.size(); ++i) { gd = fmax(gd, fabs(g_exact[i] - g_quad[i])); gm = fmax(gm, fabs(g_exact[i])); }
     printf("max |grad (quadrature) - grad (exact form)| = %.3e  (max |grad| %.3e)\n", gd, gm);
   }
-  if (n == 12 && econ) {   // the two-workgroups-per-CU forward experiment against the library's forward kernel
+  if (n == 12 && econ && kind == 0 && argc > 9) {   // the two-workgroups-per-CU forward experiment against the library's forward kernel
     double2 *d_alt, *d_alt2;
     CK(hipMalloc(&d_alt, sizeof(double2) * psi.size()));
     CK(hipMalloc(&d_alt2, sizeof(double2) * psi.size()));
