@@ -171,6 +171,7 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
                                "random Ising drift, X_k controls on half of the qubits and Y_k controls on the other half (I/Q drives): complex "
                                "Hermitian and a sum of Pauli strings -- the state-column form in complex arithmetic (statecol.hip)")
         ent["state_columns"] = e3.info("state_columns")
+        ent["state_columns_quad_nodes"] = e3.info("state_columns_quad_nodes")
         out["xy_drives_state_columns"] = ent
         e3.set_option("state_columns", 0)
         ent, g3 = scheme_entry(e3, torch, u_dev, a.dt, psi0, d, K,
@@ -184,6 +185,23 @@ def by_input_structure(eng, a, dev, u_all, psi0, grad_ref, loss_ref):
                                "the same X / Y-drive inputs on the general complex tape (structure ignored)")
         ent["max_abs_grad_diff_vs_column_form"] = float((g4 - g3).abs().max().item())
         out["xy_drives_complex_tape"] = ent
+    torch.cuda.empty_cache()
+    # (4) the reference's own control set (demo_maxcut.py:44-79) at the headline's size: ring QAOA, ZZ-edge controls on the diagonal and
+    # X-vertex controls, K = 2 n; pulse amplitudes of the same scale (the table's first n columns twice)
+    H0, Hs, M = problems.qaoa_ring_torch(n, dev)
+    with Engine(d, 2 * n, device=dev.index or 0) as e4:
+        e4.use_torch_stream()
+        e4.set_hamiltonians(H0, Hs)
+        e4.set_observable(M)
+        e4.set_option("plan_steps", max(a.chain, K))
+        del H0, Hs, M
+        u2 = torch.cat([u_dev, u_dev], dim=1).contiguous()
+        ent, _ = scheme_entry(e4, torch, u2, a.dt, psi0, d, K,
+                              "ring analog QAOA at n = 12 (the reference demo's Hamiltonians, demo_maxcut.py:44-79): drift sum_e (I - Z_i Z_j), "
+                              "12 ZZ-edge controls (diagonal) + 12 X-vertex controls -- state columns, quadrature adjoint in the difference basis")
+        ent["state_columns"] = e4.info("state_columns")
+        ent["state_columns_quad_nodes"] = e4.info("state_columns_quad_nodes")
+        out["qaoa_zz_x_n12"] = ent
     torch.cuda.empty_cache()
     return out
 

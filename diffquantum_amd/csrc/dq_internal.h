@@ -330,8 +330,11 @@ struct XsPoly {
   double g[XS_LMAX + 1];
 };
 // time segments of a forward launch (xs_forward_segments_launch): cols = columns per segment (0: none), total = steps of the table
+// phase: the launch's scalar factor (see xs_center_launch) -- seg_phase[2 g], [2 g + 1] for the columns of time segment g, or (pr, pi)
 struct XsSeg {
   int cols, total;
+  const double* seg_phase;
+  double pr, pi;
 };
 // the lowest degree whose error bound stays below tol for steps of size <= theta (0: none up to XS_LMAX) and its level factors;
 // economize = 0: Taylor (g = 1).  Steps of theta > 2 keep Taylor (the power form of a Chebyshev sum loses digits as theta grows).
@@ -376,24 +379,32 @@ hipError_t xs_diag_costate_launch(const float2* psi, const double* mdiag, float2
 size_t xs_dgs_doubles(int d, int S, const XrTab& tab);       // doubles of the diagonal-weight table
 hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
                              hipStream_t st);
+// Centred diagonal (round 5).  A step's generator A = -i (Dg + offdiagonal), Dg = the rows' diagonal weights (dgs).  Subtracting the
+// midpoint c of Dg's range changes exp(A) by the scalar e^{-i c} only, and leaves a generator whose norm is half the RANGE of Dg plus
+// the off-diagonal row sum -- for a drift like the reference demo's sum_e (I - Z_i Z_j) >= 0 (demo_maxcut.py:44-58) half of what the
+// uncentred bound gives, one polynomial degree = one sweep in every pass.  xs_center_launch rewrites every row of the table in place
+// as Dg - c and leaves c and the half-range per row (rows = S with diagonal controls, else 1); the kernels run in that frame and the
+// launches apply the product of the steps' scalars once: the forward launch multiplies its outputs by (pr, pi) = e^{-i sum c}, the
+// adjoint launch its inputs by e^{+i sum c} (psi and lambda alike: their pairings do not see the frame).
+hipError_t xs_center_launch(double* dgs, int d, int rows, double* cen, double* half, hipStream_t st);
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, double pr, double pi, hipStream_t st);
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, double pr, double pi, hipStream_t st);
 // the propagators of n_seg consecutive time segments (columns of the identity through the forward kernel): out[(g d + i) d ..] =
 // column i of segment g's propagator, i.e. block g is the propagator's transpose
 hipError_t xs_forward_segments_launch(double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
-                                      hipStream_t st);
+                                      const double* seg_phase, hipStream_t st);   // seg_phase: [n_seg][2] on the device, or null
 hipError_t xs_forward_segments_launch(float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
-                                      hipStream_t st);
+                                      const double* seg_phase, hipStream_t st);
 // psi: psi_S in, psi_0 out;  lam: lambda_S in, lambda_0 out;  grad[s][k] (+)= dL/du_k[s]
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
-                              int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st);  // quad != null: the quadrature form (park unused); poly = null: Taylor
+                              int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, double pr, double pi, hipStream_t st);  // quad != null: the quadrature form (park unused); poly = null: Taylor; (pr, pi): the factor the inputs take (centred diagonal)
 hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
-                              int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st);
+                              int variant, const XsQuad* quad, const XsPoly* poly, double pr, double pi, hipStream_t st);
 
 }  // namespace dq

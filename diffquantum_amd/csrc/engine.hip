@@ -325,7 +325,8 @@ struct Ctx : dq_ctx {
   std::vector<double> tab_dval_h;
   int xs_workgroups = 0;                       // > 0: at most that many workgroups per launch (tests of the several-columns-per-workgroup loop)
   double xs_part_bytes = 268435456.0;          // scratch of the adjoint sweep's per-step partial sums: the chain is swept in segments that fit
-  double xs_quad_tol = 9.094947017729282e-13;  // 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step
+  double xs_quad_tol = sizeof(T) == 8 ? 9.094947017729282e-13 : 1e-7;  // complex128: 2^-40, relative to ||dA_k|| ||lambda|| ||psi|| per step; complex64: at fp32 rounding (the
+                                                                       // 4-point rule then serves steps up to theta = 0.37 instead of 0.05)
   int xs_wide_mode = -1;                       // energy gradients of batches wider than the dimension on dim columns (do_energy_grad_xs_wide): -1 by cost (default), 0 off, 1 on
   double last_xs_wide = 0;
   int xs_compose_mode = -1;                    // products of a chain's propagators (composed forward, time slices) from state columns: -1 auto, 0 off
@@ -338,6 +339,12 @@ struct Ctx : dq_ctx {
   double last_xs_taylor_degree = 0;            // the Taylor degree the same tolerance would have needed
   double last_xs_segments = 0;                 // launches the last adjoint sweep was split into
   double last_xs_nodes = 0;                    // interior nodes of the rule the last adjoint sweep ran (0: the exact form)
+  // centred diagonal of the state-column kernels (dq_internal.h, xs_center_launch): 1 (default) on, 0 off
+  int xs_center = 1;
+  double last_xs_centered = 0;                 // 1 when the last state-column call ran in the centred frame
+  double last_xs_theta_loose = 0;              // the step bound from the sources' norms (what the degree came from before round 5)
+  DevBuf xs_cen, xs_segphase;
+  std::vector<double> uh_last;                 // host copy of the last pulse table (fetch_u)
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
   bool sparse_h = false;   // a CSR exists (controls, and the drift too if sparse_x)
@@ -1121,6 +1128,7 @@ std::vector<double> fetch_u(Ctx<T>* c, const double* u, int S) {
   c->u_dev.ensure(std::max<size_t>(n, 1) * sizeof(double));
   HIPCK(hipMemcpyAsync(c->u_dev.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPCK(hipStreamSynchronize(c->st));  // h may be pageable
+  c->uh_last = h;
   return h;
 }
 
@@ -1382,6 +1390,9 @@ int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B,
   const dq::XrTab* tab = xs_table(c);
   if (!tab) return 0;
   // the options that pin another scheme keep it
+  // (compose = 0 / 1 pins the scheme of the STATES -- swept one by one through explicit propagators / one product applied once.  Under
+  // compose = 1 the PRODUCT itself still comes from state-column segments for a Pauli-sum generator unless state_columns_compose = 0
+  // asks for the explicit-propagator tree; compose = 0 takes neither composed route, the wide-batch gradient included: ADVICE r4)
   if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || (c->compose_mode >= 0 && !for_compose)) return 0;
   // auto: from dim 512 up (at 256 a column is one wave and the tree-composed operator form is faster: 0.34 M against 0.11 M forward
   // steps/s on BASELINE configs[1]) and while the batch is at most xs_batch_ratio x dim
@@ -1411,6 +1422,15 @@ struct XsLaunch {
   bool quad_ok;      // the adjoint sweep runs the quadrature form with the rule `quad`
   dq::XsQuad quad;
   int seg_steps = 0; // steps per launch of the adjoint sweep (its partial-sum scratch is sized for that many)
+  std::vector<double> cen;   // centred frame: the midpoint of the diagonal's range per step (empty: not centred)
+  // e^{-i sum_{s0 <= s < s1} cen[s]} as (re, im): the factor of a forward launch over those steps; the adjoint launch takes its conjugate
+  void phase(int s0, int s1, double* pr, double* pi) const {
+    long double acc = 0.0L;
+    if (!cen.empty())
+      for (int s = s0; s < s1; ++s) acc += (long double)cen[(size_t)s];
+    *pr = (double)cosl(acc);
+    *pi = (double)-sinl(acc);
+  }
 };
 
 // per-call set-up: weights of every step, buffers
@@ -1428,12 +1448,7 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
   c->xs_lam.ensure(sb);
   c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
   c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
-  x.quad_ok = false;
-  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, L, c->xs_economize, c->xs_poly, &x.quad, dq::xs_quad_basis(*x.tab, c->d, c->xs_variant, sizeof(T)) ? 1 : 0) &&
-                                              dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant, sizeof(T));
-  c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
   if (backward) {
-    if (!x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
     // the per-step partial sums (workgroups x waves x slots doubles per step) are kept for a SEGMENT of the chain at a time: the sweep
     // is restartable at any step (psi and lambda are in/out, gradient rows disjoint), so a long chain costs no more scratch than a
     // segment of xs_part_bytes (default 256 MB; d = 4096: 262 KB per step, d = 512 at batch 4096: 327 KB per step)
@@ -1447,6 +1462,49 @@ XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward)
     return dq::xs_weights_launch(tb, c->u_dev.d(), c->K, S, c->d, dt, c->xs_wt.d(), c->xs_dgs.d(), &step, c->st);
   });
   x.dgs_step = step;
+  // ---- centred diagonal: every row of the diagonal-weight table minus the midpoint of its range; the step bound from half the range
+  // plus the off-diagonal row sum, and the lowest degree that bound allows (never above the one the sources' norms gave)
+  c->last_xs_centered = 0;
+  c->last_xs_theta_loose = c->last_theta;
+  if (c->xs_center != 0 && S > 0 && c->uh_last.size() >= (size_t)S * c->K) {
+    const int rows = step ? S : 1;
+    c->xs_cen.ensure(sizeof(double) * 2 * (size_t)rows);
+    double* cen_d = c->xs_cen.d();
+    c->timed(DQ_PROF_OTHER, 0.0, 16.0 * (double)rows * c->d, [&] { return dq::xs_center_launch(c->xs_dgs.d(), c->d, rows, cen_d, cen_d + rows, c->st); });
+    std::vector<double> ch(2 * (size_t)rows);
+    HIPCK(hipMemcpyAsync(ch.data(), cen_d, sizeof(double) * ch.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCK(hipStreamSynchronize(c->st));
+    x.cen.resize((size_t)S);
+    double th = 0.0;
+    for (int s = 0; s < S; ++s) {
+      const int r = step ? s : 0;
+      x.cen[(size_t)s] = ch[(size_t)r];
+      double off = 0.0;
+      const double* ur = c->uh_last.data() + (size_t)s * c->K;
+      for (int j = 0; j < tb.R; ++j) off += std::fabs(tb.kid[j] < 0 ? 1.0 : ur[tb.kid[j]]) * tb.cmag[j];
+      th = std::max(th, ch[(size_t)rows + r] + std::fabs(dt) * off);
+    }
+    c->last_xs_centered = 1;
+    if (th < c->last_theta) {
+      dq::XsPoly pol;
+      const double tol = std::min(c->expm_tol, c->xs_chain_tol / (double)std::max<long>(std::max<long>(S, c->plan_steps), 1));
+      const int L2 = dq::xs_poly_make(th, tol, c->xs_economize, &pol);
+      if (L2 > 0 && L2 <= L) {
+        L = L2;
+        x.L = L2;
+        c->xs_poly = pol;
+        c->last_theta = th;
+        dq::XsPoly tay;
+        c->last_xs_taylor_degree = dq::xs_poly_make(th, tol, 0, &tay);
+      }
+    }
+  }
+  // (the rule of the quadrature adjoint: made for the final theta and degree)
+  x.quad_ok = false;
+  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, L, c->xs_economize, c->xs_poly, &x.quad, dq::xs_quad_basis(*x.tab, c->d, c->xs_variant, sizeof(T)) ? 1 : 0) &&
+                                              dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant, sizeof(T));
+  c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
+  if (backward && !x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
   c->last_degree = L;
   c->last_squarings = 0;
   c->last_products = 0;
@@ -1483,8 +1541,10 @@ void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B,
   xs_book(c, x, (double)x.L * S, 0.0, false, B, &fl, &lb);
   const dq::XrTab tb = *x.tab;
   c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
+    double pr, pi;
+    x.phase(0, S, &pr, &pi);
     return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, x.L,
-                                 x.nblk, c->xs_variant, &c->xs_poly, c->st);
+                                 x.nblk, c->xs_variant, &c->xs_poly, pr, pi, c->st);
   });
   if (out_db)
     c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>(out_db, B, 0, (const T2*)c->xs_psi.p, d, 0, B, d, 0, 1, c->st); });
@@ -1515,9 +1575,18 @@ TT* xs_compose_segments(Ctx<T>* c, const std::vector<double>& uh, int S, double 
   double fl, lb;
   xs_book(c, x, (double)x.L * seg, 0.0, false, B, &fl, &lb);
   const dq::XrTab tb = *x.tab;
+  const double* seg_phase = nullptr;
+  if (!x.cen.empty()) {   // the scalar of every segment's propagator in the centred frame
+    std::vector<double> ph(2 * (size_t)G);
+    for (int g = 0; g < G; ++g) x.phase(g * seg, std::min(S, (g + 1) * seg), &ph[2 * (size_t)g], &ph[2 * (size_t)g + 1]);
+    c->xs_segphase.ensure(sizeof(double) * ph.size());
+    HIPCK(hipMemcpyAsync(c->xs_segphase.p, ph.data(), sizeof(double) * ph.size(), hipMemcpyHostToDevice, c->st));
+    HIPCK(hipStreamSynchronize(c->st));   // (ph is pageable)
+    seg_phase = c->xs_segphase.d();
+  }
   c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
     return dq::xs_forward_segments_launch((T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, seg, G, x.L, x.nblk,
-                                          c->xs_variant, &c->xs_poly, c->st);
+                                          c->xs_variant, &c->xs_poly, seg_phase, c->st);
   });
   // block g of the launch's output is the transpose of segment g's propagator
   T2* X = c->mat(SLOT_TP_L, (size_t)G);
@@ -1646,13 +1715,25 @@ bool mf_route(Ctx<T>* c, int S, bool need_observable, bool targets) {
   opt("checkpoint_bytes", c->mf_checkpoint_bytes);
   opt("polynomial", (double)c->xs_economize);   // (the step polynomial's options name the same thing on both engines)
   opt("chain_tol", c->xs_chain_tol);
+  opt("tol", c->expm_tol);   // (the per-step bound of the dense API holds on the routed passes too)
   if (dq_sctx_set_stream(c->mf, (void*)c->st) != DQ_OK) fail(DQ_ERR_HIP, dq_sctx_last_error());
   return true;
+}
+
+// what dq_get_info reports about the state-column paths of the LAST call: zeroed before any route is taken
+template <class T>
+void reset_call_info(Ctx<T>* c) {
+  c->last_xs_nodes = 0;
+  c->last_xs_segments = 0;
+  c->last_xs_wide = 0;
+  c->last_xs_segments_fwd = 0;
+  c->last_xs_centered = 0;
 }
 
 template <class T>
 void mf_after(Ctx<T>* c) {
   c->last_mf = 1;
+  reset_call_info(c);
   double v = 0;
   if (dq_sctx_get_info(c->mf, "degree", &v) == DQ_OK) c->last_degree = v;
   if (dq_sctx_get_info(c->mf, "theta", &v) == DQ_OK) c->last_theta = v;
@@ -1672,6 +1753,7 @@ void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d;
   const size_t sb = (size_t)d * B * sizeof(T2);
+  reset_call_info(c);
   if (mf_route(c, S, false, false)) {
     const int rc = dq_sctx_propagate(c->mf, u, S, dt, psi_in, psi_out, B);
     if (rc != DQ_OK) fail(rc, std::string("matrix-free routing: ") + dq_sctx_last_error());
@@ -2010,17 +2092,21 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
   if (S > 0) {
     double fl, lb;
     // sweeps per step: the exact form runs 3 L - 1 (L of them with the pairings), the quadrature form 2 L (L with the pairings)
+    const int L = x.L;   // (xs_prepare may have lowered the degree: centred diagonal)
     xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, !x.quad_ok, B, &fl, &lb);
     const dq::XrTab tb = *x.tab;
     c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
     for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {   // segments of the chain, last first (one launch when the whole chain fits)
       const int s0 = std::max(0, s1 - x.seg_steps), ns = s1 - s0;
       const double share = (double)ns / (double)S;
+      double pr, pi;
+      x.phase(s0, s1, &pr, &pi);
+      pi = -pi;   // (the adjoint launch takes its inputs INTO the centred frame: e^{+i sum})
       c->timed(DQ_PROF_STATECOL_BWD, fl * share, lb * share, [&] {
         return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
                                       c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, B, L, x.nblk,
                                       x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
-                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, c->st);
+                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, pr, pi, c->st);
       });
     }
   }
@@ -2068,17 +2154,21 @@ void do_energy_grad_xs_wide(Ctx<T>* c, const std::vector<double>& uh, int S, dou
   c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, Lm, d, 0, d, d, 0, 1, c->st); });
   {
     double fl, lb;
+    const int L = x.L;
     xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, !x.quad_ok, d, &fl, &lb);
     const dq::XrTab tb = *x.tab;
     c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
     for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {
       const int s0 = std::max(0, s1 - x.seg_steps), ns = s1 - s0;
       const double share = (double)ns / (double)S;
+      double pr, pi;
+      x.phase(s0, s1, &pr, &pi);
+      pi = -pi;   // (the adjoint launch takes its inputs INTO the centred frame: e^{+i sum})
       c->timed(DQ_PROF_STATECOL_BWD, fl * share, lb * share, [&] {
         return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
                                       c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, d, L, x.nblk,
                                       x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
-                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, c->st);
+                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, pr, pi, c->st);
       });
     }
   }
@@ -2113,6 +2203,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   if (S > 0 && !u && c->K > 0) fail(DQ_ERR_INVALID, "null pulse table");
   const int d = c->d, K = c->K;
   const size_t sb = (size_t)d * B * sizeof(T2);
+  reset_call_info(c);
   if (mf_route(c, S, true, targets != nullptr)) {   // a Pauli-sum generator beyond the state-column kernels' dimensions
     const int rc = dq_sctx_energy_grad(c->mf, u, S, dt, psi0, B, loss, grad_u, psi_final, energies);
     if (rc != DQ_OK) fail(rc, std::string("matrix-free routing: ") + dq_sctx_last_error());
@@ -2142,7 +2233,7 @@ void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* ps
   c->last_xs = 0;
   c->last_xs_segments_fwd = 0;
   c->last_xs_wide = 0;
-  if (S > 0 && B > d && !targets && c->xs_compose_mode != 0 && (c->xs_wide_mode > 0 || (c->xs_wide_mode < 0 && c->xs_mode < 0))) {   // (state_columns = 1 asks for the swept states)
+  if (S > 0 && B > d && !targets && c->xs_compose_mode != 0 && (c->xs_wide_mode > 0 || (c->xs_wide_mode < 0 && c->xs_mode < 0)) && c->compose_mode != 0) {   // (state_columns = 1 asks for the swept states)
     // (-1: by cost -- fwd + adjoint sweeps over B - d columns saved against the Gram product, three d^3 products and the final
     // application; rates as in do_propagate)
     // (measured at d = 4096, B = 32768, S = 20, tools/wide_adjoint_timing.py: 77 ms against 137 ms without the final application,
@@ -2289,7 +2380,11 @@ void do_slice_forward(Ctx<T>* c, const double* u, int n, double dt, void* P_out)
   const int tc = time_chunk(c, std::max(n, 1));
   c->last_chunk = tc;
   PcOff<T> pc_off{c};
-  setup_pcache(c, uh, n, dt, tc, true);
+  //  decide the state-column product first: when it is taken no propagator is ever built here, so no arena is reserved
+  // (up to 80 % of the free HBM, seconds on first allocation) and the backward call goes straight to its own column kernels
+  const bool xs_product = n > 0 && c->xs_compose_mode != 0 && xs_degree(c, uh, n, dt, c->d, true) > 0;
+  if (!xs_product) setup_pcache(c, uh, n, dt, tc, true);
+  else c->pc_limit = 0;
   // (Pauli-sum generators: the slice's product from state-column segments; the backward call then finds no cached propagators and
   // builds its own -- 0.2 ms per step on the column kernels against the 5.8 ms product per step this saves at d = 4096)
   T2* P = compose_chain(c, uh, n, dt, tc, true);
@@ -2953,7 +3048,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     const int t = (int)v;
     if (t != 0 && t != 32 && t != 64 && t != 128) fail(DQ_ERR_INVALID, "force_tile must be 0, 32, 64 or 128");
     c->force_tile = t;
-  } else if (s == "compose") {  // -1 auto (batch > dim), 0 never, 1 always
+  } else if (s == "compose") {  // -1 auto (batch > dim), 0 never (no composed route at all: explicit tree, state-column product, wide-batch gradient), 1 always
+                                // (for a Pauli-sum generator the product comes from state-column segments unless state_columns_compose = 0)
     c->compose_mode = (int)v < 0 ? -1 : ((int)v ? 1 : 0);
   } else if (s == "real_path") {  // -1 auto (real H, no forced complex tape), 0 never, q in 1..6 forced
     const int q = (int)v;
@@ -2991,6 +3087,8 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
     c->xs_mode = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "state_columns_variant") {  // bit 0: 1024 threads x 4 rows at dim 4096 (default 512 x 8); bit 1: prefetch of the next diagonal's partners in the forward kernel
     c->xs_variant = (int)v & 3;
+  } else if (s == "state_columns_center") {  // 1 (default): the kernels run on the diagonal minus the midpoint of its range (lower step bound), 0: as given
+    c->xs_center = v != 0 ? 1 : 0;
   } else if (s == "state_columns_adjoint") {  // -1 auto / 1: quadrature form of the adjoint sweep when its error bound allows; 0: exact polynomial derivative
     c->xs_adjoint = v < 0 ? -1 : (v > 0 ? 1 : 0);
   } else if (s == "state_columns_wide_adjoint") {  // energy gradients of batches wider than dim on dim columns: -1 by cost (default), 0 off, 1 on
@@ -3057,6 +3155,8 @@ double do_get_info(Ctx<T>* c, const std::string& s) {
     fail(DQ_ERR_INVALID, std::string("matrix-free routing: ") + dq_sctx_last_error());
   }
   if (s == "state_columns_quad_nodes") return c->last_xs_nodes;
+  if (s == "state_columns_centered") return c->last_xs_centered;
+  if (s == "state_columns_theta_uncentered") return c->last_xs_theta_loose;
   if (s == "state_columns_taylor_degree") return c->last_xs_taylor_degree;
   if (s == "state_columns_compose_segments") return c->last_xs_segments_fwd;
   if (s == "state_columns_wide_adjoint") return c->last_xs_wide;

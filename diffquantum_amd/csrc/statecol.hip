@@ -48,6 +48,35 @@ __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double
   }
 }
 
+// row b of the diagonal-weight table: c = (max + min) / 2 of its d entries, every entry -= c; cen[b] = c, half[b] = (max - min) / 2
+__global__ void __launch_bounds__(256) xs_center_kernel(double* __restrict__ dgs, int d, double* __restrict__ cen, double* __restrict__ half) {
+  double* row = dgs + (long)blockIdx.x * d;
+  double mn = 1e300, mx = -1e300;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const double v = row[i];
+    mn = fmin(mn, v);
+    mx = fmax(mx, v);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fmin(mn, __shfl_down(mn, off, 64));
+    mx = fmax(mx, __shfl_down(mx, off, 64));
+  }
+  __shared__ double smn[4], smx[4];
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  mn = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
+  mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+  const double c = 0.5 * (mx + mn);
+  for (int i = threadIdx.x; i < d; i += 256) row[i] -= c;
+  if (threadIdx.x == 0) {
+    cen[blockIdx.x] = c;
+    half[blockIdx.x] = 0.5 * (mx - mn);
+  }
+}
+
 // psi_out[b][:] = U_{S-1} ... U_0 psi_in[b][:] for the columns b = blockIdx.x, + gridDim.x, ...  (states stored column by
 // column: [B][D]).  dgs + s * dgs_step: the rows' diagonal weights of step s.
 template <class T, int NT, int RPT, int SIGN, bool PREF, bool CPLX>
@@ -131,8 +160,17 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
       }
     }
     T2* out = psi_out + (long)b * D;
+    {   // the scalar of the centred frame (xs_center_launch): e^{-i sum of the steps' midpoints}, per time segment or per launch
+      const T pr = (T)(seg.cols > 0 && seg.seg_phase ? seg.seg_phase[2 * (b / seg.cols)] : seg.pr);
+      const T pi = (T)(seg.cols > 0 && seg.seg_phase ? seg.seg_phase[2 * (b / seg.cols) + 1] : seg.pi);
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) out[r * NT + t] = cur[r];
+      for (int r = 0; r < RPT; ++r) {
+        T2 v;
+        v.x = cur[r].x * pr - cur[r].y * pi;
+        v.y = cur[r].x * pi + cur[r].y * pr;
+        out[r * NT + t] = v;
+      }
+    }
     __syncthreads();  // (every read of this column's images is done before the next column overwrites one)
   }
 }
@@ -390,6 +428,12 @@ size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant) {
 // dgs: d doubles, or S * d when a control has diagonal entries (xs_dgs_doubles); returns the step stride through *dgs_step
 size_t xs_dgs_doubles(int d, int S, const XrTab& tab) { return (size_t)d * (size_t)(xs_has_diag_controls(tab) ? (S > 0 ? S : 1) : 1); }
 
+hipError_t xs_center_launch(double* dgs, int d, int rows, double* cen, double* half, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(xs_center_kernel, dim3((unsigned)rows), dim3(256), 0, st, dgs, d, cen, half);
+  return hipGetLastError();
+}
+
 hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
                              hipStream_t st) {
   const int per_step = xs_has_diag_controls(tab) ? 1 : 0;
@@ -626,12 +670,13 @@ hipError_t xs_forward_t(const typename Cx<T>::type* in, typename Cx<T>::type* ou
 template <class T>
 hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                          const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
-                         int K, double dt, double* grad, int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st) {
+                         int K, double dt, double* grad, int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, double pr, double pi,
+                         hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
   const XsPoly pol = poly ? *poly : xs_poly_taylor();
   if (!xs_supported(d, L, tab.R, tab.nd, sizeof(T)) || (!park && !quad) || !part) return hipErrorInvalidValue;
-  const hipError_t e = quad ? xs_backward_quad_launch<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, *quad, part, variant, st)
-                            : xs_backward_exact_launch<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, variant, st);
+  const hipError_t e = quad ? xs_backward_quad_launch<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, *quad, part, variant, pr, pi, st)
+                            : xs_backward_exact_launch<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, variant, pr, pi, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xs_finish_kernel, dim3((unsigned)S), dim3(1024), 0, st, part, nblk, xs_waves(d, variant), xs_slots(tab),
                      xs_rm(tab), S, tab, xs_make_order(d, tab, variant, quad && XS_PAIR_LOCAL), K, dt, grad, accumulate);
@@ -641,35 +686,37 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
 }  // namespace
 
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
-  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0}, st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, double pr, double pi, hipStream_t st) {
+  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0, nullptr, pr, pi}, st);
 }
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
-                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, hipStream_t st) {
-  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0}, st);
+                             int S, int B, int L, int nblk, int variant, const XsPoly* poly, double pr, double pi, hipStream_t st) {
+  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0, nullptr, pr, pi}, st);
 }
 // The propagators of n_seg consecutive time segments of seg_steps steps each (the last one what is left of S_total): column i of
 // segment g -- exp(A_{s0+ns-1}) ... exp(A_{s0}) e_i, s0 = g seg_steps -- goes to out[(g d + i) d ..]: the d x d block of segment g
 // holds the TRANSPOSE of its propagator.  wt / dgs: the weight tables of all S_total steps.
 hipError_t xs_forward_segments_launch(double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
-                                      hipStream_t st) {
-  return xs_forward_t<double>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly, XsSeg{d, S_total}, st);
+                                      const double* seg_phase, hipStream_t st) {
+  return xs_forward_t<double>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly,
+                              XsSeg{d, S_total, seg_phase, 1.0, 0.0}, st);
 }
 hipError_t xs_forward_segments_launch(float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
-                                      hipStream_t st) {
-  return xs_forward_t<float>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly, XsSeg{d, S_total}, st);
+                                      const double* seg_phase, hipStream_t st) {
+  return xs_forward_t<float>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly,
+                             XsSeg{d, S_total, seg_phase, 1.0, 0.0}, st);
 }
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
-                              int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st) {
-  return xs_backward_t<double>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, poly, st);
+                              int accumulate, int variant, const XsQuad* quad, const XsPoly* poly, double pr, double pi, hipStream_t st) {
+  return xs_backward_t<double>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, poly, pr, pi, st);
 }
 hipError_t xs_backward_launch(float2* psi, float2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, float2* park, double* part, int K, double dt, double* grad, int accumulate,
-                              int variant, const XsQuad* quad, const XsPoly* poly, hipStream_t st) {
-  return xs_backward_t<float>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, poly, st);
+                              int variant, const XsQuad* quad, const XsPoly* poly, double pr, double pi, hipStream_t st) {
+  return xs_backward_t<float>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, K, dt, grad, accumulate, variant, quad, poly, pr, pi, st);
 }
 
 }  // namespace dq

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
                                                          XrTab tab, XsOrder ord, XsOrder ordh, const double* __restrict__ wt,
                                                          const double* __restrict__ dgs, long dgs_step, int S, int B, int L,
                                                          typename Cx<T>::type* __restrict__ park,
-                                                         double* __restrict__ part, XsPoly pol) {
+                                                         double* __restrict__ part, XsPoly pol, T pr, T pi) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
   constexpr int NW = NT / 64;
@@ -54,8 +54,13 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       const T2* li = lam + (long)b * D;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        cur[r] = in[r * NT + t];
-        Lm[r * NT + t] = li[r * NT + t];
+        const T2 a = in[r * NT + t], l = li[r * NT + t];   // (pr, pi): into the frame of the centred diagonal (xs_center_launch)
+        cur[r].x = a.x * pr - a.y * pi;
+        cur[r].y = a.x * pi + a.y * pr;
+        T2 lv;
+        lv.x = l.x * pr - l.y * pi;
+        lv.y = l.x * pi + l.y * pr;
+        Lm[r * NT + t] = lv;
       }
     }
     XS_STAMP(0);
@@ -244,7 +249,7 @@ namespace {
 
 template <class T, int NT, int RPT, bool PREF, int RM>
 hipError_t xs_backward_rm(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
-                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, const XsPoly& pol, hipStream_t st) {
+                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, const XsPoly& pol, double pr, double pi, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T));
   const bool sgn = tab.sgn != nullptr, dc = xs_has_diag_controls(tab);
@@ -252,7 +257,7 @@ hipError_t xs_backward_rm(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   for (int j = 0; j < tab.R; ++j) cplx = cplx || tab.phase[j] != 0;
   if (cplx && !sgn) return hipErrorInvalidValue;
   // (SIGN = 2 for every signed table: the exact form is the fallback of the quadrature kernels, one instantiation per class)
-  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, T2*, double*, XsPoly) =
+  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, T2*, double*, XsPoly, T, T) =
       cplx ? (dc ? xs_backward_kernel<T, NT, RPT, 2, true, RM, PREF, true> : xs_backward_kernel<T, NT, RPT, 2, false, RM, PREF, true>)
            : (sgn ? (dc ? xs_backward_kernel<T, NT, RPT, 2, true, RM, PREF, false>
                         : xs_backward_kernel<T, NT, RPT, 2, false, RM, PREF, false>)
@@ -261,40 +266,40 @@ hipError_t xs_backward_rm(typename Cx<T>::type* psi, typename Cx<T>::type* lam, 
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true),
-                     xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, false), wt, dgs, dgs_step, S, B, L, park, part, pol);
+                     xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, false), wt, dgs, dgs_step, S, B, L, park, part, pol, (T)pr, (T)pi);
   return hipGetLastError();
 }
 
 template <class T, int NT, int RPT, bool PREF>
 hipError_t xs_backward_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
-                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, const XsPoly& pol, hipStream_t st) {
+                          long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part, const XsPoly& pol, double pr, double pi, hipStream_t st) {
   return xs_rm(tab) > XR_RSMALL
-             ? xs_backward_rm<T, NT, RPT, PREF, 2 * XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
-             : xs_backward_rm<T, NT, RPT, PREF, XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
+             ? xs_backward_rm<T, NT, RPT, PREF, 2 * XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st)
+             : xs_backward_rm<T, NT, RPT, PREF, XR_RSMALL>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st);
 }
 
 template <class T, bool PREF>
 hipError_t xs_backward_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                             const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park, double* part,
-                            const XsPoly& pol, int variant, hipStream_t st) {
+                            const XsPoly& pol, int variant, double pr, double pi, hipStream_t st) {
   if constexpr (sizeof(T) == sizeof(float)) {
-    if (d == 8192) return xs_backward_go<T, 1024, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
+    if (d == 8192) return xs_backward_go<T, 1024, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st);
   }
   switch (d) {
     case 4096:
-      return (variant & 1) ? xs_backward_go<T, 1024, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
-                           : xs_backward_go<T, 512, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
+      return (variant & 1) ? xs_backward_go<T, 1024, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st)
+                           : xs_backward_go<T, 512, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st);
 #ifndef XS_PROBE_4096_ONLY
-    case 2048: return xs_backward_go<T, 256, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
+    case 2048: return xs_backward_go<T, 256, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st);
     case 1024:
-      return (variant & 1) ? xs_backward_go<T, 256, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
-                           : xs_backward_go<T, 128, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
+      return (variant & 1) ? xs_backward_go<T, 256, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st)
+                           : xs_backward_go<T, 128, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st);
     case 512:
-      return (variant & 1) ? xs_backward_go<T, 256, 2, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
-                           : xs_backward_go<T, 64, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
+      return (variant & 1) ? xs_backward_go<T, 256, 2, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st)
+                           : xs_backward_go<T, 64, 8, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st);
     default:
-      return (variant & 1) ? xs_backward_go<T, 256, 1, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st)
-                           : xs_backward_go<T, 64, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, st);
+      return (variant & 1) ? xs_backward_go<T, 256, 1, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st)
+                           : xs_backward_go<T, 64, 4, PREF>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, pr, pi, st);
 #else
     default: return hipErrorInvalidValue;
 #endif
@@ -306,14 +311,14 @@ hipError_t xs_backward_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam
 template <class T>
 hipError_t xs_backward_exact_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                                     const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park,
-                                    double* part, const XsPoly& pol, int variant, hipStream_t st) {
+                                    double* part, const XsPoly& pol, int variant, double pr, double pi, hipStream_t st) {
   // (no prefetch in the backward kernel: its sweeps carry more live registers, and the second partner buffer costs more in spills
   // than it hides in latency -- measured 24.5 against 26.7 ms per 20 steps at d = B = 4096)
-  return xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, variant, st);
+  return xs_backward_pick<T, false>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, park, part, pol, variant, pr, pi, st);
 }
 template hipError_t xs_backward_exact_launch<double>(double2*, double2*, int, const XrTab&, const double*, const double*, long, int, int, int,
-                                                     int, double2*, double*, const XsPoly&, int, hipStream_t);
+                                                     int, double2*, double*, const XsPoly&, int, double, double, hipStream_t);
 template hipError_t xs_backward_exact_launch<float>(float2*, float2*, int, const XrTab&, const double*, const double*, long, int, int, int,
-                                                    int, float2*, double*, const XsPoly&, int, hipStream_t);
+                                                    int, float2*, double*, const XsPoly&, int, double, double, hipStream_t);
 
 }  // namespace dq

@@ -27,7 +27,7 @@ template <class T, int NT, int RPT, int SIGN, bool DIAGCTL, bool CPLX, int NI, b
 __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type* __restrict__ psi, typename Cx<T>::type* __restrict__ lam,
                                                            XrTab tab, XsOrder ord, XsOrder ordh, const double* __restrict__ wt,
                                                            const double* __restrict__ dgs, long dgs_step, int S, int B, int L, XsQuad qd,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part, T pr, T pi) {
   typedef typename Cx<T>::type T2;
   constexpr int D = NT * RPT;
   constexpr int NW = NT / 64;
@@ -72,9 +72,14 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       const T2* in = psi + (long)b * D;
       const T2* li = lam + (long)b * D;
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        cur[r] = in[r * NT + t];
-        Lm[r * NT + t] = li[r * NT + t];
+      for (int r = 0; r < RPT; ++r) {   // (pr, pi): into the frame of the centred diagonal (dq_internal.h, xs_center_launch)
+        const T2 a = in[r * NT + t], l = li[r * NT + t];
+        cur[r].x = a.x * pr - a.y * pi;
+        cur[r].y = a.x * pi + a.y * pr;
+        T2 lv;
+        lv.x = l.x * pr - l.y * pi;
+        lv.y = l.x * pi + l.y * pr;
+        Lm[r * NT + t] = lv;
       }
     }
     XS_STAMP(0);
@@ -317,19 +322,19 @@ namespace {
 template <class T, int NT, int RPT, int SIGN, bool DIAGCTL, bool CPLX, bool U2L>
 hipError_t xs_backward_q_start(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const XsOrder& ord, const XsOrder& ordh,
                                const double* wt, const double* dgs, long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd,
-                               double* part, hipStream_t st) {
+                               double* part, double pr, double pi, hipStream_t st) {
   typedef typename Cx<T>::type T2;
   const size_t lds = xs_lds_bytes(NT * RPT, sizeof(T)) + (U2L ? sizeof(float2) * (size_t)(NT * RPT) : 0);   // + the u_2 slots
-  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, XsQuad, double*) =
+  void (*kf)(T2*, T2*, XrTab, XsOrder, XsOrder, const double*, const double*, long, int, int, int, XsQuad, double*, T, T) =
       xs_backward_q_kernel<T, NT, RPT, SIGN, DIAGCTL, CPLX, 2, U2L>;
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, qd, part);
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, qd, part, (T)pr, (T)pi);
   return hipGetLastError();
 }
 template <class T, int NT, int RPT>
 hipError_t xs_backward_q_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam, const XrTab& tab, const double* wt, const double* dgs,
-                            long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part, hipStream_t st) {
+                            long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part, double pr, double pi, hipStream_t st) {
   const int var = xs_threads(NT * RPT, 0) == NT ? 0 : 1;
   if (!xs_quad_supported(tab, qd.ni, NT * RPT, var, sizeof(T))) return hipErrorInvalidValue;
   const bool sgn = tab.sgn != nullptr, dc = xs_has_diag_controls(tab), cplx = xs_table_is_complex(tab);
@@ -339,7 +344,7 @@ hipError_t xs_backward_q_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam
   if (qd.basis != 0 && !UL) return hipErrorInvalidValue;
   const XsOrder ord = xs_make_order(NT * RPT, tab, var, true), ordh = xs_make_order(NT * RPT, tab, var, false);
   const bool rs = xs_order_row_signs(ord) || xs_order_row_signs(ordh);   // SIGN = 2: some diagonal's sign has a row factor
-#define XS_QGO(SG, DC, CX, U) xs_backward_q_start<T, NT, RPT, SG, DC, CX, U>(psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st)
+#define XS_QGO(SG, DC, CX, U) xs_backward_q_start<T, NT, RPT, SG, DC, CX, U>(psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st)
 #define XS_QSG(DC, CX, U) (rs ? XS_QGO(2, DC, CX, U) : XS_QGO(1, DC, CX, U))
   if (!sgn && !dc && !qd.basis) return XS_QGO(0, false, false, false);
   if constexpr (UL) {   // (signed tables / diagonal controls always take the difference basis on these shapes: xs_quad_basis)
@@ -359,23 +364,23 @@ hipError_t xs_backward_q_go(typename Cx<T>::type* psi, typename Cx<T>::type* lam
 template <class T>
 hipError_t xs_backward_q_pick(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                               const double* dgs, long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part,
-                              int variant, hipStream_t st) {
+                              int variant, double pr, double pi, hipStream_t st) {
   // (no 1024-thread shapes -- d = 8192 in complex64, the wide form of d = 4096: xs_quad_supported keeps them on the exact kernel)
   switch (d) {
     case 4096:
       return (variant & 1) ? hipErrorInvalidValue
-                           : xs_backward_q_go<T, 512, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);
+                           : xs_backward_q_go<T, 512, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st);
 #ifndef XS_PROBE_4096_ONLY
-    case 2048: return xs_backward_q_go<T, 256, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);
+    case 2048: return xs_backward_q_go<T, 256, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st);
     case 1024:
-      return (variant & 1) ? xs_backward_q_go<T, 256, 4>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st)
-                           : xs_backward_q_go<T, 128, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);
+      return (variant & 1) ? xs_backward_q_go<T, 256, 4>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st)
+                           : xs_backward_q_go<T, 128, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st);
     case 512:
-      return (variant & 1) ? xs_backward_q_go<T, 256, 2>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st)
-                           : xs_backward_q_go<T, 64, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);
+      return (variant & 1) ? xs_backward_q_go<T, 256, 2>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st)
+                           : xs_backward_q_go<T, 64, 8>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st);
     default:
-      return (variant & 1) ? xs_backward_q_go<T, 256, 1>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st)
-                           : xs_backward_q_go<T, 64, 4>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, st);
+      return (variant & 1) ? xs_backward_q_go<T, 256, 1>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st)
+                           : xs_backward_q_go<T, 64, 4>(psi, lam, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, pr, pi, st);
 #else
     default: return hipErrorInvalidValue;
 #endif
@@ -387,12 +392,12 @@ hipError_t xs_backward_q_pick(typename Cx<T>::type* psi, typename Cx<T>::type* l
 template <class T>
 hipError_t xs_backward_quad_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                                    const double* dgs, long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part,
-                                   int variant, hipStream_t st) {
-  return xs_backward_q_pick<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, variant, st);
+                                   int variant, double pr, double pi, hipStream_t st) {
+  return xs_backward_q_pick<T>(psi, lam, d, tab, wt, dgs, dgs_step, S, B, L, nblk, qd, part, variant, pr, pi, st);
 }
 template hipError_t xs_backward_quad_launch<double>(double2*, double2*, int, const XrTab&, const double*, const double*, long, int, int, int,
-                                                    int, const XsQuad&, double*, int, hipStream_t);
+                                                    int, const XsQuad&, double*, int, double, double, hipStream_t);
 template hipError_t xs_backward_quad_launch<float>(float2*, float2*, int, const XrTab&, const double*, const double*, long, int, int, int, int,
-                                                   const XsQuad&, double*, int, hipStream_t);
+                                                   const XsQuad&, double*, int, double, double, hipStream_t);
 
 }  // namespace dq

@@ -590,10 +590,10 @@ bool xs_order_row_signs(const XsOrder& o);
 template <class T>
 hipError_t xs_backward_exact_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                                     const double* dgs, long dgs_step, int S, int B, int L, int nblk, typename Cx<T>::type* park,
-                                    double* part, const XsPoly& pol, int variant, hipStream_t st);
+                                    double* part, const XsPoly& pol, int variant, double pr, double pi, hipStream_t st);
 template <class T>
 hipError_t xs_backward_quad_launch(typename Cx<T>::type* psi, typename Cx<T>::type* lam, int d, const XrTab& tab, const double* wt,
                                    const double* dgs, long dgs_step, int S, int B, int L, int nblk, const XsQuad& qd, double* part,
-                                   int variant, hipStream_t st);
+                                   int variant, double pr, double pi, hipStream_t st);
 
 }  // namespace dq

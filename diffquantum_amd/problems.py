@@ -86,6 +86,29 @@ def xy_drives_torch(n: int, seed: int, device, n_x: int = 6, n_y: int = 6):
     return H0, Hs, H0.clone()
 
 
+def qaoa_ring_torch(n: int, device):
+    """The n-qubit ring analog-QAOA problem of qaoa_ring / the reference demo (demo_maxcut.py:44-79: H0 = sum_e (I - Z_i Z_j) by the
+    demo's aliasing, controls = the n edge strings Z_i Z_j and the n vertex strings X_i), built in device memory: K = 2 n controls,
+    M = H_cost = -H0 / 2.  (The dense host arrays of qaoa_ring are 6.7 GB at n = 12.)"""
+    import torch
+    d = 1 << n
+    idx = torch.arange(d, device=device)
+    zsign = lambda q: 1.0 - 2.0 * ((idx >> (n - 1 - q)) & 1).to(torch.float64)
+    Hs = torch.zeros((2 * n, d, d), dtype=torch.complex128, device=device)
+    diag0 = torch.zeros(d, dtype=torch.float64, device=device)
+    for e in range(n):
+        zz = zsign(e) * zsign((e + 1) % n)
+        Hs[e, idx, idx] = zz.to(torch.complex128)
+        diag0 += 1.0 - zz
+    for q in range(n):
+        Hs[n + q, idx, idx ^ (1 << (n - 1 - q))] = 1.0
+    H0 = torch.zeros((d, d), dtype=torch.complex128, device=device)
+    H0.diagonal().copy_(diag0.to(torch.complex128))
+    M = torch.zeros((d, d), dtype=torch.complex128, device=device)
+    M.diagonal().copy_((-0.5 * diag0).to(torch.complex128))
+    return H0, Hs, M
+
+
 def random_dense_torch(n: int, K: int, seed: int, device, complex_h: bool = False, drift_norm1: float = 12.0,
                        control_norm1: float = 1.0):
     """(H0, Hs[K], M) DENSE random matrices built in device memory: real symmetric (stored complex128, imaginary parts

@@ -73,8 +73,9 @@ int dq_device_count(int* n);
 /* Host-only (no GPU call): the step polynomial p(A) = sum_{m <= degree} factors[m] A^m / m! the state-column kernels use for
  * exp(A), A anti-Hermitian with ||A|| <= theta, at sup-norm error <= tol on the spectrum -- the Chebyshev-economized form
  * (economize = 1; one to four degrees below Taylor's) or the Taylor polynomial (0: factors = 1).  factors: 25 doubles;
- * degree = 0 when no degree up to 24 reaches tol.  (The reference's step is torch.matrix_exp, diffqc.cc:83-88, through
- * scipy.linalg.expm's Pade form on the CPU: any polynomial within tol of exp is the same step to that tolerance.) */
+ * degree = 0 when no degree up to 24 reaches tol.  (The reference's step is Eigen's `dH.exp()`, diffqc.cc:198, and
+ * `scipy.linalg.expm(dH)`, sim_plain.py:145 -- scaling-and-squaring Pade forms on the CPU: any polynomial within tol of exp on the
+ * spectrum is the same step to that tolerance.) */
 int dq_step_polynomial(double theta, double tol, int economize, int* degree, double* factors);
 
 /* Context = one Hilbert-space dimension + one set of Hamiltonians on one GPU.

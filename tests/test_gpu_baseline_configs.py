@@ -290,3 +290,54 @@ def test_dimension_1536_matches_oracle(oracle, kind):
                 assert e.info("sparse_generator") == 1
         assert np.max(np.abs(fin - rf)) < TOL and abs(loss - rl) < TOL * B
         assert np.max(np.abs(grad - rg)) < TOL, (kind, compose, np.max(np.abs(grad - rg)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[3]'s shape on one GPU: n = 12, the WHOLE 32768-state batch (8 GPUs x 4096 in BASELINE; one GPU holds it)
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_config4_shape_whole_batch_on_one_gpu(oracle):
+    """d = 4096, B = 32768 (configs[3]'s global batch), S = 3, fp64, fwd + adjoint: the wide-batch form (adjoint sweep on the 4096
+    columns of (P R, 2 M P), engine.hip do_energy_grad_xs_wide -- the form one GPU runs that job in, and one rank's program of the
+    column-sharded multi-GPU form) against the sweep over the 32768 states themselves -- loss, dL/du, per-state energies -- and four
+    columns of Psi(T) with their energies against the oracle's chain (diffqc.cc:190-200 on the same inputs)."""
+    import torch
+    from diffquantum_amd.engine import Engine
+    n, B, S, dt = 12, 32768, 3, 1e-3
+    d = 1 << n
+    dev = torch.device("cuda:0")
+    H0t, Hst, Mt = problems.random_ising_torch(n, 0, dev)
+    u = problems.pulse_table(n, 2000, 2000 * dt, seed=0)[:S].copy()
+    u[1] += 0.37 * np.random.default_rng(5).uniform(-1, 1, n)
+    u[2] -= 0.21 * np.random.default_rng(6).uniform(-1, 1, n)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    psi0 = torch.randn((d, B), dtype=torch.float64, device=dev, generator=gen) + 1j * torch.randn((d, B), dtype=torch.float64, device=dev, generator=gen)
+    psi0 = (psi0 / torch.linalg.vector_norm(psi0, dim=0, keepdim=True)).contiguous()
+    with Engine(d, n) as e:
+        e.use_torch_stream()
+        e.set_hamiltonians(H0t, Hst)
+        e.set_observable(Mt)
+        e.set_option("state_columns_wide_adjoint", 1)
+        l1, g1, f1, e1 = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns_wide_adjoint") == 1 and e.info("state_columns_compose_segments") >= 1
+        l2, g2, _, _ = e.energy_grad(u, dt, psi0, want_final=False, want_energies=False)
+        assert e.info("state_columns_wide_adjoint") == 1
+        e.set_option("state_columns", 1)
+        e.set_option("state_columns_wide_adjoint", 0)
+        l0, g0, f0, e0 = e.energy_grad(u, dt, psi0)
+        assert e.info("state_columns") == 1 and e.info("state_columns_wide_adjoint") == 0
+        assert e.info("state_columns_quad_nodes") == 2     # (the swept states: the headline's kernels)
+    scale = max(1.0, float(np.max(np.abs(g0))))
+    assert abs(l1 - l0) < TOL * B and abs(l2 - l0) < TOL * B, (l1 - l0, l2 - l0)
+    assert np.max(np.abs(g1 - g0)) < TOL * scale and np.max(np.abs(g2 - g0)) < TOL * scale, (np.max(np.abs(g1 - g0)), scale)
+    assert np.max(np.abs(e1 - e0)) < TOL * 10 and float((f1 - f0).abs().max().item()) < TOL * 10
+    assert abs(float(np.sum(e1)) - l1) < TOL * B and np.max(np.abs(g0)) > 1e-3
+    # four columns against the oracle
+    H0, Hs, M = problems.random_ising(n, seed=0)
+    assert float((H0t - torch.from_numpy(H0).to(dev)).abs().max().item()) == 0.0
+    cols = psi0[:, :4].cpu().numpy()
+    ref = oracle.propagate(H0, list(Hs), u, dt, cols)
+    ren = oracle.energies(M, ref)
+    assert np.max(np.abs(f1[:, :4].cpu().numpy() - ref)) < TOL and np.max(np.abs(f0[:, :4].cpu().numpy() - ref)) < TOL
+    assert np.max(np.abs(e1[:4] - ren)) < TOL and np.max(np.abs(e0[:4] - ren)) < TOL

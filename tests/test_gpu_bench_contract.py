@@ -114,8 +114,16 @@ def test_bench_line_fits_the_driver_window_as_the_driver_runs_it():
         m = d["roofline_mfma"]
         assert m["kernel"].startswith("zgemm_lin_kernel") and m["peak"] == 78.6 and 0.5 < m["frac"] < 1.0 and m["launches"] > 0
         assert abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-6
+        # BASELINE configs[2] at FULL size under -m gpu: the S = 2000, d = B = 4096 gradient of the state-column kernels
+        # against the checkpointed explicit-propagator GEMM chain on the same inputs (benchlib/measure.py full_chain)
         fc = d["full_chain"]
         assert fc[0] == 2000 and fc[1] > 0 and fc[2] is not None and fc[2] < 1e-10      # max |dL/du - the checkpointed GEMM chain's|
+        # round 5: the reference's own control sets run the quadrature adjoint (4-point rule: 2 interior nodes) at the headline's size
+        ex = json.load(open(os.path.join(ROOT, d["extras"])))
+        st = ex["by_input_structure"]
+        assert st["xy_drives_state_columns"]["state_columns_quad_nodes"] == 2 and st["xy_drives_state_columns"]["state_columns"] == 1
+        assert st["qaoa_zz_x_n12"]["state_columns_quad_nodes"] == 2 and st["qaoa_zz_x_n12"]["state_columns"] == 1
+        assert "qaoa_zz_x_n12" in d["by_input_structure"] and d["by_input_structure"]["qaoa_zz_x_n12"][0] > 0
 
 
 def test_bench_general_path_only():

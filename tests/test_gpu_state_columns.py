@@ -85,6 +85,12 @@ def test_state_columns_match_oracle(oracle, case, n, workgroups):
     with _engine(H0, Hs, M, state_columns=1 if n == 8 else -1, state_columns_workgroups=workgroups) as e:     # (auto takes the form from dim 512 up)
         loss, grad, fin, en = e.energy_grad(u, dt, psi0)
         assert e.info("state_columns") == 1, "a Pauli-string generator did not take the state-column form"
+        # every table class -- unsigned, parity-signed / complex (X / Y drives, two-body strings), diagonal controls (ZZ-edge QAOA) -- runs
+        # the quadrature form of the adjoint sweep (d = 512: the difference-basis kernels with u_2 in LDS; d = 256: the node basis)
+        # (the 4-point rule serves steps up to theta = 0.053 at its 2^-40 bound: the ZZ-control ring at n = 9 has theta = 0.07 here)
+        assert e.info("state_columns_quad_nodes") == 2 or e.info("theta") > 0.053, "the quadrature form of the adjoint sweep did not run"
+        if case in ("xy_drives", "mixed_two_body") or n == 8:
+            assert e.info("state_columns_quad_nodes") == 2
         fwd = e.propagate(u, dt, psi0)
         assert e.info("state_columns") == 1
         e.set_option("state_columns", 0)
@@ -288,8 +294,8 @@ def test_full_2000_step_chain_matches_the_oracle_fixture(case, variant, adjoint)
         loss, grad, fin, en = e.energy_grad(P["u"], P["dt"], P["psi0"])
         assert e.info("state_columns") == 1
         nodes = e.info("state_columns_quad_nodes")
-        # (tables with row signs -- xyz9 -- run the exact form whatever is asked, as long as the library is built without XS_QUAD_SIGNED)
-        assert nodes == 0 if adjoint == 0 else (nodes > 0 or case == "xyz9"), "the requested form of the adjoint sweep did not run"
+        # (round 5: signed / complex tables and diagonal controls -- xyz9 -- run the quadrature form too)
+        assert nodes == (0 if adjoint == 0 else 2), "the requested form of the adjoint sweep did not run"
         fwd = e.propagate(P["u"], P["dt"], P["psi0"])
     assert np.max(np.abs(fin - a["fin"])) < TOL and np.max(np.abs(fwd - a["fin"])) < TOL
     assert np.max(np.abs(en - a["energies"])) < TOL and abs(loss - a["loss"]) < TOL
@@ -457,8 +463,55 @@ def test_wide_batch_energy_gradient_on_dim_columns(oracle, case, n, S, B, dtype,
         assert e.info("state_columns_wide_adjoint") == 1 and e.info("state_columns_compose_segments") >= 1
         l2, g2, _, _ = e.energy_grad(u, dt, psi0, want_final=False, want_energies=False)     # (no application of P to the batch)
         assert e.info("state_columns_wide_adjoint") == 1
+        # the oracle on a slice: loss and gradient are sums over the states, so the wide form on the batch WITHOUT three of its states
+        # (still wider than the dimension) must differ from the full batch's by exactly the oracle's answer for those three
+        NS = 3
+        l3, g3, _, _ = e.energy_grad(u, dt, np.ascontiguousarray(psi0[:, NS:]), want_final=False, want_energies=False)
+        assert e.info("state_columns_wide_adjoint") == 1
+    ls, gs, fs = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0[:, :NS].astype(np.complex128))
+    otol = tol * max(1.0, float(np.max(np.abs(g2))))   # (a difference of two sums over B states: rounding of the sums, not of the slice)
+    assert abs((l2 - l3) - ls) < otol * 10 and np.max(np.abs((g2 - g3) - gs)) < otol, (abs((l2 - l3) - ls), np.max(np.abs((g2 - g3) - gs)))
+    assert np.max(np.abs(f1[:, :NS] - fs)) < tol * 10
     scale = max(1.0, float(np.max(np.abs(g0))))
     assert abs(l1 - l0) < tol * B and abs(l2 - l0) < tol * B
     assert np.max(np.abs(g1 - g0)) < tol * scale and np.max(np.abs(g2 - g0)) < tol * scale, np.max(np.abs(g1 - g0))
     assert np.max(np.abs(f1 - f0)) < tol * 10 and np.max(np.abs(e1 - e0)) < tol * 100
-    assert np.max(np.abs(g0)) > 1e-5
+    assert np.max(np.abs(g0)) > 1e-5 and np.max(np.abs(gs)) > 1e-7
+
+
+@pytest.mark.parametrize("case,n", [("qaoa_ring_zz_controls", 9), ("qaoa_ring_zz_controls", 8), ("xy_drives", 9), ("ising_x", 10)])
+def test_centred_diagonal_matches_the_uncentred_kernels_and_the_oracle(oracle, case, n):
+    """Round 5: the kernels run on the diagonal minus the midpoint of its range (exp(A) = e^{-ic} exp(A + ic): a lower step bound,
+    for the reference demo's drift sum_e (I - Z_i Z_j) >= 0 half of it) and the launches restore the scalar.  Same amplitudes, loss
+    and gradient as with state_columns_center = 0 and as the oracle, over a chain long enough for the scalar to wind around (the
+    adjoint sweep in 3 launches: every launch applies its own segment's scalar), forward pass and composed product included."""
+    H0, Hs, M = _qaoa(n) if case == "qaoa_ring_zz_controls" else CASES[case](n)
+    K, d = len(Hs), 1 << n
+    S, B, dt = 30, 5, 2.5e-2 if case != "ising_x" else 4e-3
+    dt = dt / (1.0 + 0.25 * K)
+    u = np.random.default_rng(n + 7).uniform(-1, 1, (S, K))
+    psi0 = problems.random_states(d, B, seed=9)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    out = {}
+    with _engine(H0, Hs, M, state_columns=1) as e:
+        e.set_option("state_columns_part_bytes", 14000.0)   # (ten steps of partial sums per launch: 1280 B per step for 5 columns)
+        for center in (1, 0):
+            e.set_option("state_columns_center", center)
+            loss, grad, fin, en = e.energy_grad(u, dt, psi0)
+            assert e.info("state_columns") == 1 and e.info("state_columns_centered") == center
+            th, deg, segs = e.info("theta"), e.info("degree"), e.info("state_columns_segments")
+            fwd = e.propagate(u, dt, psi0)
+            out[center] = (loss, grad, fin, fwd, th, deg, segs)
+        e.set_option("state_columns_center", 1)
+        e.set_option("state_columns", -1)
+        e.set_option("compose", 1)
+        comp = e.propagate(u, dt, psi0)          # the product of the chain from state-column segments, each with its own scalar
+        assert e.info("state_columns_compose_segments") >= 1 and e.info("state_columns_centered") == 1
+    (l1, g1, f1, w1, th1, L1, seg1), (l0, g0, f0, w0, th0, L0, _) = out[1], out[0]
+    assert th1 <= th0 * (1 + 1e-12) and L1 <= L0 and seg1 == 3
+    if case == "qaoa_ring_zz_controls":
+        assert th1 < 0.8 * th0, (th1, th0)       # the drift's range [0, 2 n] centred: half its share of the bound
+    for (l, g, f, w) in ((l1, g1, f1, w1), (l0, g0, f0, w0)):
+        assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL and np.max(np.abs(f - rf)) < TOL and np.max(np.abs(w - rf)) < TOL
+    assert np.max(np.abs(comp - rf)) < TOL
+    assert np.max(np.abs(rg)) > 1e-5

@@ -307,7 +307,7 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 3; ++rep) {
     float msf = 0, msb = 0;
     CK(hipEventRecord(e0));
-    CK(dq::xs_forward_launch(d_in, d_psi, d, tab, d_wt, d_dgs, step, S, B, L, nblk, variant, &pol, nullptr));
+    CK(dq::xs_forward_launch(d_in, d_psi, d, tab, d_wt, d_dgs, step, S, B, L, nblk, variant, &pol, 1.0, 0.0, nullptr));
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&msf, e0, e1));
@@ -318,7 +318,7 @@ int main(int argc, char** argv) {
 #endif
     CK(hipEventRecord(e0));
     CK(dq::xs_backward_launch(d_psi, d_lam, d, tab, d_wt, d_dgs, step, S, B, L, nblk, d_park, d_part, K, 1e-3, d_grad, 0, variant,
-                              form ? &quad : nullptr, &pol, nullptr));
+                              form ? &quad : nullptr, &pol, 1.0, 0.0, nullptr));
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&msb, e0, e1));
@@ -352,7 +352,7 @@ int main(int argc, char** argv) {
       CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&ms, e0, e1));
       CK(hipEventRecord(e0));
-      CK(dq::xs_forward_launch(d_in, d_lam, d, tab, d_wt, d_dgs, step, S, B, L, nblk, variant, &pol, nullptr));
+      CK(dq::xs_forward_launch(d_in, d_lam, d, tab, d_wt, d_dgs, step, S, B, L, nblk, variant, &pol, 1.0, 0.0, nullptr));
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&ms0, e0, e1));
