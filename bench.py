@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 # timed regions).  The names the contract tests use stay importable from here.
 from benchlib import report  # noqa: E402
 from benchlib.launch import Dist, launch_ranks  # noqa: E402,F401
-from benchlib.measure import run_config2, run_config3, run_config5  # noqa: E402
+from benchlib.measure import run_config1, run_config2, run_config3, run_config5  # noqa: E402
 from benchlib.report import (LINE_LIMIT, PEAK_F64_MFMA_TFLOPS, PEAK_HBM_GBPS, PEAK_LDS_GBPS, TRAFFIC, claim_stdout, compact_line,  # noqa: E402,F401
                              executed_tflops, ranked, roofline_blocks, short_roofline)
 
@@ -57,8 +57,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed Trotter steps (default 20; config 2: 1000)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5),
-                    help="3 = headline (BASELINE configs[2]/[3]); 2 = configs[1] (n=8 QAOA forward); 5 = configs[4] (n=18, c64, matrix-free)")
+    ap.add_argument("--config", type=int, default=3, choices=(1, 2, 3, 5),
+                    help="3 = headline (BASELINE configs[2]/[3]); 1 = configs[0] (demo_maxcut.py: training epochs/s, oracle CPU loop beside it); "
+                         "2 = configs[1] (n=8 QAOA forward); 5 = configs[4] (n=18, c64, matrix-free)")
     ap.add_argument("--workload", choices=("ising", "dense-real", "dense-complex"), default="ising",
                     help="config 3 inputs: BASELINE's random Ising + X_k (default) or dense random matrices of the same size and norm")
     ap.add_argument("--qubits", type=int, default=12)
@@ -79,7 +80,7 @@ def main():
     ap.add_argument("--state-columns", type=int, default=-1, choices=(-1, 0, 1),
                     help="config 3: -1 auto (Pauli-sum generators run the state-column form), 0 = the explicit-propagator GEMM chain as the "
                          "timed workload (profiling the north-star kernel on the headline's inputs), 1 = whenever the kernels exist")
-    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated", "propagators"), default="replicated",
+    ap.add_argument("--multi-gpu", choices=("auto", "sliced", "replicated", "propagators", "columns"), default="replicated",
                     help="N > 1: 'replicated' (default; north_star / SURVEY 8-E1) = every rank runs the whole chain on its batch shard, one "
                          "all-reduce of loss + dL/du; 'sliced' = chain split over time across the ranks (operator form; three collectives); "
                          "auto = both checked and tried, the faster one timed; 'propagators' = SURVEY 8-F2 as written: state-form "
@@ -96,7 +97,7 @@ def main():
     if a.extras:
         report.set_extras_path(os.path.abspath(a.extras))
     D = Dist(a)
-    {2: run_config2, 3: run_config3, 5: run_config5}[a.config](a, D)
+    {1: run_config1, 2: run_config2, 3: run_config3, 5: run_config5}[a.config](a, D)
     D.close()  # (only on success: a failing rank must not enter a barrier its peers will never reach -- it exits non-zero)
 
 

@@ -433,6 +433,94 @@ def run_config2(a, D):
         emit(out)
 
 
+G5_LOSSES = (-2.0000395860025693, -1.9829188702462983, -2.060480806327015, -2.1216781468721955, -2.1870484989606345)   # SURVEY 8-C3 (reference run)
+
+
+def oracle_demo_epochs(n_epoch, seed=0, lr=2e-2, n_basis=6, per_step=10):
+    """The reference's training loop (sim_plain.py:253-296: forward solve, <M>, one-sample MC gradient, Adam) on the demo's problem with
+    the ORACLE's arithmetic on the host (scipy expm per step, as sim_plain.py:145): the cpu_baseline leg of --config 1.  Consumes the
+    global numpy RNG exactly as the reference does (init draw, then one uniform per epoch).  Returns (seconds, losses - ground)."""
+    import torch
+    from diffquantum_amd import problems
+    from oracle import trotter_oracle as orc
+    p = problems.maxcut_problem()
+    H0, Hs, M, om, T, psi0 = p["H0"], list(p["Hs"]), p["H_cost"], p["omegas"], float(p["T"]), p["psi0"].reshape(-1, 1).astype(np.complex128)
+    np.random.seed(seed)
+    coeff = torch.tensor(np.random.normal(0, 1e-3, [len(Hs), n_basis]), requires_grad=True)
+    opt = torch.optim.Adam([coeff], lr=lr)
+    ground = float(np.linalg.eigvalsh(M)[0])
+    losses = []
+    t0 = time.perf_counter()
+    for _ in range(n_epoch):
+        c = coeff.detach().numpy().copy()
+        fin, _, _ = orc.trotter_sim_plain(H0, Hs, c, om, T, "BSpline", per_step, psi0, 0, T)
+        loss = float(np.real(fin[:, 0].conj() @ (M @ fin[:, 0])))
+        s = np.random.uniform() * T
+        g, _, _ = orc.mc_gradient(H0, Hs, M, c, om, T, "BSpline", per_step, psi0, s)
+        opt.zero_grad()
+        coeff.grad = torch.from_numpy(g)
+        opt.step()
+        losses.append(loss - ground)
+    return time.perf_counter() - t0, losses
+
+
+def run_config1(a, D):
+    """BASELINE configs[0]: demo_maxcut.py's 4-vertex analog QAOA (d = 16, 8 controls, batch 1, 30 Trotter steps per solve) -- training
+    epochs per second through SimulatorPlain.train_energy on the engine (one epoch = forward solve + the reference's one-sample MC
+    gradient estimate, 17 chains as one device-resident batch, + Adam; demo_maxcut.py:86, sim_plain.py:253-296), the first five losses
+    against the reference's recorded trace, and the same loop through the oracle on the host beside it."""
+    import torch
+    from diffquantum_amd import problems
+    from diffquantum_amd.qobj import Qobj
+    from diffquantum_amd.sim_plain import SimulatorPlain
+    K = a.steps if a.steps is not None else 60
+    p = problems.maxcut_problem()
+    log_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "logs")
+    os.makedirs(os.path.join(log_dir, "text"), exist_ok=True)
+
+    def make(n_epoch):
+        sim = SimulatorPlain(lr=2e-2, n_basis=6, n_epoch=n_epoch, log_dir=log_dir)
+        sim.T, sim.omegas = p["T"], list(p["omegas"])
+        return sim
+    args = (Qobj(p["H_cost"]), Qobj(p["H0"]), [Qobj(h) for h in p["Hs"]], Qobj(p["psi0"]))
+    np.random.seed(0)
+    sim = make(max(5, a.warmup))
+    sim.train_energy(*args)                                   # warm-up; its first five epochs are the reference's trace G5
+    trace = [float(x) for x in sim.losses_energy[:5]]
+    ground = float(np.linalg.eigvalsh(p["H_cost"])[0])
+    trace_err = float(np.max(np.abs(np.array(trace) + ground - np.array(G5_LOSSES))))   # (losses_energy = loss - ground; G5 holds the losses)
+    times = []
+    for _ in range(max(1, a.trials)):
+        sim = make(K)
+        np.random.seed(1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sim.train_energy(*args)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    el = float(np.median(times))
+    cpu = None
+    if not a.skip_cpu_baseline:
+        n_cpu = 12
+        sec, closs = oracle_demo_epochs(n_cpu)
+        cpu = {"value": n_cpu / sec, "unit": "training epochs/s", "cores": 1, "kind": "port",
+               "sample": "{} epochs of the same loop through the oracle on the host (scipy expm per Trotter step, 17 chains per epoch one "
+                         "after the other, as the reference runs them): {:.2f} s; first losses {}".format(
+                             n_cpu, sec, ", ".join("{:.6f}".format(x + ground) for x in closs[:3]))}
+    out = {"metric": "training epochs/sec, demo_maxcut.py 4-vertex analog QAOA (batch 1)", "value": K / el, "unit": "training epochs/s",
+           "n_gpus": 1, "steps": K, "warmup": max(5, a.warmup), "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "the demo's own problem (no dataset)", "backend": D.name(),
+           "trials": {"n": len(times), "ms_per_step_median": el / K * 1e3, "ms_per_step_min": min(times) / K * 1e3,
+                      "ms_per_step_max": max(times) / K * 1e3},
+           "config": {"workload": "BASELINE configs[0]: demo_maxcut.py 4-vertex analog QAOA (d=16, 8 controls, batch 1, 30 Trotter steps per "
+                                  "solve), SimulatorPlain.train_energy: one step = one epoch (forward solve + one-sample MC gradient: 17 chains "
+                                  "as one device batch + Adam)",
+                      "n_qubits": 4, "dim": 16, "n_controls": 8, "batch_per_gpu": 1, "global_batch": 1, "chain_steps": 30, "parallelism": "dp1",
+                      "first_five_losses": [x + ground for x in trace], "max_abs_diff_vs_reference_trace_G5": trace_err,
+                      "note": "latency-bound: d = 16, batch 1 -- a handful of microsecond kernels per epoch; host time (pulse tables, "
+                              "Python, Adam) is most of an epoch"},
+           "roofline": None, "cpu_baseline": cpu}
+    emit(out)
+
+
 def run_config5(a, D):
     S = a.steps if a.steps is not None else 20
     total = a.batch if a.batch is not None else 512
@@ -470,7 +558,8 @@ def run_config5(a, D):
 def run_config3(a, D):
     import torch
     from diffquantum_amd import problems
-    from diffquantum_amd.distributed import allreduce_loss_grad, propagator_sharded_energy_grad, time_sliced_energy_grad
+    from diffquantum_amd.distributed import (allreduce_loss_grad, column_sharded_energy_grad, propagator_sharded_energy_grad,
+                                             time_sliced_energy_grad)
     from diffquantum_amd.engine import Engine
     dist = D.dist
     rank, world, dev = D.rank, D.world, D.dev
@@ -528,6 +617,14 @@ def run_config3(a, D):
         grad_dev.copy_(torch.from_numpy(g).to(dev))
         return loss, grad_dev
 
+    def run_columns(u_dev, grad_dev):
+        # the WHOLE global batch's energy gradient with the adjoint sweep split over the dim COLUMNS of (P R, 2 M P) (round 5): Gram
+        # matrix of this rank's states, all-reduce of R (16 d^2 bytes), P built by every rank, d / world columns swept, one all-reduce
+        # of (loss, dL/du).  Strong scaling of the job that one GPU runs on dim columns -- batch shards only add states
+        loss, g = column_sharded_energy_grad(eng, u_dev, a.dt, psi0, device=dev)
+        grad_dev.copy_(torch.from_numpy(g).to(dev))
+        return loss, grad_dev
+
     # Which multi-GPU form runs.  Default = north_star's partitioning: every rank runs the whole chain on its own
     # batch shard, ONE all-reduce of (loss, dL/du) -- 'replicated'.  'sliced' / 'propagators' / 'auto' stay as options.  No
     # exception handling around anything that contains a collective: every rank issues the same collectives in the same order
@@ -536,13 +633,27 @@ def run_config3(a, D):
     force = bool(os.environ.get("DQ_FORCE_COLLECTIVES")) and D.on
     multi = world > 1 or force
     both = multi and a.multi_gpu == "auto"
-    mode = "sliced" if (a.multi_gpu == "sliced" and D.on) or both else ("propagators" if a.multi_gpu == "propagators" else "replicated")
+    mode = "sliced" if (a.multi_gpu == "sliced" and D.on) or both else (a.multi_gpu if a.multi_gpu in ("propagators", "columns") else "replicated")
     want_beside = multi and a.multi_gpu in ("replicated", "auto") and not a.no_beside
     forms = {}
     sliced_check = None
+    columns_check = None
+    columns_ok = a.workload == "ising" and a.state_columns != 0   # (needs a Pauli-sum generator on the state-column kernels)
+    if mode == "columns" and not columns_ok:
+        raise SystemExit("--multi-gpu columns needs the Ising workload with the state-column form")
     if W > 0:
         uw = torch.from_numpy(u_all[:W].copy()).to(dev)
         lr, gr = run_replicated(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+        if columns_ok and (mode == "columns" or want_beside):
+            lc, gc = run_columns(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+            errc = float((gc - gr).abs().max().item())
+            columns_check = {"max_abs_grad_diff_vs_replicated": errc, "abs_loss_diff_vs_replicated": abs(lc - lr)}
+            okc = errc <= 1e-9 * (1.0 + float(gr.abs().max().item())) and abs(lc - lr) <= 1e-9 * (1.0 + abs(lr))
+            flagc = torch.tensor([1.0 if okc else 0.0], dtype=torch.float64, device=dev)
+            D.all_reduce_(flagc, dist.ReduceOp.MIN)
+            columns_check["agreed_on_every_rank"] = bool(flagc.item() >= 1.0)
+            if flagc.item() < 1.0 and mode == "columns":
+                raise SystemExit("column-sharded form disagrees with the replicated form: {}".format(columns_check))
         if mode == "sliced" or want_beside:
             # the warm-up doubles as the check: same loss and gradient from both forms on every rank
             ls, gs = run_sliced(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
@@ -569,6 +680,14 @@ def run_config3(a, D):
             l2, g2 = fn(u_t, g2)
             D.fence()
             forms[name] = {"seconds": D.max_over_ranks(time.perf_counter() - t1), "loss": l2, "grad": g2.clone()}
+    if want_beside and columns_ok and columns_check and columns_check["agreed_on_every_rank"]:
+        g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
+        run_columns(u_t[:1].contiguous(), torch.zeros((1, n), dtype=torch.float64, device=dev))   # (allocations)
+        D.fence()
+        t1 = time.perf_counter()
+        l2, g2 = run_columns(u_t, g2)
+        D.fence()
+        forms["columns"] = {"seconds": D.max_over_ranks(time.perf_counter() - t1), "loss": l2, "grad": g2.clone()}
     if both:
         mode = "replicated" if forms["replicated"]["seconds"] < forms["sliced"]["seconds"] else "sliced"
     whole = None
@@ -586,7 +705,7 @@ def run_config3(a, D):
     if mode == "propagators" and W > 0:   # the warm-up chain doubles as the check against the replicated form
         lp, gp = run_propagators(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
         prop_check = {"max_abs_grad_diff_vs_replicated": float((gp - gr).abs().max().item()), "abs_loss_diff_vs_replicated": abs(lp - lr)}
-    run = {"sliced": run_sliced, "propagators": run_propagators}.get(mode, run_replicated)
+    run = {"sliced": run_sliced, "propagators": run_propagators, "columns": run_columns}.get(mode, run_replicated)
     eng.profile_enable(True)
     eng.profile_reset()
 
@@ -609,7 +728,7 @@ def run_config3(a, D):
     if forms:
         forms_out = {name: {"value": world * K / f["seconds"], "ms_per_step": f["seconds"] / max(K, 1) * 1e3, "loss": f["loss"]}
                      for name, f in forms.items()}
-        if "replicated" in forms:
+        if "replicated" in forms and "sliced" in forms:
             forms_out["max_abs_grad_diff_sliced_vs_replicated"] = float((forms["sliced"]["grad"] - forms["replicated"]["grad"]).abs().max().item())
             forms_out["abs_loss_diff_sliced_vs_replicated"] = abs(forms["sliced"]["loss"] - forms["replicated"]["loss"])
         forms_out["note"] = "one untimed trial of each form on the same K-step chain (max over ranks); the timed region ran '{}'".format(mode)
@@ -644,6 +763,8 @@ def run_config3(a, D):
             beside["sliced_form"] = [world * K / forms["sliced"]["seconds"], forms["sliced"]["seconds"] / K * 1e3]
         if whole is not None:
             beside["one_gpu_whole_global_batch"] = [world * K / whole, whole / K * 1e3]
+        if "columns" in forms:   # the whole global batch's gradient, adjoint sweep split over the dim columns across the ranks
+            beside["columns_form"] = [world * K / forms["columns"]["seconds"], forms["columns"]["seconds"] / K * 1e3]
     out = {
         "metric": "Trotter steps/sec (fwd+adjoint), n={} qubits batch={}".format(n, B),
         "value": steps_per_s,
@@ -671,15 +792,23 @@ def run_config3(a, D):
             "input_structure": structure_note,
             "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
             "chain_steps": K, "dt": a.dt,
+            # (SURVEY D1 "pulse-table upload included": the table is 8 K S bytes -- 2 KB here -- and is handed over as a DEVICE tensor that is
+            # resident before the clock starts; inside the timed call the library copies it to the host once for the step bound and back)
+            "pulse_table": "device-resident before the timed region ({} B); read back by the call for the step bound".format(8 * K * n),
             "parallelism": "dp{}".format(world),
             "parallelism_detail": ("dp{} (batch shards, one all-reduce of loss+dL/du)".format(world) if mode == "replicated" else
                                    "dp{0} over the batch, the propagators of every window of {0} steps built one per rank and all-gathered; "
                                    "state-form chain, reduce-scatter of the propagators' cotangents (SURVEY 8-F2 as written)".format(world)
                                    if mode == "propagators" else
+                                   "the whole {1}-state batch's energy gradient on the dim columns of (P R, 2 M P): Gram matrices all-reduced "
+                                   "(16 d^2 bytes), P built by every rank, d / {0} columns swept per rank, one all-reduce of loss + dL/du "
+                                   "(strong scaling of the job one GPU runs on dim columns)".format(world, B * world)
+                                   if mode == "columns" else
                                    "dp{0} over the batch x {0} time slices: operator form, each rank builds and sweeps 1/{0} of "
                                    "the chain for the whole batch; all-gather of the slice products, all-reduce of W_S "
                                    "(d x d) and of dL/du".format(world)),
             "multi_gpu_form": mode, "sliced_warmup_check": sliced_check, "propagators_warmup_check": prop_check,
+            "columns_warmup_check": columns_check,
             "multi_gpu_forms": forms_out,
             "collectives_forced_at_world_1": force and world == 1,
             "expm": describe_expm(info),

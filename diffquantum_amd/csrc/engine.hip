@@ -2120,42 +2120,36 @@ void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, dou
 // -- the state-column adjoint sweep as it stands on the d columns of (psi_S, lambda_S) = (P R, 2 M P), with P from the state-column
 // segments of compose_chain; three d^3 products and the Gram product per call.  Final states / per-state energies, when asked for,
 // cost one more d x d x B product.
+// The sweep of do_energy_grad_xs_wide over the columns [col0, col0 + ncols) of (P R, 2 M P): partial loss 1/2 Re sum_i <lambda_i, y_i>
+// and partial dL/du of those columns (grad_dev).  Rm: R = sum over ALL states of psi_0 psi_0^H (d x d, device).  Returns P (pool slot).
 template <class T>
-void do_energy_grad_xs_wide(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, const void* psi0, int B, double* loss,
-                            double* grad_u, void* psi_final, double* energies, int L) {
+TT* xs_wide_columns(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, const TT* Rm, int col0, int ncols, double* loss, int L) {
   typedef TT T2;
   const int d = c->d, K = c->K;
-  const size_t sb = (size_t)d * B * sizeof(T2);
-  c->psi[0].ensure(sb);
-  c->psi[1].ensure(sb);
-  c->lam[0].ensure(sb);
   c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
-  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
   const int tc = time_chunk(c, std::max(S, 1));
   T2* P = compose_chain(c, uh, S, dt, tc, true);
   if (!P || c->last_xs_segments_fwd <= 0) fail(DQ_ERR_STATE, "wide-batch adjoint: the product of the chain did not come from state columns");
-  T2* Rm = c->mat(SLOT_TP_Q, 1);
   T2* Ym = c->mat(SLOT_TP_Z, 1);
   T2* Lm = c->mat(SLOT_TP_R, 1);
-  c->zgemm(0, 1, d, d, B, 1.0, p0, B, 0, p0, B, 0, 0.0, Rm, d, 0, 1);                 // R = Psi0 Psi0^H
   c->zgemm(0, 0, d, d, d, 1.0, P, d, 0, Rm, d, 0, 0.0, Ym, d, 0, 1);                  // Y = P R
   c->zgemm(3, 0, d, d, d, 2.0, (const T2*)c->M.p, d, 0, P, d, 0, 0.0, Lm, d, 0, 1);   // Lambda = 2 M P   (M Hermitian)
   // L = sum_i <p_i| M |y_i> = 1/2 Re sum_i <lambda_i, y_i>
-  c->e_dev.ensure(sizeof(double) * ((size_t)std::max(B, d) + 1));
-  c->part.ensure(sizeof(double) * (size_t)dq::coldot_chunks(d) * std::max(B, d));
-  c->timed(DQ_PROF_OTHER, 4.0 * d * d, 4.0 * sizeof(T) * d * d,
-           [&] { return dq::coldot_launch<T>(Ym, d, Lm, d, d, d, 0.5, c->e_dev.d(), c->part.d(), c->st); });
-  c->timed(DQ_PROF_OTHER, d, 8.0 * d, [&] { return dq::sum_launch(c->e_dev.d(), d, c->e_dev.d() + d, c->st); });
+  c->e_dev.ensure(sizeof(double) * ((size_t)d + 1));
+  c->part.ensure(sizeof(double) * (size_t)dq::coldot_chunks(d) * d);
+  c->timed(DQ_PROF_OTHER, 4.0 * d * ncols, 4.0 * sizeof(T) * d * ncols,
+           [&] { return dq::coldot_launch<T>(Ym + col0, d, Lm + col0, d, d, ncols, 0.5, c->e_dev.d(), c->part.d(), c->st); });
+  c->timed(DQ_PROF_OTHER, ncols, 8.0 * ncols, [&] { return dq::sum_launch(c->e_dev.d(), ncols, c->e_dev.d() + d, c->st); });
   if (loss) out_copy(c, loss, c->e_dev.d() + d, sizeof(double));
-  // the adjoint sweep over the d columns
-  const XsLaunch<T> x = xs_prepare(c, S, dt, d, L, true);
-  const double by = 2.0 * sizeof(T2) * (double)d * d;
-  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_psi.p, d, 0, Ym, d, 0, d, d, 0, 1, c->st); });
-  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, Lm, d, 0, d, d, 0, 1, c->st); });
+  // the adjoint sweep over the columns
+  const XsLaunch<T> x = xs_prepare(c, S, dt, ncols, L, true);
+  const double by = 2.0 * sizeof(T2) * (double)d * ncols;
+  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_psi.p, d, 0, Ym + col0, d, 0, d, ncols, 0, 1, c->st); });
+  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, Lm + col0, d, 0, d, ncols, 0, 1, c->st); });
   {
     double fl, lb;
-    const int L = x.L;
-    xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, !x.quad_ok, d, &fl, &lb);
+    const int Lx = x.L;
+    xs_book(c, x, (x.quad_ok ? 2.0 * Lx : 3.0 * Lx - 1.0) * S, (double)Lx * S, !x.quad_ok, ncols, &fl, &lb);
     const dq::XrTab tb = *x.tab;
     c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
     for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {
@@ -2166,18 +2160,91 @@ void do_energy_grad_xs_wide(Ctx<T>* c, const std::vector<double>& uh, int S, dou
       pi = -pi;   // (the adjoint launch takes its inputs INTO the centred frame: e^{+i sum})
       c->timed(DQ_PROF_STATECOL_BWD, fl * share, lb * share, [&] {
         return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
-                                      c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, d, L, x.nblk,
+                                      c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, ncols, Lx, x.nblk,
                                       x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
                                       c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, pr, pi, c->st);
       });
     }
   }
+  return P;
+}
+
+template <class T>
+void do_energy_grad_xs_wide(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, const void* psi0, int B, double* loss,
+                            double* grad_u, void* psi_final, double* energies, int L) {
+  typedef TT T2;
+  const int d = c->d, K = c->K;
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  c->psi[0].ensure(sb);
+  c->psi[1].ensure(sb);
+  c->lam[0].ensure(sb);
+  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
+  T2* Rm = c->mat(SLOT_TP_Q, 1);
+  c->zgemm(0, 1, d, d, B, 1.0, p0, B, 0, p0, B, 0, 0.0, Rm, d, 0, 1);                 // R = Psi0 Psi0^H
+  T2* P = xs_wide_columns(c, uh, S, dt, Rm, 0, d, loss, L);
   if (grad_u && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
   if (psi_final || energies) {   // Psi_S = P Psi0 (the pool slot of P is untouched by the sweep)
     c->zgemm(0, 0, d, B, d, 1.0, P, d, 0, p0, B, 0, 0.0, (T2*)c->psi[0].p, B, 0, 1);
     if (psi_final) out_copy(c, psi_final, c->psi[0].p, sb);
     if (energies) do_energy(c, (const T2*)c->psi[0].p, B, (T2*)c->lam[0].p, energies, nullptr);
   }
+  c->last_xs = 0;
+  c->last_xs_wide = 1;
+  c->last_composed = 1;
+  c->last_opback = 0;
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+// ---- the column-sharded multi-GPU form of the wide-batch gradient (BASELINE configs[3]: 32768 states over 8 GPUs) ----------------
+// L = tr(M P R P^H) depends on the batch through R = sum_b psi0_b psi0_b^H alone: every rank forms the Gram matrix of ITS states
+// (dq_gram), one all-reduce makes R (16 d^2 bytes), every rank builds P (replicated: the chain's product from state-column segments) and
+// sweeps d / N of the d columns of (P R, 2 M P) (dq_energy_grad_columns); one all-reduce of (loss, dL/du) finishes.  The sweep -- all
+// of the job that grows with the chain -- is split N ways: strong scaling of the whole job, where batch shards only add states.
+// Reference loop distributed: diffqc.cc:190-200, loss sim_plain.py:281.
+template <class T>
+void do_gram(Ctx<T>* c, const void* psi0, int B, void* R_out) {
+  typedef TT T2;
+  check_ctx(c);
+  if (B <= 0) fail(DQ_ERR_INVALID, "batch must be > 0");
+  if (!psi0 || !R_out) fail(DQ_ERR_INVALID, "null pointer");
+  const int d = c->d;
+  const size_t sb = (size_t)d * B * sizeof(T2);
+  c->psi[1].ensure(sb);
+  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
+  T2* Rm = c->mat(SLOT_TP_Q, 1);
+  c->zgemm(0, 1, d, d, B, 1.0, p0, B, 0, p0, B, 0, 0.0, Rm, d, 0, 1);
+  out_copy(c, R_out, Rm, c->mat_bytes());
+  HIPCK(hipStreamSynchronize(c->st));
+}
+
+template <class T>
+void do_energy_grad_columns(Ctx<T>* c, const double* u, int S, double dt, const void* R, int col0, int ncols, double* loss, double* grad_u) {
+  typedef TT T2;
+  check_ctx(c);
+  require_H(c);
+  if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
+  if (S <= 0) fail(DQ_ERR_INVALID, "n_steps must be > 0");
+  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
+  if (!R || (!u && c->K > 0)) fail(DQ_ERR_INVALID, "null pointer");
+  const int d = c->d, K = c->K;
+  if (col0 < 0 || ncols < 0 || col0 + ncols > d) fail(DQ_ERR_INVALID, "column range outside [0, dim)");
+  reset_call_info(c);
+  std::vector<double> uh = fetch_u(c, u, S);
+  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
+  if (ncols == 0) {   // (more ranks than columns: nothing to sweep)
+    if (loss) *loss = 0.0;
+    if (grad_u) HIPCK(hipMemsetAsync(c->grad_dev.p, 0, sizeof(double) * (size_t)S * K, c->st));
+    if (grad_u && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
+    HIPCK(hipStreamSynchronize(c->st));
+    return;
+  }
+  const int L = xs_degree(c, uh, S, dt, d, true);
+  if (!L || c->xs_compose_mode == 0)
+    fail(DQ_ERR_UNSUPPORTED, "dq_energy_grad_columns needs a Pauli-sum generator at a dimension the state-column kernels hold (512 .. 4096; 8192 in complex64)");
+  T2* Rm = c->mat(SLOT_TP_Q, 1);
+  if ((const void*)Rm != R) HIPCK(hipMemcpyAsync(Rm, R, c->mat_bytes(), hipMemcpyDefault, c->st));
+  xs_wide_columns(c, uh, S, dt, Rm, col0, ncols, loss, L);
+  if (grad_u && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
   c->last_xs = 0;
   c->last_xs_wide = 1;
   c->last_composed = 1;
@@ -3331,6 +3398,15 @@ int dq_energy(dq_ctx* c, const void* psi, int batch, double* energies, double* t
 int dq_energy_grad(dq_ctx* c, const double* u, int n_steps, double dt, const void* psi0, int batch, double* loss,
                    double* grad_u, void* psi_final, double* energies) {
   return with_ctx(c, [&](auto* t) { do_energy_grad(t, u, n_steps, dt, psi0, batch, loss, grad_u, psi_final, energies); });
+}
+
+int dq_gram(dq_ctx* c, const void* psi0, int batch, void* R_out) {
+  return with_ctx(c, [&](auto* t) { do_gram(t, psi0, batch, R_out); });
+}
+
+int dq_energy_grad_columns(dq_ctx* c, const double* u, int n_steps, double dt, const void* R, int col0, int n_cols, double* loss,
+                           double* grad_u) {
+  return with_ctx(c, [&](auto* t) { do_energy_grad_columns(t, u, n_steps, dt, R, col0, n_cols, loss, grad_u); });
 }
 
 int dq_fidelity_grad(dq_ctx* c, const double* u, int n_steps, double dt, const void* psi0, const void* targets, int batch,

@@ -16,6 +16,14 @@ d x d matrices W_S = Lambda_S Psi_S^H are all-reduced (the only batch reduction)
 backward from W_{b_r} = R_r^H W_S R_r with R_r = P_{G-1} ... P_{r+1}.  Three collectives per gradient evaluation
 (all-gather of P, all-reduce of W_S, all-reduce of the gradient rows + loss), all issued in the same order with the
 same sizes on every rank; per-rank work = 1/G of the chain + (G + 2) extra d x d products.
+
+Column-sharded form of the wide-batch energy gradient (`column_sharded_energy_grad`, round 5; BASELINE configs[3]: 32768 states over
+8 GPUs).  For a batch wider than the dimension and a Pauli-sum generator one GPU already runs the whole job on dim columns (engine.hip
+do_energy_grad_xs_wide): L = tr(M P R P^H) depends on the states through R = sum_b psi0_b psi0_b^H alone.  Sharding the BATCH therefore
+shortens nothing -- every rank would sweep all dim columns for its own R.  Instead: rank r forms the Gram matrix of its states, ONE
+all-reduce makes R (16 d^2 bytes: 268 MB at d = 4096, ~2 ms per ring step over xGMI), every rank builds P (replicated: 1/3 of a
+forward pass over dim columns) and sweeps dim / G of the columns of (P R, 2 M P); one all-reduce of (loss, dL/du).  The adjoint sweep --
+2/3 of the single-GPU time -- is split G ways: 1 / (1/3 + 2/(3 G)) = 2.4x at G = 8 with P replicated.
 """
 from __future__ import annotations
 
@@ -93,6 +101,60 @@ def _sliced_phases(engine, u, dt, psi0_shard, rank, world, targets=None, want_fi
     buf[-1] = loss
     buf = yield ("all_reduce", buf)
     return float(buf[-1]), np.array(buf[:-1]).reshape(S, K), fin, en
+
+
+# ---- column-sharded wide-batch gradient --------------------------------------------------------------------------------
+
+def _columns_phases(engine, u, dt, psi0_shard, rank, world):
+    """The per-rank program of the column-sharded form as a generator of collective requests (as _sliced_phases): the Gram matrix of
+    this rank's states, all-reduce, the sweep over this rank's columns, all-reduce of (dL/du, loss)."""
+    S, K = int(u.shape[0]), engine.n_controls
+    R = engine.gram(psi0_shard)
+    R = yield ("all_reduce", R)
+    first, count = shard_range(engine.dim, rank, world)
+    loss, grad = engine.energy_grad_columns(u, dt, R, first, count)
+    buf = np.empty(S * K + 1, dtype=np.float64)
+    buf[:-1] = np.asarray(grad, dtype=np.float64).reshape(-1)
+    buf[-1] = loss
+    buf = yield ("all_reduce", buf)
+    return float(buf[-1]), np.array(buf[:-1]).reshape(S, K), None, None
+
+
+def _drive(gen, world, group, device):
+    """Run one rank's generator of collective requests through torch.distributed (locally at world size 1)."""
+    import torch.distributed as dist
+    local_only = world == 1 and not (os.environ.get("DQ_FORCE_COLLECTIVES") and dist.is_available() and dist.is_initialized())
+    req = next(gen)
+    while True:
+        kind, x = req
+        if local_only:
+            res = [x] if kind == "all_gather" else x
+        else:
+            res = _torch_collective(kind, x, group, device)
+        try:
+            req = gen.send(res)
+        except StopIteration as done:
+            return done.value
+
+
+def column_sharded_energy_grad(engine, u, dt, psi0_shard, group=None, device=None):
+    """Loss and dL/du of the WHOLE batch (energy objective) with the adjoint sweep split over the dim COLUMNS of (P R, 2 M P) across
+    the ranks of `group`; psi0_shard: this rank's states (any split of the batch, empty shards excluded).  Returns
+    (loss, grad_u[S][K] numpy) -- the sums over all ranks' states, equal to rounding to engine.energy_grad of the whole batch.
+    Needs a Pauli-sum generator at a dimension the state-column kernels hold and dq_set_observable."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        rank, world = 0, 1
+    else:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    loss, grad, _, _ = _drive(_columns_phases(engine, u, dt, psi0_shard, rank, world), world, group, device)
+    return loss, grad
+
+
+def virtual_column_sharded_energy_grad(engines, u, dt, psi0_shards):
+    """The same program for len(engines) VIRTUAL ranks in one process (tests, single-GPU rehearsal); returns the per-rank results."""
+    world = len(engines)
+    return _run_virtual([_columns_phases(engines[r], u, dt, psi0_shards[r], r, world) for r in range(world)])
 
 
 # ---- SURVEY.md 8-F2 in its literal form: the propagators of a chain built 1/G per rank and all-gathered ---------------------
@@ -346,8 +408,13 @@ def virtual_time_sliced_energy_grad(engines, u, dt, psi0_shards, targets=None):
     programs advance in lockstep and the collectives are carried out on the spot.  engines[r] holds rank r's context
     (all with the same Hamiltonians), psi0_shards[r] its columns.  Returns the list of per-rank results."""
     world = len(engines)
-    gens = [_sliced_phases(engines[r], u, dt, psi0_shards[r], r, world, None if targets is None else targets[r],
-                           want_final=True, want_energies=True) for r in range(world)]
+    return _run_virtual([_sliced_phases(engines[r], u, dt, psi0_shards[r], r, world, None if targets is None else targets[r],
+                                        want_final=True, want_energies=True) for r in range(world)])
+
+
+def _run_virtual(gens):
+    """Advance the rank programs `gens` in lockstep, carrying out their collectives on the spot."""
+    world = len(gens)
     reqs = [next(g) for g in gens]
     results = [None] * world
     while any(r is not None for r in reqs):

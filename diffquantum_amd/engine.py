@@ -275,6 +275,27 @@ class Engine:
                                (torch.complex128 if self.dtype == "c128" else torch.complex64), device=like.device)
         return np.empty((self.dim, self.dim), dtype=self.cdtype)
 
+    # ---- column-sharded form of the wide-batch energy gradient (distributed.column_sharded_energy_grad) ----
+    def gram(self, psi0):
+        """R = Psi0 Psi0^H ([dim][dim]) of these states: what the loss of a batch depends on (include/diffqc_hip.h, dq_gram).
+        A matrix of the kind of psi0 (torch tensor on its device, or numpy)."""
+        pp, kp, B = self._psi(psi0)
+        R = self._mat_like(psi0)
+        pr, kr = self._c(R, (self.dim, self.dim), "R")
+        _lib.check(self._lib.dq_gram(self._ctx, pp, B, pr))
+        return R
+
+    def energy_grad_columns(self, u, dt: float, R, col0: int, n_cols: int):
+        """The share of (loss, dL/du[n_steps][n_controls]) that the columns [col0, col0 + n_cols) of (P R, 2 M P) carry, R the Gram
+        matrix of the WHOLE batch (dq_energy_grad_columns); summed over a partition of [0, dim) it is energy_grad of that batch."""
+        pu, ku, S = self._u(u)
+        pr, kr = self._c(R, (self.dim, self.dim), "R")
+        grad = np.zeros((S, self.n_controls), dtype=np.float64)
+        loss = C.c_double()
+        _lib.check(self._lib.dq_energy_grad_columns(self._ctx, pu, S, float(dt), pr, int(col0), int(n_cols), C.addressof(loss),
+                                                    grad.ctypes.data))
+        return loss.value, grad
+
     def slice_forward(self, u, dt: float, like=None):
         """P = U_{n-1} ... U_0 of the slice's own pulse rows u[n][K] (identity for n = 0); the propagator
         intermediates stay cached for slice_backward. Returns a [dim][dim] matrix of the kind of `like`."""

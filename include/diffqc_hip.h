@@ -211,6 +211,21 @@ int dq_energy(dq_ctx* ctx, const void* psi, int batch, double* energies, double*
 int dq_energy_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* psi0, int batch, double* loss,
                    double* grad_u, void* psi_final, double* energies);
 
+/* ---- Column-sharded form of the wide-batch energy gradient (BASELINE configs[3]: 32768 states over 8 GPUs; round 5).
+ * The loss of the reference's loop (diffqc.cc:190-200, sim_plain.py:281) summed over a batch is L = tr(M P R P^H) with P the chain's
+ * product and R = sum_b psi0_b psi0_b^H: it depends on the states through the d x d Gram matrix alone.  A rank
+ *   1. dq_gram:                 R_rank = Psi0_rank Psi0_rank^H of ITS states ([dim][dim] complex, out to host or device memory);
+ *   2. all-reduces R over the ranks (the caller's collective: 16 dim^2 bytes);
+ *   3. dq_energy_grad_columns:  builds P itself (Pauli-sum generators: the state-column kernels on the identity's columns) and runs
+ *      the adjoint sweep on the columns [col0, col0 + n_cols) of (P R, 2 M P): loss = its share 1/2 Re sum_i <lambda_i, y_i>,
+ *      grad_u[t][k] = its share of dL/du;
+ *   4. all-reduces (loss, grad_u).
+ * The sums over all ranks equal dq_energy_grad of the whole batch on one GPU.  Needs dq_set_observable and a generator the
+ * state-column kernels take (else DQ_ERR_UNSUPPORTED); n_cols = 0 is allowed (more ranks than columns). */
+int dq_gram(dq_ctx* ctx, const void* psi0, int batch, void* R_out);
+int dq_energy_grad_columns(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* R, int col0, int n_cols,
+                           double* loss, double* grad_u);
+
 /* Fidelity objective for a batch of (initial, target) pairs -- the batched form of train_fidelity's
  * M = |psi1><psi1| (sim_plain.py:436-455): loss = sum_b (1 - |<target_b|psi_b(T)>|^2), grad_u as above,
  * fidelities[b] = |<target_b|psi_b(T)>|^2.  targets is [dim][batch] like psi0. */

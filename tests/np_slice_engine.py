@@ -84,3 +84,32 @@ class NumpySliceEngine:
     def energy(self, psi):
         en = np.real(np.sum(psi.conj() * (self.M @ psi), axis=0))
         return en, float(en.sum())
+
+    # ---- column-sharded wide-batch gradient (Engine.gram / energy_grad_columns), with the oracle's arithmetic ----
+    def gram(self, psi0):
+        psi0 = np.asarray(psi0, dtype=np.complex128)
+        return psi0 @ psi0.conj().T
+
+    def energy_grad_columns(self, u, dt, R, col0, n_cols):
+        """The share of (L, dL/du) of the columns [col0, col0 + n_cols) of (P R, 2 M P): L = tr(M P R P^H) = 1/2 Re sum_i <lam_i, y_i>,
+        dL/du_k[t] = Re sum_i <lam_i(t+1)| dU_t |y_i(t)> with y_i(t) = U_t^H y_i(t+1), lam_i(t) = U_t^H lam_i(t+1)."""
+        u = np.asarray(u, dtype=np.float64).reshape(-1, self.n_controls)
+        S = u.shape[0]
+        gens = [orc.step_generator(self.H0, self.Hs, row, dt) for row in u]
+        Us = [sla.expm(A) for A in gens]
+        P = np.eye(self.dim, dtype=np.complex128)
+        for U in Us:
+            P = U @ P
+        sl = slice(col0, col0 + n_cols)
+        Y = (P @ np.asarray(R, dtype=np.complex128))[:, sl]
+        Lam = (2.0 * self.M @ P)[:, sl]
+        loss = 0.5 * float(np.real(np.sum(Lam.conj() * Y)))
+        grad = np.zeros((S, self.n_controls))
+        for t in range(S - 1, -1, -1):
+            Yt = Us[t].conj().T @ Y
+            for k, Hk in enumerate(self.Hs):
+                dU = sla.expm_frechet(gens[t], -1j * dt * Hk, compute_expm=False)
+                grad[t, k] = np.real(np.sum(Lam.conj() * (dU @ Yt)))
+            Y = Yt
+            Lam = Us[t].conj().T @ Lam
+        return loss, grad

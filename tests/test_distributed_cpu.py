@@ -220,3 +220,69 @@ def test_virtual_ranks_propagator_sharded_numpy():
             f0, c0 = shard_range(7, r, world)
             assert abs(l - loss) < 1e-12 and np.max(np.abs(g - grad)) < 1e-12
             assert np.max(np.abs(f - fin[:, f0:f0 + c0])) < 1e-12
+
+
+# ---- column-sharded wide-batch gradient (round 5; BASELINE configs[3]) ---------------------------------------------------------------
+
+def test_virtual_ranks_column_sharded_equals_oracle():
+    """G virtual ranks (numpy twin = the oracle's arithmetic): any split of the batch, the dim columns of (P R, 2 M P) split over the
+    ranks -- more ranks than columns included -- give the oracle's loss and gradient of the whole batch on every rank."""
+    from diffquantum_amd import problems
+    from diffquantum_amd.distributed import shard_range, virtual_column_sharded_energy_grad
+    from oracle import trotter_oracle as orc
+    from tests.np_slice_engine import NumpySliceEngine
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    dt, B = 0.1, 11                                  # batch wider than the dimension (4)
+    full = problems.random_states(4, B, seed=9)
+    for S in (1, 5):
+        u = np.random.default_rng(S).uniform(-1, 1, (S, 2))
+        loss, grad, _ = orc.energy_grad(H0, list(Hs), M, u, dt, full)
+        for world in (1, 2, 3, 6):                   # 6 ranks, 4 columns: two ranks sweep nothing
+            engines = [NumpySliceEngine(H0, Hs, M) for _ in range(world)]
+            shards = [full[:, f:f + c] for f, c in (shard_range(B, r, world) for r in range(world))]
+            for l, g, _, _ in virtual_column_sharded_energy_grad(engines, u, dt, shards):
+                assert abs(l - loss) < 1e-11 and g.shape == (S, 2) and np.max(np.abs(g - grad)) < 1e-11
+
+
+def _columns_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from diffquantum_amd import problems
+    from diffquantum_amd.distributed import column_sharded_energy_grad, shard_range
+    from tests.np_slice_engine import NumpySliceEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (6, 2))
+    B = 9
+    first, count = shard_range(B, rank, world)
+    psi = problems.random_states(4, count, seed=9, first=first)
+    out = [column_sharded_energy_grad(NumpySliceEngine(H0, Hs, M), u, 0.1, psi) for _ in range(2)]   # twice: collectives stay matched
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_column_sharded_equals_single_process():
+    import torch.multiprocessing as mp
+    from diffquantum_amd import problems
+    from oracle import trotter_oracle as orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_columns_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H0, Hs, M = problems.random_hermitian_problem(2, 2, seed=5)
+    u = np.random.default_rng(1).uniform(-1, 1, (6, 2))
+    loss, grad, _ = orc.energy_grad(H0, list(Hs), M, u, 0.1, problems.random_states(4, 9, seed=9))
+    for rank, out in res:
+        for l, g in out:
+            assert abs(l - loss) < 1e-11 and np.max(np.abs(g - grad)) < 1e-11
