@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(1, 2, 3, 5),
                     help="3 = headline (BASELINE configs[2]/[3]); 1 = configs[0] (demo_maxcut.py: training epochs/s, oracle CPU loop beside it); "
                          "2 = configs[1] (n=8 QAOA forward); 5 = configs[4] (n=18, c64, matrix-free)")
-    ap.add_argument("--workload", choices=("ising", "dense-real", "dense-complex"), default="ising",
+    ap.add_argument("--workload", choices=("ising", "dense-real", "dense-complex", "xy-drives", "qaoa-ring"), default="ising",
                     help="config 3 inputs: BASELINE's random Ising + X_k (default) or dense random matrices of the same size and norm")
     ap.add_argument("--qubits", type=int, default=12)
     ap.add_argument("--batch", type=int, default=None, help="states per GPU (config 5: the WHOLE batch, default 512)")

@@ -570,11 +570,18 @@ def run_config3(a, D):
     # ---- inputs, resident in HBM before the clock starts --------------------------------------
     if a.workload == "ising":
         H0, Hs, M = problems.random_ising_torch(n, a.seed, dev)
+    elif a.workload == "xy-drives":     # I/Q drives: X_k on half of the qubits, Y_k on the others (by_input_structure's inputs)
+        H0, Hs, M = problems.xy_drives_torch(n, a.seed, dev, n_x=n // 2, n_y=n - n // 2)
+    elif a.workload == "qaoa-ring":     # the reference demo's Hamiltonians at n qubits: ZZ-edge + X-vertex controls (K = 2 n)
+        H0, Hs, M = problems.qaoa_ring_torch(n, dev)
     else:
         H0, Hs, M = problems.random_dense_torch(n, n, a.seed, dev, complex_h=(a.workload == "dense-complex"))
+    nc = int(Hs.shape[0])               # controls
     u_all = problems.pulse_table(n, max(K, W, 1), a.dt * max(K, W, 1), seed=a.seed)
+    if nc != n:
+        u_all = np.concatenate([u_all] * (nc // n), axis=1)
     psi0 = torch.from_numpy(problems.random_states(d, B, a.seed, first=rank * B)).to(dev)
-    eng = Engine(d, n, device=D.local)
+    eng = Engine(d, nc, device=D.local)
     eng.use_torch_stream()
     eng.set_hamiltonians(H0, Hs)
     eng.set_observable(M)
@@ -584,7 +591,7 @@ def run_config3(a, D):
     eng.set_option("state_columns", a.state_columns)
     eng.set_option("plan_steps", max(a.chain, K))  # checkpoint/rebuild ratio of the full 2000-step chain
     u_t = torch.from_numpy(u_all[:K].copy()).to(dev)
-    grad_t = torch.zeros((K, n), dtype=torch.float64, device=dev)
+    grad_t = torch.zeros((K, nc), dtype=torch.float64, device=dev)
 
     # Propagator cache of the sliced form: a rank's slice of the planned chain is short enough to be cached WHOLE
     # ((q + 3) d^2 fp64 words per step, 2q + 2 with the sparse-generator scheme: 0.8-1.07 GB per step at q = 3), so the budget is
@@ -638,14 +645,14 @@ def run_config3(a, D):
     forms = {}
     sliced_check = None
     columns_check = None
-    columns_ok = a.workload == "ising" and a.state_columns != 0   # (needs a Pauli-sum generator on the state-column kernels)
+    columns_ok = a.workload in ("ising", "xy-drives", "qaoa-ring") and a.state_columns != 0   # (needs a Pauli-sum generator on the state-column kernels)
     if mode == "columns" and not columns_ok:
         raise SystemExit("--multi-gpu columns needs the Ising workload with the state-column form")
     if W > 0:
         uw = torch.from_numpy(u_all[:W].copy()).to(dev)
-        lr, gr = run_replicated(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+        lr, gr = run_replicated(uw, torch.zeros((W, nc), dtype=torch.float64, device=dev))
         if columns_ok and (mode == "columns" or want_beside):
-            lc, gc = run_columns(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+            lc, gc = run_columns(uw, torch.zeros((W, nc), dtype=torch.float64, device=dev))
             errc = float((gc - gr).abs().max().item())
             columns_check = {"max_abs_grad_diff_vs_replicated": errc, "abs_loss_diff_vs_replicated": abs(lc - lr)}
             okc = errc <= 1e-9 * (1.0 + float(gr.abs().max().item())) and abs(lc - lr) <= 1e-9 * (1.0 + abs(lr))
@@ -656,7 +663,7 @@ def run_config3(a, D):
                 raise SystemExit("column-sharded form disagrees with the replicated form: {}".format(columns_check))
         if mode == "sliced" or want_beside:
             # the warm-up doubles as the check: same loss and gradient from both forms on every rank
-            ls, gs = run_sliced(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+            ls, gs = run_sliced(uw, torch.zeros((W, nc), dtype=torch.float64, device=dev))
             err = float((gs - gr).abs().max().item())
             ok = err <= 1e-9 * (1.0 + float(gr.abs().max().item())) and abs(ls - lr) <= 1e-9 * (1.0 + abs(lr))
             flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
@@ -674,15 +681,15 @@ def run_config3(a, D):
         for name, fn in (("sliced", run_sliced), ("replicated", run_replicated)):
             if name == "replicated" and not both:
                 continue
-            g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
+            g2 = torch.zeros((K, nc), dtype=torch.float64, device=dev)
             D.fence()
             t1 = time.perf_counter()
             l2, g2 = fn(u_t, g2)
             D.fence()
             forms[name] = {"seconds": D.max_over_ranks(time.perf_counter() - t1), "loss": l2, "grad": g2.clone()}
     if want_beside and columns_ok and columns_check and columns_check["agreed_on_every_rank"]:
-        g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
-        run_columns(u_t[:1].contiguous(), torch.zeros((1, n), dtype=torch.float64, device=dev))   # (allocations)
+        g2 = torch.zeros((K, nc), dtype=torch.float64, device=dev)
+        run_columns(u_t[:1].contiguous(), torch.zeros((1, nc), dtype=torch.float64, device=dev))   # (allocations)
         D.fence()
         t1 = time.perf_counter()
         l2, g2 = run_columns(u_t, g2)
@@ -695,7 +702,7 @@ def run_config3(a, D):
         psi_all = torch.from_numpy(problems.random_states(d, B * world, a.seed, first=0)).to(dev) if world > 1 else psi0
         eng.set_option("plan_steps", max(a.chain, K))
         eng.set_option("cache_bytes", 0)
-        g2 = torch.zeros((K, n), dtype=torch.float64, device=dev)
+        g2 = torch.zeros((K, nc), dtype=torch.float64, device=dev)
         eng.energy_grad(u_t[:1].contiguous(), a.dt, psi_all, want_final=False, want_energies=False)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         eng.energy_grad(u_t, a.dt, psi_all, want_final=False, want_energies=False, grad_out=g2)
@@ -703,7 +710,7 @@ def run_config3(a, D):
         del psi_all
     prop_check = None
     if mode == "propagators" and W > 0:   # the warm-up chain doubles as the check against the replicated form
-        lp, gp = run_propagators(uw, torch.zeros((W, n), dtype=torch.float64, device=dev))
+        lp, gp = run_propagators(uw, torch.zeros((W, nc), dtype=torch.float64, device=dev))
         prop_check = {"max_abs_grad_diff_vs_replicated": float((gp - gr).abs().max().item()), "abs_loss_diff_vs_replicated": abs(lp - lr)}
     run = {"sliced": run_sliced, "propagators": run_propagators, "columns": run_columns}.get(mode, run_replicated)
     eng.profile_enable(True)
@@ -753,6 +760,8 @@ def run_config3(a, D):
                   "and for dense inputs of the same size)") if info.get("xor_regular", 0) > 0 else
                  ("diagonal Ising drift + X_k controls: real AND sparse -- the engine runs the step exponential as sparse x dense passes "
                   "(input-structure-specific path; see by_input_structure for dense inputs of the same size)"),
+        "xy-drives": "Ising drift + X / Y drives: a complex Hermitian sum of Pauli strings on the state-column kernels",
+        "qaoa-ring": "drift sum_e (I - Z_i Z_j), ZZ-edge controls (diagonal) + X-vertex controls: a sum of Pauli strings on the state-column kernels",
         "dense-real": "dense random real symmetric H0 / H_k: cos X + i sin X on real symmetric-output MFMA products",
         "dense-complex": "dense random complex Hermitian H0 / H_k: the general complex tape"}[a.workload]
     beside = None
@@ -785,12 +794,14 @@ def run_config3(a, D):
             "workload": "BASELINE configs[{}]: {}-qubit {} (d={}), {} controls, B={} states per GPU, fwd+adjoint, fp64 complex, "
                         "{} of {} Trotter steps timed".format(2 if world == 1 else 3, n,
                                                               {"ising": "random Ising H + X_k", "dense-real": "dense random real symmetric H",
-                                                               "dense-complex": "dense random complex Hermitian H"}[a.workload], d, n, B, K,
+                                                               "dense-complex": "dense random complex Hermitian H",
+                                                               "xy-drives": "random Ising drift + X_k / Y_k drives (not a BASELINE config: by_input_structure's inputs as the timed workload)",
+                                                               "qaoa-ring": "ring QAOA, ZZ-edge + X-vertex controls (the reference demo's Hamiltonians at n = 12; not a BASELINE config)"}[a.workload], d, nc, B, K,
                                                               max(a.chain, K)),
             "workload_detail": "stored dense; dt={}; batch >= dim: operator-form backward sweep, no state checkpoints, per-step cost "
                                "independent of the chain length; otherwise the slice uses the checkpoint stride of the full chain".format(a.dt),
             "input_structure": structure_note,
-            "n_qubits": n, "dim": d, "n_controls": n, "batch_per_gpu": B, "global_batch": B * world,
+            "n_qubits": n, "dim": d, "n_controls": nc, "batch_per_gpu": B, "global_batch": B * world,
             "chain_steps": K, "dt": a.dt,
             # (SURVEY D1 "pulse-table upload included": the table is 8 K S bytes -- 2 KB here -- and is handed over as a DEVICE tensor that is
             # resident before the clock starts; inside the timed call the library copies it to the host once for the step bound and back)

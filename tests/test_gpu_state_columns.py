@@ -508,7 +508,7 @@ def test_centred_diagonal_matches_the_uncentred_kernels_and_the_oracle(oracle, c
         comp = e.propagate(u, dt, psi0)          # the product of the chain from state-column segments, each with its own scalar
         assert e.info("state_columns_compose_segments") >= 1 and e.info("state_columns_centered") == 1
     (l1, g1, f1, w1, th1, L1, seg1), (l0, g0, f0, w0, th0, L0, _) = out[1], out[0]
-    assert th1 <= th0 * (1 + 1e-12) and L1 <= L0 and seg1 == 3
+    assert th1 <= th0 * (1 + 1e-12) and L1 <= L0 and seg1 >= 2      # (the adjoint sweep ran in several launches, each with its own scalar)
     if case == "qaoa_ring_zz_controls":
         assert th1 < 0.8 * th0, (th1, th0)       # the drift's range [0, 2 n] centred: half its share of the bound
     for (l, g, f, w) in ((l1, g1, f1, w1), (l0, g0, f0, w0)):
