@@ -1371,375 +1371,8 @@ int forward_chain(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, in
 }
 
 // ---- state-column form (statecol.hip) -------------------------------------------------------------------------------------
-// For XOR-regular (Pauli-string) generators the chain psi <- exp(-i dt H(t)) psi (diffqc.cc:190-200, sim_plain.py:135-150) needs
-// no propagator at all: a workgroup holds one state column in LDS and applies the Taylor polynomial of every step as sweeps of
-// partner reads; the adjoint sweep runs the same way on (psi, lambda) and leaves dL/du as per-diagonal sums.  Cost ~ batch x
-// dim x diagonals per step instead of dim^3: chosen (auto) while the batch is at most xs_batch_ratio x dim.
-template <class T>
-const dq::XrTab* xs_table(Ctx<T>* c) {
-  if (c->xor_mode == 0 || c->xs_mode == 0) return nullptr;
-  // (the state-column kernels take the signs as parities -- one Pauli string per diagonal; other sign patterns keep the column form)
-  if (c->real_h && c->xr_ok && c->sparse_mode != 0 && c->sparse_gen_mode != 0) return c->xr_tab.parity ? &c->xr_tab : nullptr;
-  if (!c->real_h && c->zxr_ok) return c->zxr_tab.parity ? &c->zxr_tab : nullptr;
-  return nullptr;
-}
-
-// Taylor degree of the whole chain's polynomial (the largest step decides), or 0 when the state-column form is not to be used
-template <class T>
-int xs_degree(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int B, bool for_compose = false) {
-  const dq::XrTab* tab = xs_table(c);
-  if (!tab) return 0;
-  // the options that pin another scheme keep it
-  // (compose = 0 / 1 pins the scheme of the STATES -- swept one by one through explicit propagators / one product applied once.  Under
-  // compose = 1 the PRODUCT itself still comes from state-column segments for a Pauli-sum generator unless state_columns_compose = 0
-  // asks for the explicit-propagator tree; compose = 0 takes neither composed route, the wide-batch gradient included: ADVICE r4)
-  if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || (c->compose_mode >= 0 && !for_compose)) return 0;
-  // auto: from dim 512 up (at 256 a column is one wave and the tree-composed operator form is faster: 0.34 M against 0.11 M forward
-  // steps/s on BASELINE configs[1]) and while the batch is at most xs_batch_ratio x dim
-  // (for_compose: the columns are the identity's, d of them per time segment -- neither bound concerns it)
-  if (!for_compose && c->xs_mode < 0 && (c->d < c->xs_min_dim || (double)B > c->xs_batch_ratio * (double)c->d)) return 0;
-  double th = 0.0;
-  for (int t = 0; t < S; ++t) th = std::max(th, theta_bound(c, uh.data() + (size_t)t * c->K, dt));
-  if ((size_t)4 * sizeof(T) * (size_t)c->d > c->max_lds) return 0;  // two images of a column must fit the device's LDS
-  // the step polynomial: Chebyshev-economized on the spectral interval i [-theta, theta] (dq_internal.h, XsPoly), same error bound as
-  // the Taylor polynomial it replaces with one to four degrees fewer -- every sweep of the kernels is one degree
-  dq::XsPoly pol;
-  const double tol = std::min(c->expm_tol, c->xs_chain_tol / (double)std::max<long>(std::max<long>(S, c->plan_steps), 1));
-  const int L = dq::xs_poly_make(th, tol, c->xs_economize, &pol);
-  if (L <= 0 || !dq::xs_supported(c->d, L, tab->R, tab->nd, sizeof(T))) return 0;
-  c->xs_poly = pol;
-  c->last_theta = th;
-  dq::XsPoly tay;
-  c->last_xs_taylor_degree = dq::xs_poly_make(th, tol, 0, &tay);
-  return L;
-}
-
-template <class T>
-struct XsLaunch {
-  int L, nblk, lds_diag;
-  long dgs_step;
-  const dq::XrTab* tab;
-  bool quad_ok;      // the adjoint sweep runs the quadrature form with the rule `quad`
-  dq::XsQuad quad;
-  int seg_steps = 0; // steps per launch of the adjoint sweep (its partial-sum scratch is sized for that many)
-  std::vector<double> cen;   // centred frame: the midpoint of the diagonal's range per step (empty: not centred)
-  // e^{-i sum_{s0 <= s < s1} cen[s]} as (re, im): the factor of a forward launch over those steps; the adjoint launch takes its conjugate
-  void phase(int s0, int s1, double* pr, double* pi) const {
-    long double acc = 0.0L;
-    if (!cen.empty())
-      for (int s = s0; s < s1; ++s) acc += (long double)cen[(size_t)s];
-    *pr = (double)cosl(acc);
-    *pi = (double)-sinl(acc);
-  }
-};
-
-// per-call set-up: weights of every step, buffers
-template <class T>
-XsLaunch<T> xs_prepare(Ctx<T>* c, int S, double dt, int B, int L, bool backward) {
-  typedef TT T2;
-  XsLaunch<T> x;
-  x.L = L;
-  x.tab = xs_table(c);
-  x.nblk = dq::xs_blocks(c->d, sizeof(T), B, c->n_cu, c->xs_variant);
-  if (c->xs_workgroups > 0) x.nblk = std::min(x.nblk, c->xs_workgroups);   // (tests: several columns per workgroup at any batch)
-  x.lds_diag = dq::xs_lds_diagonals(c->d, *x.tab, c->xs_variant);
-  const size_t sb = (size_t)c->d * B * sizeof(T2);
-  c->xs_psi.ensure(sb);
-  c->xs_lam.ensure(sb);
-  c->xs_wt.ensure(sizeof(double) * std::max<size_t>((size_t)S * x.tab->R, 1));
-  c->xs_dgs.ensure(sizeof(double) * dq::xs_dgs_doubles(c->d, S, *x.tab));
-  if (backward) {
-    // the per-step partial sums (workgroups x waves x slots doubles per step) are kept for a SEGMENT of the chain at a time: the sweep
-    // is restartable at any step (psi and lambda are in/out, gradient rows disjoint), so a long chain costs no more scratch than a
-    // segment of xs_part_bytes (default 256 MB; d = 4096: 262 KB per step, d = 512 at batch 4096: 327 KB per step)
-    const size_t per_step = sizeof(double) * std::max<size_t>(dq::xs_part_doubles(c->d, 1, x.nblk, *x.tab, c->xs_variant), 1);
-    x.seg_steps = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), (size_t)(c->xs_part_bytes / (double)per_step)));
-    c->xs_part.ensure(per_step * (size_t)x.seg_steps);
-  }
-  const dq::XrTab tb = *x.tab;
-  long step = 0;
-  c->timed(DQ_PROF_OTHER, 0.0, 8.0 * ((double)S * tb.R + (double)dq::xs_dgs_doubles(c->d, S, tb)), [&] {
-    return dq::xs_weights_launch(tb, c->u_dev.d(), c->K, S, c->d, dt, c->xs_wt.d(), c->xs_dgs.d(), &step, c->st);
-  });
-  x.dgs_step = step;
-  // ---- centred diagonal: every row of the diagonal-weight table minus the midpoint of its range; the step bound from half the range
-  // plus the off-diagonal row sum, and the lowest degree that bound allows (never above the one the sources' norms gave)
-  c->last_xs_centered = 0;
-  c->last_xs_theta_loose = c->last_theta;
-  if (c->xs_center != 0 && S > 0 && c->uh_last.size() >= (size_t)S * c->K) {
-    const int rows = step ? S : 1;
-    c->xs_cen.ensure(sizeof(double) * 2 * (size_t)rows);
-    double* cen_d = c->xs_cen.d();
-    c->timed(DQ_PROF_OTHER, 0.0, 16.0 * (double)rows * c->d, [&] { return dq::xs_center_launch(c->xs_dgs.d(), c->d, rows, cen_d, cen_d + rows, c->st); });
-    std::vector<double> ch(2 * (size_t)rows);
-    HIPCK(hipMemcpyAsync(ch.data(), cen_d, sizeof(double) * ch.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCK(hipStreamSynchronize(c->st));
-    x.cen.resize((size_t)S);
-    double th = 0.0;
-    for (int s = 0; s < S; ++s) {
-      const int r = step ? s : 0;
-      x.cen[(size_t)s] = ch[(size_t)r];
-      double off = 0.0;
-      const double* ur = c->uh_last.data() + (size_t)s * c->K;
-      for (int j = 0; j < tb.R; ++j) off += std::fabs(tb.kid[j] < 0 ? 1.0 : ur[tb.kid[j]]) * tb.cmag[j];
-      th = std::max(th, ch[(size_t)rows + r] + std::fabs(dt) * off);
-    }
-    c->last_xs_centered = 1;
-    if (th < c->last_theta) {
-      dq::XsPoly pol;
-      const double tol = std::min(c->expm_tol, c->xs_chain_tol / (double)std::max<long>(std::max<long>(S, c->plan_steps), 1));
-      const int L2 = dq::xs_poly_make(th, tol, c->xs_economize, &pol);
-      if (L2 > 0 && L2 <= L) {
-        L = L2;
-        x.L = L2;
-        c->xs_poly = pol;
-        c->last_theta = th;
-        dq::XsPoly tay;
-        c->last_xs_taylor_degree = dq::xs_poly_make(th, tol, 0, &tay);
-      }
-    }
-  }
-  // (the rule of the quadrature adjoint: made for the final theta and degree)
-  x.quad_ok = false;
-  if (backward && c->xs_adjoint != 0) x.quad_ok = dq::xs_quad_make(c->last_theta, c->xs_quad_tol, 2, L, c->xs_economize, c->xs_poly, &x.quad, dq::xs_quad_basis(*x.tab, c->d, c->xs_variant, sizeof(T)) ? 1 : 0) &&
-                                              dq::xs_quad_supported(*x.tab, x.quad.ni, c->d, c->xs_variant, sizeof(T));
-  c->last_xs_nodes = backward && x.quad_ok ? x.quad.ni : 0;
-  if (backward && !x.quad_ok) c->xs_park.ensure(sizeof(T2) * dq::xs_park_elems(c->d, L, x.nblk));
-  c->last_degree = L;
-  c->last_squarings = 0;
-  c->last_products = 0;
-  c->last_real_q = c->real_h ? (L - 1) / 2 : 0;
-  c->last_spx = c->real_h ? 1 : 0;
-  c->last_xr = c->real_h ? 1 : 2;
-  c->last_xs = 1;
-  c->last_chunk = S;
-  c->last_cstride = 0;
-  c->last_composed = 0;
-  c->last_opback = 0;
-  return x;
-}
-
-// flops / LDS bytes of `sweeps` sweeps over B columns, `dot_sweeps` of them carrying the gradient pairings.  The plain sweeps take
-// the partners at offsets without lane bits from registers; so do the pairing sweeps of the quadrature form, those of the exact
-// form read every partner from LDS (dot_all_lds)  (classes DQ_PROF_STATECOL_FWD / _BWD)
-template <class T>
-void xs_book(Ctx<T>* c, const XsLaunch<T>& x, double sweeps, double dot_sweeps, bool dot_all_lds, int B, double* flops, double* lds_bytes) {
-  const double rows = (double)c->d * B;
-  *flops = rows * (sweeps * (4.0 * x.tab->R + 8.0) + dot_sweeps * 4.0 * x.tab->R);
-  *lds_bytes = rows * ((sweeps - dot_sweeps) * (double)x.lds_diag + dot_sweeps * (dot_all_lds ? (double)x.tab->R : (double)x.lds_diag)) * 2.0 *
-               sizeof(T);
-}
-
-// psi (dev, [d][B]) -> U_{S-1} ... U_0 psi in c->xs_psi ([B][d]); the result's [d][B] image goes to `out_db` if given
-template <class T>
-void xs_forward(Ctx<T>* c, const XsLaunch<T>& x, const TT* psi_db, int S, int B, TT* out_db) {
-  typedef TT T2;
-  const int d = c->d;
-  const double by = 2.0 * sizeof(T2) * (double)d * B;
-  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, psi_db, B, 0, d, B, 0, 1, c->st); });
-  double fl, lb;
-  xs_book(c, x, (double)x.L * S, 0.0, false, B, &fl, &lb);
-  const dq::XrTab tb = *x.tab;
-  c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
-    double pr, pi;
-    x.phase(0, S, &pr, &pi);
-    return dq::xs_forward_launch((const T2*)c->xs_lam.p, (T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, B, x.L,
-                                 x.nblk, c->xs_variant, &c->xs_poly, pr, pi, c->st);
-  });
-  if (out_db)
-    c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>(out_db, B, 0, (const T2*)c->xs_psi.p, d, 0, B, d, 0, 1, c->st); });
-}
-
-// The propagators of the chain's time segments from the state-column forward kernel (see compose_chain): n stacked d x d matrices
-// in time order (pool slot SLOT_TP_L), or null when the generator / the options do not allow the state-column form.
-template <class T>
-TT* xs_compose_segments(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, int* n_out) {
-  typedef TT T2;
-  *n_out = 0;
-  if (S <= 0 || c->xs_compose_mode == 0) return nullptr;
-  const int d = c->d;
-  const int L = xs_degree(c, uh, S, dt, d, true);
-  if (!L) return nullptr;
-  // segments: as many as it takes for d columns each to fill the chip's workgroup slots once (d = 256: 20, d = 4096: 1); each costs
-  // a d^3 product in the tree afterwards
-  const int cap = dq::xs_blocks(d, sizeof(T), 1 << 30, c->n_cu, c->xs_variant);
-  int G0 = std::max(1, (cap + d - 1) / d), G2 = 1;
-  while (2 * G2 <= G0) G2 *= 2;   // a power of two: full levels in the tree of products, the same count of columns on every SIMD
-                                  // (configs[1], d = 256: 16 segments 0.92 ms, 20 segments 1.04 - 1.11 ms, 8 segments 1.03 ms)
-  int G = std::max(1, std::min(S, c->xs_compose_mode > 0 ? c->xs_compose_mode : G2));   // (option value > 0: that many)
-  const int seg = (S + G - 1) / G;
-  G = (S + seg - 1) / seg;
-  const int B = G * d;
-  XsLaunch<T> x = xs_prepare(c, S, dt, B, L, false);
-  x.nblk = dq::xs_blocks(d, sizeof(T), B, c->n_cu, c->xs_variant);
-  double fl, lb;
-  xs_book(c, x, (double)x.L * seg, 0.0, false, B, &fl, &lb);
-  const dq::XrTab tb = *x.tab;
-  const double* seg_phase = nullptr;
-  if (!x.cen.empty()) {   // the scalar of every segment's propagator in the centred frame
-    std::vector<double> ph(2 * (size_t)G);
-    for (int g = 0; g < G; ++g) x.phase(g * seg, std::min(S, (g + 1) * seg), &ph[2 * (size_t)g], &ph[2 * (size_t)g + 1]);
-    c->xs_segphase.ensure(sizeof(double) * ph.size());
-    HIPCK(hipMemcpyAsync(c->xs_segphase.p, ph.data(), sizeof(double) * ph.size(), hipMemcpyHostToDevice, c->st));
-    HIPCK(hipStreamSynchronize(c->st));   // (ph is pageable)
-    seg_phase = c->xs_segphase.d();
-  }
-  c->timed(DQ_PROF_STATECOL_FWD, fl, lb, [&] {
-    return dq::xs_forward_segments_launch((T2*)c->xs_psi.p, d, tb, c->xs_wt.d(), c->xs_dgs.d(), x.dgs_step, S, seg, G, x.L, x.nblk,
-                                          c->xs_variant, &c->xs_poly, seg_phase, c->st);
-  });
-  // block g of the launch's output is the transpose of segment g's propagator
-  T2* X = c->mat(SLOT_TP_L, (size_t)G);
-  const long nn = (long)c->nn();
-  c->timed(DQ_PROF_OTHER, 0.0, 2.0 * sizeof(T2) * (double)nn * G,
-           [&] { return dq::ztranspose_launch<T>(X, d, nn, (const T2*)c->xs_psi.p, d, nn, d, d, 0, G, c->st); });
-  c->last_xs_segments_fwd = G;
-  c->last_xs = 0;   // ("state_columns" reports the STATES' path; this product is reported by state_columns_compose_segments)
-  *n_out = G;
-  return X;
-}
-
-// ---- matrix-free routing (structured.hip behind the dense API) --------------------------------------------------------------------
-template <class T>
-const dq::XrTab* mf_table(Ctx<T>* c) {
-  if (c->xor_mode == 0) return nullptr;
-  if (c->real_h && c->xr_ok && c->sparse_mode != 0 && c->sparse_gen_mode != 0) return &c->xr_tab;
-  if (!c->real_h && c->zxr_ok) return &c->zxr_tab;
-  return nullptr;
-}
-
-// in-place Walsh-Hadamard transform: f[z] <- (1 / n) sum_i f[i] (-1)^popcount(i & z) -- the coefficients of the Z-strings of a diagonal
-inline void mf_wht(std::vector<double>& f) {
-  const size_t n = f.size();
-  for (size_t h = 1; h < n; h <<= 1)
-    for (size_t i = 0; i < n; i += h << 1)
-      for (size_t j = i; j < i + h; ++j) {
-        const double a = f[j], b = f[j + h];
-        f[j] = a + b;
-        f[j + h] = a - b;
-      }
-  const double inv = 1.0 / (double)n;
-  for (double& v : f) v *= inv;
-}
-
-// The table as Pauli strings (kron order of the reference, demo_maxcut.py:49-56: index bit b of a row <-> string position n-1-b;
-// masks are index-bit masks).  XOR-diagonal j: entries H[i, i ^ x] = (-1)^s_ij c i^ph.  It is ONE string a P, P = X on the bits of
-// x & ~z, Z on z & ~x, Y on x & z, iff s_ij = s_0j ^ parity(i & z) for a mask z; then P[i, i ^ x] = (-i)^ny (-1)^parity(i & z)
-// (ny = popcount(x & z)) and a = (-1)^s0 c i^(ph + ny), real for a Hermitian source.  Offset-0 diagonals: Z-strings by their
-// Walsh-Hadamard coefficients.  Returns false when a sign pattern is not a parity (a sum of strings of equal weight that the
-// table cannot tell apart): such inputs keep the explicit-propagator chain.
-template <class T>
-bool mf_build(Ctx<T>* c) {
-  if (!c->mf_dirty) return c->mf_possible;
-  c->mf_dirty = false;
-  c->mf_possible = false;
-  c->mf_has_obs = false;
-  if (c->mf) { (void)dq_sctx_destroy(c->mf); c->mf = nullptr; }
-  const dq::XrTab* tab = mf_table(c);
-  const int d = c->d;
-  int n = 0;
-  while ((1 << n) < d) ++n;
-  if (!tab || (1 << n) != d || n < 9 || n > 30) return false;
-  if (c->tab_sgn_h.size() != (size_t)d || c->tab_dval_h.size() < (size_t)tab->nd * d) return false;
-  std::vector<int> owner;
-  std::vector<unsigned> xm, zm;
-  std::vector<double> w;
-  auto parity = [](unsigned v) { return (unsigned)__builtin_popcount(v) & 1u; };
-  for (int j = 0; j < tab->R; ++j) {
-    const unsigned s0 = tab->sgn ? (c->tab_sgn_h[0] >> j) & 1u : 0u;
-    unsigned z = 0;
-    if (tab->sgn) {
-      for (int b = 0; b < n; ++b)
-        if (((c->tab_sgn_h[(size_t)1 << b] >> j) & 1u) != s0) z |= 1u << b;
-      for (int i = 0; i < d; ++i)
-        if (((c->tab_sgn_h[i] >> j) & 1u) != (s0 ^ parity((unsigned)i & z))) return false;
-    }
-    const unsigned x = (unsigned)tab->xoff[j];
-    const int ny = __builtin_popcount(x & z), e = tab->phase[j] + ny;
-    if (e & 1) return false;   // (an imaginary coefficient: not a Hermitian source -- cannot happen past the Hermiticity check)
-    double a = tab->cmag[j] * (s0 ? -1.0 : 1.0) * (((e >> 1) & 1) ? -1.0 : 1.0);
-    owner.push_back(tab->kid[j]);
-    xm.push_back(x);
-    zm.push_back(z);
-    w.push_back(a);
-  }
-  auto add_diagonal = [&](int own, const double* dg) {
-    std::vector<double> f(dg, dg + d);
-    double mx = 0.0;
-    for (double v : f) mx = std::max(mx, std::fabs(v));
-    mf_wht(f);
-    for (int z = 0; z < d; ++z)
-      if (std::fabs(f[z]) > 1e-15 * mx) {   // (dropped coefficients: below the rounding of the diagonal itself)
-        owner.push_back(own);
-        xm.push_back(0u);
-        zm.push_back((unsigned)z);
-        w.push_back(f[z]);
-      }
-  };
-  for (int jd = 0; jd < tab->nd; ++jd) add_diagonal(tab->dkid[jd], c->tab_dval_h.data() + (size_t)jd * d);
-  if (c->have_M && c->m_is_diag) {
-    std::vector<double> md((size_t)d);
-    HIPCK(hipMemcpyAsync(md.data(), c->m_diag.p, sizeof(double) * (size_t)d, hipMemcpyDeviceToHost, c->st));
-    HIPCK(hipStreamSynchronize(c->st));
-    add_diagonal(-2, md.data());
-    c->mf_has_obs = true;
-  }
-  auto ck = [&](int rc, const char* what) {
-    if (rc != DQ_OK) fail(rc, std::string("matrix-free routing: ") + what + ": " + dq_sctx_last_error());
-  };
-  ck(dq_sctx_create(&c->mf, n, c->K, c->dev, c->dtype), "dq_sctx_create");
-  ck(dq_sctx_set_stream(c->mf, (void*)c->st), "dq_sctx_set_stream");
-  ck(dq_sctx_set_terms(c->mf, (int)owner.size(), owner.data(), xm.data(), zm.data(), w.data()), "dq_sctx_set_terms");
-  c->mf_possible = true;
-  return true;
-}
-
-// does this call run on the matrix-free passes?
-template <class T>
-bool mf_route(Ctx<T>* c, int S, bool need_observable, bool targets) {
-  c->last_mf = 0;
-  if (c->mf_mode == 0 || S <= 0 || targets) return false;
-  const dq::XrTab* tab = mf_table(c);
-  if (!tab) return false;
-  // the options that pin another scheme keep it (as for the state-column form)
-  if (c->force_degree > 0 || c->force_s >= 0 || c->real_mode != -1 || c->compose_mode >= 0) return false;
-  // auto: only where the state-column kernels do not exist (their cost per step is far below a pass over HBM)
-  if (c->mf_mode < 0 && (c->d < 512 || dq::xs_supported(c->d, 1, tab->R, tab->nd, sizeof(T)))) return false;
-  if (need_observable && !(c->have_M && c->m_is_diag)) return false;   // (a general M is not a string table here)
-  if (!mf_build(c)) return false;
-  if (need_observable && !c->mf_has_obs) return false;
-  auto opt = [&](const char* name, double v) {
-    if (dq_sctx_set_option(c->mf, name, v) != DQ_OK) fail(DQ_ERR_INVALID, std::string("matrix-free routing: ") + dq_sctx_last_error());
-  };
-  opt("plan_steps", (double)c->plan_steps);
-  opt("checkpoint_bytes", c->mf_checkpoint_bytes);
-  opt("polynomial", (double)c->xs_economize);   // (the step polynomial's options name the same thing on both engines)
-  opt("chain_tol", c->xs_chain_tol);
-  opt("tol", c->expm_tol);   // (the per-step bound of the dense API holds on the routed passes too)
-  if (dq_sctx_set_stream(c->mf, (void*)c->st) != DQ_OK) fail(DQ_ERR_HIP, dq_sctx_last_error());
-  return true;
-}
-
-// what dq_get_info reports about the state-column paths of the LAST call: zeroed before any route is taken
-template <class T>
-void reset_call_info(Ctx<T>* c) {
-  c->last_xs_nodes = 0;
-  c->last_xs_segments = 0;
-  c->last_xs_wide = 0;
-  c->last_xs_segments_fwd = 0;
-  c->last_xs_centered = 0;
-}
-
-template <class T>
-void mf_after(Ctx<T>* c) {
-  c->last_mf = 1;
-  reset_call_info(c);
-  double v = 0;
-  if (dq_sctx_get_info(c->mf, "degree", &v) == DQ_OK) c->last_degree = v;
-  if (dq_sctx_get_info(c->mf, "theta", &v) == DQ_OK) c->last_theta = v;
-  if (dq_sctx_get_info(c->mf, "checkpoint_stride", &v) == DQ_OK) c->last_cstride = v;
-  c->last_squarings = 0; c->last_products = 0; c->last_xs = 0; c->last_composed = 0; c->last_opback = 0;
-}
+#include "engine_statecol.inc"
+#include "engine_matrix_free.inc"
 
 template <class T>
 void do_propagate(Ctx<T>* c, const double* u, int S, double dt, const void* psi_in, void* psi_out, int B) {
@@ -2055,202 +1688,7 @@ void chunk_vjp(Ctx<T>* c, const ExpmPlan& p, int c0, int n, double dt) {
   });
 }
 
-template <class T>
-void do_energy_grad_xs(Ctx<T>* c, int S, double dt, const void* psi0, int B, double* loss, double* grad_u, void* psi_final,
-                       double* energies, const void* targets, int L) {
-  typedef TT T2;
-  const int d = c->d, K = c->K;
-  const size_t sb = (size_t)d * B * sizeof(T2);
-  const XsLaunch<T> x = xs_prepare(c, S, dt, B, L, true);
-  c->psi[0].ensure(sb);
-  c->psi[1].ensure(sb);
-  c->lam[0].ensure(sb);
-  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
-  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
-  const bool diag_m = !targets && c->m_is_diag;
-  const double by = 2.0 * sizeof(T2) * (double)d * B;
-  if (diag_m) {
-    // diagonal observable: Lambda_S = 2 m .* Psi_S and the energies on the state columns themselves (no product, no transposes)
-    const bool want_fin = psi_final != nullptr;
-    xs_forward(c, x, p0, S, B, want_fin ? (T2*)c->psi[0].p : nullptr);
-    if (want_fin) out_copy(c, psi_final, c->psi[0].p, sb);
-    c->e_dev.ensure(sizeof(double) * ((size_t)B + 1));
-    c->timed(DQ_PROF_OTHER, 6.0 * d * B, by, [&] {
-      return dq::xs_diag_costate_launch((const T2*)c->xs_psi.p, c->m_diag.d(), (T2*)c->xs_lam.p, c->e_dev.d(), d, B, c->st);
-    });
-    c->timed(DQ_PROF_OTHER, B, 8.0 * B, [&] { return dq::sum_launch(c->e_dev.d(), B, c->e_dev.d() + B, c->st); });
-    if (energies) out_copy(c, energies, c->e_dev.p, sizeof(double) * (size_t)B);
-    if (loss) out_copy(c, loss, c->e_dev.d() + B, sizeof(double));
-  } else {
-    xs_forward(c, x, p0, S, B, (T2*)c->psi[0].p);
-    terminal_costate(c, (const T2*)c->psi[0].p, B, targets, loss, energies);
-    if (psi_final) out_copy(c, psi_final, c->psi[0].p, sb);
-    if (S > 0)
-      c->timed(DQ_PROF_OTHER, 0.0, by,
-               [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, (const T2*)c->lam[0].p, B, 0, d, B, 0, 1, c->st); });
-  }
-  if (S > 0) {
-    double fl, lb;
-    // sweeps per step: the exact form runs 3 L - 1 (L of them with the pairings), the quadrature form 2 L (L with the pairings)
-    const int L = x.L;   // (xs_prepare may have lowered the degree: centred diagonal)
-    xs_book(c, x, (x.quad_ok ? 2.0 * L : 3.0 * L - 1.0) * S, (double)L * S, !x.quad_ok, B, &fl, &lb);
-    const dq::XrTab tb = *x.tab;
-    c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
-    for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {   // segments of the chain, last first (one launch when the whole chain fits)
-      const int s0 = std::max(0, s1 - x.seg_steps), ns = s1 - s0;
-      const double share = (double)ns / (double)S;
-      double pr, pi;
-      x.phase(s0, s1, &pr, &pi);
-      pi = -pi;   // (the adjoint launch takes its inputs INTO the centred frame: e^{+i sum})
-      c->timed(DQ_PROF_STATECOL_BWD, fl * share, lb * share, [&] {
-        return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
-                                      c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, B, L, x.nblk,
-                                      x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
-                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, pr, pi, c->st);
-      });
-    }
-  }
-  if (grad_u && S > 0 && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
-  HIPCK(hipStreamSynchronize(c->st));
-}
-
-// Energy objective, batch wider than the dimension, Pauli-sum generator: the gradient of L = sum_b <psi_b|M|psi_b> = tr(M P R P^H)
-// (R = Psi0 Psi0^H, P = the chain's product) needs no sweep over the B states:
-//     dL/du_k[t] = 2 Re tr(M Q_{t+1} dU_t P_t R P^H) = Re sum_i <lambda_i(t+1)| dU_t |y_i(t)>,   y_i = P_t R e_i,  lambda_i = Q_{t+1}^H 2 M P e_i
-// -- the state-column adjoint sweep as it stands on the d columns of (psi_S, lambda_S) = (P R, 2 M P), with P from the state-column
-// segments of compose_chain; three d^3 products and the Gram product per call.  Final states / per-state energies, when asked for,
-// cost one more d x d x B product.
-// The sweep of do_energy_grad_xs_wide over the columns [col0, col0 + ncols) of (P R, 2 M P): partial loss 1/2 Re sum_i <lambda_i, y_i>
-// and partial dL/du of those columns (grad_dev).  Rm: R = sum over ALL states of psi_0 psi_0^H (d x d, device).  Returns P (pool slot).
-template <class T>
-TT* xs_wide_columns(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, const TT* Rm, int col0, int ncols, double* loss, int L) {
-  typedef TT T2;
-  const int d = c->d, K = c->K;
-  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
-  const int tc = time_chunk(c, std::max(S, 1));
-  T2* P = compose_chain(c, uh, S, dt, tc, true);
-  if (!P || c->last_xs_segments_fwd <= 0) fail(DQ_ERR_STATE, "wide-batch adjoint: the product of the chain did not come from state columns");
-  T2* Ym = c->mat(SLOT_TP_Z, 1);
-  T2* Lm = c->mat(SLOT_TP_R, 1);
-  c->zgemm(0, 0, d, d, d, 1.0, P, d, 0, Rm, d, 0, 0.0, Ym, d, 0, 1);                  // Y = P R
-  c->zgemm(3, 0, d, d, d, 2.0, (const T2*)c->M.p, d, 0, P, d, 0, 0.0, Lm, d, 0, 1);   // Lambda = 2 M P   (M Hermitian)
-  // L = sum_i <p_i| M |y_i> = 1/2 Re sum_i <lambda_i, y_i>
-  c->e_dev.ensure(sizeof(double) * ((size_t)d + 1));
-  c->part.ensure(sizeof(double) * (size_t)dq::coldot_chunks(d) * d);
-  c->timed(DQ_PROF_OTHER, 4.0 * d * ncols, 4.0 * sizeof(T) * d * ncols,
-           [&] { return dq::coldot_launch<T>(Ym + col0, d, Lm + col0, d, d, ncols, 0.5, c->e_dev.d(), c->part.d(), c->st); });
-  c->timed(DQ_PROF_OTHER, ncols, 8.0 * ncols, [&] { return dq::sum_launch(c->e_dev.d(), ncols, c->e_dev.d() + d, c->st); });
-  if (loss) out_copy(c, loss, c->e_dev.d() + d, sizeof(double));
-  // the adjoint sweep over the columns
-  const XsLaunch<T> x = xs_prepare(c, S, dt, ncols, L, true);
-  const double by = 2.0 * sizeof(T2) * (double)d * ncols;
-  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_psi.p, d, 0, Ym + col0, d, 0, d, ncols, 0, 1, c->st); });
-  c->timed(DQ_PROF_OTHER, 0.0, by, [&] { return dq::ztranspose_launch<T>((T2*)c->xs_lam.p, d, 0, Lm + col0, d, 0, d, ncols, 0, 1, c->st); });
-  {
-    double fl, lb;
-    const int Lx = x.L;
-    xs_book(c, x, (x.quad_ok ? 2.0 * Lx : 3.0 * Lx - 1.0) * S, (double)Lx * S, !x.quad_ok, ncols, &fl, &lb);
-    const dq::XrTab tb = *x.tab;
-    c->last_xs_segments = (double)((S + x.seg_steps - 1) / x.seg_steps);
-    for (int s1 = S; s1 > 0; s1 -= x.seg_steps) {
-      const int s0 = std::max(0, s1 - x.seg_steps), ns = s1 - s0;
-      const double share = (double)ns / (double)S;
-      double pr, pi;
-      x.phase(s0, s1, &pr, &pi);
-      pi = -pi;   // (the adjoint launch takes its inputs INTO the centred frame: e^{+i sum})
-      c->timed(DQ_PROF_STATECOL_BWD, fl * share, lb * share, [&] {
-        return dq::xs_backward_launch((T2*)c->xs_psi.p, (T2*)c->xs_lam.p, d, tb, c->xs_wt.d() + (size_t)s0 * tb.R,
-                                      c->xs_dgs.d() + (size_t)s0 * (size_t)x.dgs_step, x.dgs_step, ns, ncols, Lx, x.nblk,
-                                      x.quad_ok ? nullptr : (T2*)c->xs_park.p, c->xs_part.d(), K, dt, c->grad_dev.d() + (size_t)s0 * K, 0,
-                                      c->xs_variant, x.quad_ok ? &x.quad : nullptr, &c->xs_poly, pr, pi, c->st);
-      });
-    }
-  }
-  return P;
-}
-
-template <class T>
-void do_energy_grad_xs_wide(Ctx<T>* c, const std::vector<double>& uh, int S, double dt, const void* psi0, int B, double* loss,
-                            double* grad_u, void* psi_final, double* energies, int L) {
-  typedef TT T2;
-  const int d = c->d, K = c->K;
-  const size_t sb = (size_t)d * B * sizeof(T2);
-  c->psi[0].ensure(sb);
-  c->psi[1].ensure(sb);
-  c->lam[0].ensure(sb);
-  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
-  T2* Rm = c->mat(SLOT_TP_Q, 1);
-  c->zgemm(0, 1, d, d, B, 1.0, p0, B, 0, p0, B, 0, 0.0, Rm, d, 0, 1);                 // R = Psi0 Psi0^H
-  T2* P = xs_wide_columns(c, uh, S, dt, Rm, 0, d, loss, L);
-  if (grad_u && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
-  if (psi_final || energies) {   // Psi_S = P Psi0 (the pool slot of P is untouched by the sweep)
-    c->zgemm(0, 0, d, B, d, 1.0, P, d, 0, p0, B, 0, 0.0, (T2*)c->psi[0].p, B, 0, 1);
-    if (psi_final) out_copy(c, psi_final, c->psi[0].p, sb);
-    if (energies) do_energy(c, (const T2*)c->psi[0].p, B, (T2*)c->lam[0].p, energies, nullptr);
-  }
-  c->last_xs = 0;
-  c->last_xs_wide = 1;
-  c->last_composed = 1;
-  c->last_opback = 0;
-  HIPCK(hipStreamSynchronize(c->st));
-}
-
-// ---- the column-sharded multi-GPU form of the wide-batch gradient (BASELINE configs[3]: 32768 states over 8 GPUs) ----------------
-// L = tr(M P R P^H) depends on the batch through R = sum_b psi0_b psi0_b^H alone: every rank forms the Gram matrix of ITS states
-// (dq_gram), one all-reduce makes R (16 d^2 bytes), every rank builds P (replicated: the chain's product from state-column segments) and
-// sweeps d / N of the d columns of (P R, 2 M P) (dq_energy_grad_columns); one all-reduce of (loss, dL/du) finishes.  The sweep -- all
-// of the job that grows with the chain -- is split N ways: strong scaling of the whole job, where batch shards only add states.
-// Reference loop distributed: diffqc.cc:190-200, loss sim_plain.py:281.
-template <class T>
-void do_gram(Ctx<T>* c, const void* psi0, int B, void* R_out) {
-  typedef TT T2;
-  check_ctx(c);
-  if (B <= 0) fail(DQ_ERR_INVALID, "batch must be > 0");
-  if (!psi0 || !R_out) fail(DQ_ERR_INVALID, "null pointer");
-  const int d = c->d;
-  const size_t sb = (size_t)d * B * sizeof(T2);
-  c->psi[1].ensure(sb);
-  const T2* p0 = in_dev(c, psi0, sb, c->psi[1]);
-  T2* Rm = c->mat(SLOT_TP_Q, 1);
-  c->zgemm(0, 1, d, d, B, 1.0, p0, B, 0, p0, B, 0, 0.0, Rm, d, 0, 1);
-  out_copy(c, R_out, Rm, c->mat_bytes());
-  HIPCK(hipStreamSynchronize(c->st));
-}
-
-template <class T>
-void do_energy_grad_columns(Ctx<T>* c, const double* u, int S, double dt, const void* R, int col0, int ncols, double* loss, double* grad_u) {
-  typedef TT T2;
-  check_ctx(c);
-  require_H(c);
-  if (!c->have_M) fail(DQ_ERR_STATE, "dq_set_observable has not been called");
-  if (S <= 0) fail(DQ_ERR_INVALID, "n_steps must be > 0");
-  if (!std::isfinite(dt)) fail(DQ_ERR_INVALID, "dt must be finite");
-  if (!R || (!u && c->K > 0)) fail(DQ_ERR_INVALID, "null pointer");
-  const int d = c->d, K = c->K;
-  if (col0 < 0 || ncols < 0 || col0 + ncols > d) fail(DQ_ERR_INVALID, "column range outside [0, dim)");
-  reset_call_info(c);
-  std::vector<double> uh = fetch_u(c, u, S);
-  c->grad_dev.ensure(std::max<size_t>((size_t)S * K, 1) * sizeof(double));
-  if (ncols == 0) {   // (more ranks than columns: nothing to sweep)
-    if (loss) *loss = 0.0;
-    if (grad_u) HIPCK(hipMemsetAsync(c->grad_dev.p, 0, sizeof(double) * (size_t)S * K, c->st));
-    if (grad_u && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
-    HIPCK(hipStreamSynchronize(c->st));
-    return;
-  }
-  const int L = xs_degree(c, uh, S, dt, d, true);
-  if (!L || c->xs_compose_mode == 0)
-    fail(DQ_ERR_UNSUPPORTED, "dq_energy_grad_columns needs a Pauli-sum generator at a dimension the state-column kernels hold (512 .. 4096; 8192 in complex64)");
-  T2* Rm = c->mat(SLOT_TP_Q, 1);
-  if ((const void*)Rm != R) HIPCK(hipMemcpyAsync(Rm, R, c->mat_bytes(), hipMemcpyDefault, c->st));
-  xs_wide_columns(c, uh, S, dt, Rm, col0, ncols, loss, L);
-  if (grad_u && K > 0) out_copy(c, grad_u, c->grad_dev.p, sizeof(double) * (size_t)S * K);
-  c->last_xs = 0;
-  c->last_xs_wide = 1;
-  c->last_composed = 1;
-  c->last_opback = 0;
-  HIPCK(hipStreamSynchronize(c->st));
-}
+#include "engine_statecol_grad.inc"
 
 template <class T>
 void do_energy_grad(Ctx<T>* c, const double* u, int S, double dt, const void* psi0, int B, double* loss,
