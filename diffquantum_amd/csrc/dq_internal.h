@@ -377,8 +377,10 @@ hipError_t xs_offdiag_launch(const float2* M, int d, double* out, double* mdiag,
 hipError_t xs_diag_costate_launch(const double2* psi, const double* mdiag, double2* lam, double* e, int d, int B, hipStream_t st);
 hipError_t xs_diag_costate_launch(const float2* psi, const double* mdiag, float2* lam, double* e, int d, int B, hipStream_t st);
 size_t xs_dgs_doubles(int d, int S, const XrTab& tab);       // doubles of the diagonal-weight table
-hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
-                             hipStream_t st);
+// nt: threads per column of the kernels that will read the table (xs_threads(d, variant)): a vector is stored thread-major for them
+hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, int nt, double* wt, double* dgs,
+                             long* dgs_step, hipStream_t st);
+int xs_threads(int d, int variant);
 // Centred diagonal (round 5).  A step's generator A = -i (Dg + offdiagonal), Dg = the rows' diagonal weights (dgs).  Subtracting the
 // midpoint c of Dg's range changes exp(A) by the scalar e^{-i c} only, and leaves a generator whose norm is half the RANGE of Dg plus
 // the off-diagonal row sum -- for a drift like the reference demo's sum_e (I - Z_i Z_j) >= 0 (demo_maxcut.py:44-58) half of what the

@@ -26,8 +26,11 @@ namespace dq {
 
 // wt[s][j] = dt u[s][kid_j] cmag_j;  dgs: the rows' diagonal weights dt (H0 + sum_k u_k H_k)[i][i] -- one vector [d] when only
 // the drift has diagonal entries (per_step = 0), else one per step [S][d].  grid: (ceil(d / 256), per_step ? S : 1) + S blocks for wt
+// Layout of a vector (round 5): THREAD-major for the kernels' shape -- row i = r nt + t of the column is entry t (d / nt) + r, so that a
+// thread's rows are contiguous (64 B at 8 rows: 16-byte loads off ONE address; the row-major table cost every kernel 8 address pairs
+// that its loop optimizer kept as induction variables and, in the adjoint kernels, spilled once per step).
 __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double* __restrict__ u, int K, int S, int d, double dt,
-                                                         int per_step, double* __restrict__ wt, double* __restrict__ dgs) {
+                                                         int per_step, int nt, double* __restrict__ wt, double* __restrict__ dgs) {
   const int nbd = (d + 255) / 256, nds = per_step ? S : 1;
   const int b = blockIdx.x, t = threadIdx.x;
   if (b < nbd * nds) {
@@ -39,7 +42,7 @@ __global__ void __launch_bounds__(256) xs_weights_kernel(XrTab tab, const double
         const int k = tab.dkid[jd];
         v += (k < 0 ? 1.0 : ur[k]) * tab.dval[(long)jd * d + i];
       }
-      dgs[(long)s * d + i] = dt * v;
+      dgs[(long)s * d + (long)(i % nt) * (d / nt) + i / nt] = dt * v;
     }
   } else {
     const int s = b - nbd * nds;
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
       for (int r = 0; r < RPT; ++r) {
         acc[r].x = g0 * cur[r].x;
         acc[r].y = g0 * cur[r].y;
-        dg[r] = (T)dgr[r * NT + t];
+        dg[r] = (T)dgr[t * RPT + r];
       }
       for (int m = 1; m <= L; ++m) {
         T2 o[RPT];
@@ -434,14 +437,14 @@ hipError_t xs_center_launch(double* dgs, int d, int rows, double* cen, double* h
   return hipGetLastError();
 }
 
-hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, double* wt, double* dgs, long* dgs_step,
-                             hipStream_t st) {
+hipError_t xs_weights_launch(const XrTab& tab, const double* u, int K, int S, int d, double dt, int nt, double* wt, double* dgs,
+                             long* dgs_step, hipStream_t st) {
   const int per_step = xs_has_diag_controls(tab) ? 1 : 0;
   *dgs_step = per_step ? d : 0;
   if (S <= 0) return hipSuccess;
   const int nbd = (d + 255) / 256;
   hipLaunchKernelGGL(xs_weights_kernel, dim3((unsigned)(nbd * (per_step ? S : 1) + S)), dim3(256), 0, st, tab, u, K, S, d, dt, per_step,
-                     wt, dgs);
+                     nt, wt, dgs);
   return hipGetLastError();
 }
 

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       {  // (scope of dg: the reversal and the forward terms keep the rows' diagonal weights in registers)
       T dg[RPT];
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) dg[r] = (T)dgr[r * NT + t];
+      for (int r = 0; r < RPT; ++r) dg[r] = (T)dgr[t * RPT + r];
       // ---- reversal: psi_s = sum_m (-A)^m psi_{s+1} / m! -------------------------------------------------------------
       publish(cur);
       {
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
         const T gl = (T)pol.g[l];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          const T dgv = (T)dgr[r * NT + t];  // (L2-resident table; not kept in registers across the sweep)
+          const T dgv = (T)dgr[t * RPT + r];  // (L2-resident table; not kept in registers across the sweep)
           const T2 g = Lm[r * NT + t];
           o[r].x = xs_fma(-dgv, cur[r].y, gl * g.x);  // g_l lam - (-i dg y)
           o[r].y = xs_fma(dgv, cur[r].x, gl * g.y);

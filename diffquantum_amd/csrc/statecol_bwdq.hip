@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           for (int i = 0; i < NI; ++i) cf[i] = (T)qd.c1[m][i];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {  // + i dg v
-            const T dgv = (T)dgr[r * NT + t];
+            const T dgv = (T)dgr[t * RPT + r];
             const T ox = xs_fma(-dgv, zc[r].y, o[r].x) * inv;
             const T oy = xs_fma(dgv, zc[r].x, o[r].y) * inv;
             zc[r].x = ox;
@@ -186,11 +186,6 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       }
       XS_STAMP(1);
       // ---- phase 2: psi_s = sum_m r_m with the level pairings -----------------------------------------------------------------
-      xs_acc16 dacc[1];
-      dacc[0] = 0.0;
-      double rowacc[DIAGCTL ? RPT : 1];
-#pragma unroll
-      for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
       T2 acc[RPT];
       {
         const T g0 = (T)qd.g[0];
@@ -201,6 +196,13 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         }
       }
       publish(cur);
+      // (the accumulators are born here, behind the publish: declared at the top of the phase the 32 registers of zeros were spilled
+      // across it -- 128 B per thread and step of scratch traffic in the signed kernels)
+      xs_acc16 dacc[1];
+      dacc[0] = 0.0;
+      double rowacc[DIAGCTL ? RPT : 1];
+#pragma unroll
+      for (int r = 0; r < (DIAGCTL ? RPT : 1); ++r) rowacc[r] = 0.0;
       for (int m = 0; m < L; ++m) {
         if (m > 0) {
           T cw[NI];
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         T2 o[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          const T dgv = (T)dgr[r * NT + t];
+          const T dgv = (T)dgr[t * RPT + r];
           o[r].x = -dgv * cur[r].y;  // i dg r_m
           o[r].y = dgv * cur[r].x;
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)q[r].y - (double)cur[r].y * (double)q[r].x;

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const double inv = 1.0 / m, gm = pol.g[m];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          const double dgv = dgs[r * NT + t];
+          const double dgv = dgs[t * RPT + r];
           const double ox = __builtin_fma(dgv, cur[r].y, o[r].x) * inv;
           const double oy = __builtin_fma(-dgv, cur[r].x, o[r].y) * inv;
           cur[r].x = ox;
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         const double inv = 1.0 / m, gm = pol.g[m];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          const double dgv = dgs[r * NT + t];
+          const double dgv = dgs[t * RPT + r];
           const double ox = __builtin_fma(dgv, cur[r].y, o[r].x) * inv;
           const double oy = __builtin_fma(-dgv, cur[r].x, o[r].y) * inv;
           cur[r].x = ox;
@@ -294,7 +294,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_park, sizeof(double2) * dq::xs_park_elems(d, L, nblk)));
   CK(hipMemcpy(d_in, psi.data(), sizeof(double2) * psi.size(), hipMemcpyHostToDevice));
   long step = 0;
-  CK(dq::xs_weights_launch(tab, d_u, K, S, d, 1e-3, d_wt, d_dgs, &step, nullptr));
+  CK(dq::xs_weights_launch(tab, d_u, K, S, d, 1e-3, dq::xs_threads(d, variant), d_wt, d_dgs, &step, nullptr));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
