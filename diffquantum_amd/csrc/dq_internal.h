@@ -331,10 +331,12 @@ struct XsPoly {
 };
 // time segments of a forward launch (xs_forward_segments_launch): cols = columns per segment (0: none), total = steps of the table
 // phase: the launch's scalar factor (see xs_center_launch) -- seg_phase[2 g], [2 g + 1] for the columns of time segment g, or (pr, pi)
+constexpr int XS_SEGMAX = 16;   // segments whose factors travel in the kernel arguments (more: a device table)
 struct XsSeg {
   int cols, total;
   const double* seg_phase;
   double pr, pi;
+  double ph[2 * XS_SEGMAX];   // cols > 0 and seg_phase == null: (re, im) of segment g at [2 g], [2 g + 1]
 };
 // the lowest degree whose error bound stays below tol for steps of size <= theta (0: none up to XS_LMAX) and its level factors;
 // economize = 0: Taylor (g = 1).  Steps of theta > 2 keep Taylor (the power form of a Chebyshev sum loses digits as theta grows).
@@ -389,6 +391,8 @@ int xs_threads(int d, int variant);
 // launches apply the product of the steps' scalars once: the forward launch multiplies its outputs by (pr, pi) = e^{-i sum c}, the
 // adjoint launch its inputs by e^{+i sum c} (psi and lambda alike: their pairings do not see the frame).
 hipError_t xs_center_launch(double* dgs, int d, int rows, double* cen, double* half, hipStream_t st);
+// every entry of one vector of the table minus c (the drift-only table: its midpoint is known on the host, dq_set_hamiltonians)
+hipError_t xs_shift_launch(double* dgs, int d, double c, hipStream_t st);
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                              int S, int B, int L, int nblk, int variant, const XsPoly* poly, double pr, double pi, hipStream_t st);
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
@@ -397,7 +401,7 @@ hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& 
 // column i of segment g's propagator, i.e. block g is the propagator's transpose
 hipError_t xs_forward_segments_launch(double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
-                                      const double* seg_phase, hipStream_t st);   // seg_phase: [n_seg][2] on the device, or null
+                                      const double* seg_phase, hipStream_t st);   // seg_phase: [n_seg][2] in HOST memory, or null
 hipError_t xs_forward_segments_launch(float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
                                       const double* seg_phase, hipStream_t st);

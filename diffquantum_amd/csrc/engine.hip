@@ -343,7 +343,10 @@ struct Ctx : dq_ctx {
   int xs_center = 1;
   double last_xs_centered = 0;                 // 1 when the last state-column call ran in the centred frame
   double last_xs_theta_loose = 0;              // the step bound from the sources' norms (what the degree came from before round 5)
-  DevBuf xs_cen, xs_segphase;
+  DevBuf xs_cen;
+  // range of the drift's diagonal when it is the only offset-0 source (xs_prepare then needs no read-back): (max + min) / 2, (max - min) / 2
+  bool xs_drift_range_ok = false;
+  double xs_drift_mid = 0, xs_drift_half = 0;
   std::vector<double> uh_last;                 // host copy of the last pulse table (fetch_u)
   int fuse_levels = 1;  // sparse-generator reverse mode: gradient levels fused into the X Xbar passes (0: separate kernel)
   long sp_nnz = 0, sp_nnz_c = 0;  // entries in the CSR / those of them that belong to controls
@@ -2160,6 +2163,25 @@ void find_xor_regular(Ctx<T>* c, const std::vector<long>& rowptr, long nnz) {
   c->xr_ok = true;
   c->tab_sgn_h = sgn;
   c->tab_dval_h = dval;
+  {   // the drift's diagonal alone (no diagonal control): its range, for the centred frame of the state-column kernels
+    bool only_drift = !dval.empty();
+    int jd0 = -1;
+    for (int jd = 0; jd < tab.nd; ++jd) {
+      if (tab.dkid[jd] >= 0) only_drift = false;
+      else jd0 = jd;
+    }
+    c->xs_drift_range_ok = false;
+    if (only_drift && jd0 >= 0 && tab.nd == 1) {
+      double mn = dval[0], mx = dval[0];
+      for (int i = 1; i < d; ++i) {
+        mn = std::min(mn, dval[(size_t)jd0 * d + i]);
+        mx = std::max(mx, dval[(size_t)jd0 * d + i]);
+      }
+      c->xs_drift_mid = 0.5 * (mx + mn);
+      c->xs_drift_half = 0.5 * (mx - mn);
+      c->xs_drift_range_ok = true;
+    }
+  }
 }
 
 // Complex Hermitian H0 / H_k that are sums of Pauli strings with X and Y factors (XOR-regular pattern, every XOR-diagonal of one
@@ -2266,6 +2288,25 @@ void find_zxor_regular(Ctx<T>* c) {
   c->zxr_ok = true;
   c->tab_sgn_h = sgn;
   c->tab_dval_h = dval;
+  {   // the drift's diagonal alone (no diagonal control): its range, for the centred frame of the state-column kernels
+    bool only_drift = !dval.empty();
+    int jd0 = -1;
+    for (int jd = 0; jd < tab.nd; ++jd) {
+      if (tab.dkid[jd] >= 0) only_drift = false;
+      else jd0 = jd;
+    }
+    c->xs_drift_range_ok = false;
+    if (only_drift && jd0 >= 0 && tab.nd == 1) {
+      double mn = dval[0], mx = dval[0];
+      for (int i = 1; i < d; ++i) {
+        mn = std::min(mn, dval[(size_t)jd0 * d + i]);
+        mx = std::max(mx, dval[(size_t)jd0 * d + i]);
+      }
+      c->xs_drift_mid = 0.5 * (mx + mn);
+      c->xs_drift_half = 0.5 * (mx - mn);
+      c->xs_drift_range_ok = true;
+    }
+  }
 }
 
 // CSR of the Hamiltonians' nonzeros (real path), if they are sparse enough to pay: at most sparse_fill nonzeros per row

@@ -164,8 +164,9 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
     }
     T2* out = psi_out + (long)b * D;
     {   // the scalar of the centred frame (xs_center_launch): e^{-i sum of the steps' midpoints}, per time segment or per launch
-      const T pr = (T)(seg.cols > 0 && seg.seg_phase ? seg.seg_phase[2 * (b / seg.cols)] : seg.pr);
-      const T pi = (T)(seg.cols > 0 && seg.seg_phase ? seg.seg_phase[2 * (b / seg.cols) + 1] : seg.pi);
+      const int g = seg.cols > 0 ? b / seg.cols : 0;
+      const T pr = (T)(seg.cols > 0 ? (seg.seg_phase ? seg.seg_phase[2 * g] : seg.ph[2 * (g < XS_SEGMAX ? g : 0)]) : seg.pr);
+      const T pi = (T)(seg.cols > 0 ? (seg.seg_phase ? seg.seg_phase[2 * g + 1] : seg.ph[2 * (g < XS_SEGMAX ? g : 0) + 1]) : seg.pi);
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         T2 v;
@@ -431,6 +432,14 @@ size_t xs_part_doubles(int d, int S, int nblk, const XrTab& tab, int variant) {
 // dgs: d doubles, or S * d when a control has diagonal entries (xs_dgs_doubles); returns the step stride through *dgs_step
 size_t xs_dgs_doubles(int d, int S, const XrTab& tab) { return (size_t)d * (size_t)(xs_has_diag_controls(tab) ? (S > 0 ? S : 1) : 1); }
 
+__global__ void __launch_bounds__(256) xs_shift_kernel(double* __restrict__ dgs, int d, double c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < d) dgs[i] -= c;
+}
+hipError_t xs_shift_launch(double* dgs, int d, double c, hipStream_t st) {
+  hipLaunchKernelGGL(xs_shift_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, dgs, d, c);
+  return hipGetLastError();
+}
 hipError_t xs_center_launch(double* dgs, int d, int rows, double* cen, double* half, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(xs_center_kernel, dim3((unsigned)rows), dim3(256), 0, st, dgs, d, cen, half);
@@ -688,13 +697,25 @@ hipError_t xs_backward_t(typename Cx<T>::type* psi, typename Cx<T>::type* lam, i
 
 }  // namespace
 
+namespace {
+// the segments' factors: by value up to XS_SEGMAX of them (host table), identity when there is none
+XsSeg xs_seg_make(int d, int S_total, int n_seg, const double* seg_phase_host) {
+  XsSeg sg{d, S_total, nullptr, 1.0, 0.0, {}};
+  for (int g = 0; g < XS_SEGMAX; ++g) {
+    sg.ph[2 * g] = seg_phase_host && g < n_seg ? seg_phase_host[2 * g] : 1.0;
+    sg.ph[2 * g + 1] = seg_phase_host && g < n_seg ? seg_phase_host[2 * g + 1] : 0.0;
+  }
+  return sg;
+}
+}  // namespace
+
 hipError_t xs_forward_launch(const double2* in, double2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                              int S, int B, int L, int nblk, int variant, const XsPoly* poly, double pr, double pi, hipStream_t st) {
-  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0, nullptr, pr, pi}, st);
+  return xs_forward_t<double>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0, nullptr, pr, pi, {}}, st);
 }
 hipError_t xs_forward_launch(const float2* in, float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                              int S, int B, int L, int nblk, int variant, const XsPoly* poly, double pr, double pi, hipStream_t st) {
-  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0, nullptr, pr, pi}, st);
+  return xs_forward_t<float>(in, out, d, tab, wt, dgs, dgs_step, S, B, L, nblk, variant, poly, XsSeg{0, 0, nullptr, pr, pi, {}}, st);
 }
 // The propagators of n_seg consecutive time segments of seg_steps steps each (the last one what is left of S_total): column i of
 // segment g -- exp(A_{s0+ns-1}) ... exp(A_{s0}) e_i, s0 = g seg_steps -- goes to out[(g d + i) d ..]: the d x d block of segment g
@@ -703,13 +724,13 @@ hipError_t xs_forward_segments_launch(double2* out, int d, const XrTab& tab, con
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
                                       const double* seg_phase, hipStream_t st) {
   return xs_forward_t<double>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly,
-                              XsSeg{d, S_total, seg_phase, 1.0, 0.0}, st);
+                              xs_seg_make(d, S_total, n_seg, seg_phase), st);
 }
 hipError_t xs_forward_segments_launch(float2* out, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                                       int S_total, int seg_steps, int n_seg, int L, int nblk, int variant, const XsPoly* poly,
                                       const double* seg_phase, hipStream_t st) {
   return xs_forward_t<float>(nullptr, out, d, tab, wt, dgs, dgs_step, seg_steps, n_seg * d, L, nblk, variant, poly,
-                             XsSeg{d, S_total, seg_phase, 1.0, 0.0}, st);
+                             xs_seg_make(d, S_total, n_seg, seg_phase), st);
 }
 hipError_t xs_backward_launch(double2* psi, double2* lam, int d, const XrTab& tab, const double* wt, const double* dgs, long dgs_step,
                               int S, int B, int L, int nblk, double2* park, double* part, int K, double dt, double* grad,
