@@ -224,6 +224,14 @@ template <int N>
 __device__ __forceinline__ void xs_ds_wait(xs_d2& q) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q) : "n"(N));
 }
+// one counted wait for the reads of TWO slots (XS_RING_WAIT2: a wait per pair of rows instead of one per row)
+template <int N>
+__device__ __forceinline__ void xs_ds_wait2(xs_d2& q0, xs_d2& q1) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(q0), "+v"(q1) : "n"(N));
+}
+#ifndef XS_RING_WAIT2
+#define XS_RING_WAIT2 0
+#endif
 template <int R0, int R1, class F>
 __device__ __forceinline__ void xs_rows(F&& f) {
   if constexpr (R0 < R1) {
@@ -298,7 +306,11 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     xs_rows<0, RPT>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      xs_ds_wait<DEPTH - 1>(v[r % NSLOT]);
+      if constexpr (XS_RING_WAIT2 && DEPTH >= 2 && RPT % 2 == 0) {
+        if constexpr (r % 2 == 0) xs_ds_wait2<DEPTH - 2>(v[r % NSLOT], v[(r + 1) % NSLOT]);
+      } else {
+        xs_ds_wait<DEPTH - 1>(v[r % NSLOT]);
+      }
       xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r % NSLOT], o[r], xm, s);
       constexpr int k = r + DEPTH;  // the element whose read goes out now
       if constexpr (k < RPT) {
@@ -320,7 +332,12 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     xs_rows<0, RPT>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      xs_ds_wait<(RPT - 1 - r < DEPTH - 1 ? RPT - 1 - r : DEPTH - 1)>(v[r % NSLOT]);
+      if constexpr (XS_RING_WAIT2 && DEPTH >= 2 && RPT % 2 == 0) {
+        constexpr int c = RPT - r < DEPTH ? RPT - r : DEPTH;   // reads in flight at this pair
+        if constexpr (r % 2 == 0) xs_ds_wait2<(c >= 2 ? c - 2 : 0)>(v[r % NSLOT], v[(r + 1) % NSLOT]);
+      } else {
+        xs_ds_wait<(RPT - 1 - r < DEPTH - 1 ? RPT - 1 - r : DEPTH - 1)>(v[r % NSLOT]);
+      }
       xs_ring_use<SIGN && RS, DOT, PH, r>(w, (SIGN && RS) ? (rm >> r) & 1u : 0u, v[r % NSLOT], o[r], xm, s);
       constexpr int k = r + DEPTH;
       if constexpr (k < RPT) {
