@@ -57,7 +57,7 @@ SIGNATURES = {
     "dq_energy": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "dq_energy_grad": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "dq_gram": (C.c_int, [_vp, _vp, C.c_int, _vp]),
-    "dq_energy_grad_columns": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "dq_energy_grad_columns": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dq_fidelity_grad": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "dq_mc_shift_grad": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, C.c_int, C.c_double, _vp, C.c_int, C.c_double,
                                    _vp, _vp]),

@@ -2883,9 +2883,9 @@ int dq_gram(dq_ctx* c, const void* psi0, int batch, void* R_out) {
   return with_ctx(c, [&](auto* t) { do_gram(t, psi0, batch, R_out); });
 }
 
-int dq_energy_grad_columns(dq_ctx* c, const double* u, int n_steps, double dt, const void* R, int col0, int n_cols, double* loss,
-                           double* grad_u) {
-  return with_ctx(c, [&](auto* t) { do_energy_grad_columns(t, u, n_steps, dt, R, col0, n_cols, loss, grad_u); });
+int dq_energy_grad_columns(dq_ctx* c, const double* u, int n_steps, double dt, const void* R, const void* P, int col0, int n_cols,
+                           double* loss, double* grad_u) {
+  return with_ctx(c, [&](auto* t) { do_energy_grad_columns(t, u, n_steps, dt, R, P, col0, n_cols, loss, grad_u); });
 }
 
 int dq_fidelity_grad(dq_ctx* c, const double* u, int n_steps, double dt, const void* psi0, const void* targets, int batch,

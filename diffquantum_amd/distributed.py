@@ -23,7 +23,11 @@ do_energy_grad_xs_wide): L = tr(M P R P^H) depends on the states through R = sum
 shortens nothing -- every rank would sweep all dim columns for its own R.  Instead: rank r forms the Gram matrix of its states, ONE
 all-reduce makes R (16 d^2 bytes: 268 MB at d = 4096, ~2 ms per ring step over xGMI), every rank builds P (replicated: 1/3 of a
 forward pass over dim columns) and sweeps dim / G of the columns of (P R, 2 M P); one all-reduce of (loss, dL/du).  The adjoint sweep --
-2/3 of the single-GPU time -- is split G ways: 1 / (1/3 + 2/(3 G)) = 2.4x at G = 8 with P replicated.
+2/3 of the single-GPU time -- is split G ways: 1 / (1/3 + 2/(3 G)) = 2.4x at G = 8 with P replicated.  With `slice_product` (default: where it pays, `slice_product_pays`)
+P is built in time slices as well: rank r runs the forward kernel over ITS S / G steps (Engine.slice_forward), the G slice products
+are all-gathered (G x 16 d^2 bytes) and multiplied on every rank (G - 1 products of 8 d^3 flop: 8 ms each at d = 4096) -- at configs[3]
+(2000 steps) 0.46 s of replicated forward pass become 0.06 s + ~0.07 s of products and gather: ~5.8x at G = 8 by the single-GPU
+kernel times (1.74 s for the whole job on one GPU).
 """
 from __future__ import annotations
 
@@ -105,14 +109,35 @@ def _sliced_phases(engine, u, dt, psi0_shard, rank, world, targets=None, want_fi
 
 # ---- column-sharded wide-batch gradient --------------------------------------------------------------------------------
 
-def _columns_phases(engine, u, dt, psi0_shard, rank, world):
+def slice_product_pays(n_steps, dim, world):
+    """The chain's product in time slices costs world - 1 products of 8 dim^3 flop on every rank (and the all-gather) and saves
+    (1 - 1/world) of a forward pass over dim columns: by the single-GPU kernel times (0.23 ms per forward step, 8 ms per product at
+    dim = 4096; both ratios scale with dim) it pays beyond ~45 steps per rank at dim = 4096."""
+    return world > 1 and n_steps > 45.0 * world * dim / 4096.0
+
+
+def _columns_phases(engine, u, dt, psi0_shard, rank, world, slice_product=None):
     """The per-rank program of the column-sharded form as a generator of collective requests (as _sliced_phases): the Gram matrix of
-    this rank's states, all-reduce, the sweep over this rank's columns, all-reduce of (dL/du, loss)."""
+    this rank's states, all-reduce; with slice_product the chain's product in TIME SLICES (this rank's steps through
+    Engine.slice_forward, all-gather, G - 1 products on every rank) instead of a whole forward pass on every rank; the sweep over
+    this rank's columns; all-reduce of (dL/du, loss)."""
     S, K = int(u.shape[0]), engine.n_controls
     R = engine.gram(psi0_shard)
     R = yield ("all_reduce", R)
+    P = None
+    if slice_product is None:
+        slice_product = slice_product_pays(S, engine.dim, world)
+    if slice_product and world > 1:
+        first, count = shard_range(S, rank, world)
+        u_own = u[first:first + count]
+        if hasattr(u_own, "contiguous"):
+            u_own = u_own.contiguous()
+        Ps = yield ("all_gather", engine.slice_forward(u_own, dt, like=psi0_shard))
+        P = Ps[0]
+        for j in range(1, world):          # P = P_{G-1} ... P_0
+            P = engine.matmul(Ps[j], P)
     first, count = shard_range(engine.dim, rank, world)
-    loss, grad = engine.energy_grad_columns(u, dt, R, first, count)
+    loss, grad = engine.energy_grad_columns(u, dt, R, first, count, P=P)
     buf = np.empty(S * K + 1, dtype=np.float64)
     buf[:-1] = np.asarray(grad, dtype=np.float64).reshape(-1)
     buf[-1] = loss
@@ -137,7 +162,7 @@ def _drive(gen, world, group, device):
             return done.value
 
 
-def column_sharded_energy_grad(engine, u, dt, psi0_shard, group=None, device=None):
+def column_sharded_energy_grad(engine, u, dt, psi0_shard, group=None, device=None, slice_product=None):
     """Loss and dL/du of the WHOLE batch (energy objective) with the adjoint sweep split over the dim COLUMNS of (P R, 2 M P) across
     the ranks of `group`; psi0_shard: this rank's states (any split of the batch, empty shards excluded).  Returns
     (loss, grad_u[S][K] numpy) -- the sums over all ranks' states, equal to rounding to engine.energy_grad of the whole batch.
@@ -147,14 +172,14 @@ def column_sharded_energy_grad(engine, u, dt, psi0_shard, group=None, device=Non
         rank, world = 0, 1
     else:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-    loss, grad, _, _ = _drive(_columns_phases(engine, u, dt, psi0_shard, rank, world), world, group, device)
+    loss, grad, _, _ = _drive(_columns_phases(engine, u, dt, psi0_shard, rank, world, slice_product), world, group, device)
     return loss, grad
 
 
-def virtual_column_sharded_energy_grad(engines, u, dt, psi0_shards):
+def virtual_column_sharded_energy_grad(engines, u, dt, psi0_shards, slice_product=None):
     """The same program for len(engines) VIRTUAL ranks in one process (tests, single-GPU rehearsal); returns the per-rank results."""
     world = len(engines)
-    return _run_virtual([_columns_phases(engines[r], u, dt, psi0_shards[r], r, world) for r in range(world)])
+    return _run_virtual([_columns_phases(engines[r], u, dt, psi0_shards[r], r, world, slice_product) for r in range(world)])
 
 
 # ---- SURVEY.md 8-F2 in its literal form: the propagators of a chain built 1/G per rank and all-gathered ---------------------

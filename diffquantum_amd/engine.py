@@ -285,14 +285,18 @@ class Engine:
         _lib.check(self._lib.dq_gram(self._ctx, pp, B, pr))
         return R
 
-    def energy_grad_columns(self, u, dt: float, R, col0: int, n_cols: int):
+    def energy_grad_columns(self, u, dt: float, R, col0: int, n_cols: int, P=None):
         """The share of (loss, dL/du[n_steps][n_controls]) that the columns [col0, col0 + n_cols) of (P R, 2 M P) carry, R the Gram
-        matrix of the WHOLE batch (dq_energy_grad_columns); summed over a partition of [0, dim) it is energy_grad of that batch."""
+        matrix of the WHOLE batch (dq_energy_grad_columns); summed over a partition of [0, dim) it is energy_grad of that batch.
+        P: the chain's product U_{S-1} ... U_0 when it was made elsewhere (time slices); None: the call builds it."""
         pu, ku, S = self._u(u)
         pr, kr = self._c(R, (self.dim, self.dim), "R")
+        pp = 0
+        if P is not None:
+            pp, kp = self._c(P, (self.dim, self.dim), "P")
         grad = np.zeros((S, self.n_controls), dtype=np.float64)
         loss = C.c_double()
-        _lib.check(self._lib.dq_energy_grad_columns(self._ctx, pu, S, float(dt), pr, int(col0), int(n_cols), C.addressof(loss),
+        _lib.check(self._lib.dq_energy_grad_columns(self._ctx, pu, S, float(dt), pr, pp, int(col0), int(n_cols), C.addressof(loss),
                                                     grad.ctypes.data))
         return loss.value, grad
 

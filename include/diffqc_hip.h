@@ -216,14 +216,16 @@ int dq_energy_grad(dq_ctx* ctx, const double* u, int n_steps, double dt, const v
  * product and R = sum_b psi0_b psi0_b^H: it depends on the states through the d x d Gram matrix alone.  A rank
  *   1. dq_gram:                 R_rank = Psi0_rank Psi0_rank^H of ITS states ([dim][dim] complex, out to host or device memory);
  *   2. all-reduces R over the ranks (the caller's collective: 16 dim^2 bytes);
- *   3. dq_energy_grad_columns:  builds P itself (Pauli-sum generators: the state-column kernels on the identity's columns) and runs
- *      the adjoint sweep on the columns [col0, col0 + n_cols) of (P R, 2 M P): loss = its share 1/2 Re sum_i <lambda_i, y_i>,
- *      grad_u[t][k] = its share of dL/du;
+ *   3. dq_energy_grad_columns:  runs the adjoint sweep on the columns [col0, col0 + n_cols) of (P R, 2 M P): loss = its share
+ *      1/2 Re sum_i <lambda_i, y_i>, grad_u[t][k] = its share of dL/du.  P = NULL: the call builds the chain's product itself
+ *      (the state-column kernels on the identity's columns: a forward pass over dim columns, replicated on every rank); P given
+ *      ([dim][dim], U_{S-1} ... U_0): made elsewhere -- e.g. one time slice per rank by dq_slice_forward, all-gathered and multiplied
+ *      (dq_zgemm), which splits that forward pass over the ranks as well;
  *   4. all-reduces (loss, grad_u).
  * The sums over all ranks equal dq_energy_grad of the whole batch on one GPU.  Needs dq_set_observable and a generator the
  * state-column kernels take (else DQ_ERR_UNSUPPORTED); n_cols = 0 is allowed (more ranks than columns). */
 int dq_gram(dq_ctx* ctx, const void* psi0, int batch, void* R_out);
-int dq_energy_grad_columns(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* R, int col0, int n_cols,
+int dq_energy_grad_columns(dq_ctx* ctx, const double* u, int n_steps, double dt, const void* R, const void* P, int col0, int n_cols,
                            double* loss, double* grad_u);
 
 /* Fidelity objective for a batch of (initial, target) pairs -- the batched form of train_fidelity's

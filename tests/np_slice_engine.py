@@ -90,16 +90,17 @@ class NumpySliceEngine:
         psi0 = np.asarray(psi0, dtype=np.complex128)
         return psi0 @ psi0.conj().T
 
-    def energy_grad_columns(self, u, dt, R, col0, n_cols):
+    def energy_grad_columns(self, u, dt, R, col0, n_cols, P=None):
         """The share of (L, dL/du) of the columns [col0, col0 + n_cols) of (P R, 2 M P): L = tr(M P R P^H) = 1/2 Re sum_i <lam_i, y_i>,
         dL/du_k[t] = Re sum_i <lam_i(t+1)| dU_t |y_i(t)> with y_i(t) = U_t^H y_i(t+1), lam_i(t) = U_t^H lam_i(t+1)."""
         u = np.asarray(u, dtype=np.float64).reshape(-1, self.n_controls)
         S = u.shape[0]
         gens = [orc.step_generator(self.H0, self.Hs, row, dt) for row in u]
         Us = [sla.expm(A) for A in gens]
-        P = np.eye(self.dim, dtype=np.complex128)
-        for U in Us:
-            P = U @ P
+        if P is None:
+            P = np.eye(self.dim, dtype=np.complex128)
+            for U in Us:
+                P = U @ P
         sl = slice(col0, col0 + n_cols)
         Y = (P @ np.asarray(R, dtype=np.complex128))[:, sl]
         Lam = (2.0 * self.M @ P)[:, sl]

@@ -240,8 +240,9 @@ def test_virtual_ranks_column_sharded_equals_oracle():
         for world in (1, 2, 3, 6):                   # 6 ranks, 4 columns: two ranks sweep nothing
             engines = [NumpySliceEngine(H0, Hs, M) for _ in range(world)]
             shards = [full[:, f:f + c] for f, c in (shard_range(B, r, world) for r in range(world))]
-            for l, g, _, _ in virtual_column_sharded_energy_grad(engines, u, dt, shards):
-                assert abs(l - loss) < 1e-11 and g.shape == (S, 2) and np.max(np.abs(g - grad)) < 1e-11
+            for slice_product in (True, False):      # the chain's product in time slices (one per rank, gathered) / built by every rank
+                for l, g, _, _ in virtual_column_sharded_energy_grad(engines, u, dt, shards, slice_product=slice_product):
+                    assert abs(l - loss) < 1e-11 and g.shape == (S, 2) and np.max(np.abs(g - grad)) < 1e-11
 
 
 def _columns_worker(rank, world, port, q):

@@ -36,8 +36,10 @@ def test_virtual_ranks_match_the_single_gpu_gradient_and_the_oracle(oracle, case
     engines = [_engine(H0, Hs, M) for _ in range(world)]
     try:
         shards = [np.ascontiguousarray(full[:, f:f + c]) for f, c in (shard_range(B, r, world) for r in range(world))]
-        res = virtual_column_sharded_energy_grad(engines, u, dt, shards)
+        res = virtual_column_sharded_energy_grad(engines, u, dt, shards, slice_product=False)   # P built by every rank
         assert all(e.info("state_columns_wide_adjoint") == 1 and e.info("state_columns_compose_segments") >= 1 for e in engines)
+        res += virtual_column_sharded_energy_grad(engines, u, dt, shards, slice_product=True)    # P in time slices, one per rank
+        assert all(e.info("state_columns_wide_adjoint") == 1 for e in engines)
         engines[0].set_option("state_columns", 1)              # the whole batch on one GPU, swept state by state
         engines[0].set_option("state_columns_wide_adjoint", 0)
         l0, g0, _, _ = engines[0].energy_grad(u, dt, full, want_final=False, want_energies=False)
