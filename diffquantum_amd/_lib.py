@@ -44,6 +44,7 @@ SIGNATURES = {
     "dq_last_error": (C.c_char_p, []),
     "dq_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "dq_step_polynomial": (C.c_int, [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), _dp]),
+    "dq_quadrature_rule": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp, _dp]),
     "dq_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
     "dq_create_ex": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     "dq_destroy": (C.c_int, [_vp]),

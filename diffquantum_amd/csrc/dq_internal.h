@@ -341,6 +341,7 @@ struct XsSeg {
 // the lowest degree whose error bound stays below tol for steps of size <= theta (0: none up to XS_LMAX) and its level factors;
 // economize = 0: Taylor (g = 1).  Steps of theta > 2 keep Taylor (the power form of a Chebyshev sum loses digits as theta grows).
 int xs_poly_make(double theta, double tol, int economize, XsPoly* p);
+void xs_poly_of_degree(double theta, int L, int economize, XsPoly* p);   // the polynomial of a given degree
 // Quadrature form of the adjoint sweep (xs_backward_q_kernel): a Gauss-Lobatto rule on [0, 1] with ni interior nodes s_i.  The node
 // values exp(-s_i A) lambda are polynomials of the same degree on the shorter interval s_i theta, with their own level factors g_i[m]:
 // c1[m][i] = g_i[m] s_i^m, c2[m][i] = -w_i g_i[m] s_i^m, w0 = minus the weight of the end point 0, w1[m] = -g[m] x the weight of the

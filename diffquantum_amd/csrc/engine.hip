@@ -2761,6 +2761,28 @@ int dq_step_polynomial(double theta, double tol, int economize, int* degree, dou
   });
 }
 
+int dq_quadrature_rule(double theta, double tol, int degree, int economize, int basis, int* nodes, double* w0, double* w1, double* c1,
+                       double* c2) {
+  return guarded([&] {
+    if (!nodes || !w0 || !w1 || !c1 || !c2) fail(DQ_ERR_INVALID, "null output");
+    if (!(theta >= 0.0) || !(tol > 0.0) || degree < 1 || degree > dq::XS_LMAX) fail(DQ_ERR_INVALID, "theta >= 0, tol > 0, 1 <= degree <= 24");
+    dq::XsPoly p;
+    dq::xs_poly_of_degree(theta, degree, economize, &p);
+    dq::XsQuad qd;
+    *nodes = 0;
+    if (!dq::xs_quad_make(theta, tol, 2, degree, economize, p, &qd, basis ? 1 : 0)) return;
+    *nodes = qd.ni;
+    *w0 = qd.w0;
+    for (int m = 0; m <= dq::XS_LMAX; ++m) {
+      w1[m] = qd.w1[m];
+      for (int i = 0; i < 2; ++i) {
+        c1[2 * m + i] = qd.c1[m][i];
+        c2[2 * m + i] = qd.c2[m][i];
+      }
+    }
+  });
+}
+
 int dq_device_count(int* n) {
   return guarded([&] {
     if (!n) fail(DQ_ERR_INVALID, "null output");

@@ -510,6 +510,12 @@ void xs_poly_factors(double theta, int L, double* g) {
 }
 }  // namespace
 
+// the polynomial of a GIVEN degree (level factors of the Chebyshev sum cut there, or Taylor's ones)
+void xs_poly_of_degree(double theta, int L, int economize, XsPoly* p) {
+  *p = xs_poly_taylor();
+  if (economize && theta > 0.0 && theta <= 2.0 && L >= 1 && L <= XS_LMAX) xs_poly_factors(theta, L, p->g);
+}
+
 int xs_poly_make(double theta, double tol, int economize, XsPoly* p) {
   *p = xs_poly_taylor();
   if (!(theta >= 0.0)) return 0;

@@ -77,6 +77,14 @@ int dq_device_count(int* n);
  * `scipy.linalg.expm(dH)`, sim_plain.py:145 -- scaling-and-squaring Pade forms on the CPU: any polynomial within tol of exp on the
  * spectrum is the same step to that tolerance.) */
 int dq_step_polynomial(double theta, double tol, int economize, int* degree, double* factors);
+/* Host-only: the tables of the quadrature form of the state-column adjoint sweep for a step of size <= theta and a step polynomial of
+ * the given degree -- the 4-point Gauss-Lobatto rule of dL/du_k[t] = Re int_0^1 <lambda(s), dA_k psi(s)> ds (nodes = 2 interior nodes;
+ * 0 when the rule's error bound 6.6e-7 (2 theta)^6 exceeds tol).  basis 0: node values, phase 1 accumulates vector i with c1[2 m + i]
+ * (lambda(s_i) = sum_m c1 z_m) and q_m = w1[m] lambda_t + sum_i c2[2 m + i] lambda(s_i) (+ w0 lambda_{t+1} at m = 0); basis 1: the same
+ * rule in the difference basis of the kernels that keep its second vector in LDS as fp32 (u_1, u_2 of order theta, theta^2; same
+ * formulas, transformed tables).  w1, c1, c2: 25, 50, 50 doubles.  tests/np_state_column.py holds the numpy twin. */
+int dq_quadrature_rule(double theta, double tol, int degree, int economize, int basis, int* nodes, double* w0, double* w1, double* c1,
+                       double* c2);
 
 /* Context = one Hilbert-space dimension + one set of Hamiltonians on one GPU.
  * Replaces the process-global store g_H0/g_Hs of diffqc.cc:21-25 with an explicit handle. */

@@ -515,3 +515,27 @@ def test_centred_diagonal_matches_the_uncentred_kernels_and_the_oracle(oracle, c
         assert abs(l - rl) < TOL * B and np.max(np.abs(g - rg)) < TOL and np.max(np.abs(f - rf)) < TOL and np.max(np.abs(w - rf)) < TOL
     assert np.max(np.abs(comp - rf)) < TOL
     assert np.max(np.abs(rg)) > 1e-5
+
+
+@pytest.mark.parametrize("case,n", [("ising_x", 9), ("xy_drives", 9), ("qaoa_ring_zz_controls", 8)])
+def test_complex64_takes_the_quadrature_form_at_moderate_steps(oracle, case, n):
+    """the rule's bound defaults to fp32 rounding in complex64 (1e-7 instead of 2^-40), so the 2L-sweep form serves steps up
+    to theta ~ 0.3 there instead of 0.05 -- here theta ~ 0.15: the quadrature form runs (node basis: fp32 vectors fit the registers for
+    every table class) and agrees with the oracle at the fp32 tolerance."""
+    H0, Hs, M = _qaoa(n) if case == "qaoa_ring_zz_controls" else CASES[case](n)
+    K, d = len(Hs), 1 << n
+    S, B = 6, 5
+    u = np.random.default_rng(n + 3).uniform(-1, 1, (S, K))
+    n1 = lambda A: np.abs(A).sum(axis=0).max()
+    dt = 0.15 / (n1(H0) + sum(n1(h) for h in Hs))
+    psi0 = problems.random_states(d, B, seed=2)
+    rl, rg, rf = oracle.energy_grad(H0, list(Hs), M, u, dt, psi0)
+    with _engine(H0, Hs, M, dtype="c64", state_columns=1) as e:
+        loss, grad, fin, en = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("state_columns") == 1 and e.info("state_columns_quad_nodes") == 2, (e.info("theta"), e.info("state_columns_quad_nodes"))
+        e.set_option("state_columns_adjoint", 0)
+        l0, g0, _, _ = e.energy_grad(u, dt, psi0.astype(np.complex64))
+        assert e.info("state_columns_quad_nodes") == 0
+    scale = max(1.0, float(np.max(np.abs(rg))))
+    assert np.max(np.abs(fin - rf)) < 2e-5 and abs(loss - rl) < 1e-4 * B
+    assert np.max(np.abs(grad - rg)) < 1e-4 * scale and np.max(np.abs(g0 - rg)) < 1e-4 * scale

@@ -1,6 +1,8 @@
 """The state-column recurrences (tests/np_state_column.py: the numpy twin of csrc/statecol.hip) against the oracle: forward
 amplitudes, loss and dL/du at 1e-10 for real Pauli sums (Ising + X_k; reference problems: demo_maxcut.py:36-79), complex ones
 (X and Y drives) and Z/ZZ-type controls with diagonal entries."""
+import math
+
 import numpy as np
 import pytest
 
@@ -164,3 +166,48 @@ def test_wide_batch_gradient_on_dim_columns_model(oracle, name, prob):
     assert abs(loss - rl) < 1e-10 * B
     assert np.max(np.abs(grad - rg)) < 1e-11 * B, np.max(np.abs(grad - rg))
     assert np.max(np.abs(rg)) > 1e-6
+
+
+def test_library_quadrature_rule_in_both_bases_matches_the_model():
+    """dq_quadrature_rule (host-only entry of the C-ABI): the tables of the quadrature adjoint (csrc/statecol.hip xs_quad_make) against
+    the numpy construction of tests/np_state_column.py::backward_step_quad -- node basis entry by entry; DIFFERENCE basis (round 5: the
+    kernels that keep the rule's second vector in LDS as fp32) by what it must reproduce: the same q_m from (lambda_t, u_1, u_2) as
+    from the node values, for random Taylor terms z_m of the sizes a step produces, with |u_1| = O(theta), |u_2| = O(theta^2)."""
+    import ctypes as C
+    from diffquantum_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for theta, econ in ((0.0295, 1), (0.0295, 0), (0.05, 1), (0.011, 1)):
+        L = nsc.economized_degree(theta) if econ else nsc.taylor_degree(theta)
+        g = nsc.poly_factors(theta, L) if econ else np.ones(L + 1)
+        s, wq = nsc.lobatto(4)
+        gi = [nsc.poly_factors(theta * s[i], L) if econ else np.ones(L + 1) for i in (1, 2)]
+        out = {}
+        for basis in (0, 1):
+            n, w0 = C.c_int(), C.c_double()
+            w1, c1, c2 = (C.c_double * 25)(), (C.c_double * 50)(), (C.c_double * 50)()
+            assert lib.dq_quadrature_rule(theta, 2.0 ** -40, L, econ, basis, C.byref(n), C.byref(w0), w1, c1, c2) == 0
+            assert n.value == 2
+            out[basis] = (w0.value, np.array(w1[:L + 1]), np.array(c1[:2 * (L + 1)]).reshape(-1, 2), np.array(c2[:2 * (L + 1)]).reshape(-1, 2))
+        w0, w1, c1, c2 = out[0]
+        # node basis: c1[m][i] = g_i[m] s_i^m, c2 = -w_i c1, w1[m] = -w_end g[m], w0 = -w_0 (the sign: <q, dA r> = -<r, dA q>)
+        for m in range(L + 1):
+            for i in range(2):
+                assert abs(c1[m, i] - gi[i][m] * s[i + 1] ** m) < 1e-15 and abs(c2[m, i] + wq[i + 1] * c1[m, i]) < 1e-15
+            assert abs(w1[m] + wq[3] * g[m]) < 1e-15
+        assert abs(w0 + wq[0]) < 1e-15
+        # difference basis: same q_m for any Taylor terms
+        v0, v1, d1, d2 = out[1]
+        assert abs(v0 - w0) < 1e-16 and np.all(d1[0] == 0.0) and d1[1, 1] == 0.0
+        z = [(rng.standard_normal(5) + 1j * rng.standard_normal(5)) * theta ** m / math.factorial(m) for m in range(L + 1)]
+        lam_t = sum(g[m] * z[m] for m in range(L + 1))
+        nd = [sum(c1[m, i] * z[m] for m in range(L + 1)) for i in range(2)]
+        uu = [sum(d1[m, i] * z[m] for m in range(L + 1)) for i in range(2)]
+        assert np.max(np.abs(uu[0])) < 1.5 * theta * 3 and np.max(np.abs(uu[1])) < 1.5 * theta ** 2 * 3
+        for m in range(L):
+            q_nodes = w1[m] * lam_t + c2[m, 0] * nd[0] + c2[m, 1] * nd[1]
+            q_diff = v1[m] * lam_t + d2[m, 0] * uu[0] + d2[m, 1] * uu[1]
+            assert np.max(np.abs(q_nodes - q_diff)) < 4e-15, (theta, m)       # (rounding: the vectors are O(1))
+    n, w0 = C.c_int(), C.c_double()
+    w1, c1, c2 = (C.c_double * 25)(), (C.c_double * 50)(), (C.c_double * 50)()
+    assert lib.dq_quadrature_rule(0.2, 2.0 ** -40, 9, 1, 0, C.byref(n), C.byref(w0), w1, c1, c2) == 0 and n.value == 0   # beyond the 4-point rule's bound
