@@ -118,8 +118,22 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
     p ^= 1;
     xs_put<T, NT, RPT>(img + p * D, t, cur);
     __syncthreads();
+    // the step's weights (and, where the shape has the registers: 512 threads and fewer, its diagonal) are requested a step ahead:
+    // at the head of the step nothing hides their latency
+    constexpr bool PFD = XS_W_PREFETCH && NT <= 512;
+    double wnext = ns > 0 ? ctl.fetch_step(wt + (long)s0 * tab.R, t & 63) : 0.0;
+    T dgn[PFD ? RPT : 1];
+    if (PFD && ns > 0) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) dgn[r] = (T)dgs[(long)s0 * dgs_step + t * RPT + r];
+    }
     for (int s = 0; s < ns; ++s) {
+#if XS_W_PREFETCH
+      ctl.w = wnext;
+      if (s + 1 < ns) wnext = ctl.fetch_step(wt + (long)(s0 + s + 1) * tab.R, t & 63);
+#else
       ctl.load_step(wt + (long)(s0 + s) * tab.R, t & 63);
+#endif
       const double* dgr = dgs + (long)(s0 + s) * dgs_step;
       T2 acc[RPT];
       T dg[RPT];  // the rows' diagonal weights of this step (registers: a load per sweep would sit in the vmcnt queue of every wait)
@@ -128,7 +142,11 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
       for (int r = 0; r < RPT; ++r) {
         acc[r].x = g0 * cur[r].x;
         acc[r].y = g0 * cur[r].y;
-        dg[r] = (T)dgr[t * RPT + r];
+        dg[r] = PFD ? dgn[r] : (T)dgr[t * RPT + r];
+      }
+      if (PFD && s + 1 < ns) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) dgn[r] = (T)dgr[dgs_step + t * RPT + r];
       }
       for (int m = 1; m <= L; ++m) {
         T2 o[RPT];
@@ -179,7 +197,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
   }
 }
 
-// grad[s][k] (+)= dt * (sum_j [kid_j == k] cmag_j sum part[.., j] + sum_jd [dkid_jd == k] sum part[.., RM + jd]); one workgroup
+// grad[s][k] (+)= dt * (sum_j [kid_j == k] cmag_j sum part[.., j] + sum_jd [dkid_jd == k] (dmag_jd) sum part[.., RM + jd]); one workgroup
 // per step: lane group q sums slot q over the nblk * nw partial rows in a fixed order
 __global__ void __launch_bounds__(1024) xs_finish_kernel(const double* __restrict__ part, int nblk, int nw, int ns, int rm, int S,
                                                          XrTab tab, XsOrder ord, int K, double dt, double* __restrict__ grad,
@@ -205,7 +223,7 @@ __global__ void __launch_bounds__(1024) xs_finish_kernel(const double* __restric
     }
     if (ns > rm)
       for (int jd = 0; jd < tab.nd; ++jd)
-        if (tab.dkid[jd] == k) g += dt * s_j[rm + jd];
+        if (tab.dkid[jd] == k) g += dt * (tab.dstring ? tab.dmag[jd] : 1.0) * s_j[rm + jd];   // (Z-string sources: the kernels leave the magnitude out)
     grad[s * K + k] = g;
   }
 }

@@ -31,6 +31,8 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
   const unsigned dsg = (DIAGCTL && tab.dstring) ? xs_diag_thread_signs(tab, t) : 0u;
+  XsDiagCtl dct;
+  if (DIAGCTL) dct.load(tab, __builtin_ctz(NT));
   XsCtl ctl, ctlh;  // (ctlh: the order of the pairing sweeps -- every partner from LDS, phase 0 first)
   ctl.load_table(tab, ord, lane);
   if (SIGN) ctl.load_row_signs(tab, lane, __builtin_ctz(NT));
@@ -64,9 +66,19 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
       }
     }
     XS_STAMP(0);
+    double wnext = ctl.fetch_step(wt + (long)(S - 1) * tab.R, lane), wnexth = ctlh.fetch_step(wt + (long)(S - 1) * tab.R, lane);
     for (int s = S - 1; s >= 0; --s) {
+#if XS_W_PREFETCH   // (requested a step ahead: statecol_bwdq.hip)
+      ctl.w = wnext;
+      ctlh.w = wnexth;
+      if (s > 0) {
+        wnext = ctl.fetch_step(wt + (long)(s - 1) * tab.R, lane);
+        wnexth = ctlh.fetch_step(wt + (long)(s - 1) * tab.R, lane);
+      }
+#else
       ctl.load_step(wt + (long)s * tab.R, lane);
       ctlh.load_step(wt + (long)s * tab.R, lane);
+#endif
       const double* dgr = dgs + (long)s * dgs_step;
       {  // (scope of dg: the reversal and the forward terms keep the rows' diagonal weights in registers)
       T dg[RPT];
@@ -200,12 +212,12 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
         for (int j = 0; j < 16; ++j) da[j] = dacc[g][j];
         const double v = xs_wave_sums16(da, lane);
-        if (lane < 16) prow[g * 16 + lane] = first ? v : prow[g * 16 + lane] + v;
+        if (lane < 16) xs_part_add(prow + g * 16 + lane, v, first);
       }
       if (DIAGCTL) {
         double dv[XR_DMAX];
         if (tab.dstring) {   // Z-string controls: signs from the masks (statecol_dev.h), no table reads
-          xs_diag_string_sums<RPT>(tab, rowacc, dsg, __builtin_ctz(NT), dv);
+          xs_diag_string_sums<RPT>(dct, rowacc, dsg, dv);
         } else {
 #pragma unroll
           for (int jd = 0; jd < XR_DMAX; ++jd) dv[jd] = 0.0;
@@ -220,7 +232,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           }
         }
         const double v = xs_wave_sums16(dv, lane);
-        if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
+        if (lane < 16) xs_part_add(prow + RM + lane, v, first);
       }
       // psi_s = x_0 is in the registers (the last sweep's pairing partner): the next (earlier) step starts from it
 #pragma unroll

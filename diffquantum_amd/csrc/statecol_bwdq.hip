@@ -52,6 +52,8 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
   const unsigned dsg = (DIAGCTL && tab.dstring) ? xs_diag_thread_signs(tab, t) : 0u;
+  XsDiagCtl dct;
+  if (DIAGCTL) dct.load(tab, __builtin_ctz(NT));
   XsCtl ctl, ctlh;
   ctl.load_table(tab, ord, lane);
   if (SIGN) ctl.load_row_signs(tab, lane, __builtin_ctz(NT));
@@ -83,8 +85,15 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
       }
     }
     XS_STAMP(0);
+    double wnext = ctl.fetch_step(wt + (long)(S - 1) * tab.R, lane);
     for (int s = S - 1; s >= 0; --s) {
+      // (the step's weights were requested a step ahead: the load sat at the head of every step with nothing to hide it)
+#if XS_W_PREFETCH
+      ctl.w = wnext;
+      if (s > 0) wnext = ctl.fetch_step(wt + (long)(s - 1) * tab.R, lane);
+#else
       ctl.load_step(wt + (long)s * tab.R, lane);
+#endif
       ctlh.load_step(wt + (long)s * tab.R, lane);
       const double* dgr = dgs + (long)s * dgs_step;
       T2 nd[NI][RPT];  // the interior node values lambda(s_i)
@@ -273,12 +282,12 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
 #pragma unroll
         for (int j = 0; j < 16; ++j) da[j] = dacc[0][j];
         const double v = xs_wave_sums16(da, lane);
-        if (lane < 16) prow[lane] = first ? v : prow[lane] + v;
+        if (lane < 16) xs_part_add(prow + lane, v, first);
       }
       if (DIAGCTL) {
         double dv[XR_DMAX];
         if (tab.dstring) {
-          xs_diag_string_sums<RPT>(tab, rowacc, dsg, __builtin_ctz(NT), dv);
+          xs_diag_string_sums<RPT>(dct, rowacc, dsg, dv);
         } else {
 #pragma unroll
           for (int jd = 0; jd < XR_DMAX; ++jd) dv[jd] = 0.0;
@@ -293,7 +302,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           }
         }
         const double v = xs_wave_sums16(dv, lane);
-        if (lane < 16) prow[RM + lane] = first ? v : prow[RM + lane] + v;
+        if (lane < 16) xs_part_add(prow + RM + lane, v, first);
       }
       XS_STAMP(4);
     }

@@ -158,6 +158,7 @@ struct XsCtl {
     return w;
   }
   __device__ __forceinline__ void load_step(const double* __restrict__ wrow, int lane) { w = lane < R ? wrow[perm] : 0.0; }
+  __device__ __forceinline__ double fetch_step(const double* __restrict__ wrow, int lane) const { return lane < R ? wrow[perm] : 0.0; }
 };
 
 // partner values by LDS reads (volatile: neighbours are not to be merged into ds_read2 forms, which the LDS array serves at half
@@ -510,7 +511,45 @@ namespace {
 
 // 16 per-lane values -> lane l < 16 holds the wave's total of value l (17 exchanges instead of 96).  Every stage has its own
 // constant-indexed array, so that the values stay in registers.
+// The four stages inside a row of 16 lanes take their partner through DPP (a register move in the vector pipe: no LDS round trip,
+// where __shfl_xor is two ds_bpermute_b32 and their latency per exchange).  gfx9 DPP has no XOR patterns beyond the quad, but a
+// reduction does not need them: the masks 8 (row_ror:8), 7 (row_half_mirror), 3 and 1 (quad_perm) generate the row's 16 lanes as
+// well as 8, 4, 2, 1 do, and lane bit 3 / 2 / 1 / 0 still tells the two partners of a stage apart (every mask flips its bit).
+#ifndef XS_DPP_SUMS
+#define XS_DPP_SUMS 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ double xs_dpp_move(double v) {
+  // (mov_dpp: no `old` operand -- update_dpp cost a v_mov 0 and two wait states in front of every move)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xs_wave_sums16_dpp(const double* a, int lane) {
+  double b8[8], b4[4], b2[2];
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b8[i] = (up ? a[i + 8] : a[i]) + xs_dpp_move<0x128>(up ? a[i] : a[i + 8]);   // row_ror:8 = lane ^ 8
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b4[i] = (up ? b8[i + 4] : b8[i]) + xs_dpp_move<0x141>(up ? b8[i] : b8[i + 4]);   // row_half_mirror = lane ^ 7
+  }
+  {
+    const bool up = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b2[i] = (up ? b4[i + 2] : b4[i]) + xs_dpp_move<0x1b>(up ? b4[i] : b4[i + 2]);   // quad_perm:[3,2,1,0] = lane ^ 3
+  }
+  const bool up = (lane & 1) != 0;
+  double v = (up ? b2[1] : b2[0]) + xs_dpp_move<0xb1>(up ? b2[0] : b2[1]);   // quad_perm:[1,0,3,2] = lane ^ 1
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;  // lane l: the total of value (l & 15)
+}
 __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
+  if (XS_DPP_SUMS) return xs_wave_sums16_dpp(a, lane);
   double b8[8], b4[4], b2[2];
   {
     const bool up = (lane & 8) != 0;
@@ -534,13 +573,46 @@ __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
   return v;  // lane l: the total of value (l & 15)
 }
 
+// A wave's step sums into its slots of `part` (lanes < 16; a slot belongs to one wave, which adds its columns in order).  The
+// read-modify-write had its load latency exposed at the end of every step (nothing else is left to do there); the add without a
+// return value (global_atomic_add_f64) leaves the wave at once, and adds of one wave to one address keep their order.
+#ifndef XS_W_PREFETCH
+#define XS_W_PREFETCH 1
+#endif
+#ifndef XS_PART_ATOMIC
+#define XS_PART_ATOMIC 1
+#endif
+__device__ __forceinline__ void xs_part_add(double* slot, double v, bool first) {
+  if (first) {
+    *slot = v;
+  } else if (XS_PART_ATOMIC) {
+    (void)unsafeAtomicAdd(slot, v);
+  } else {
+    *slot += v;
+  }
+}
+
 // Diagonal controls that are Z-strings (XrTab::dstring): the step's sums sum_i D_jd[i] rho[i] over the thread's rows, rho = rowacc.
 // D_jd[i] = dmag (-1)^parity(i & z), i = r NT + t: the rows' factor parity(r & (z / NT)) makes the sum over r a Walsh-Hadamard
 // coefficient of rowacc (all RPT of them: RPT log2 RPT additions), the thread's factor parity(t & z) is one sign flip per source
 // (bit jd of dsg).  dv[jd] = this thread's share of source jd.  Replaces nd x RPT table reads per thread and step (they were 19 k of
 // the 22 k cycles a ring-QAOA step spent after its sweeps).
+// The result leaves the magnitudes out: dv[jd] = (thread's sign) w[zh_jd], and xs_finish_kernel multiplies the step's total by
+// dmag[jd] -- what the kernel needs per source is then 3 bits, all 16 sources in one 64-bit scalar (XsDiagCtl::zpack).  (Round 5's
+// first form read dzmask / dmag / dkid from the kernel argument per source: three scalar loads and a wait each, in sequence; tables
+// one per lane were spilled by the allocator, and so were the 16 sign masks it hoisted out of the step loop: 5.5 k of the 8.5 k
+// cycles a ring-QAOA step spent behind its sweeps.)
+struct XsDiagCtl {
+  unsigned long long zpack;   // bits 4 jd .. 4 jd + 2: (dzmask[jd] / NT) & 7; bit 4 jd + 3: the source is a control
+  __device__ __forceinline__ void load(const XrTab& tab, int log_nt) {
+    unsigned long long z = 0;
+    for (int jd = 0; jd < XR_DMAX; ++jd)
+      if (jd < tab.nd && tab.dkid[jd] >= 0) z |= (unsigned long long)(((tab.dzmask[jd] >> log_nt) & 7u) | 8u) << (4 * jd);
+    zpack = z;
+  }
+};
 template <int RPT>
-__device__ __forceinline__ void xs_diag_string_sums(const XrTab& tab, const double* rowacc, unsigned dsg, int log_nt, double* dv) {
+__device__ __forceinline__ void xs_diag_string_sums(const XsDiagCtl& dct, const double* rowacc, unsigned dsg, double* dv) {
   typedef double wvec __attribute__((ext_vector_type(8)));
   static_assert(RPT <= 8, "rows per thread");
   wvec w = 0.0;
@@ -559,13 +631,12 @@ __device__ __forceinline__ void xs_diag_string_sums(const XrTab& tab, const doub
 #pragma unroll
     for (int r = 0; r < 8; ++r) w[r] = a[r];   // w[zh] = sum_r (-1)^parity(r & zh) rowacc[r]
   }
+  asm volatile("" : "+v"(dsg));   // (the sign masks are formed here, per step: hoisted, they were 32 more live registers -- spilled)
+  const unsigned zlo = __builtin_amdgcn_readfirstlane((unsigned)dct.zpack), zhi = __builtin_amdgcn_readfirstlane((unsigned)(dct.zpack >> 32));
 #pragma unroll
   for (int jd = 0; jd < XR_DMAX; ++jd) {
-    dv[jd] = 0.0;
-    if (jd < tab.nd && tab.dkid[jd] >= 0) {
-      const int zh = (int)(tab.dzmask[jd] >> log_nt) & 7;
-      dv[jd] = xs_flip(tab.dmag[jd] * w[zh], (dsg >> jd) & 1u);
-    }
+    const unsigned e = ((jd < 8 ? zlo : zhi) >> (4 * (jd & 7))) & 15u;   // wave-uniform: the vector is indexed through s_set_gpr_idx
+    dv[jd] = (e & 8u) ? xs_flip(w[e & 7u], (dsg >> jd) & 1u) : 0.0;
   }
 }
 // bit jd: this thread's factor of Z-string source jd, parity(t & dzmask[jd])
