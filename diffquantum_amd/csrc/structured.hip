@@ -163,6 +163,8 @@ struct SApply {
   double* part;     // [nblocks * waves][n_ovl][2]
   const int* omap;  // DMA form: applied string m -> its index among the overlap strings, or -1 (the strings' partner rows are shared)
   T2* out2;         // chain form (schain_dma_kernel): the next application's partial sums, see there
+  const T2* coef2 = nullptr;  // chain form: coefficients of the application out2 STARTS when that one belongs to the next step (null: coef);
+                              // its diagonal then comes in as `diag` (the link reads the diagonal for out2 only)
   const T2* zo2;    // reverse chain form (srchain_dma_kernel): cotangent operand of the NEXT stage's overlaps, and their weight
   T ovl2_scale;     //   relative to this stage's (the two stages' sums share one accumulator set)
 };
@@ -643,14 +645,15 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaW
   T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
   const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
   unsigned xl[SD_SIMPLE_T];
-  T cr[SD_SIMPLE_T];
+  T cr[SD_SIMPLE_T], cr2[SD_SIMPLE_T];   // cr2: the strings' coefficients in the application the pass starts (the next step's at a handover)
 #pragma unroll
   for (int m = 0; m < SD_SIMPLE_T; ++m) {
-    xl[m] = 0; cr[m] = (T)0;
+    xl[m] = 0; cr[m] = (T)0; cr2[m] = (T)0;
     if (m < a.nterms) {
       const DTerm t = a.terms[m];
       xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * EB));
       cr[m] = sd_uniform(a.coef[t.slot].x);
+      cr2[m] = sd_uniform((a.coef2 ? a.coef2 : a.coef)[t.slot].x);
     }
   }
   const bool has_diag = a.diag != nullptr;  // uniform
@@ -696,7 +699,7 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaW
     if (more) issue(u + gridDim.x, buf ^ 1);
     unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (ROWS * SBC));
     V s[SD_RPT];
-    auto gather = [&]() {
+    auto gather = [&](const T* cf) {
 #pragma unroll
       for (int q = 0; q < SD_RPT; ++q) s[q] = (V)((T)0);
 #pragma unroll
@@ -706,11 +709,11 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaW
 #pragma unroll
           for (int q = 0; q < SD_RPT; ++q) {
             const V v = *(const V*)(tb + ((ra | (unsigned)(q * RSTEP * SBC * EB)) ^ xl[m]));
-            s[q] += cr[m] * v;
+            s[q] += cf[m] * v;
           }
         }
     };
-    gather();  // H_g y
+    gather(cr);  // H_g y
     if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     V z[SD_RPT];
@@ -728,7 +731,7 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaW
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) *(V*)(tb + (ra | (unsigned)(q * RSTEP * SBC * EB))) = z[q];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    gather();  // H_g z'
+    gather(cr2);  // H_g z' (at a handover: the next step's H_g)
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
@@ -1308,6 +1311,13 @@ struct SCtx : dq_sctx {
   std::vector<Group> hgroups, mgroups;
   SBuf d_wre, d_wim, d_owner, d_coef, d_coefM;
   SBuf D0, Dk, Dkidx, Dt, DM;       // diagonals: drift, per-control, step, observable
+  // Handover between STEPS (round 5): the pass that finishes step t's Horner chain also starts step t + 1's (it holds psi_{t+1}'s tile:
+  // out2 = D_{t+1} psi_{t+1} + H_g^{t+1} psi_{t+1}) -- a 5-unit link where a 4-unit finish and a 2-unit start pass ran (the start pass
+  // at 3.1 TB/s: 10.9 us per tile against 16 us for 2.5 x the bytes).  Step t + 1's coefficients and diagonal are made into the second
+  // set before step t's last pass and the sets change places behind it.
+  SBuf d_coef2, Dt2;
+  int step_handover = 1;
+  void swap_step_sets() { std::swap(d_coef.p, d_coef2.p); std::swap(d_coef.bytes, d_coef2.bytes); std::swap(Dt.p, Dt2.p); std::swap(Dt.bytes, Dt2.bytes); }
   std::vector<int> diag_controls;
   bool has_D0 = false, has_DM = false;
   double wsum0 = 0;                 // sum |w| of the drift strings
@@ -1692,14 +1702,15 @@ void apply_groups(SCtx<T>* c, std::vector<Group>& groups, const typename SCtx<T>
 }
 
 template <class T>
-void step_coefficients(SCtx<T>* c, int t) {
+void step_coefficients(SCtx<T>* c, int t, bool next_set = false) {
   typedef typename SCtx<T>::T2 T2;
   const double* u_row = (const double*)c->u_dev.p + (size_t)t * c->K;
+  if (next_set) { c->d_coef2.ensure(c->d_coef.bytes); c->Dt2.ensure(c->Dt.bytes); }
   if (c->n_hslots)
-    hipLaunchKernelGGL(scoef_kernel<T>, dim3((c->n_hslots + 63) / 64), dim3(64), 0, c->st, (T2*)c->d_coef.p,
+    hipLaunchKernelGGL(scoef_kernel<T>, dim3((c->n_hslots + 63) / 64), dim3(64), 0, c->st, (T2*)(next_set ? c->d_coef2.p : c->d_coef.p),
                        (const double*)c->d_wre.p, (const double*)c->d_wim.p, (const int*)c->d_owner.p, u_row, c->n_hslots);
   if (c->has_D0 || !c->diag_controls.empty())
-    hipLaunchKernelGGL(sdiag_step_kernel<T>, dim3((c->d + 255) / 256), dim3(256), 0, c->st, (T*)c->Dt.p,
+    hipLaunchKernelGGL(sdiag_step_kernel<T>, dim3((c->d + 255) / 256), dim3(256), 0, c->st, (T*)(next_set ? c->Dt2.p : c->Dt.p),
                        c->has_D0 ? (const T*)c->D0.p : (const T*)nullptr, (const T*)c->Dk.p, u_row,
                        (const int*)c->Dkidx.p, (int)c->diag_controls.size(), c->d);
   SHIP(hipGetLastError());
@@ -1774,7 +1785,8 @@ bool chain_ok(SCtx<T>* c, int B) {
 // 2 finish (out = add + s (prev + H_g y))
 template <class T>
 void chain_pass(SCtx<T>* c, int g, int which, const typename SCtx<T>::T2* y, const typename SCtx<T>::T2* prev,
-                const typename SCtx<T>::T2* add, typename SCtx<T>::T2* out, typename SCtx<T>::T2* out2, double sr, double si, int B) {
+                const typename SCtx<T>::T2* add, typename SCtx<T>::T2* out, typename SCtx<T>::T2* out2, double sr, double si, int B,
+                bool next_step = false) {   // next_step (links only): the application out2 starts is the NEXT step's (second coefficient set)
   const size_t sb = c->state_bytes(B);
   Group& G = c->hgroups[g];
   SApply<T> a;
@@ -1783,6 +1795,10 @@ void chain_pass(SCtx<T>* c, int g, int which, const typename SCtx<T>::T2* y, con
   a.diag = (which == 2) ? nullptr : step_diag(c);
   a.terms = (const DTerm*)G.d_apply.p;
   a.coef = (const typename SCtx<T>::T2*)c->d_coef.p;
+  if (next_step && which == 1) {
+    a.coef2 = (const typename SCtx<T>::T2*)c->d_coef2.p;
+    a.diag = step_diag(c) ? (const T*)c->Dt2.p : (const T*)nullptr;
+  }
   a.nterms = (int)G.apply.size();
   a.n = c->n; a.p = G.p; a.lmask = G.lmask; a.B = B;
   a.sr = which == 0 ? (T)1 : (T)sr; a.si = which == 0 ? (T)0 : (T)si;
@@ -1805,7 +1821,8 @@ struct ChainLink { int g = 0, pb = 0; bool set = false; };
 // from: the start of this chain was done by the chain before (zhi = its result); to: start the next chain in this one's last pass.
 template <class T, class Dst>
 void taylor_chain(SCtx<T>* c, int jhi, int jlo, double dt, double sign, const typename SCtx<T>::T2* in,
-                  const typename SCtx<T>::T2* zhi, int B, Dst dst, const ChainLink* from = nullptr, ChainLink* to = nullptr) {
+                  const typename SCtx<T>::T2* zhi, int B, Dst dst, const ChainLink* from = nullptr, ChainLink* to = nullptr,
+                  bool to_next_step = false) {   // to_next_step: the chain `to` starts is the next step's (SCtx::step_handover)
   typedef typename SCtx<T>::T2 T2;
   const size_t sb = c->state_bytes(B);
   c->tmp[0].ensure(sb); c->tmp[1].ensure(sb);
@@ -1817,7 +1834,8 @@ void taylor_chain(SCtx<T>* c, int jhi, int jlo, double dt, double sign, const ty
     g ^= 1;  // the application is finished on the other group ...
     T2* znew = dst(j - 1);
     if (j > jlo || to) {  // ... which also starts the next one (of this chain, or of the chain that follows)
-      chain_pass<T>(c, g, 1, zj, (const T2*)c->tmp[pb].p, in, znew, (T2*)c->tmp[pb ^ 1].p, 0.0, -sign * dt * c->rho[j], B);
+      chain_pass<T>(c, g, 1, zj, (const T2*)c->tmp[pb].p, in, znew, (T2*)c->tmp[pb ^ 1].p, 0.0, -sign * dt * c->rho[j], B,
+                    to_next_step && j == jlo);
       pb ^= 1;
     } else {
       chain_pass<T>(c, g, 2, zj, (const T2*)c->tmp[pb].p, in, znew, nullptr, 0.0, -sign * dt * c->rho[j], B);
@@ -1891,7 +1909,7 @@ void reverse_chain(SCtx<T>* c, int m, double dt, int B, const std::vector<const 
 // z_out = T_m(sign * A_t) z_in  (Horner); if zs_store != null keeps the iterates z_m..z_1 there (z_j in zs_store[j])
 template <class T>
 void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx<T>::T2* in, typename SCtx<T>::T2* out,
-                  int B, std::vector<SBuf>* store, ChainLink* to = nullptr) {
+                  int B, std::vector<SBuf>* store, ChainLink* to = nullptr, const ChainLink* from = nullptr, bool to_next_step = false) {
   typedef typename SCtx<T>::T2 T2;
   const size_t sb = c->state_bytes(B);
   // z_m = in;  z_{j-1} = in + (A z_j)/j,  A = -i dt H * sign  ->  scale = (0, -sign*dt/j)
@@ -1901,9 +1919,10 @@ void taylor_apply(SCtx<T>* c, int m, double dt, double sign, const typename SCtx
       if (store) { (*store)[jm1].ensure(sb); return (T2*)(*store)[jm1].p; }
       c->zbar[(jm1 + 1) & 1].ensure(sb);
       return (T2*)c->zbar[(jm1 + 1) & 1].p;
-    }, nullptr, to);
+    }, from, to, to_next_step);
     return;
   }
+  if (from && from->set) sfail(DQ_ERR_STATE, "internal: a step handover reached the pass-per-group form");
   const T2* zj = in;
   for (int j = m; j >= 1; --j) {
     T2* dst;
@@ -1936,9 +1955,16 @@ void s_propagate(SCtx<T>* c, const double* u, int S, double dt, const void* psi_
   SHIP(hipMemcpyAsync(c->psi[0].p, psi_in, sb, hipMemcpyDefault, c->st));
   c->last_passes = 0; c->last_bytes = 0; c->last_dma_passes = 0;
   int cur = 0;
+  const bool xstep = c->step_handover != 0 && m >= 1 && chain_ok(c, B);   // (SCtx::step_handover)
+  ChainLink hand;
   for (int t = 0; t < S; ++t) {
-    step_coefficients(c, t);
-    taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
+    if (!hand.set) step_coefficients(c, t);
+    const bool over = xstep && t + 1 < S;
+    if (over) step_coefficients(c, t + 1, true);
+    ChainLink next;
+    taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr, over ? &next : nullptr, &hand, over);
+    if (over) c->swap_step_sets();
+    hand = next;
     cur ^= 1;
   }
   SHIP(hipMemcpyAsync(psi_out, c->psi[cur].p, sb, hipMemcpyDefault, c->st));
@@ -2038,6 +2064,8 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
   // ---- forward ----
   SHIP(hipMemcpyAsync(c->psi[0].p, psi0, sb, hipMemcpyDefault, c->st));
   int cur = 0;
+  const bool xstep = c->step_handover != 0 && m >= 1 && chain_ok(c, B);   // the last pass of a step's chain starts the next step's
+  ChainLink hand;
   for (int t = 0; t < S; ++t) {
     if (t % cstride == 0) {
       if (host_ck) {  // snapshot on the chain's stream (a device copy), the way down on the copy stream behind it
@@ -2049,8 +2077,13 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         SHIP(hipEventRecord(c->ev_down, c->copy_st));
       } else SHIP(hipMemcpyAsync(c->ck[t / cstride].p, c->psi[cur].p, sb, hipMemcpyDeviceToDevice, c->st));
     }
-    step_coefficients(c, t);
-    taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr);
+    if (!hand.set) step_coefficients(c, t);   // (else: made by step t - 1 into the second set, which is the first by now)
+    const bool over = xstep && t + 1 < S;
+    if (over) step_coefficients(c, t + 1, true);
+    ChainLink next;
+    taylor_apply(c, m, dt, 1.0, (const T2*)c->psi[cur].p, (T2*)c->psi[cur ^ 1].p, B, nullptr, over ? &next : nullptr, &hand, over);
+    if (over) c->swap_step_sets();
+    hand = next;
     cur ^= 1;
   }
   s_energy(c, (const T2*)c->psi[cur].p, (T2*)c->lam[0].p, B, energies, loss);
@@ -2153,18 +2186,26 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         }
       }
       auto psi_of = [&](int t) -> T2* { return (t == t0 && !host_ck) ? (T2*)c->ck[seg].p : (T2*)c->segpsi[t - t0].p; };
+      ChainLink shand;
       for (int t = t0; t < t1; ++t) {  // the segment once more, iterates kept (the last step needs no psi_{t1}: iterates only)
         auto& zs = c->segz[t - t0];
         if ((int)zs.size() < m + 1) zs.resize(m + 1);
-        step_coefficients(c, t);
+        if (!shand.set) step_coefficients(c, t);
         if (t + 1 < t1) {
           c->segpsi[t + 1 - t0].ensure(sb);
-          taylor_apply(c, m, dt, 1.0, (const T2*)psi_of(t), psi_of(t + 1), B, &zs);
+          // (handed over to the next step unless that one is the segment's last and has no chain of its own to start: m < 2)
+          const bool over = xstep && (t + 2 < t1 || m >= 2);
+          if (over) step_coefficients(c, t + 1, true);
+          ChainLink next;
+          taylor_apply(c, m, dt, 1.0, (const T2*)psi_of(t), psi_of(t + 1), B, &zs, over ? &next : nullptr, &shand, over);
+          if (over) c->swap_step_sets();
+          shand = next;
         } else if (chain_ok(c, B)) {
-          taylor_chain<T>(c, m, 2, dt, 1.0, (const T2*)psi_of(t), (const T2*)psi_of(t), B, [&](int jm1) -> T2* {
-            zs[jm1].ensure(sb);
-            return (T2*)zs[jm1].p;
-          });
+          if (m >= 2)
+            taylor_chain<T>(c, m, 2, dt, 1.0, (const T2*)psi_of(t), (const T2*)psi_of(t), B, [&](int jm1) -> T2* {
+              zs[jm1].ensure(sb);
+              return (T2*)zs[jm1].p;
+            }, &shand);
         } else {
           const T2* zj = psi_of(t);
           for (int j = m; j >= 2; --j) {
@@ -2298,6 +2339,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     else if (s == "host_checkpoints") t->host_checkpoints = v != 0 ? 1 : 0;
     else if (s == "host_checkpoint_bytes") { if (v < 0) sfail(DQ_ERR_INVALID, "host_checkpoint_bytes must be >= 0"); t->host_checkpoint_bytes = v; }
     else if (s == "chain") t->chain = v != 0 ? 1 : 0;
+    else if (s == "step_handover") t->step_handover = v != 0 ? 1 : 0;
     else if (s == "reverse_chain") t->reverse_chain = v != 0 ? 1 : 0;
     else if (s == "interleave_groups") t->interleave_groups = v > 0 ? (int)v : 0;
     else if (s == "plan_steps") { if (v < 0 || v > 1e9) sfail(DQ_ERR_INVALID, "plan_steps must be 0..1e9"); t->plan_steps = (int)v; }

@@ -334,6 +334,55 @@ def test_two_level_checkpoints(dtype, B, tol):
     assert np.max(np.abs(ga)) > 1e-3
 
 
+@pytest.mark.parametrize("dtype,n,B,tol", [("c128", 10, 16, 1e-12), ("c64", 11, 32, 2e-6), ("c64", 10, 16, 2e-6)])
+def test_step_handover_changes_the_passes_not_the_numbers(dtype, n, B, tol):
+    """`step_handover` (round 5, default on): the pass that finishes step t's Horner chain also starts step t + 1's, with step t + 1's
+    coefficients and diagonal from a second set -- a link where a finish and a start pass ran.  One walk less per step in the forward
+    pass and in a segment's recomputation; the same states, loss and gradient under every checkpoint plan (all states kept / two
+    levels / one level with reversals), in `propagate` too, and against the dense engine."""
+    K, S, dt = n, 60, 0.01
+    terms = ising_x_terms(n, seed=41)
+    u = problems.pulse_table(K, S, S * dt, seed=42)
+    psi0 = problems.random_states(1 << n, B, seed=43)
+    if dtype == "c64":
+        psi0 = psi0.astype(np.complex64)
+    sb = (1 << n) * B * (16 if dtype == "c128" else 8)
+    rl, rg, rf, _ = _dense_reference(terms, n, K, u, dt, psi0)
+    out = {}
+    for hand in (1, 0):
+        with StructuredEngine(n, K, dtype=dtype) as e:
+            e.set_terms(terms)
+            assert e.info("groups") == 2
+            e.set_option("step_handover", hand)
+            res = [e.energy_grad(u, dt, psi0)]                       # every state kept
+            passes = [e.info("passes")]
+            assert e.info("checkpoint_stride") == 1
+            m = int(e.info("degree"))
+            s2 = max(2, round((S / m) ** 0.5))
+            e.set_option("checkpoint_bytes", sb * (-(-S // s2) + m * s2 + 1))
+            res.append(e.energy_grad(u, dt, psi0))                   # two levels: segments recomputed with their iterates
+            passes.append(e.info("passes"))
+            assert e.info("two_level") == 1 and e.info("checkpoint_stride") == s2
+            e.set_option("two_level", 0)
+            e.set_option("checkpoint_bytes", sb * 6)
+            res.append(e.energy_grad(u, dt, psi0))                   # one level: reversal chains in the backward pass
+            passes.append(e.info("passes"))
+            assert e.info("two_level") == 0 and e.info("checkpoint_stride") > 1
+            fwd = e.propagate(u, dt, psi0)
+            passes.append(e.info("passes"))
+            assert e.info("dma_passes") == e.info("passes")
+        out[hand] = (res, passes, fwd)
+    (r1, p1, f1), (r0, p0, f0) = out[1], out[0]
+    assert p1[0] == p0[0] - (S - 1) and p1[3] == p0[3] - (S - 1) and p1[2] == p0[2] - (S - 1)   # forward pass: one walk less per step but the last
+    assert p1[1] < p0[1] - (S - 1)                                                             # and in the segments' recomputation
+    for (l, g, f, _), (lo, go, fo, _) in zip(r1, r0):
+        assert abs(l - lo) <= tol * B and np.max(np.abs(g - go)) < tol * B and np.max(np.abs(f - fo)) < tol
+    assert np.max(np.abs(f1 - f0)) < tol and np.max(np.abs(f1 - r1[0][2])) < tol
+    big = 1e-10 if dtype == "c128" else 1e-4
+    l, g, f, _ = r1[1]
+    assert np.max(np.abs(f - rf)) < big and abs(l - rl) < big * B and np.max(np.abs(g - rg)) < big * B and np.max(np.abs(rg)) > 1e-3
+
+
 @pytest.mark.parametrize("n", [10, 12])
 def test_fp32_gradient_over_the_full_4000_step_chain(n):
     """configs[4]'s kernels over configs[4]'s chain length: 4000 steps, 32 states, complex64, the LDS-DMA forms with both checkpoint
