@@ -419,6 +419,10 @@ static_assert(SDm<float>::P == LocalBits<float>::P && SDm<double>::P == LocalBit
 #define S_GLOAD8(dst_, base_, off_) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(dst_) : "v"(off_), "s"(base_) : "memory")
 __device__ __forceinline__ void sd_gload_real(float& dst, const float* base, unsigned off) { S_GLOAD4(dst, base, off); }
 __device__ __forceinline__ void sd_gload_real(double& dst, const double* base, unsigned off) { S_GLOAD8(dst, base, off); }
+__device__ __forceinline__ float sd_readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ double sd_readlane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ float sd_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ double sd_uniform(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -645,16 +649,22 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaW
   T2* tiles = (T2*)sd_raw;  // [2][512 * 16]
   const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
   unsigned xl[SD_SIMPLE_T];
-  T cr[SD_SIMPLE_T], cr2[SD_SIMPLE_T];   // cr2: the strings' coefficients in the application the pass starts (the next step's at a handover)
+  // the strings' coefficients, one per lane (lane m: string m), read back with v_readlane inside the gathers: crl for the application
+  // the pass finishes, cr2l for the one it starts (the next step's at a handover).  Two sets of scalars beside the offsets did not
+  // fit the scalar file: 735 / 1603 spilled SGPRs (complex64 / complex128) where the one-set kernel had 27 / 29.
+  T crl = (T)0, cr2l = (T)0;
+  {
+    const int ln = threadIdx.x & 63;
+    if (ln < a.nterms && ln < SD_SIMPLE_T) {
+      const int slot = a.terms[ln].slot;
+      crl = a.coef[slot].x;
+      cr2l = (a.coef2 ? a.coef2 : a.coef)[slot].x;
+    }
+  }
 #pragma unroll
   for (int m = 0; m < SD_SIMPLE_T; ++m) {
-    xl[m] = 0; cr[m] = (T)0; cr2[m] = (T)0;
-    if (m < a.nterms) {
-      const DTerm t = a.terms[m];
-      xl[m] = __builtin_amdgcn_readfirstlane(t.xloc * (unsigned)(SBC * EB));
-      cr[m] = sd_uniform(a.coef[t.slot].x);
-      cr2[m] = sd_uniform((a.coef2 ? a.coef2 : a.coef)[t.slot].x);
-    }
+    xl[m] = 0;
+    if (m < a.nterms) xl[m] = __builtin_amdgcn_readfirstlane(a.terms[m].xloc * (unsigned)(SBC * EB));
   }
   const bool has_diag = a.diag != nullptr;  // uniform
   const int c = (threadIdx.x % SD::TPR) * SD::CPT;
@@ -699,21 +709,22 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaW
     if (more) issue(u + gridDim.x, buf ^ 1);
     unsigned char* tb = (unsigned char*)(tiles + (size_t)buf * (ROWS * SBC));
     V s[SD_RPT];
-    auto gather = [&](const T* cf) {
+    auto gather = [&](T cfl) {
 #pragma unroll
       for (int q = 0; q < SD_RPT; ++q) s[q] = (V)((T)0);
 #pragma unroll
       for (int m = 0; m < SD_SIMPLE_T; ++m)
         if (m < a.nterms) {  // uniform
           asm volatile("" : "+s"(xl[m]));
+          const T cf = sd_readlane(cfl, m);
 #pragma unroll
           for (int q = 0; q < SD_RPT; ++q) {
             const V v = *(const V*)(tb + ((ra | (unsigned)(q * RSTEP * SBC * EB)) ^ xl[m]));
-            s[q] += cf[m] * v;
+            s[q] += cf * v;
           }
         }
     };
-    gather(cr);  // H_g y
+    gather(crl);  // H_g y
     if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SD_RPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     V z[SD_RPT];
@@ -731,7 +742,7 @@ __global__ void __launch_bounds__(STHREADS) schain_dma_kernel(SApply<T> a, SDmaW
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) *(V*)(tb + (ra | (unsigned)(q * RSTEP * SBC * EB))) = z[q];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    gather(cr2);  // H_g z' (at a handover: the next step's H_g)
+    gather(cr2l);  // H_g z' (at a handover: the next step's H_g)
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
       const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
@@ -1131,53 +1142,57 @@ __global__ void __launch_bounds__(STHREADS) soverlap_kernel(SOverlap<T> a) {
 }
 
 // part[blk][m] as soverlap_kernel (blk = blockIdx.x; at most SOVL_TCH strings).  The cotangent rows of tile t + 1 are requested one
-// tile ahead as well (registers), so neither operand's latency is exposed.
-__global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<float> a, SDmaWalk wk) {
-  typedef float2 T2;
-  typedef CVec<T2, 2> VT;
+// tile ahead as well (registers), so neither operand's latency is exposed.  Both dtypes since round 5 (the shapes of SDm<T>: a lane's
+// 16 bytes are two complex64 columns or one complex128 column of a row).
+template <class T>
+__global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<T> a, SDmaWalk wk) {
+  typedef typename dq::Cx<T>::type T2;
+  typedef SDm<T> SD;
+  typedef typename SD::V V;
+  constexpr int ROWS = 1 << SD::P, RSTEP = STHREADS / SD::TPR, EB = SD::EB;
+  static_assert(ROWS / RSTEP == SD_RPT, "4 rows per thread in both forms");
   extern __shared__ __align__(16) unsigned char sd_raw[];
-  T2* tiles = (T2*)sd_raw;
   __shared__ DTerm tt[SOVL_TCH];
   __shared__ double red[2][SOVL_TCH][STHREADS / 64];
   const unsigned full = (a.n >= 32) ? 0xffffffffu : ((1u << a.n) - 1u);
   for (int m = threadIdx.x; m < a.nterms; m += STHREADS) tt[m] = a.terms[m];
-  const int c = (threadIdx.x % 8) * 2;
-  const int rbase = threadIdx.x / 8;
+  const int c = (threadIdx.x % SD::TPR) * SD::CPT;
+  const int rbase = threadIdx.x / SD::TPR;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   unsigned dep[SD_RPT];
 #pragma unroll
-  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * SD_RSTEP), a.lmask);
-  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)tiles;
+  for (int q = 0; q < SD_RPT; ++q) dep[q] = deposit_bits((unsigned)(rbase + q * RSTEP), a.lmask);
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void*)sd_raw;
   auto issue = [&](unsigned u, int buf) {
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) {
-      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * 8u;
-      const unsigned ld = lds0 + (unsigned)buf * (SD_ROWS * SBC * 8) + (unsigned)(wave * 8 + q * SD_RSTEP) * (SBC * 8);
+      const unsigned off = ((base | dep[q]) * (unsigned)a.B + (unsigned)(c0 + c)) * (unsigned)EB;
+      const unsigned ld = lds0 + (unsigned)buf * (ROWS * SBC * EB) + (unsigned)(wave * (64 / SD::TPR) + q * RSTEP) * (SBC * EB);
       S_DMA16(a.zb, off, ld);
     }
   };
-  auto load_u = [&](unsigned u, VT* dst) {
+  auto load_u = [&](unsigned u, V* dst) {
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
     const int c0 = (int)wk.chunk(u) * SBC;
 #pragma unroll
-    for (int q = 0; q < SD_RPT; ++q) dst[q] = *(const VT*)(a.za + (size_t)(base | dep[q]) * a.B + c0 + c);
+    for (int q = 0; q < SD_RPT; ++q) dst[q] = *(const V*)(a.za + (size_t)(base | dep[q]) * a.B + c0 + c);
   };
-  float px[SOVL_TCH], py[SOVL_TCH];
+  T px[SOVL_TCH], py[SOVL_TCH];
 #pragma unroll
   for (int mm = 0; mm < SOVL_TCH; ++mm) { px[mm] = 0; py[mm] = 0; }
-  VT un[SD_RPT];
+  V un[SD_RPT];
   unsigned u = blockIdx.x;
   if (u < wk.nunits) { issue(u, 0); load_u(u, un); }
   int buf = 0;
   for (; u < wk.nunits; u += gridDim.x, buf ^= 1) {
-    VT uc[SD_RPT];
+    V uc[SD_RPT];
 #pragma unroll
     for (int q = 0; q < SD_RPT; ++q) uc[q] = un[q];  // (waits for this tile's cotangent rows: requested a tile ago)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile u has landed in every wave's pieces
     if (u + gridDim.x < wk.nunits) { issue(u + gridDim.x, buf ^ 1); load_u(u + gridDim.x, un); }
-    const T2* tile = tiles + (size_t)buf * (SD_ROWS * SBC);
+    const T2* tile = (const T2*)sd_raw + (size_t)buf * (ROWS * SBC);
     const unsigned base = deposit_bits(wk.tile(u), full & ~a.lmask);
 #pragma unroll
     for (int mm = 0; mm < SOVL_TCH; ++mm)
@@ -1185,14 +1200,9 @@ __global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<float> 
         const DTerm t = tt[mm];
 #pragma unroll
         for (int q = 0; q < SD_RPT; ++q) {
-          const int r = rbase + q * SD_RSTEP;
-          const VT v = *(const VT*)(tile + (r ^ t.xloc) * SBC + c);
-          float qx = 0, qy = 0;
-#pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            qx += uc[q].v[w].x * v.v[w].x + uc[q].v[w].y * v.v[w].y;   // conj(u) * v
-            qy += uc[q].v[w].x * v.v[w].y - uc[q].v[w].y * v.v[w].x;
-          }
+          const int r = rbase + q * RSTEP;
+          const V v = *(const V*)(tile + (r ^ t.xloc) * SBC + c);
+          T qx = sd_cre(uc[q], v), qy = sd_cim(uc[q], v);   // conj(u) * v over the lane's complex numbers
           if (t.zmask != 0 && (__popc(((base | dep[q]) ^ t.xmask) & t.zmask) & 1)) { qx = -qx; qy = -qy; }
           px[mm] += qx; py[mm] += qy;
         }
@@ -1201,7 +1211,7 @@ __global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<float> 
 #pragma unroll
   for (int mm = 0; mm < SOVL_TCH; ++mm)
     if (mm < a.nterms) {
-      float vx = px[mm], vy = py[mm];
+      T vx = px[mm], vy = py[mm];
       for (int off = 32; off > 0; off >>= 1) { vx += __shfl_down(vx, off, 64); vy += __shfl_down(vy, off, 64); }
       if (lane == 0) { red[0][mm][wave] = (double)vx; red[1][mm][wave] = (double)vy; }
     }
@@ -1214,12 +1224,12 @@ __global__ void __launch_bounds__(STHREADS) soverlap_dma_kernel(SOverlap<float> 
   }
 }
 
-inline void soverlap_dma_launch(const SOverlap<float>& o, SDmaWalk wk, int nblk, hipStream_t st) {
+template <class T>
+void soverlap_dma_launch(const SOverlap<T>& o, SDmaWalk wk, int nblk, hipStream_t st) {
   const size_t lds = SD_LDS;
-  (void)hipFuncSetAttribute((const void*)soverlap_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(soverlap_dma_kernel, dim3((unsigned)nblk), dim3(STHREADS), lds, st, o, wk);
+  (void)hipFuncSetAttribute((const void*)soverlap_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(soverlap_dma_kernel<T>, dim3((unsigned)nblk), dim3(STHREADS), lds, st, o, wk);
 }
-inline void soverlap_dma_launch(const SOverlap<double>&, SDmaWalk, int, hipStream_t) {}
 
 // grad[k(slot)] += fac * Im( phase_slot * sum_blk part[blk][m] ) * weight_slot      (fixed-order sum: deterministic)
 __global__ void __launch_bounds__(256) soverlap_finish_kernel(const double* part, int nblk, int nterms, const int* slots,
@@ -2129,7 +2139,7 @@ void s_energy_grad(SCtx<T>* c, const double* u, int S, double dt, const void* ps
         const unsigned ychunks = (B + SBC - 1) / SBC;
         o.tpw = (int)std::max(1u, std::min(8u, (o.ntiles * ychunks) / 512u));  // keep >= ~512 workgroups (2 per CU)
         dim3 grid((o.ntiles + o.tpw - 1) / o.tpw, ychunks);
-        const bool use_dma = sizeof(T) == sizeof(float) && sdma_ok<T>(o.p, B, o.nterms, c->dma, c->n) && o.nterms <= SOVL_TCH;   // (the separate overlap pass has a DMA form in complex64 only)
+        const bool use_dma = sdma_ok<T>(o.p, B, o.nterms, c->dma, c->n) && o.nterms <= SOVL_TCH;   // (both dtypes since round 5)
         SDmaWalk wk = sdma_walk(o.ntiles, ychunks, o.lmask);
         const int nblk = use_dma ? sdma_blocks(wk.nunits, c->n_cu) : (int)(grid.x * grid.y);
         c->part.ensure((size_t)nblk * o.nterms * 16);
