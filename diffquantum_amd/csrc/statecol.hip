@@ -156,11 +156,12 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
           o[r].y = 0;
         }
         xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, img + p * D, cur, t, (T)1, o, nullptr, nullptr);
-        const T inv = (T)1 / (T)m, gm = (T)pol.g[m];
+        // (no division: the recurrence runs on A^m psi and the factorials sit in the table, pol.g[m] = g_m / m!: xs_forward_go)
+        const T gm = (T)pol.g[m];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {  // + the diagonal: -i dg v
-          const T ox = xs_fma(dg[r], cur[r].y, o[r].x) * inv;
-          const T oy = xs_fma(-dg[r], cur[r].x, o[r].y) * inv;
+          const T ox = xs_fma(dg[r], cur[r].y, o[r].x);
+          const T oy = xs_fma(-dg[r], cur[r].x, o[r].y);
           cur[r].x = ox;
           cur[r].y = oy;
           acc[r].x = xs_fma(gm, ox, acc[r].x);
@@ -656,6 +657,16 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
   if (cplx && !sgn) return hipErrorInvalidValue;  // (complex tables always carry sign words)
   const XsOrder ord = xs_make_order(NT * RPT, tab, xs_threads(NT * RPT, 0) == NT ? 0 : 1, true);
   const bool rs = xs_order_row_signs(ord);   // (SIGN = 2: the loops of row-signed diagonals exist; 1: parity signs within the thread bits)
+  // the kernel's recurrence is v_m = A v_{m-1} without the division by m (16 multiplications and an f64 division per sweep and
+  // thread): the factorials go into the level factors, g_m / m!
+  XsPoly pk = pol;
+  {
+    double f = 1.0;
+    for (int m = 1; m <= XS_LMAX; ++m) {
+      f /= (double)m;
+      pk.g[m] = pol.g[m] * f;
+    }
+  }
   void (*kf)(const T2*, T2*, XrTab, XsOrder, const double*, const double*, long, int, int, int, XsPoly, XsSeg) =
       cplx ? (rs ? (pref ? xs_forward_kernel<T, NT, RPT, 2, true, true> : xs_forward_kernel<T, NT, RPT, 2, false, true>)
                  : (pref ? xs_forward_kernel<T, NT, RPT, 1, true, true> : xs_forward_kernel<T, NT, RPT, 1, false, true>))
@@ -665,7 +676,7 @@ hipError_t xs_forward_go(const typename Cx<T>::type* in, typename Cx<T>::type* o
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, in, out, tab, ord, wt, dgs,
-                     dgs_step, S, B, L, pol, seg);
+                     dgs_step, S, B, L, pk, seg);
   return hipGetLastError();
 }
 

@@ -134,15 +134,17 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             o[r].y = 0;
           }
           xs_gather<T, NT, RPT, SIGN, false, 1, false, true, CPLX, true>(ctl, sg, W, zc, t, (T)-1, o, nullptr, nullptr);
-          const T inv = (T)1 / (T)m, gm = (T)qd.g[m];
+          // (no division by m: the sweeps run on (-A)^m lambda and (-A)^m psi, the factorials sit in the rule's tables -- the launcher
+          // hands over g[m], c1[m], c2[m], w1[m] divided by m!: xs_backward_q_start)
+          const T gm = (T)qd.g[m];
           T cf[NI];
 #pragma unroll
           for (int i = 0; i < NI; ++i) cf[i] = (T)qd.c1[m][i];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {  // + i dg v
             const T dgv = (T)dgr[t * RPT + r];
-            const T ox = xs_fma(-dgv, zc[r].y, o[r].x) * inv;
-            const T oy = xs_fma(dgv, zc[r].x, o[r].y) * inv;
+            const T ox = xs_fma(-dgv, zc[r].y, o[r].x);
+            const T oy = xs_fma(dgv, zc[r].x, o[r].y);
             zc[r].x = ox;
             zc[r].y = oy;
             acc[r].x = xs_fma(gm, ox, acc[r].x);
@@ -262,11 +264,11 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
 #else
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, q, dacc);
 #endif
-        const T inv = (T)1 / (T)(m + 1), gm = (T)qd.g[m + 1];
+        const T gm = (T)qd.g[m + 1];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-          cur[r].x = o[r].x * inv;
-          cur[r].y = o[r].y * inv;
+          cur[r].x = o[r].x;
+          cur[r].y = o[r].y;
           acc[r].x = xs_fma(gm, cur[r].x, acc[r].x);
           acc[r].y = xs_fma(gm, cur[r].y, acc[r].y);
         }
@@ -340,7 +342,20 @@ hipError_t xs_backward_q_start(typename Cx<T>::type* psi, typename Cx<T>::type* 
       xs_backward_q_kernel<T, NT, RPT, SIGN, DIAGCTL, CPLX, 2, U2L>;
   hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, qd, part, (T)pr, (T)pi);
+  XsQuad qk = qd;   // the factorials of the division-free recurrence, into the tables (row m / m!)
+  {
+    double f = 1.0;
+    for (int m = 1; m <= XS_LMAX; ++m) {
+      f /= (double)m;
+      qk.g[m] *= f;
+      qk.w1[m] *= f;
+      for (int i = 0; i < XS_NIMAX; ++i) {
+        qk.c1[m][i] *= f;
+        qk.c2[m][i] *= f;
+      }
+    }
+  }
+  hipLaunchKernelGGL(kf, dim3((unsigned)nblk), dim3(NT), lds, st, psi, lam, tab, ord, ordh, wt, dgs, dgs_step, S, B, L, qk, part, (T)pr, (T)pi);
   return hipGetLastError();
 }
 template <class T, int NT, int RPT>
