@@ -161,13 +161,25 @@ struct XsCtl {
   __device__ __forceinline__ double fetch_step(const double* __restrict__ wrow, int lane) const { return lane < R ? wrow[perm] : 0.0; }
 };
 
+__device__ __forceinline__ unsigned xs_lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+// the images of a column start at multiples of NT * sizeof(complex) in LDS (xs_fetch / xs_lds_ring fold the image's offset into the
+// diagonal's scalar and XOR the thread's part onto it): dynamic LDS at offset 0 and images D * sizeof apart make it so -- trap otherwise
+template <int NT, class T2>
+__device__ __forceinline__ void xs_lds_aligned(const T2* first_image) {
+  if ((xs_lds_addr(first_image) & (unsigned)(NT * sizeof(T2) - 1)) != 0u) __builtin_trap();
+}
 // partner values by LDS reads (volatile: neighbours are not to be merged into ds_read2 forms, which the LDS array serves at half
 // the rate).  PERM: the offset permutes the thread's row list as well (xh != 0)
 template <class T, int NT, int RPT, bool PERM>
 __device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __restrict__ src, int t, typename Cx<T>::type* v) {
   typedef typename XsV2<T>::type V2;
   typedef const volatile __attribute__((address_space(3))) V2* lds_ptr;
-  lds_ptr base = (lds_ptr)(src + (t ^ (xo & (NT - 1))));
+  // address = image + ((t ^ xlo) << log2 sizeof): the images start at multiples of NT * sizeof (checked by xs_lds_aligned at kernel
+  // start), so the image's offset and the diagonal's go into ONE scalar and the thread's part is one v_xor (was: v_bitop3 + v_lshl_add)
+  const unsigned sa = xs_lds_addr(src) | ((unsigned)(xo & (NT - 1)) * (unsigned)sizeof(V2));
+  lds_ptr base = (lds_ptr)(__attribute__((address_space(3))) void*)(unsigned long long)(((unsigned)t * (unsigned)sizeof(V2)) ^ sa);
   const int xh = xo / NT;
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
@@ -210,9 +222,6 @@ __device__ __forceinline__ void xs_fetch(int xo, const typename Cx<T>::type* __r
 #define XS_RING_DEPTH_PAIR 4
 #endif
 typedef double xs_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned xs_lds_addr(const void* p) {
-  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
-}
 template <int OFF>
 __device__ __forceinline__ void xs_ds_read_first(xs_d2& q, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "n"(OFF));
@@ -280,9 +289,9 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
   static_assert(NSLOT == RPT || (NSLOT == DEPTH && RPT % DEPTH == 0), "ring slots");
   if (n <= 0) return;
   xs_d2 v[NSLOT];
-  const unsigned base = xs_lds_addr(src);
+  const unsigned base = xs_lds_addr(src), t16 = (unsigned)t << 4;   // (one v_xor per address: xs_fetch)
   int e = __builtin_amdgcn_readlane(ctl.ent, q0);
-  unsigned a = base + (unsigned)((t ^ (e & (NT - 1))) << 4);
+  unsigned a = t16 ^ (base | ((unsigned)(e & (NT - 1)) << 4));
   int xh = (e & 0xffff) / NT;
   xs_rows<0, DEPTH>([&](auto rc) {
     constexpr int r = decltype(rc)::value;
@@ -300,7 +309,7 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
 #pragma clang loop unroll(disable)
   for (int q = q0; q + 1 < qe; ++q) {
     const int en = __builtin_amdgcn_readlane(ctl.ent, q + 1);
-    const unsigned an = base + (unsigned)((t ^ (en & (NT - 1))) << 4);
+    const unsigned an = t16 ^ (base | ((unsigned)(en & (NT - 1)) << 4));
     const int xhn = (en & 0xffff) / NT;
     const unsigned tb = SIGN ? (sg >> ((e >> 20) & 31)) & 1u : 0u, rm = (SIGN && RS) ? ((unsigned)e >> 24) & 0xfeu : 0u;
     const double w = xs_flip(sgn * xs_readlane(ctl.w, q), tb);   // (the thread's factor of the sign goes into the weight)
