@@ -239,6 +239,9 @@ template <int N>
 __device__ __forceinline__ void xs_ds_wait2(xs_d2& q0, xs_d2& q1) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(q0), "+v"(q1) : "n"(N));
 }
+#ifndef XS_RING_CHAINS
+#define XS_RING_CHAINS 2   // chains of the pairing sums per diagonal in the ring (4 until round 5: two more additions per diagonal)
+#endif
 #ifndef XS_RING_WAIT2
 #define XS_RING_WAIT2 0
 #endif
@@ -267,7 +270,7 @@ __device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, do
     o.y = __builtin_fma(-w, v.x, o.y);
   }
   if (DOT) {
-    constexpr int c = (R & 1) * 2;
+    constexpr int c = XS_RING_CHAINS == 4 ? (R & 1) * 2 : 0;   // (two chains: a chain's FMAs are 4 instructions apart as it is -- the row's two updates of o in between)
     if (PH) {
       s[c] = __builtin_fma(v.x, xm[R].x, s[c]);
       s[c + 1] = __builtin_fma(v.y, xm[R].y, s[c + 1]);
@@ -302,7 +305,8 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
   const int qe = q0 + n;
   auto finish = [&](int q, const double* s, unsigned tb) {
     if (DOT) {
-      const double tot = PH ? -((s[0] + s[1]) + (s[2] + s[3])) : (s[0] - s[1]) + (s[2] - s[3]);
+      const double tot = XS_RING_CHAINS == 4 ? (PH ? -((s[0] + s[1]) + (s[2] + s[3])) : (s[0] - s[1]) + (s[2] - s[3]))
+                                             : (PH ? -(s[0] + s[1]) : s[0] - s[1]);
       (*(xs_acc16*)dacc)[q - SB] += xs_flip(tot, tb);   // (the pairing takes the thread's factor once per diagonal)
     }
   };
