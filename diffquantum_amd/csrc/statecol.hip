@@ -116,9 +116,6 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
         cur[r].y = (T)0;
       }
     }
-    p ^= 1;
-    xs_put<T, NT, RPT>(img + p * D, t, cur);
-    __syncthreads();
     // the step's weights (and, where the shape has the registers: 512 threads and fewer, its diagonal) are requested a step ahead:
     // at the head of the step nothing hides their latency
     constexpr bool PFD = XS_W_PREFETCH && NT <= 512;
@@ -128,6 +125,66 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
 #pragma unroll
       for (int r = 0; r < RPT; ++r) dgn[r] = (T)dgs[(long)s0 * dgs_step + t * RPT + r];
     }
+#if XS_FWD_SPLIT
+    // Split sweeps: o += (register classes) runs BEHIND the writes that publish the sweep's input and in front of the barrier -- the
+    // image drains into LDS (8 ds_write_b128 per thread at a third of the read rate, nothing else of the workgroup running) while the
+    // vector pipes work on the thread's own rows; the LDS classes follow the barrier.  o lives across it (the kernel has the registers).
+    T2 o[RPT];
+    auto publish_and_start = [&]() {   // cur is the next sweep's input, ctl.w that sweep's weights
+      p ^= 1;
+      xs_put<T, NT, RPT>(img + p * D, t, cur);
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        o[r].x = 0;
+        o[r].y = 0;
+      }
+      xs_gather_local<T, RPT, SIGN, CPLX>(ctl, sg, cur, (T)1, o);
+      __syncthreads();
+    };
+    ctl.w = wnext;
+    if (ns > 0) publish_and_start();
+    for (int s = 0; s < ns; ++s) {
+      if (s + 1 < ns) wnext = ctl.fetch_step(wt + (long)(s0 + s + 1) * tab.R, t & 63);
+      const double* dgr = dgs + (long)(s0 + s) * dgs_step;
+      T2 acc[RPT];
+      T dg[RPT];  // the rows' diagonal weights of this step (registers: a load per sweep would sit in the vmcnt queue of every wait)
+      const T g0 = (T)pol.g[0];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        acc[r].x = g0 * cur[r].x;
+        acc[r].y = g0 * cur[r].y;
+        dg[r] = PFD ? dgn[r] : (T)dgr[t * RPT + r];
+      }
+      if (PFD && s + 1 < ns) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) dgn[r] = (T)dgr[dgs_step + t * RPT + r];
+      }
+      for (int m = 1; m <= L; ++m) {
+        xs_gather_lds<T, NT, RPT, SIGN, 1, PREF, CPLX>(ctl, sg, img + p * D, t, (T)1, o);
+        // (no division: the recurrence runs on A^m psi and the factorials sit in the table, pol.g[m] = g_m / m!: xs_forward_go)
+        const T gm = (T)pol.g[m];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {  // + the diagonal: -i dg v
+          const T ox = xs_fma(dg[r], cur[r].y, o[r].x);
+          const T oy = xs_fma(-dg[r], cur[r].x, o[r].y);
+          cur[r].x = ox;
+          cur[r].y = oy;
+          acc[r].x = xs_fma(gm, ox, acc[r].x);
+          acc[r].y = xs_fma(gm, oy, acc[r].y);
+        }
+        if (m < L) publish_and_start();
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
+      if (s + 1 < ns) {
+        ctl.w = wnext;   // (the next step's weights: its first sweep's register classes run in publish_and_start)
+        publish_and_start();
+      }
+    }
+#else
+    p ^= 1;
+    xs_put<T, NT, RPT>(img + p * D, t, cur);
+    __syncthreads();
     for (int s = 0; s < ns; ++s) {
 #if XS_W_PREFETCH
       ctl.w = wnext;
@@ -182,6 +239,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
         __syncthreads();
       }
     }
+#endif
     T2* out = psi_out + (long)b * D;
     {   // the scalar of the centred frame (xs_center_launch): e^{-i sum of the steps' midpoints}, per time segment or per launch
       const int g = seg.cols > 0 ? b / seg.cols : 0;

@@ -60,11 +60,20 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
   if (SIGN) ctl.load_row_signs(tab, lane, __builtin_ctz(NT));
   ctlh.load_table(tab, ordh, lane);
   if (SIGN) ctlh.load_row_signs(tab, lane, __builtin_ctz(NT));
-  auto publish = [&](const T2* v) {
+  // Split sweeps (round 5, XS_BWD_SPLIT): a sweep's input is published in two halves -- publish_begin (barrier: every wave is done with
+  // the old image; then the thread's 8 ds_write_b128) and, BEHIND the sweep's register-only work (the classes whose partners are the
+  // thread's own rows; in phase 2 also q_m and the diagonal term), the barrier that makes the image visible to the LDS classes.  The
+  // writes drain at a third of the read rate with nothing else of the workgroup running: the vector work now runs under them.
+  auto publish_begin = [&](const T2* v) {
     __syncthreads();
     xs_put<T, NT, RPT>(W, t, v);
+  };
+#if !XS_BWD_SPLIT
+  auto publish = [&](const T2* v) {
+    publish_begin(v);
     __syncthreads();
   };
+#endif
   bool first = true;
 #ifdef XS_STAMPS
   long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = clock64();
@@ -126,7 +135,11 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             u2f[r].y = 0;
           }
         }
+#if XS_BWD_SPLIT
+        publish_begin(zc);
+#else
         publish(zc);
+#endif
         for (int m = 1; m <= L; ++m) {
           T2 o[RPT];
 #pragma unroll
@@ -134,7 +147,13 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
             o[r].x = 0;
             o[r].y = 0;
           }
+#if XS_BWD_SPLIT
+          xs_gather_local<T, RPT, SIGN, CPLX>(ctl, sg, zc, (T)-1, o);
+          __syncthreads();
+          xs_gather_lds<T, NT, RPT, SIGN, 1, false, CPLX>(ctl, sg, W, t, (T)-1, o);
+#else
           xs_gather<T, NT, RPT, SIGN, false, 1, false, true, CPLX, true>(ctl, sg, W, zc, t, (T)-1, o, nullptr, nullptr);
+#endif
           // (no division by m: the sweeps run on (-A)^m lambda and (-A)^m psi, the factorials sit in the rule's tables -- the launcher
           // hands over g[m], c1[m], c2[m], w1[m] divided by m!: xs_backward_q_start)
           const T gm = (T)qd.g[m];
@@ -160,7 +179,11 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
               u2f[r].y = xs_fma(cf[NI - 1], oy, u2f[r].y);
             }
           }
+#if XS_BWD_SPLIT
+          if (m < L) publish_begin(zc);
+#else
           if (m < L) publish(zc);
+#endif
         }
         T cw[NI];
 #pragma unroll
@@ -207,7 +230,11 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           acc[r].y = g0 * cur[r].y;
         }
       }
+#if XS_BWD_SPLIT
+      publish_begin(cur);
+#else
       publish(cur);
+#endif
       // (the accumulators are born here, behind the publish: declared at the top of the phase the 32 registers of zeros were spilled
       // across it -- 128 B per thread and step of scratch traffic in the signed kernels)
       xs_acc16 dacc[1];
@@ -256,6 +283,9 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         // the partners at offsets without lane bits are the thread's own rows of r_m: those diagonals FIRST, while cur is still
         // live and the partner ring of the LDS classes is not yet (the two share registers in time), then the LDS classes
         xs_local_classes<T, RPT, 1, SIGN, true, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, (T)-1, o, q, (double*)&dacc[0]);
+#if XS_BWD_SPLIT
+        __syncthreads();   // (the image of r_m, written by publish_begin in front of q_m, the diagonal term and the register classes)
+#endif
         xs_lds_group<T, NT, RPT, SIGN, true, RM, false, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
         if constexpr (CPLX)
           xs_lds_group<T, NT, RPT, SIGN, true, RM, false, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
@@ -263,6 +293,9 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
         if constexpr (CPLX)
           xs_lds_group<T, NT, RPT, SIGN, true, RM, true, false, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
 #else
+#if XS_BWD_SPLIT
+        __syncthreads();
+#endif
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, q, dacc);
 #endif
         const T gm = (T)qd.g[m + 1];
@@ -273,7 +306,11 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
           acc[r].x = xs_fma(gm, cur[r].x, acc[r].x);
           acc[r].y = xs_fma(gm, cur[r].y, acc[r].y);
         }
+#if XS_BWD_SPLIT
+        if (m + 1 < L) publish_begin(cur);
+#else
         if (m + 1 < L) publish(cur);
+#endif
       }
 #pragma unroll
       for (int r = 0; r < RPT; ++r) cur[r] = acc[r];

@@ -512,6 +512,21 @@ __device__ __forceinline__ void xs_gather(const XsCtl& ctl, unsigned sg, const t
   if (LOCAL && !local_first) xs_local_classes<T, RPT, 1, SIGN, DOT, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, xm, dacc);
 }
 
+// the two halves of xs_gather on their own, for sweeps that run the register classes BEHIND the publish of their input (the writes of
+// the image drain while the vector pipes work on the thread's own rows; the LDS classes follow the barrier)
+template <class T, int NT, int RPT, int SIGN, int RM, bool PREF, bool CPLX>
+__device__ __forceinline__ void xs_gather_lds(const XsCtl& ctl, unsigned sg, const typename Cx<T>::type* __restrict__ src, int t, T sgn,
+                                              typename Cx<T>::type* o) {
+  xs_lds_group<T, NT, RPT, SIGN, false, RM, false, PREF, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, src, t, sgn, o, nullptr, nullptr);
+  if constexpr (CPLX) xs_lds_group<T, NT, RPT, SIGN, false, RM, false, PREF, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, src, t, sgn, o, nullptr, nullptr);
+  xs_lds_group<T, NT, RPT, SIGN, false, RM, true, PREF, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, src, t, sgn, o, nullptr, nullptr);
+  if constexpr (CPLX) xs_lds_group<T, NT, RPT, SIGN, false, RM, true, PREF, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, src, t, sgn, o, nullptr, nullptr);
+}
+template <class T, int RPT, int SIGN, bool CPLX>
+__device__ __forceinline__ void xs_gather_local(const XsCtl& ctl, unsigned sg, const typename Cx<T>::type* cur, T sgn, typename Cx<T>::type* o) {
+  xs_local_classes<T, RPT, 1, SIGN, false, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, sgn, o, nullptr, nullptr);
+}
+
 template <class T, int NT, int RPT>
 __device__ __forceinline__ void xs_put(typename Cx<T>::type* img, int t, const typename Cx<T>::type* v) {
 #pragma unroll
@@ -591,6 +606,12 @@ __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
 // return value (global_atomic_add_f64) leaves the wave at once, and adds of one wave to one address keep their order.
 #ifndef XS_W_PREFETCH
 #define XS_W_PREFETCH 1
+#endif
+#ifndef XS_BWD_SPLIT
+#define XS_BWD_SPLIT 1   // quadrature adjoint kernel: the same for both of its phases (statecol_bwdq.hip, publish_begin)
+#endif
+#ifndef XS_FWD_SPLIT
+#define XS_FWD_SPLIT 1   // forward kernel: the register classes of a sweep run between the writes of its input image and the barrier
 #endif
 #ifndef XS_PART_ATOMIC
 #define XS_PART_ATOMIC 1
