@@ -41,10 +41,14 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   if (SIGN) ctlh.load_row_signs(tab, lane, __builtin_ctz(NT));
   T2* pk = park + (long)blockIdx.x * L * D;  // [l][r * NT + t] (uniform base, lane index t)
   // in-place update of the work image: every read of the sweep that just ran is done before any row is overwritten
-  auto publish = [&](const T2* v) {
+  // (split sweeps as in statecol_bwdq.hip: publish_begin = barrier + the thread's writes; the barrier that makes the image visible
+  // follows the sweep's register-only work -- the register classes of the plain sweeps, the bracket of the Horner levels)
+  // (512 threads and fewer: the 1024-thread shapes have 128 registers and spill what lives across one more barrier)
+  constexpr bool SPLIT = NT <= 512;
+  auto publish_begin = [&](const T2* v) {
     __syncthreads();
     xs_put<T, NT, RPT>(W, t, v);
-    __syncthreads();
+    if constexpr (!SPLIT) __syncthreads();
   };
   bool first = true;
 #ifdef XS_STAMPS
@@ -86,7 +90,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
       for (int r = 0; r < RPT; ++r) dg[r] = (T)dgr[t * RPT + r];
       // ---- reversal: psi_s = sum_m (-A)^m psi_{s+1} / m! -------------------------------------------------------------
-      publish(cur);
+      publish_begin(cur);
       {
         T2 acc[RPT];
         const T g0 = (T)pol.g[0];
@@ -102,7 +106,13 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
             o[r].x = 0;
             o[r].y = 0;
           }
-          xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, W, cur, t, (T)-1, o, nullptr, nullptr);
+          if constexpr (SPLIT) {
+            xs_gather_local<T, RPT, SIGN, CPLX>(ctl, sg, cur, (T)-1, o);
+            __syncthreads();
+            xs_gather_lds<T, NT, RPT, SIGN, 1, PREF, CPLX>(ctl, sg, W, t, (T)-1, o);
+          } else {
+            xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, W, cur, t, (T)-1, o, nullptr, nullptr);
+          }
           const T inv = (T)1 / (T)m, gm = (T)pol.g[m];
 #pragma unroll
           for (int r = 0; r < RPT; ++r) {  // + i dg v
@@ -113,7 +123,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
             acc[r].x = xs_fma(gm, ox, acc[r].x);
             acc[r].y = xs_fma(gm, oy, acc[r].y);
           }
-          if (m < L) publish(cur);
+          if (m < L) publish_begin(cur);
         }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) cur[r] = acc[r];
@@ -124,7 +134,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
 #pragma unroll
       for (int r = 0; r < RPT; ++r) pk[r * NT + t] = cur[r];
 #endif
-      if (L > 1) publish(cur);
+      if (L > 1) publish_begin(cur);
       for (int l = 1; l < L; ++l) {
         T2 o[RPT];
 #pragma unroll
@@ -132,7 +142,13 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].x = 0;
           o[r].y = 0;
         }
-        xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, W, cur, t, (T)1, o, nullptr, nullptr);
+        if constexpr (SPLIT) {
+          xs_gather_local<T, RPT, SIGN, CPLX>(ctl, sg, cur, (T)1, o);
+          __syncthreads();
+          xs_gather_lds<T, NT, RPT, SIGN, 1, PREF, CPLX>(ctl, sg, W, t, (T)1, o);
+        } else {
+          xs_gather<T, NT, RPT, SIGN, false, 1, PREF, true, CPLX>(ctl, sg, W, cur, t, (T)1, o, nullptr, nullptr);
+        }
         const T inv = (T)1 / (T)l;
         T2* pl = pk + (long)l * D;
 #pragma unroll
@@ -145,7 +161,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           pl[r * NT + t] = cur[r];
 #endif
         }
-        if (l < L - 1) publish(cur);
+        if (l < L - 1) publish_begin(cur);
       }
       }  // (dg)
       XS_STAMP(2);
@@ -169,7 +185,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           cur[r].y = g.y * inv;
         }
       }
-      publish(cur);
+      publish_begin(cur);
       for (int l = L - 1; l >= 0; --l) {  // forms y_{l-1} from y_l (l = 0: lambda_s), pairing y_l with x_l
         T2 o[RPT];
         if (l < L - 1) {  // this level's forward term (x_{L-1} is still in the registers).  No prefetch of the next one: its buffer
@@ -190,6 +206,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
           o[r].y = xs_fma(dgv, cur[r].x, gl * g.y);
           if (DIAGCTL) rowacc[r] += (double)cur[r].x * (double)xm[r].y - (double)cur[r].y * (double)xm[r].x;
         }
+        if constexpr (SPLIT) __syncthreads();   // (the image of y_l: written in front of this level's forward term and bracket)
         xs_gather_pairings<T, NT, RPT, SIGN, RM, CPLX>(ctlh, sg, W, t, (T)-1, o, xm, dacc);
         if (l > 0) {
           const T inv = (T)1 / (T)l;
@@ -198,7 +215,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
             cur[r].x = o[r].x * inv;
             cur[r].y = o[r].y * inv;
           }
-          publish(cur);
+          publish_begin(cur);
         } else {
 #pragma unroll
           for (int r = 0; r < RPT; ++r) Lm[r * NT + t] = o[r];
