@@ -466,7 +466,9 @@ template <class T, int FLAGS, bool SIMPLE, bool OVL = false>
 __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<T> a, SDmaWalk wk) {
   static_assert(!OVL || SIMPLE, "fused overlaps exist for the pure X-string form only");
   constexpr bool HAS_PREV = FLAGS & 1, HAS_ADD = FLAGS & 2, HAS_ACC = FLAGS & 4, HAS_DIAG = FLAGS & 8;
-  constexpr int NSTORE = SD_RPT * (1 + (HAS_ACC ? 1 : 0));  // vector-memory stores a thread issues per tile
+  constexpr bool NO_OUT = FLAGS & 16;   // the result is only accumulated (acc), not kept: the last stage of the reverse sweep's chain (zbar_m is read by nobody)
+  static_assert(!NO_OUT || HAS_ACC, "a pass without `out` must have `acc`");
+  constexpr int NSTORE = SD_RPT * ((NO_OUT ? 0 : 1) + (HAS_ACC ? 1 : 0));  // vector-memory stores a thread issues per tile
   typedef typename dq::Cx<T>::type T2;
   typedef SDm<T> SD;
   typedef typename SD::V V;
@@ -611,7 +613,7 @@ __global__ void __launch_bounds__(STHREADS) sapply_dma_kernel(SApply<T> a, SDmaW
       if (HAS_PREV && !OVL) w += pv[q];
       V o = sd_rot(a.sr, a.si, w);
       if (HAS_ADD) o += ad[q];
-      S_STORE16((unsigned char*)a.out + off, o);
+      if (!NO_OUT) S_STORE16((unsigned char*)a.out + off, o);
       if (HAS_ACC) S_STORE16((unsigned char*)a.acc + off, ac[q] + o);
     }
   }
@@ -955,6 +957,11 @@ template <class T>
 void sapply_dma_launch(const SApply<T>& a, SDmaWalk wk, int nblk, hipStream_t st, bool simple) {
   const int f = (a.prev ? 1 : 0) | (a.add ? 2 : 0) | (a.acc ? 4 : 0) | (a.diag ? 8 : 0);
   if (a.zo) {  // fused overlaps: the caller has checked simple && sapply_ovl_flags_ok(f)
+    if (!a.out) {   // (accumulate only: built for the operand set of the reverse chain's last stage)
+      if (f != 5) sfail(DQ_ERR_STATE, "internal: a pass without `out` in an operand set that is not built");
+      sapply_dma_launch_ovl<T, 5 | 16>(a, wk, nblk, st);
+      return;
+    }
     switch (f) {
       case 0: sapply_dma_launch_ovl<T, 0>(a, wk, nblk, st); break;
       case 1: sapply_dma_launch_ovl<T, 1>(a, wk, nblk, st); break;
@@ -1327,6 +1334,7 @@ struct SCtx : dq_sctx {
   // set before step t's last pass and the sets change places behind it.
   SBuf d_coef2, Dt2;
   int step_handover = 1;
+  int reverse_keep_last = 0;   // 1: the reverse chain's last stage stores zbar_m as well (nobody reads it: the form before round 5)
   void swap_step_sets() { std::swap(d_coef.p, d_coef2.p); std::swap(d_coef.bytes, d_coef2.bytes); std::swap(Dt.p, Dt2.p); std::swap(Dt.bytes, Dt2.bytes); }
   std::vector<int> diag_controls;
   bool has_D0 = false, has_DM = false;
@@ -1883,7 +1891,7 @@ void reverse_chain(SCtx<T>* c, int m, double dt, int B, const std::vector<const 
     c->oparts[g].ensure((size_t)nblk * (STHREADS / 64) * std::max(1, a.n_ovl) * 16);
     a.part = (double*)c->oparts[g].p;
     G.last_nblk = nblk * (STHREADS / 64);
-    const double units = which == 0 ? 3.0 : (which == 1 ? 8.0 : 6.0);
+    const double units = which == 0 ? 3.0 : (which == 1 ? 8.0 : (out ? 6.0 : 5.0));
     if (which == 1) c->timed(units * sb, [&] { srchain_dma_launch(a, wk, nblk, c->st); });
     else c->timed(units * sb, [&] { sapply_dma_launch(a, wk, nblk, c->st, true); });
     c->last_passes += 1; c->last_dma_passes += 1; c->last_bytes += units * sb;
@@ -1908,8 +1916,8 @@ void reverse_chain(SCtx<T>* c, int m, double dt, int B, const std::vector<const 
     if (j < m) {
       pass(g, 1, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], z[j + 1], zb_new, (T2*)c->tmp[pb ^ 1].p, dt * c->rho[j], c->rho[j + 1] / c->rho[j]);
       pb ^= 1;
-    } else {
-      pass(g, 2, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], nullptr, zb_new, nullptr, dt * c->rho[j], 0.0);
+    } else {   // (the last stage: zbar_m goes into lambda_t and nowhere else -- no store of it: 5 units instead of 6)
+      pass(g, 2, zprev, (const T2*)c->tmp[pb].p, acc_in, z[j], nullptr, c->reverse_keep_last ? zb_new : (T2*)nullptr, nullptr, dt * c->rho[j], 0.0);
     }
     finish(g, dt * c->rho[j]);
     zprev = zb_new;
@@ -2350,6 +2358,7 @@ int dq_sctx_set_option(dq_sctx* c, const char* name, double v) {
     else if (s == "host_checkpoint_bytes") { if (v < 0) sfail(DQ_ERR_INVALID, "host_checkpoint_bytes must be >= 0"); t->host_checkpoint_bytes = v; }
     else if (s == "chain") t->chain = v != 0 ? 1 : 0;
     else if (s == "step_handover") t->step_handover = v != 0 ? 1 : 0;
+    else if (s == "reverse_keep_last") t->reverse_keep_last = v != 0 ? 1 : 0;
     else if (s == "reverse_chain") t->reverse_chain = v != 0 ? 1 : 0;
     else if (s == "interleave_groups") t->interleave_groups = v > 0 ? (int)v : 0;
     else if (s == "plan_steps") { if (v < 0 || v > 1e9) sfail(DQ_ERR_INVALID, "plan_steps must be 0..1e9"); t->plan_steps = (int)v; }
