@@ -371,6 +371,11 @@ def test_step_handover_changes_the_passes_not_the_numbers(dtype, n, B, tol):
             fwd = e.propagate(u, dt, psi0)
             passes.append(e.info("passes"))
             assert e.info("dma_passes") == e.info("passes")
+            if hand:   # the reverse chain's last stage with its (dead) store of zbar_m: the same gradient
+                e.set_option("reverse_keep_last", 1)
+                lk, gk, fk, _ = e.energy_grad(u, dt, psi0)
+                l1, g1, f1_, _ = res[2]
+                assert lk == l1 and np.array_equal(gk, g1) and np.array_equal(fk, f1_)
         out[hand] = (res, passes, fwd)
     (r1, p1, f1), (r0, p0, f0) = out[1], out[0]
     assert p1[0] == p0[0] - (S - 1) and p1[3] == p0[3] - (S - 1) and p1[2] == p0[2] - (S - 1)   # forward pass: one walk less per step but the last
