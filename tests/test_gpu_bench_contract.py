@@ -113,7 +113,7 @@ def test_bench_line_fits_the_driver_window_as_the_driver_runs_it():
         # round 4: the north-star kernel and the full chain are in the driver-parsed line
         m = d["roofline_mfma"]
         assert m["kernel"].startswith("zgemm_lin_kernel") and m["peak"] == 78.6 and 0.5 < m["frac"] < 1.0 and m["launches"] > 0
-        assert abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-6
+        assert abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-5   # (both printed with six significant digits)
         # BASELINE configs[2] at FULL size under -m gpu: the S = 2000, d = B = 4096 gradient of the state-column kernels
         # against the checkpointed explicit-propagator GEMM chain on the same inputs (benchlib/measure.py full_chain)
         fc = d["full_chain"]
