@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
 #if XS_BWD_SPLIT
           xs_gather_local<T, RPT, SIGN, CPLX>(ctl, sg, zc, (T)-1, o);
           __syncthreads();
-          xs_gather_lds<T, NT, RPT, SIGN, 1, false, CPLX>(ctl, sg, W, t, (T)-1, o);
+          xs_gather_lds<T, NT, RPT, SIGN, (SIGN != 0 ? 2 : 1), false, CPLX>(ctl, sg, W, t, (T)-1, o);   // (signed tables: the partner ring here too)
 #else
           xs_gather<T, NT, RPT, SIGN, false, 1, false, true, CPLX, true>(ctl, sg, W, zc, t, (T)-1, o, nullptr, nullptr);
 #endif

@@ -370,7 +370,9 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, un
                                              const typename Cx<T>::type* xm, double* dacc) {  // (SB: accumulator lane = position - SB)
   typedef typename Cx<T>::type T2;
   if (n <= 0) return;
-  if constexpr (!PREF && RPT == 8 && sizeof(T) == sizeof(double) && ((DOT && XS_RING_PAIR) || (!DOT && XS_RING_PLAIN))) {
+  // (RM == 2 on a plain sweep: the caller asks for the ring there too -- phase 1 of the quadrature adjoint on parity-signed tables, where
+  // it is 3 - 4 % faster per launch; on unsigned tables and in the forward kernel the burst loop is 4 - 7 % faster: round 5's A/B)
+  if constexpr (!PREF && RPT == 8 && sizeof(T) == sizeof(double) && ((DOT && XS_RING_PAIR) || (!DOT && (XS_RING_PLAIN || RM == 2)))) {
     constexpr int DEPTH = DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN;
     xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DEPTH, RS, (XS_RING_SLOTS_DEPTH && RPT % DEPTH == 0) ? DEPTH : RPT>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
     return;
