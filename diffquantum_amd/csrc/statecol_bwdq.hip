@@ -32,6 +32,9 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
   constexpr int D = NT * RPT;
   constexpr int NW = NT / 64;
   constexpr int RM = XR_RSMALL;
+  // the one-instruction accumulator update (xs_acc_add) in the kernels without diagonal controls: complex128, 8 rows per thread
+  constexpr bool ACCA = !DIAGCTL && sizeof(T) == sizeof(double) && RPT == 8 && NT == 512;   // (d = 4096: the shape the pinned tuple was checked on)
+  constexpr int RMP = ACCA ? 17 : RM;   // (what the pairing sweeps' LDS classes are told: statecol_dev.h, xs_lds_class)
   constexpr int NS = RM + (DIAGCTL ? XR_DMAX : 0);
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
   T2* W = (T2*)xs_lds_raw;
@@ -282,16 +285,16 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
 #if XS_PAIR_LOCAL
         // the partners at offsets without lane bits are the thread's own rows of r_m: those diagonals FIRST, while cur is still
         // live and the partner ring of the LDS classes is not yet (the two share registers in time), then the LDS classes
-        xs_local_classes<T, RPT, 1, SIGN, true, CPLX>(ctl, ctl.n0 + ctl.n1, sg, cur, (T)-1, o, q, (double*)&dacc[0]);
+        xs_local_classes<T, RPT, 1, SIGN, true, CPLX, ACCA>(ctl, ctl.n0 + ctl.n1, sg, cur, (T)-1, o, q, (double*)&dacc[0]);
 #if XS_BWD_SPLIT
         __syncthreads();   // (the image of r_m, written by publish_begin in front of q_m, the diagonal term and the register classes)
 #endif
-        xs_lds_group<T, NT, RPT, SIGN, true, RM, false, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+        xs_lds_group<T, NT, RPT, SIGN, true, RMP, false, false, 0>(ctl, 0, ctl.n0 - ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
         if constexpr (CPLX)
-          xs_lds_group<T, NT, RPT, SIGN, true, RM, false, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
-        xs_lds_group<T, NT, RPT, SIGN, true, RM, true, false, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+          xs_lds_group<T, NT, RPT, SIGN, true, RMP, false, false, 1>(ctl, ctl.n0 - ctl.n0p1, ctl.n0p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+        xs_lds_group<T, NT, RPT, SIGN, true, RMP, true, false, 0>(ctl, ctl.n0, ctl.n1 - ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
         if constexpr (CPLX)
-          xs_lds_group<T, NT, RPT, SIGN, true, RM, true, false, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
+          xs_lds_group<T, NT, RPT, SIGN, true, RMP, true, false, 1>(ctl, ctl.n0 + ctl.n1 - ctl.n1p1, ctl.n1p1, sg, W, t, (T)-1, o, q, (double*)&dacc[0]);
 #else
 #if XS_BWD_SPLIT
         __syncthreads();

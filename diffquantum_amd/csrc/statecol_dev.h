@@ -34,6 +34,29 @@ __device__ inline float xs_fma(float a, float b, float c) { return __builtin_fma
 // diagonal where its paths merge, an unrolled loop over the diagonals drowns the register allocator
 typedef double xs_acc16 __attribute__((ext_vector_type(16)));
 
+// acc[slot] += tot for a wave-uniform slot as ONE vector instruction: v_add_f64 with its first source and its destination indexed
+// (s_set_gpr_idx_on ..., SRC0 | DST).  hipcc's inline asm cannot name a register of a 32-register operand, so the accumulator vector
+// is pinned to a fixed physical tuple and the instruction names its first pair; what the compiler makes of `acc[slot] += tot` is two
+// indexed reads, the add and two indexed writes in three s_set_gpr_idx windows: 5 vector + 6 scalar instructions per diagonal.
+// Taken by the quadrature kernels WITHOUT diagonal controls (ACCA; v[4:35] is where the allocator keeps the vector in those kernels
+// anyway): adjoint launch -2.0 % on the headline table, -1.0 % on X/Y drives; with diagonal controls the pinned tuple collides with the
+// row accumulators (ring QAOA +13 %, X/Z controls +16 %: spills) -- those keep the compiler's form.  (m0: saved and restored inside.)
+#ifndef XS_ACC_ASM
+#define XS_ACC_ASM 1
+#endif
+template <bool ACCA>
+__device__ __forceinline__ void xs_acc_add(xs_acc16& acc, int slot, double tot) {
+  if constexpr (ACCA && XS_ACC_ASM) {
+    unsigned m0_keep;
+    const unsigned idx = (unsigned)__builtin_amdgcn_readfirstlane(slot) * 2u;
+    asm volatile("s_mov_b32 %0, m0\n\ts_set_gpr_idx_on %3, 0x9\n\tv_add_f64 v[4:5], v[4:5], %2\n\ts_set_gpr_idx_off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_keep), "+{v[4:35]}"(acc)
+                 : "v"(tot), "s"(idx));
+  } else {
+    acc[slot] += tot;
+  }
+}
+
 // dacc[j] += s for a wave-uniform j (register arrays need static indices: a binary tree of scalar compares)
 template <int LO, int HI>
 __device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
@@ -59,7 +82,7 @@ __device__ __forceinline__ void xs_acc(double* dacc, int j, double s) {
 // row -- a shift, a mask and an xor per row and diagonal in every sweep, twice in the pairing sweeps.)
 // ej = table entry >> 20: the diagonal's index in the table (5 bits), row-sign bits of rows 1 .. 7 at bits 5 .. 11.
 // DOT: the level's gradient pairing of the partners with the thread's own rows xm, into lane `slot` of the accumulator vector.
-template <class T, int RPT, int SIGN, bool DOT, int PH, bool RS = false>
+template <class T, int RPT, int SIGN, bool DOT, int PH, bool RS = false, bool ACCA = false>
 __device__ __forceinline__ void xs_use(int ej, int slot, T w, unsigned tsg, const typename Cx<T>::type* v, typename Cx<T>::type* o,
                                        const typename Cx<T>::type* xm, double* dacc) {
   // RS: the diagonal has a row factor (the host orders those last within every class and phase: a loop of their own, no branch here)
@@ -103,7 +126,7 @@ __device__ __forceinline__ void xs_use(int ej, int slot, T w, unsigned tsg, cons
     }
     double tot = (double)sa + (double)sb;
     if (SIGN) tot = xs_flip(tot, tb);   // the thread's factor, once per diagonal
-    (*(xs_acc16*)dacc)[slot] += tot;
+    xs_acc_add<ACCA>(*(xs_acc16*)dacc, slot, tot);
   }
 }
 
@@ -285,7 +308,7 @@ __device__ __forceinline__ void xs_ring_use(double w, unsigned sbit, xs_d2 v, do
 // NSLOT: registers of the ring in complex numbers -- RPT (a slot per row) or DEPTH (RPT a multiple of DEPTH: element k of the class's
 // (diagonal, row) sequence lives in slot k % DEPTH and its slot takes the read of element k + DEPTH as soon as it has been used: the
 // same schedule in half the registers at DEPTH = 4, for the kernels that have none to spare)
-template <int NT, int RPT, int SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH, bool RS, int NSLOT = RPT>
+template <int NT, int RPT, int SIGN, bool DOT, bool PERM, int PH, int SB, int DEPTH, bool RS, int NSLOT = RPT, bool ACCA = false>
 __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, unsigned sg, const double2* __restrict__ src, int t,
                                             double sgn, double2* o, const double2* xm, double* dacc) {
   static_assert(DEPTH >= 1 && DEPTH <= RPT, "ring depth");
@@ -307,7 +330,7 @@ __device__ __forceinline__ void xs_lds_ring(const XsCtl& ctl, int q0, int n, uns
     if (DOT) {
       const double tot = XS_RING_CHAINS == 4 ? (PH ? -((s[0] + s[1]) + (s[2] + s[3])) : (s[0] - s[1]) + (s[2] - s[3]))
                                              : (PH ? -(s[0] + s[1]) : s[0] - s[1]);
-      (*(xs_acc16*)dacc)[q - SB] += xs_flip(tot, tb);   // (the pairing takes the thread's factor once per diagonal)
+      xs_acc_add<ACCA>(*(xs_acc16*)dacc, q - SB, xs_flip(tot, tb));   // (the pairing takes the thread's factor once per diagonal)
     }
   };
 #pragma clang loop unroll(disable)
@@ -374,7 +397,7 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, un
   // it is 3 - 4 % faster per launch; on unsigned tables and in the forward kernel the burst loop is 4 - 7 % faster: round 5's A/B)
   if constexpr (!PREF && RPT == 8 && sizeof(T) == sizeof(double) && ((DOT && XS_RING_PAIR) || (!DOT && (XS_RING_PLAIN || RM == 2)))) {
     constexpr int DEPTH = DOT ? XS_RING_DEPTH_PAIR : XS_RING_DEPTH_PLAIN;
-    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DEPTH, RS, (XS_RING_SLOTS_DEPTH && RPT % DEPTH == 0) ? DEPTH : RPT>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);
+    xs_lds_ring<NT, RPT, SIGN, DOT, PERM, PH, SB, DEPTH, RS, (XS_RING_SLOTS_DEPTH && RPT % DEPTH == 0) ? DEPTH : RPT, (DOT && RM == 17)>(ctl, q0, n, sg, src, t, sgn, o, xm, dacc);   // (RM == 17: 16 accumulators, updated by xs_acc_add's one-instruction form)
     return;
   }
   if (PREF) {
@@ -387,21 +410,21 @@ __device__ __forceinline__ void xs_lds_class(const XsCtl& ctl, int q0, int n, un
     for (; q + 1 < qe; q += 2) {
       e1 = __builtin_amdgcn_readlane(ctl.ent, q + 1);
       xs_fetch<T, NT, RPT, PERM>(e1 & 0xffff, src, t, vb);
-      xs_use<T, RPT, SIGN, DOT, PH, RS>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH, RS, (DOT && RM == 17)>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
       if (q + 2 < qe) {
         e0 = __builtin_amdgcn_readlane(ctl.ent, q + 2);
         xs_fetch<T, NT, RPT, PERM>(e0 & 0xffff, src, t, va);
       }
-      xs_use<T, RPT, SIGN, DOT, PH, RS>(e1 >> 20, q + 1 - SB, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH, RS, (DOT && RM == 17)>(e1 >> 20, q + 1 - SB, sgn * (T)xs_readlane(ctl.w, q + 1), sg, vb, o, xm, dacc);
     }
-    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH, RS>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
+    if (q < qe) xs_use<T, RPT, SIGN, DOT, PH, RS, (DOT && RM == 17)>(e0 >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, va, o, xm, dacc);
   } else {
 #pragma clang loop unroll(disable)
     for (int q = q0; q < q0 + n; ++q) {
       const int e = __builtin_amdgcn_readlane(ctl.ent, q);
       T2 v[RPT];
       xs_fetch<T, NT, RPT, PERM>(e & 0xffff, src, t, v);
-      xs_use<T, RPT, SIGN, DOT, PH, RS>(e >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+      xs_use<T, RPT, SIGN, DOT, PH, RS, (DOT && RM == 17)>(e >> 20, q - SB, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
     }
   }
 }
@@ -452,7 +475,7 @@ __device__ __forceinline__ void xs_gather_pairings(const XsCtl& ctl, unsigned sg
 }
 
 // the diagonals whose partners are the thread's own rows r ^ XH (register copies), class by class, phase 0 then phase 1
-template <class T, int RPT, int XH, int SIGN, bool DOT, int PH, bool RS = false>
+template <class T, int RPT, int XH, int SIGN, bool DOT, int PH, bool RS = false, bool ACCA = false>
 __device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                             typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
 #pragma clang loop unroll(disable)
@@ -461,12 +484,12 @@ __device__ __forceinline__ int xs_local_run(const XsCtl& ctl, int q, int n, unsi
     typename Cx<T>::type v[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) v[r] = cur[r ^ XH];
-    xs_use<T, RPT, SIGN, DOT, PH, RS>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
+    xs_use<T, RPT, SIGN, DOT, PH, RS, ACCA>(e >> 20, q, sgn * (T)xs_readlane(ctl.w, q), sg, v, o, xm, dacc);
   }
   return q;
 }
 // one register class and phase: the diagonals without a row factor of the sign, then those with one
-template <class T, int RPT, int XH, int SIGN, bool DOT, int PH>
+template <class T, int RPT, int XH, int SIGN, bool DOT, int PH, bool ACCA = false>
 __device__ __forceinline__ int xs_local_group(const XsCtl& ctl, int q, int n, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                               typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
   constexpr int G = 8 + (XH - 1) * 4 + PH * 2;
@@ -474,22 +497,22 @@ __device__ __forceinline__ int xs_local_group(const XsCtl& ctl, int q, int n, un
     if (((unsigned)(ctl.gmask >> G) & 3u) == 0u) return q;
     int nrs = __builtin_amdgcn_readlane(ctl.rsn, 4 + 2 * (XH - 1) + PH);
     nrs = nrs > n ? n : nrs;
-    if ((unsigned)(ctl.gmask >> G) & 1u) q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, false>(ctl, q, n - nrs, sg, cur, sgn, o, xm, dacc);
-    if ((unsigned)(ctl.gmask >> G) & 2u) q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, true>(ctl, q, nrs, sg, cur, sgn, o, xm, dacc);
+    if ((unsigned)(ctl.gmask >> G) & 1u) q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, false, ACCA>(ctl, q, n - nrs, sg, cur, sgn, o, xm, dacc);
+    if ((unsigned)(ctl.gmask >> G) & 2u) q = xs_local_run<T, RPT, XH, SIGN, DOT, PH, true, ACCA>(ctl, q, nrs, sg, cur, sgn, o, xm, dacc);
     return q;
   } else {
-    return xs_local_run<T, RPT, XH, SIGN, DOT, PH, false>(ctl, q, n, sg, cur, sgn, o, xm, dacc);
+    return xs_local_run<T, RPT, XH, SIGN, DOT, PH, false, ACCA>(ctl, q, n, sg, cur, sgn, o, xm, dacc);
   }
 }
-template <class T, int RPT, int XH, int SIGN, bool DOT, bool CPLX>
+template <class T, int RPT, int XH, int SIGN, bool DOT, bool CPLX, bool ACCA = false>
 __device__ __forceinline__ void xs_local_classes(const XsCtl& ctl, int q, unsigned sg, const typename Cx<T>::type* cur, T sgn,
                                                  typename Cx<T>::type* o, const typename Cx<T>::type* xm, double* dacc) {
   if constexpr (XH < RPT && XH < 8) {
     if (((unsigned)(ctl.gmask >> (8 + (XH - 1) * 4)) & 15u) != 0u) {   // (an empty class: one test)
-      q = xs_local_group<T, RPT, XH, SIGN, DOT, 0>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
-      if constexpr (CPLX) q = xs_local_group<T, RPT, XH, SIGN, DOT, 1>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+      q = xs_local_group<T, RPT, XH, SIGN, DOT, 0, ACCA>(ctl, q, ctl.nloc[XH] - ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
+      if constexpr (CPLX) q = xs_local_group<T, RPT, XH, SIGN, DOT, 1, ACCA>(ctl, q, ctl.nlocp1[XH], sg, cur, sgn, o, xm, dacc);
     }
-    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, CPLX>(ctl, q, sg, cur, sgn, o, xm, dacc);
+    xs_local_classes<T, RPT, XH + 1, SIGN, DOT, CPLX, ACCA>(ctl, q, sg, cur, sgn, o, xm, dacc);
   }
 }
 
