@@ -118,7 +118,7 @@ class StructuredEngine:
 
     def set_option(self, name, value):
         """dq_sctx_set_option (include/diffqc_hip.h): "tol", "force_degree", "checkpoint_bytes", "plan_steps", "two_level", "profile",
-        and the kernel-form switches "dma", "dma_workgroups", "chain", "reverse_chain", "fuse_overlaps", "interleave_groups" (the last
+        and the kernel-form switches "dma", "dma_workgroups", "chain", "reverse_chain", "step_handover", "reverse_keep_last", "fuse_overlaps", "interleave_groups" (the last
         one before set_terms).  info(): "degree", "theta", "groups", "checkpoint_stride", "two_level", "passes", "dma_passes", ..."""
         self._ck(self._lib.dq_sctx_set_option(self._ctx, name.encode(), float(value)))
 

@@ -346,6 +346,9 @@ int dq_sctx_set_terms(dq_sctx* ctx, int n_terms, const int* owner, const unsigne
  *   "dma_workgroups" (persistent workgroups per pass; default = the device's CU count),
  *   "chain" (1, default: a Horner chain over two pure X-string groups finishes one application and starts the next in one pass),
  *   "reverse_chain" (1, default: so does the reverse sweep, overlaps of both stages included),
+ *   "step_handover" (1, default: the pass that finishes a step's Horner chain also starts the next step's, with that step's
+ *   coefficients and diagonal from a second set; 0: a finish pass and a start pass), "reverse_keep_last" (0, default: the reverse
+ *   chain's last stage stores no zbar_m -- nobody reads it; 1: the form with the store),
  *   "interleave_groups" (set before dq_sctx_set_terms; 2, default: two groups of single-qubit flips get the qubits in turn, so that
  *                    both tiles touch few 2 MB regions; 0: low qubits to one group, high qubits to the other),
  *   "fuse_overlaps" (1: the reverse-mode apply pass of a group also forms that group's control overlaps, in every kernel form;
