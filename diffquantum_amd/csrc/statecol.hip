@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(NT) xs_forward_kernel(const typename Cx<T>::ty
   extern __shared__ __align__(16) unsigned char xs_lds_raw[];
   T2* img = (T2*)xs_lds_raw;  // two images of D
   xs_lds_aligned<NT>(img);
+  xs_stagger_priority(threadIdx.x, NT);
   const int t = threadIdx.x;
   const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
   XsCtl ctl;

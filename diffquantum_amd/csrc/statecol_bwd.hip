@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(NT) xs_backward_kernel(typename Cx<T>::type* _
   T2* W = (T2*)xs_lds_raw;
   T2* Lm = W + D;
   xs_lds_aligned<NT>(W);
+  xs_stagger_priority(threadIdx.x, NT);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const unsigned sg = SIGN ? XsCtl::thread_signs(tab, t) : 0u;   // bit j: this thread's factor of diagonal j's sign (parity-signed table)
   const unsigned dsg = (DIAGCTL && tab.dstring) ? xs_diag_thread_signs(tab, t) : 0u;

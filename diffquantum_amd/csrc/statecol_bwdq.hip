@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(NT) xs_backward_q_kernel(typename Cx<T>::type*
   T2* W = (T2*)xs_lds_raw;
   T2* Lm = W + D;
   xs_lds_aligned<NT>(W);
+  xs_stagger_priority(threadIdx.x, NT);
   // U2L (difference basis, XsQuad::basis = 1; complex128, 8 rows per thread): the rule's second vector u_2 = O(theta^2) |lambda|
   // spends phase 2 in the LDS a column's two images leave free, rounded to fp32 (8 B per row: 32 of the 160 KB at d = 4096), two rows
   // to a 16-byte slot [k NT + t].  Relative to |lambda| that rounding is 6e-8 x 0.16 theta^2 (2e-11 at theta = 0.05), and it enters q_m

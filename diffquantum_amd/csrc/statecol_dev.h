@@ -632,6 +632,19 @@ __device__ __forceinline__ double xs_wave_sums16(const double* a, int lane) {
 #ifndef XS_W_PREFETCH
 #define XS_W_PREFETCH 1
 #endif
+#ifndef XS_SETPRIO
+#define XS_SETPRIO 0   // probe: 1 = the second of the two waves that share a SIMD (waves w and w + 4 of a 512-thread workgroup) runs at a lower issue priority
+#endif
+__device__ __forceinline__ void xs_stagger_priority(int t, int nt) {
+#if XS_SETPRIO
+  if (nt >= 512) {
+    if ((t >> 8) & 1) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(XS_SETPRIO);
+  }
+#else
+  (void)t; (void)nt;
+#endif
+}
 #ifndef XS_BWD_SPLIT
 #define XS_BWD_SPLIT 1   // quadrature adjoint kernel: the same for both of its phases (statecol_bwdq.hip, publish_begin)
 #endif
