@@ -2592,7 +2592,7 @@ void do_set_option(Ctx<T>* c, const std::string& s, double v) {
   else if (s == "force_squarings") c->force_s = (int)v;
   else if (s == "force_tile") {
     const int t = (int)v;
-    if (t != 0 && t != 32 && t != 64 && t != 128) fail(DQ_ERR_INVALID, "force_tile must be 0, 32, 64 or 128");
+    if (t != 0 && t != 16 && t != 32 && t != 64 && t != 128) fail(DQ_ERR_INVALID, "force_tile must be 0, 16, 32, 64 or 128");
     c->force_tile = t;
   } else if (s == "compose") {  // -1 auto (batch > dim), 0 never (no composed route at all: explicit tree, state-column product, wide-batch gradient), 1 always
                                 // (for a Pauli-sum generator the product comes from state-column segments unless state_columns_compose = 0)

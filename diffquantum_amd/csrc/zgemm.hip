@@ -439,6 +439,9 @@ static void launch_cfg(ZgemmArgs<T> g, hipStream_t st, int n_cu) {
 
 // Tile choice: the 128x128 tile needs >= ~1 wave of workgroups to pay; small problems
 // (d <= 64, or a thin batch) take the 64x64 / 32x32 tiles so that more CUs get work.
+#ifndef XS_ZGEMM_SMALL
+#define XS_ZGEMM_SMALL 1
+#endif
 int zgemm_pick_tile(int M, int N, int batch) {
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
   if (M >= 128 && N >= 128 && t128 >= 64) return 128;
@@ -451,7 +454,11 @@ template <>
 hipError_t zgemm_launch<double>(const ZgemmArgs<double>& g, hipStream_t st, int force_tile, int alg, int n_cu) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return hipSuccess;
   if (g.herm && g.M != g.N) return hipErrorInvalidValue;
-  const int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
+  int tile = force_tile ? force_tile : zgemm_pick_tile(g.M, g.N, g.batch);
+  // few tiles (the last levels of a product tree, one d = 256 product: 16 tiles of 64 x 64): the launch lasts as long as ONE wave's
+  // chain of MFMAs over K, whatever the tile -- a 64 x 64 tile on four waves and a 32 x 32 tile on one are the same 32 x 32 per wave.
+  // 32 x 32 tiles on four waves of 16 x 16 quarter that chain (code 16; complex128 only, not the Hermitian-output form)
+  if (XS_ZGEMM_SMALL && !force_tile && tile == 64 && !g.herm && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch <= 128) tile = 16;
   if (tile == 128 && alg == 2 && g.opB == 0 && (g.opA == 1 || g.hintA != 0) && zgemm_lin_eligible(g)) {
     // left operand readable k-major: A^H as asked, or A = A^T / A^H / -A^H by the caller's hint
     if (g.opA == 1 || g.hintA == 2) return zgemm_lin_launch(g, 1, st, n_cu);
@@ -464,6 +471,7 @@ hipError_t zgemm_launch<double>(const ZgemmArgs<double>& g, hipStream_t st, int 
     if (alg >= 1) launch_cfg<double, 128, 128, 8, 2, 4, 1>(g, st, n_cu);
     else launch_cfg<double, 128, 128, 8, 2, 4, 0>(g, st, n_cu);
   } else if (tile == 64) launch_cfg<double, 64, 64, 8, 2, 2, 0>(g, st, n_cu);
+  else if (tile == 16) launch_cfg<double, 32, 32, 8, 2, 2, 0>(g, st, n_cu);   // 32 x 32 tiles on four waves of 16 x 16: a quarter of the MFMA chain per wave
   else launch_cfg<double, 32, 32, 8, 1, 1, 0>(g, st, n_cu);
   return hipGetLastError();
 }
