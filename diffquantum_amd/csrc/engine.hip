@@ -1120,7 +1120,11 @@ std::vector<double> fetch_u(Ctx<T>* c, const double* u, int S) {
   const size_t n = (size_t)S * c->K;
   std::vector<double> h(n);
   if (n == 0) return h;
+  c->u_dev.ensure(std::max<size_t>(n, 1) * sizeof(double));
   if (is_device_ptr(u)) {
+    // a device table: the engine's copy is made on the device, in stream order (no second trip through the host and no second
+    // synchronisation: each costs a short call ~45 us of idle GPU -- configs[1]'s 0.9 ms forward call has three of them)
+    HIPCK(hipMemcpyAsync(c->u_dev.p, u, n * sizeof(double), hipMemcpyDeviceToDevice, c->st));
     HIPCK(hipMemcpyAsync(h.data(), u, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
     HIPCK(hipStreamSynchronize(c->st));
   } else {
@@ -1128,9 +1132,10 @@ std::vector<double> fetch_u(Ctx<T>* c, const double* u, int S) {
   }
   for (double v : h)
     if (!std::isfinite(v)) fail(DQ_ERR_INVALID, "pulse table contains non-finite values");
-  c->u_dev.ensure(std::max<size_t>(n, 1) * sizeof(double));
-  HIPCK(hipMemcpyAsync(c->u_dev.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->st));
-  HIPCK(hipStreamSynchronize(c->st));  // h may be pageable
+  if (!is_device_ptr(u)) {
+    HIPCK(hipMemcpyAsync(c->u_dev.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIPCK(hipStreamSynchronize(c->st));  // h may be pageable
+  }
   c->uh_last = h;
   return h;
 }
