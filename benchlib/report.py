@@ -29,7 +29,9 @@ TRAFFIC = {
     # quadrature form (xs_backward_q_kernel, round 4): no forward-term scratch; what is left per step is register spill traffic
     # (profiles/r4_bench_headline_summary.txt: 752 MB read + 640 MB written per average launch of 11 steps = the states and costates in
     # and out, 1074 MB, + 29 MB per step -- at degree 6, the economized step polynomial: 25-29 MB by run; 30.6 MB at Taylor's degree 7)
-    "statecol_bwdq_per_step": (2.9e7, "profiles/r4_bench_headline_summary.txt"),
+    # (round 5's last build, profiles/r5c_bench_headline_summary.txt: 724 MB read + 627 MB written per average launch of 11 steps =
+    # 1074 MB + 25 MB per step; 21 MB per step in profiles/r5b_bench_headline_summary.txt)
+    "statecol_bwdq_per_step": (2.5e7, "profiles/r5c_bench_headline_summary.txt"),
     "xr": (6.60e8, "profiles/r2_bench_headline_summary.txt"),        # (2 x 268.8 MB xr_forward [U written] + 1441 MB xr_reverse [Ubar
                                                                      # read + its power scratch written back and re-read]) / 3
 }
