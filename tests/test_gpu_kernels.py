@@ -22,7 +22,7 @@ def eng16():
     e.close()
 
 
-@pytest.mark.parametrize("tile", [0, 32, 64, 128])
+@pytest.mark.parametrize("tile", [0, 16, 32, 64, 128])   # (16: 32 x 32 tiles on four waves of 16 x 16, what problems of few tiles take by default)
 @pytest.mark.parametrize("opA,opB", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(16, 1, 16), (16, 16, 16), (33, 17, 9), (64, 64, 64), (130, 257, 70),
                                    (256, 96, 256), (1, 1, 1), (128, 128, 4), (5, 300, 3)])
